@@ -1,0 +1,221 @@
+/*
+ * ssf.h -- C ABI of the supersurfel_fusion per-frame hot path (extract | ICP | fuse).
+ *
+ * This header is the drop-in boundary.  It replaces, for the hot path only, the C++
+ * class supersurfel_fusion::SupersurfelFusion of the reference
+ * (core/include/supersurfel_fusion/supersurfel_fusion.hpp:40-143):
+ *
+ *   ssf_create            <- SupersurfelFusion::initialize          (supersurfel_fusion.hpp:46-74,
+ *                                                                    supersurfel_fusion.cu:49-164)
+ *   ssf_process_frame     <- SupersurfelFusion::processFrame        (supersurfel_fusion.hpp:75-76,
+ *                                                                    supersurfel_fusion.cu:166-530)
+ *   ssf_get_pose          <- getPose()                              (supersurfel_fusion.hpp:84)
+ *   ssf_get_model/_frame  <- getModel()/getFrame()                  (supersurfel_fusion.hpp:81-82,
+ *                                                                    supersurfels.hpp:32-93)
+ *   ssf_get_counts        <- getnbSupersurfels()/getStamp()         (supersurfel_fusion.hpp:85-90)
+ *   ssf_get_index_map ... <- TPS_RGBD::getIndexImage() etc.         (TPS_RGBD.hpp:77-81)
+ *   ssf_export_model_txt  <- exportModel(std::string)               (supersurfel_fusion.cu:595-633)
+ *   ssf_apply_deformation <- DeformationGraph::applyGraphToModel    (deformation_graph.cu:840-861,
+ *                                                                    deformation_graph_kernels.cu:27-73)
+ *   ssf_stage_*           <- the stage seams inside processFrame:
+ *        extract  = TPS_RGBD::compute/filter/computeDepthImage + generateSupersurfels
+ *                   (supersurfel_fusion.cu:189-194, TPS_RGBD.cu:101-525)
+ *        icp_*    = DenseRegistration::featureConstrainedSymmetricICP
+ *                   (dense_registration.hpp:57-72, dense_registration.cu:245-424)
+ *        match/fuse = the fuse block (supersurfel_fusion.cu:351-483)
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success and a
+ * negative ssf_status on failure (the reference calls exit(-1), cuda_error_check.h:30-66; this
+ * ABI never exits).  A handle is thread-compatible: one frame in flight per handle, callers
+ * serialise (the reference is driven from one ROS spin thread).
+ *
+ * Two shared libraries export exactly this ABI:
+ *   - libssf_hip.so     (supersurfel_fusion_amd/csrc, hand-written HIP for gfx950)  = the product
+ *   - libssf_oracle.so  (oracle/, plain C++ restatement of the reference)           = test checker
+ */
+#ifndef SSF_H
+#define SSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSF_ABI_VERSION 1
+
+typedef enum ssf_status {
+    SSF_OK = 0,
+    SSF_ERR_INVALID_ARG = -1,
+    SSF_ERR_DEVICE = -2,       /* HIP runtime error, see ssf_last_error */
+    SSF_ERR_NO_DEVICE = -3,    /* product library loaded on a box without a gfx950 GPU */
+    SSF_ERR_CAPACITY = -4,
+    SSF_ERR_STATE = -5,        /* stage called out of order */
+    SSF_ERR_IO = -6
+} ssf_status;
+
+/* Number of values in one ICP normal-equation record: JtJ upper triangle (21, row-major order
+ * 00,01,..,05,11,..,55), Jtr (6), sum r2^2 (1), inlier count (1).  Mirrors MotionTrackingData
+ * (dense_registration_types.hpp:55-60), but carried as exact fixed-point int64:
+ *   [0..20]  JtJ   scale 2^20      [21..26] Jtr  scale 2^24
+ *   [27]     r     scale 2^44      [28]     inliers (count)
+ * Integer sums are order independent, so the record is bit-identical for any thread/block/rank
+ * decomposition; a SUM all-reduce over ranks is exact. */
+#define SSF_ICP_RECORD 29
+#define SSF_ICP_SCALE_JTJ 1048576.0          /* 2^20 */
+#define SSF_ICP_SCALE_JTR 16777216.0         /* 2^24 */
+#define SSF_ICP_SCALE_R   17592186044416.0   /* 2^44 */
+
+/* POD mirror of the path-relevant arguments of SupersurfelFusion::initialize
+ * (supersurfel_fusion.hpp:46-74) + CamParam (cam_param.hpp:27-31).  Defaults (ssf_default_config)
+ * are the reference's C++ default arguments. */
+typedef struct ssf_config {
+    /* CamParam */
+    int   width, height;
+    float fx, fy, cx, cy;
+    /* TPS_RGBD */
+    int   cell_size;           /* 16 */
+    float lambda_pos;          /* 50 */
+    float lambda_bound;        /* 1000 */
+    float lambda_size;         /* 10000 */
+    float lambda_disp;         /* 1e6 */
+    float thresh_disp;         /* 1e-4 */
+    int   seg_iter;            /* 10 */
+    int   seg_use_ransac;      /* 1 */
+    int   nb_samples;          /* 16 */
+    int   filter_iter;         /* 4 */
+    float filter_alpha;        /* 0.1 */
+    float filter_beta;         /* 1.0 */
+    float filter_threshold;    /* 0.05 */
+    /* model */
+    float range_min;           /* 0.2 */
+    float range_max;           /* 5.0 */
+    int   delta_t;             /* 20 */
+    float conf_thresh;         /* 2500 */
+    int   nb_supersurfels_max; /* 50000 */
+    /* ICP */
+    int    icp_iter;           /* 10 */
+    double icp_cov_thresh;     /* 0.04 */
+    /* ---- build-specific (no reference counterpart) ---- */
+    uint64_t rng_seed;         /* 1234 (the reference seeds cuRAND with 1234, TPS_RGBD_kernels.cu:321) */
+    int   icp_force_iters;     /* 1: never early-stop on the 0.9995 ratio (BASELINE config 3) */
+    int   device_id;           /* HIP device ordinal (product only) */
+    void* stream;              /* hipStream_t to launch on, NULL = library-owned stream */
+    int   rank, nranks;        /* model shard of this handle; 0/1 = unsharded */
+    float shard_tile;          /* world-space tile edge (m) hashed to the owning rank, 0.5 */
+    int   profile;             /* 1: bracket every kernel with hipEvents (ssf_get_kernel_times) */
+} ssf_config;
+
+typedef struct ssf_handle ssf_handle;
+
+/* Host-side view of a supersurfel set in the reference's SoA layout (supersurfels.hpp:34-40):
+ * positions float3, colors float3 (sRGB 0..255), stamps int2 (t_init,t_last), orientations Mat33
+ * (row-major rows = major, minor, normal), shapes Cov3 (xx,xy,xz,yy,yz,zz), dims float2,
+ * confidences float (-1 = invalid).  104 bytes per supersurfel.  Any pointer may be NULL (skipped). */
+typedef struct ssf_surfels {
+    float*   positions;     /* 3*n */
+    float*   colors;        /* 3*n */
+    int32_t* stamps;        /* 2*n */
+    float*   orientations;  /* 9*n */
+    float*   shapes;        /* 6*n */
+    float*   dims;          /* 2*n */
+    float*   confidences;   /* n   */
+} ssf_surfels;
+
+typedef struct ssf_frame_result {
+    float pose[12];      /* row-major 3x3 R then t: camera-to-map, as Transform3 (matrix_types.h:38-42) */
+    int   icp_valid;     /* featureConstrainedSymmetricICP return value (0 also when ICP did not run) */
+    int   icp_iters;     /* executed iterations */
+    int   n_model;       /* nbSupersurfels after the frame (this shard) */
+    int   n_visible;     /* nbVisible after the frame (this shard) */
+    int   n_removed;
+    int   n_inserted;
+    int   n_updated;
+    int   stamp;         /* stamp the frame was processed at */
+    float stage_ms[3];   /* extract | icp | fuse wall time on the library's stream */
+} ssf_frame_result;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int  ssf_abi_version(void);
+/* "hip-gfx950" for the product, "cpu-oracle" for the checker. */
+const char* ssf_backend_name(void);
+void ssf_default_config(ssf_config* cfg);
+int  ssf_create(const ssf_config* cfg, ssf_handle** out);
+void ssf_destroy(ssf_handle* h);
+/* Last error text of this handle (or of ssf_create when h == NULL). */
+const char* ssf_last_error(const ssf_handle* h);
+
+/* ---- whole frame (single shard) ------------------------------------------------------------- */
+/* rgb: H*W*3 uint8, RGB order (the node passes RGB, supersurfel_fusion_rgbd_benchmark_node.cpp);
+ * depth_m: H*W float32 metres, 0 = hole (after the node's convertTo(CV_32FC1, depthScale)).
+ * prior_pose: nullable 12 floats (the sparse-VO pose prior of supersurfel_fusion.cu:225-228);
+ *             NULL = previous pose.
+ * dynamic_mask: nullable S bytes, non-zero marks a dynamic superpixel: frame confidence := -1
+ *             (the MOD hook, motion_detection.cu:573-578).
+ * Host-pointer and device-pointer variants; the device variant reads buffers already in HBM. */
+int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth_m,
+                      const float* prior_pose, const uint8_t* dynamic_mask, ssf_frame_result* out);
+int ssf_process_frame_device(ssf_handle* h, const void* d_rgb, const void* d_depth_m,
+                             const float* prior_pose, const uint8_t* dynamic_mask,
+                             ssf_frame_result* out);
+
+/* ---- stage seams (used by the sharded multi-GPU driver and by the parity tests) ------------- */
+/* extract: ingest + TPS segmentation + plane filter + plane depth + frame supersurfels. */
+int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth_m, int on_device,
+                      const uint8_t* dynamic_mask);
+/* Stop the segmentation after max_passes relabelling passes (0 = all); test/bisect aid. */
+int ssf_debug_set_max_passes(ssf_handle* h, int max_passes);
+/* Global (all-shard) model counts and this shard's global id offset; must precede icp_begin when
+ * nranks > 1.  Unsharded handles ignore it. */
+int ssf_stage_set_shard(ssf_handle* h, int64_t id_offset, int64_t global_n_model,
+                        int64_t global_n_visible);
+int ssf_stage_icp_begin(ssf_handle* h, const float* prior_pose);
+/* One pass over this shard's visible supersurfels with the current increment; sums[29]. */
+int ssf_stage_icp_accumulate(ssf_handle* h, int64_t* sums);
+/* Host Gauss-Newton step on the (rank-reduced) record; *again = 1 while iterations remain. */
+int ssf_stage_icp_update(ssf_handle* h, const int64_t* sums, int* again);
+int ssf_stage_icp_end(ssf_handle* h, int* valid);
+/* Projective association of this shard's visible supersurfels.  best[S]: packed
+ * (dist_bits << 32 | global_id), UINT64_MAX = none; matched[S] as findBestMatches sets it. */
+int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched);
+/* update winners owned by this shard, insert owned unmatched frame surfels, classify, reorder. */
+int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched,
+                   ssf_frame_result* out);
+
+/* ---- read back -------------------------------------------------------------------------------- */
+int ssf_get_pose(const ssf_handle* h, float* pose12);
+int ssf_set_pose(ssf_handle* h, const float* pose12);
+int ssf_get_counts(const ssf_handle* h, int* n_model, int* n_visible, int* stamp, int* n_superpixels);
+/* Copy-out of model rows [first, first+count) / the S frame supersurfels into caller arrays. */
+int ssf_get_model(ssf_handle* h, int first, int count, ssf_surfels* out);
+int ssf_get_frame(ssf_handle* h, ssf_surfels* out);
+/* Replace the model (import / synthetic seeding): rows [0,n), first n_visible rows visible. */
+int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, int stamp);
+int ssf_get_index_map(ssf_handle* h, int32_t* out /* H*W */);
+int ssf_get_boundary_map(ssf_handle* h, int32_t* out /* H*W */);
+int ssf_get_inlier_map(ssf_handle* h, uint8_t* out /* H*W */);
+int ssf_get_plane_depth(ssf_handle* h, float* out /* H*W */);
+/* SuperpixelRGBD table (TPS_RGBD.hpp:32-37) as 9 floats per superpixel:
+ * cx, cy, r, g, b, theta_a, theta_b, theta_c, size. */
+int ssf_get_superpixels(ssf_handle* h, float* out /* 9*S */);
+/* Device-resident views (product only; valid until the next call on the handle). */
+int ssf_get_model_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_model);
+int ssf_export_model_txt(ssf_handle* h, const char* path);
+
+/* ---- "next" row: loop-closure deformation apply ---------------------------------------------- */
+/* nodes: positions 3*m, rotations 9*m (row-major), translations 3*m; per model surfel 4 weights
+ * and 4 node indices (deformation_graph_kernels.cu:27-73).  Applies to rows [0, n_model). */
+int ssf_apply_deformation(ssf_handle* h, const float* node_positions, const float* node_rotations,
+                          const float* node_translations, int n_nodes, const float* weights4,
+                          const int32_t* idx4);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* With cfg.profile = 1: per-kernel accumulated hipEvent time since the last reset.
+ * names: up to max_k C strings (library-owned), ms / calls arrays of max_k.  Returns count. */
+int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k);
+int ssf_reset_kernel_times(ssf_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSF_H */

@@ -1,0 +1,242 @@
+// oracle_abi.cpp -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+//
+// Exports the C ABI of include/ssf.h on top of the CPU restatement so that the same host code
+// (tests, bench cpu_baseline leg) can drive the checker exactly like the HIP product.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include "oracle.h"
+
+using namespace orc;
+
+struct ssf_handle { State s; };
+static std::string g_create_err;
+
+static void pose_to12(const Pose& p, float* o) {
+    for (int i = 0; i < 3; i++) { o[3 * i] = p.R.r[i].x; o[3 * i + 1] = p.R.r[i].y; o[3 * i + 2] = p.R.r[i].z; }
+    o[9] = p.t.x; o[10] = p.t.y; o[11] = p.t.z;
+}
+
+extern "C" {
+
+int ssf_abi_version(void) { return SSF_ABI_VERSION; }
+const char* ssf_backend_name(void) { return "cpu-oracle"; }
+
+void ssf_default_config(ssf_config* c) {      // supersurfel_fusion.hpp:46-74 default arguments
+    std::memset(c, 0, sizeof(*c));
+    c->width = 640; c->height = 480; c->fx = 525.f; c->fy = 525.f; c->cx = 319.5f; c->cy = 239.5f;
+    c->cell_size = 16; c->lambda_pos = 50.f; c->lambda_bound = 1000.f; c->lambda_size = 10000.f;
+    c->lambda_disp = 1e6f; c->thresh_disp = 1e-4f; c->seg_iter = 10; c->seg_use_ransac = 1;
+    c->nb_samples = 16; c->filter_iter = 4; c->filter_alpha = 0.1f; c->filter_beta = 1.0f;
+    c->filter_threshold = 0.05f; c->range_min = 0.2f; c->range_max = 5.0f; c->delta_t = 20;
+    c->conf_thresh = 2500.f; c->nb_supersurfels_max = 50000; c->icp_iter = 10; c->icp_cov_thresh = 0.04;
+    c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
+    c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
+}
+
+int ssf_create(const ssf_config* cfg, ssf_handle** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return SSF_ERR_INVALID_ARG; }
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->cell_size <= 0 || cfg->nb_samples <= 0 ||
+        cfg->nb_supersurfels_max <= 0 || cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) {
+        g_create_err = "invalid configuration"; return SSF_ERR_INVALID_ARG;
+    }
+    ssf_handle* h = new (std::nothrow) ssf_handle();
+    if (!h) return SSF_ERR_DEVICE;
+    State& s = h->s;
+    s.cfg = *cfg;
+    s.W = cfg->width; s.H = cfg->height;
+    s.gx = (s.W + cfg->cell_size - 1) / cfg->cell_size;     // TPS_RGBD.cu:113-116
+    s.gy = (s.H + cfg->cell_size - 1) / cfg->cell_size;
+    s.S = s.gx * s.gy;
+    if (cfg->nb_supersurfels_max < s.S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
+    const size_t P = (size_t)s.W * s.H;
+    s.rgba.assign(P, 0); s.disp.assign(P, 0.f); s.plane_depth.assign(P, 0.f);
+    s.label.assign(P, 0); s.label_tmp.assign(P, 0); s.inlier.assign(P, 0);
+    s.sums.resize(s.S); s.sp.resize(s.S);
+    s.samples.assign((size_t)s.S * cfg->nb_samples * 4, 0.f);
+    s.rng_counter.assign((size_t)s.S * cfg->nb_samples, 0u);
+    s.frame.resize(s.S); s.frame.zero(s.S); s.frame_lab.assign(s.S, mk3(0, 0, 0));
+    s.model.resize(cfg->nb_supersurfels_max); s.model.zero(cfg->nb_supersurfels_max);
+    s.model_lab.assign(cfg->nb_supersurfels_max, mk3(0, 0, 0));
+    s.pose.R = identity33(); s.pose.t = mk3(0, 0, 0);
+    *out = h;
+    return SSF_OK;
+}
+void ssf_destroy(ssf_handle* h) { delete h; }
+const char* ssf_last_error(const ssf_handle* h) { return h ? h->s.err.c_str() : g_create_err.c_str(); }
+
+static void frame_lab_refresh(State& s) {
+    for (int k = 0; k < s.S; k++) s.frame_lab[k] = rgbToLab(s.frame.col[k]);
+}
+
+int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    (void)on_device;
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    extract(h->s, (const uint8_t*)rgb, (const float*)depth, mask);
+    frame_lab_refresh(h->s);
+    return SSF_OK;
+}
+int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->s.max_passes = n; return SSF_OK; }
+int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    h->s.id_offset = off; h->s.global_n_model = gm; h->s.global_n_visible = gv; return SSF_OK;
+}
+int ssf_stage_icp_begin(ssf_handle* h, const float* prior) {
+    if (!h || !h->s.have_frame) return SSF_ERR_STATE;
+    icp_begin(h->s, prior); return SSF_OK;
+}
+int ssf_stage_icp_accumulate(ssf_handle* h, int64_t* sums) {
+    if (!h || !sums) return SSF_ERR_INVALID_ARG;
+    icp_accumulate(h->s, sums); return SSF_OK;
+}
+int ssf_stage_icp_update(ssf_handle* h, const int64_t* sums, int* again) {
+    if (!h || !sums || !again) return SSF_ERR_INVALID_ARG;
+    icp_update(h->s, sums, again); return SSF_OK;
+}
+int ssf_stage_icp_end(ssf_handle* h, int* valid) {
+    if (!h || !valid) return SSF_ERR_INVALID_ARG;
+    icp_end(h->s, valid); return SSF_OK;
+}
+int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched) {
+    if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
+    if (!h->s.have_frame) return SSF_ERR_STATE;
+    match(h->s, best, matched); return SSF_OK;
+}
+int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
+    if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
+    if (!h->s.have_frame) return SSF_ERR_STATE;
+    fuse(h->s, best, matched, out); return SSF_OK;
+}
+
+int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, const float* prior,
+                      const uint8_t* mask, ssf_frame_result* out) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    State& s = h->s;
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    extract(s, rgb, depth, mask);
+    frame_lab_refresh(s);
+    auto t1 = clk::now();
+    icp_begin(s, prior);
+    int again = s.icp.active ? 1 : 0, valid = 0;
+    int64_t sums[SSF_ICP_RECORD];
+    while (again) { icp_accumulate(s, sums); icp_update(s, sums, &again); }
+    icp_end(s, &valid);
+    auto t2 = clk::now();
+    std::vector<uint64_t> best(s.S); std::vector<uint8_t> matched(s.S);
+    match(s, best.data(), matched.data());
+    ssf_frame_result r;
+    fuse(s, best.data(), matched.data(), &r);
+    auto t3 = clk::now();
+    r.stage_ms[0] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    r.stage_ms[1] = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    r.stage_ms[2] = std::chrono::duration<float, std::milli>(t3 - t2).count();
+    if (out) *out = r;
+    return SSF_OK;
+}
+int ssf_process_frame_device(ssf_handle* h, const void* rgb, const void* depth, const float* prior,
+                             const uint8_t* mask, ssf_frame_result* out) {
+    return ssf_process_frame(h, (const uint8_t*)rgb, (const float*)depth, prior, mask, out);
+}
+
+int ssf_get_pose(const ssf_handle* h, float* p) { if (!h || !p) return SSF_ERR_INVALID_ARG; pose_to12(h->s.pose, p); return SSF_OK; }
+int ssf_set_pose(ssf_handle* h, const float* p) {
+    if (!h || !p) return SSF_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; i++) h->s.pose.R.r[i] = mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    h->s.pose.t = mk3(p[9], p[10], p[11]); return SSF_OK;
+}
+int ssf_get_counts(const ssf_handle* h, int* nm, int* nv, int* st, int* ns) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (nm) *nm = h->s.n_model; if (nv) *nv = h->s.n_visible; if (st) *st = h->s.stamp; if (ns) *ns = h->s.S;
+    return SSF_OK;
+}
+static void copy_out(const Surfels& S, int first, int count, ssf_surfels* o) {
+    for (int i = 0; i < count; i++) {
+        const int k = first + i;
+        if (o->positions) { o->positions[3 * i] = S.pos[k].x; o->positions[3 * i + 1] = S.pos[k].y; o->positions[3 * i + 2] = S.pos[k].z; }
+        if (o->colors) { o->colors[3 * i] = S.col[k].x; o->colors[3 * i + 1] = S.col[k].y; o->colors[3 * i + 2] = S.col[k].z; }
+        if (o->stamps) { o->stamps[2 * i] = S.stamps[2 * k]; o->stamps[2 * i + 1] = S.stamps[2 * k + 1]; }
+        if (o->orientations) for (int r = 0; r < 3; r++) {
+            o->orientations[9 * i + 3 * r] = S.orient[k].r[r].x; o->orientations[9 * i + 3 * r + 1] = S.orient[k].r[r].y; o->orientations[9 * i + 3 * r + 2] = S.orient[k].r[r].z; }
+        if (o->shapes) { const Cov3& c = S.shape[k]; float v[6] = {c.xx, c.xy, c.xz, c.yy, c.yz, c.zz}; std::memcpy(&o->shapes[6 * i], v, 24); }
+        if (o->dims) { o->dims[2 * i] = S.dims[2 * k]; o->dims[2 * i + 1] = S.dims[2 * k + 1]; }
+        if (o->confidences) o->confidences[i] = S.conf[k];
+    }
+}
+int ssf_get_model(ssf_handle* h, int first, int count, ssf_surfels* o) {
+    if (!h || !o || first < 0 || count < 0 || first + count > h->s.cfg.nb_supersurfels_max) return SSF_ERR_INVALID_ARG;
+    copy_out(h->s.model, first, count, o); return SSF_OK;
+}
+int ssf_get_frame(ssf_handle* h, ssf_surfels* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; copy_out(h->s.frame, 0, h->s.S, o); return SSF_OK; }
+int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, int stamp) {
+    if (!h || !in || n < 0 || n > h->s.cfg.nb_supersurfels_max || n_visible < 0 || n_visible > n) return SSF_ERR_INVALID_ARG;
+    if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
+    State& s = h->s; Surfels& M = s.model;
+    for (int i = 0; i < n; i++) {
+        M.pos[i] = mk3(in->positions[3 * i], in->positions[3 * i + 1], in->positions[3 * i + 2]);
+        M.col[i] = mk3(in->colors[3 * i], in->colors[3 * i + 1], in->colors[3 * i + 2]);
+        M.stamps[2 * i] = in->stamps[2 * i]; M.stamps[2 * i + 1] = in->stamps[2 * i + 1];
+        for (int r = 0; r < 3; r++) M.orient[i].r[r] = mk3(in->orientations[9 * i + 3 * r], in->orientations[9 * i + 3 * r + 1], in->orientations[9 * i + 3 * r + 2]);
+        const float* c = &in->shapes[6 * i]; M.shape[i] = mkcov(c[0], c[1], c[2], c[3], c[4], c[5]);
+        M.dims[2 * i] = in->dims[2 * i]; M.dims[2 * i + 1] = in->dims[2 * i + 1];
+        M.conf[i] = in->confidences[i];
+        s.model_lab[i] = rgbToLab(M.col[i]);
+    }
+    s.n_model = n; s.n_visible = n_visible; s.stamp = stamp;
+    return SSF_OK;
+}
+int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; std::memcpy(o, h->s.label.data(), h->s.label.size() * 4); return SSF_OK; }
+int ssf_get_boundary_map(ssf_handle* h, int32_t* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    State& s = h->s;
+    for (int y = 0; y < s.H; y++) for (int x = 0; x < s.W; x++) o[(size_t)y * s.W + x] = boundary_at(s, s.label, x, y);
+    return SSF_OK;
+}
+int ssf_get_inlier_map(ssf_handle* h, uint8_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; std::memcpy(o, h->s.inlier.data(), h->s.inlier.size()); return SSF_OK; }
+int ssf_get_plane_depth(ssf_handle* h, float* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; std::memcpy(o, h->s.plane_depth.data(), h->s.plane_depth.size() * 4); return SSF_OK; }
+int ssf_get_superpixels(ssf_handle* h, float* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    for (int k = 0; k < h->s.S; k++) {
+        const Superpixel& sp = h->s.sp[k];
+        float v[9] = {sp.cx, sp.cy, sp.r, sp.g, sp.b, sp.ta, sp.tb, sp.tc, sp.size};
+        std::memcpy(&o[9 * k], v, 36);
+    }
+    return SSF_OK;
+}
+int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) { (void)h; (void)o; (void)n; return SSF_ERR_NO_DEVICE; }
+
+// exportModel, supersurfel_fusion.cu:595-633 (std::to_string == "%f")
+int ssf_export_model_txt(ssf_handle* h, const char* path) {
+    if (!h || !path) return SSF_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, "w");
+    if (!f) { h->s.err = "cannot open file"; return SSF_ERR_IO; }
+    const State& s = h->s; const Surfels& M = s.model;
+    for (int i = 0; i < s.n_model; i++) {
+        if (!(M.conf[i] > s.cfg.conf_thresh)) continue;
+        std::fprintf(f, "%d %d %f\n", M.stamps[2 * i], M.stamps[2 * i + 1], M.conf[i]);
+        std::fprintf(f, "%f %f %f\n", M.pos[i].x, M.pos[i].y, M.pos[i].z);
+        std::fprintf(f, "%f %f %f\n", M.col[i].x, M.col[i].y, M.col[i].z);
+        std::fprintf(f, "%f %f\n", M.dims[2 * i], M.dims[2 * i + 1]);
+        const Mat33& o = M.orient[i];
+        std::fprintf(f, "%f %f %f %f %f %f %f %f %f\n", o.r[0].x, o.r[0].y, o.r[0].z, o.r[1].x, o.r[1].y, o.r[1].z, o.r[2].x, o.r[2].y, o.r[2].z);
+        const Cov3& c = M.shape[i];
+        std::fprintf(f, "%f %f %f %f %f %f\n\n", c.xx, c.xy, c.xz, c.yy, c.yz, c.zz);
+    }
+    std::fclose(f);
+    return SSF_OK;
+}
+
+int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const float* nt, int m,
+                          const float* w4, const int32_t* idx4) {
+    if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
+    apply_deformation(h->s, np, nr, nt, m, w4, idx4); return SSF_OK;
+}
+int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k) {
+    (void)h; (void)names; (void)ms; (void)calls; (void)max_k; return 0;
+}
+int ssf_reset_kernel_times(ssf_handle* h) { (void)h; return SSF_OK; }
+
+}  // extern "C"

@@ -1,0 +1,419 @@
+// oracle_track_fuse.cpp -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+//
+// Restatement of the ICP stage (DenseRegistration::featureConstrainedSymmetricICP,
+// core/src/dense_registration.cu:245-424; kernel computeSymmetricICPSystem,
+// core/include/supersurfel_fusion/dense_registration_kernels.cuh:175-291), of the pose
+// composition (core/src/supersurfel_fusion.cu:232-240,313-328) and of the fuse block
+// (core/src/supersurfel_fusion.cu:351-483; kernels core/src/supersurfel_fusion_kernels.cu:
+// 348-467,522-682), plus the "next" row applyDeformation (deformation_graph_kernels.cu:27-73).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include "oracle.h"
+
+namespace orc {
+
+// lroundf(v) for pixel coordinates; anything that cannot be an in-image pixel maps to -1
+// (lroundf of inf/NaN/huge is undefined in C; the reference never guards it).
+static inline int project_round(float v) {
+    if (!(fabsf(v) < 8388608.0f)) return -1;
+    return round_half_away(v);
+}
+
+static void mat4_mul(const double* a, const double* b, double* c) {
+    double r[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r[i * 4 + j] = ((a[i * 4 + 0] * b[0 * 4 + j] + a[i * 4 + 1] * b[1 * 4 + j]) + a[i * 4 + 2] * b[2 * 4 + j]) + a[i * 4 + 3] * b[3 * 4 + j];
+    std::memcpy(c, r, sizeof(r));
+}
+
+static void refresh_inc(State& s) {                       // dense_registration.cu:291-299
+    IcpState& I = s.icp;
+    for (int i = 0; i < 3; i++)
+        I.R_inc.r[i] = mk3((float)I.tf_inc[i * 4 + 0], (float)I.tf_inc[i * 4 + 1], (float)I.tf_inc[i * 4 + 2]);
+    I.t_inc = mk3((float)I.tf_inc[3], (float)I.tf_inc[7], (float)I.tf_inc[11]);
+}
+
+void icp_begin(State& s, const float* prior) {
+    IcpState& I = s.icp;
+    if (prior) {                                          // pose = vo->getPose(), supersurfel_fusion.cu:228
+        for (int i = 0; i < 3; i++) s.pose.R.r[i] = mk3(prior[3 * i], prior[3 * i + 1], prior[3 * i + 2]);
+        s.pose.t = mk3(prior[9], prior[10], prior[11]);
+    }
+    const int64_t nvis = (s.cfg.nranks > 1 && s.global_n_visible >= 0) ? s.global_n_visible : s.n_visible;
+    I.active = nvis > 0 && s.cfg.icp_iter > 0;            // if(nbVisible > 0), supersurfel_fusion.cu:232
+    I.valid = true; I.done = !I.active; I.iter = 0;
+    I.R_init = transpose(s.pose.R);                        // :234-235
+    I.t_init = neg(I.R_init * s.pose.t);
+    for (int i = 0; i < 16; i++) I.tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 36; i++) I.JtJ[i] = 0.0;
+    I.prev_error = DBL_MAX;
+    I.R_rel = identity33(); I.t_rel = mk3(0, 0, 0);
+    I.R_inc = identity33(); I.t_inc = mk3(0, 0, 0);
+    s.last_icp_valid = 0; s.last_icp_iters = 0;
+}
+
+// computeSymmetricICPSystem<128>, dense_registration_kernels.cuh:175-291, over this shard's
+// visible rows; sums are the exact fixed-point record of ssf.h (decision A4).
+void icp_accumulate(State& s, int64_t* sums) {
+    IcpState& I = s.icp;
+    const ssf_config& c = s.cfg;
+    for (int i = 0; i < SSF_ICP_RECORD; i++) sums[i] = 0;
+    refresh_inc(s);
+    I.R_corres = I.R_inc * I.R_init;                       // dense_registration.cu:298-299
+    I.t_corres = I.R_inc * I.t_init + I.t_inc;
+    const Mat33 R = I.R_corres; const f3 t = I.t_corres;
+    const int W = s.W, H = s.H;
+    for (int id = 0; id < s.n_visible; id++) {
+        f3 ps = R * s.model.pos[id] + t;
+        int u = project_round(ps.x * c.fx / ps.z + c.cx);
+        int v = project_round(ps.y * c.fy / ps.z + c.cy);
+        if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
+        const size_t p = (size_t)v * W + u;
+        const int tid = s.label[p];
+        const float zt = s.plane_depth[p];
+        if (!(s.frame.conf[tid] > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;   // hard-coded range (:224)
+        const float dist_color = length(s.model_lab[id] - s.frame_lab[tid]);
+        const f3 pt = mk3(zt * ((float)u - c.cx) / c.fx, zt * ((float)v - c.cy) / c.fy, zt);
+        const f3 nt = s.frame.orient[tid].r[2];
+        const f3 ns = normalize(R * s.model.orient[id].r[2]);
+        if (!(dist_color < 20.0f && length(ps - pt) < 0.1f && fabsf(dot(nt, ns)) > 0.8f)) continue;
+        const f3 d = pt - ps, c1 = cross(pt, ns), c2 = cross(ps, nt);
+        const float dn1 = dot(d, ns), dn2 = dot(d, nt);
+        const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
+        const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+        int k = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++, k++)
+                sums[k] += (int64_t)fx_quant32(x1[i] * x1[j] + x2[i] * x2[j], (float)SSF_ICP_SCALE_JTJ);
+        for (int i = 0; i < 6; i++)
+            sums[21 + i] += (int64_t)fx_quant32(dn1 * x1[i] + dn2 * x2[i], (float)SSF_ICP_SCALE_JTR);
+        sums[27] += fx_quant((double)(dn2 * dn2), SSF_ICP_SCALE_R, 4611686018427387904.0);
+        sums[28] += 1;
+    }
+}
+
+// host part of one iteration, dense_registration.cu:324-391
+void icp_update(State& s, const int64_t* sums, int* again) {
+    IcpState& I = s.icp;
+    *again = 0;
+    if (!I.active || I.done) return;
+    I.iter++;
+    s.last_icp_iters = I.iter;
+    static const int tri[6][6] = {{0, 1, 2, 3, 4, 5}, {1, 6, 7, 8, 9, 10}, {2, 7, 11, 12, 13, 14},
+                                  {3, 8, 12, 15, 16, 17}, {4, 9, 13, 16, 18, 19}, {5, 10, 14, 17, 19, 20}};
+    double Jtr[6];
+    for (int i = 0; i < 6; i++) {
+        for (int j = 0; j < 6; j++) I.JtJ[i * 6 + j] = (double)sums[tri[i][j]] / SSF_ICP_SCALE_JTJ;
+        Jtr[i] = (double)sums[21 + i] / SSF_ICP_SCALE_JTR;
+    }
+    const float r = (float)((double)sums[27] / SSF_ICP_SCALE_R);
+    const float inliers = (float)sums[28];
+    const double error = std::sqrt((double)(r / inliers));                      // :333
+    if (inliers < 100.0f) { I.valid = false; I.done = true; return; }           // :336-341
+    double X[6];
+    ldlt_solve6(I.JtJ, Jtr, X);                                                 // :367
+    double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
+    const double nrm = std::sqrt((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+    const double angle = 0.5 * std::atan(nrm);                                  // :373
+    double Rr[9];
+    if (nrm == 0.0) {                     // deviation: the reference divides by zero here (NaN pose)
+        for (int i = 0; i < 9; i++) Rr[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    } else {
+        for (int i = 0; i < 3; i++) axis[i] /= nrm;
+        angle_axis_to_rot_d(angle, axis, Rr);
+    }
+    const double ca = std::cos(angle);
+    for (int i = 0; i < 3; i++) tran[i] *= ca;                                  // :375
+    double tf_iter[16] = {0};                                                   // iso_rot * Trans * iso_rot (:378)
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            tf_iter[i * 4 + j] = (Rr[i * 3 + 0] * Rr[0 * 3 + j] + Rr[i * 3 + 1] * Rr[1 * 3 + j]) + Rr[i * 3 + 2] * Rr[2 * 3 + j];
+        tf_iter[i * 4 + 3] = (Rr[i * 3 + 0] * tran[0] + Rr[i * 3 + 1] * tran[1]) + Rr[i * 3 + 2] * tran[2];
+    }
+    tf_iter[15] = 1.0;
+    double R9[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R9[i * 3 + j] = tf_iter[i * 4 + j];
+    quat_normalize_rot_d(R9);                                                   // :384
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tf_iter[i * 4 + j] = R9[i * 3 + j];
+    mat4_mul(tf_iter, I.tf_inc, I.tf_inc);                                      // :386
+    if (!s.cfg.icp_force_iters && error / I.prev_error > 0.9995) { I.done = true; return; }   // :388
+    I.prev_error = error;
+    if (I.iter >= s.cfg.icp_iter) { I.done = true; return; }
+    *again = 1;
+}
+
+// dense_registration.cu:394-421 and supersurfel_fusion.cu:313-328
+void icp_end(State& s, int* valid) {
+    IcpState& I = s.icp;
+    *valid = 0;
+    if (!I.active) return;
+    bool ok = I.valid;
+    double cov[36];
+    lu_inverse6(I.JtJ, cov);
+    for (int i = 0; i < 6; i++) if (cov[i * 6 + i] > s.cfg.icp_cov_thresh) { ok = false; break; }
+    if (ok) {
+        if (length(I.t_inc) > 0.2f) ok = false;            // stale t_inc (start of the last iteration)
+        else {
+            refresh_inc(s);
+            I.R_rel = transpose(I.R_inc);
+            I.t_rel = neg(I.R_rel * I.t_inc);
+        }
+    }
+    if (ok) {
+        s.pose.t = s.pose.R * I.t_rel + s.pose.t;
+        s.pose.R = s.pose.R * I.R_rel;
+        float R9[9];
+        for (int i = 0; i < 3; i++) { R9[3 * i] = s.pose.R.r[i].x; R9[3 * i + 1] = s.pose.R.r[i].y; R9[3 * i + 2] = s.pose.R.r[i].z; }
+        quat_normalize_rot_f(R9);
+        for (int i = 0; i < 3; i++) s.pose.R.r[i] = mk3(R9[3 * i], R9[3 * i + 1], R9[3 * i + 2]);
+    }
+    *valid = ok ? 1 : 0;
+    s.last_icp_valid = *valid;
+    I.active = false;
+}
+
+// findBestMatches, supersurfel_fusion_kernels.cu:522-599 (decision A13)
+void match(State& s, uint64_t* best, uint8_t* matched) {
+    const ssf_config& c = s.cfg;
+    for (int f = 0; f < s.S; f++) { best[f] = UINT64_MAX; matched[f] = 0; }
+    const int64_t nmodel = (c.nranks > 1 && s.global_n_model >= 0) ? s.global_n_model : s.n_model;
+    const int64_t nvis = (c.nranks > 1 && s.global_n_visible >= 0) ? s.global_n_visible : s.n_visible;
+    if (!(nmodel > 0 && nvis > 0)) return;                  // supersurfel_fusion.cu:351,356
+    const Mat33 R = s.pose.R; const f3 t = s.pose.t;
+    const Mat33 Rview = transpose(R);
+    const f3 tview = neg(Rview * t);
+    const Mat33 Rt = transpose(R);
+    for (int id = 0; id < s.n_visible; id++) {
+        if (!(s.model.conf[id] > 0.0f)) continue;
+        const f3 mp = s.model.pos[id];
+        const f3 pv = Rview * mp + tview;
+        if (!(pv.z > c.range_min && pv.z < c.range_max)) continue;
+        int px = project_round(pv.x * c.fx / pv.z + c.cx), py = project_round(pv.y * c.fy / pv.z + c.cy);
+        if (!(px >= 0 && px < s.W && py >= 0 && py < s.H)) continue;
+        const int f = s.label[(size_t)py * s.W + px];
+        matched[f] = 1;                                     // unconditional (:570)
+        if (!(s.frame.conf[f] > 0.0f)) continue;
+        const f3 fp = R * s.frame.pos[f] + t;
+        const Mat33 frot = s.frame.orient[f] * Rt;
+        const f3 fn = normalize(frot.r[2]);
+        const f3 mn = normalize(s.model.orient[id].r[2]);
+        const float dist = length(mp - fp);
+        const float lab_dist = length(s.model_lab[id] - s.frame_lab[f]);
+        const float delta_norm = fabsf(dot(mn, fn));
+        if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
+            uint32_t bits; std::memcpy(&bits, &dist, 4);
+            uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)(s.id_offset + id);
+            if (key < best[f]) best[f] = key;
+        }
+    }
+}
+
+// spatial-tile owner of frame surfel f (multi-GPU sharding; no reference counterpart)
+int shard_owner(const State& s, int f, const Pose& pose) {
+    const int n = s.cfg.nranks;
+    if (n <= 1) return 0;
+    if (!(s.frame.conf[f] > 0.0f)) return f % n;
+    const f3 pw = pose.R * s.frame.pos[f] + pose.t;
+    const float tile = s.cfg.shard_tile;
+    const int32_t ix = (int32_t)floorf(pw.x / tile), iy = (int32_t)floorf(pw.y / tile), iz = (int32_t)floorf(pw.z / tile);
+    const uint32_t h = ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u);
+    return (int)(h % (uint32_t)n);
+}
+
+// updateSupersurfels, supersurfel_fusion_kernels.cu:601-682
+static void update_one(State& s, int f, int m) {
+    const Mat33 R = s.pose.R; const f3 t = s.pose.t;
+    Surfels& M = s.model; const Surfels& F = s.frame;
+    const f3 model_position = M.pos[m];
+    const f3 frame_position = R * F.pos[f] + t;
+    const Cov3 frame_shape = mult_ABAt(R, F.shape[f]);
+    const f3 frame_lab = s.frame_lab[f], model_lab = s.model_lab[m];
+    const float m_conf = M.conf[m], f_conf = F.conf[f];
+    const float ratio = 1.0f / (m_conf + f_conf);
+    M.stamps[2 * m + 1] = s.stamp;
+    const f3 fused_color = labToRgb(ratio * (f_conf * frame_lab + m_conf * model_lab));
+    Cov3 f1, m1, fused_shape, fused_1;
+    f3 fused_position;
+    const float w = ratio * f_conf;
+    bool info = false;
+    if (inverse(frame_shape, f1) && inverse(M.shape[m], m1)) {
+        fused_1 = w * f1 + (1.0f - w) * m1;
+        if (inverse(fused_1, fused_shape)) {
+            fused_position = fused_shape * ((w * f1) * frame_position + ((1.0f - w) * m1) * model_position);
+            info = true;
+        }
+    }
+    if (!info) {
+        fused_shape = ratio * (f_conf * frame_shape + m_conf * M.shape[m]);
+        fused_position = ratio * (f_conf * frame_position + m_conf * model_position);
+    }
+    M.pos[m] = fused_position;
+    M.conf[m] = m_conf + f_conf;
+    M.shape[m] = fused_shape;
+    Mat33 vecs; f3 vals;
+    eigenDecomposition(fused_shape, vecs, vals, 10);
+    M.orient[m] = vecs;
+    M.col[m] = fused_color;
+    s.model_lab[m] = rgbToLab(fused_color);
+    M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
+}
+
+void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
+    const ssf_config& c = s.cfg;
+    const int64_t nmodel_g = (c.nranks > 1 && s.global_n_model >= 0) ? s.global_n_model : s.n_model;
+    const int64_t nvis_g = (c.nranks > 1 && s.global_n_visible >= 0) ? s.global_n_visible : s.n_visible;
+    int n_updated = 0, n_inserted = 0, n_removed = 0;
+    Surfels& M = s.model;
+    if (nmodel_g > 0) {                                                         // supersurfel_fusion.cu:351
+        const Mat33 R = s.pose.R; const f3 t = s.pose.t;
+        if (nvis_g > 0)                                                         // :356, update (:386)
+            for (int f = 0; f < s.S; f++) {
+                if (!matched[f] || best[f] == UINT64_MAX) continue;             // model_id >= 0 (:626)
+                int64_t local = (int64_t)(uint32_t)(best[f] & 0xFFFFFFFFull) - s.id_offset;
+                if (local < 0 || local >= s.n_visible) continue;                // owned by another shard
+                update_one(s, f, (int)local); n_updated++;
+            }
+        // insertSupersurfels, supersurfel_fusion_kernels.cu:348-395 (decision A14)
+        const Mat33 Rt = transpose(R);
+        for (int f = 0; f < s.S; f++) {
+            if (!(s.frame.conf[f] > 0.0f) || matched[f]) continue;
+            if (shard_owner(s, f, s.pose) != c.rank) continue;
+            if (s.n_model >= c.nb_supersurfels_max) continue;
+            const int k = s.n_model++;
+            M.pos[k] = R * s.frame.pos[f] + t;
+            M.conf[k] = s.frame.conf[f];
+            M.col[k] = s.frame.col[f];
+            s.model_lab[k] = s.frame_lab[f];
+            M.stamps[2 * k] = s.stamp; M.stamps[2 * k + 1] = s.stamp;
+            M.dims[2 * k] = s.frame.dims[2 * f]; M.dims[2 * k + 1] = s.frame.dims[2 * f + 1];
+            M.orient[k] = s.frame.orient[f] * Rt;
+            M.shape[k] = mult_ABAt(R, s.frame.shape[f]);
+            n_inserted++;
+        }
+        // filterModel, supersurfel_fusion_kernels.cu:397-467
+        const Mat33 Rview = transpose(R);
+        const f3 tview = neg(Rview * t);
+        std::vector<int> state(s.n_model);
+        int n_vis = 0;
+        for (int i = 0; i < s.n_model; i++) {
+            int st = 0;
+            const int time_diff = s.stamp - M.stamps[2 * i + 1];
+            if ((time_diff > c.delta_t && M.conf[i] < c.conf_thresh && s.stamp > c.delta_t) || M.conf[i] <= 0.0f) {
+                M.conf[i] = -1.0f; st = 2;
+            } else {
+                const f3 p = Rview * M.pos[i] + tview;
+                if (p.z > c.range_min && p.z < c.range_max) {
+                    const float u = c.fx * p.x / p.z + c.cx, v = c.fy * p.y / p.z + c.cy;
+                    if (u >= 0.0f && u < (float)s.W && v >= 0.0f && v < (float)s.H) {
+                        const float z = s.plane_depth[(size_t)((int)floorf(v)) * s.W + (int)floorf(u)];
+                        if (p.z < 0.8f * z) { M.conf[i] = -1.0f; st = 2; }
+                    } else st = 1;
+                } else st = 1;
+            }
+            if (st == 0) n_vis++;
+            if (st == 2) n_removed++;
+            state[i] = st;
+        }
+        // thrust::sort_by_key(states, model) -- stable 3-way partition (supersurfel_fusion.cu:469-472)
+        Surfels tmp; tmp.resize(s.n_model);
+        std::vector<f3> lab_tmp(s.n_model);
+        int w = 0;
+        for (int pass = 0; pass < 3; pass++)
+            for (int i = 0; i < s.n_model; i++)
+                if (state[i] == pass) { tmp.copy_row(w, M, i); lab_tmp[w] = s.model_lab[i]; w++; }
+        for (int i = 0; i < s.n_model; i++) { M.copy_row(i, tmp, i); s.model_lab[i] = lab_tmp[i]; }
+        s.n_model -= n_removed;                                                 // :474
+        s.n_visible = n_vis;
+    } else {
+        // first frame: thrust::copy(frame -> model), supersurfel_fusion.cu:477-483
+        int k = 0;
+        for (int f = 0; f < s.S; f++) {
+            if (shard_owner(s, f, s.pose) != c.rank) continue;
+            if (k >= c.nb_supersurfels_max) break;
+            M.copy_row(k, s.frame, f); s.model_lab[k] = s.frame_lab[f]; k++;
+        }
+        s.n_model = k; s.n_visible = k;
+    }
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        for (int i = 0; i < 3; i++) { out->pose[3 * i] = s.pose.R.r[i].x; out->pose[3 * i + 1] = s.pose.R.r[i].y; out->pose[3 * i + 2] = s.pose.R.r[i].z; }
+        out->pose[9] = s.pose.t.x; out->pose[10] = s.pose.t.y; out->pose[11] = s.pose.t.z;
+        out->icp_valid = s.last_icp_valid; out->icp_iters = s.last_icp_iters;
+        out->n_model = s.n_model; out->n_visible = s.n_visible; out->n_removed = n_removed;
+        out->n_inserted = n_inserted; out->n_updated = n_updated; out->stamp = s.stamp;
+    }
+    s.stamp++;                                                                  // :522
+    s.global_n_model = -1; s.global_n_visible = -1;
+    s.have_frame = false;
+}
+
+// rotMatToQuat matrix_math.cuh:529-618, quatToRotMat :512-527 (the wy = q.w*q.z quirk is kept)
+static void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
+    float s, tr = (m.r[0].x + m.r[1].y) + m.r[2].z;
+    if (tr > 0) {
+        s = sqrtf(tr + 1);
+        q[3] = 0.5f * s; s = 0.5f / s;
+        q[0] = (m.r[2].y - m.r[1].z) * s; q[1] = (m.r[0].z - m.r[2].x) * s; q[2] = (m.r[1].x - m.r[0].y) * s;
+    } else {
+        int i = 0;
+        if (m.r[1].y > m.r[0].x) i = 1;
+        if (m.r[2].z > m.r[0].x || m.r[2].z > m.r[1].y) i = 2;
+        if (i == 0) {
+            s = sqrtf(((1.0f + m.r[0].x) - m.r[1].y) - m.r[2].z);
+            q[0] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r[2].y - m.r[1].z) * s; q[1] = (m.r[0].y + m.r[1].x) * s; q[2] = (m.r[0].z + m.r[2].x) * s;
+        } else if (i == 1) {
+            s = sqrtf(((1.0f + m.r[1].y) - m.r[0].x) - m.r[2].z);
+            q[1] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r[0].z - m.r[2].x) * s; q[0] = (m.r[0].y + m.r[1].x) * s; q[2] = (m.r[1].z + m.r[2].y) * s;
+        } else {
+            s = sqrtf(((1.0f + m.r[2].z) - m.r[0].x) - m.r[1].y);
+            q[2] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r[1].x - m.r[0].y) * s; q[0] = (m.r[0].z + m.r[2].x) * s; q[1] = (m.r[1].z + m.r[2].y) * s;
+        }
+    }
+}
+static Mat33 quat_to_rot(const float* q) {
+    const float x2 = q[0] * q[0], y2 = q[1] * q[1], z2 = q[2] * q[2];
+    const float xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
+    const float wx = q[3] * q[0], wy = q[3] * q[2] /* sic */, wz = q[3] * q[2];
+    Mat33 m;
+    m.r[0] = mk3(1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy));
+    m.r[1] = mk3(2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx));
+    m.r[2] = mk3(2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2));
+    return m;
+}
+
+// applyDeformation, deformation_graph_kernels.cu:27-73
+void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
+                       const float* w4, const int32_t* idx4) {
+    (void)m;
+    for (int i = 0; i < s.n_model; i++) {
+        const f3 pi = s.model.pos[i];
+        f3 po = mk3(0, 0, 0);
+        float bq[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) {
+            const int node = idx4[4 * i + k];
+            const float wk = w4[4 * i + k];
+            const f3 gk = mk3(npos[3 * node], npos[3 * node + 1], npos[3 * node + 2]);
+            Mat33 Rk;
+            for (int r = 0; r < 3; r++) Rk.r[r] = mk3(nrot[9 * node + 3 * r], nrot[9 * node + 3 * r + 1], nrot[9 * node + 3 * r + 2]);
+            const f3 tk = mk3(ntrans[3 * node], ntrans[3 * node + 1], ntrans[3 * node + 2]);
+            float qk[4]; rot_to_quat(Rk, qk);
+            po = po + wk * ((Rk * (pi - gk) + gk) + tk);
+            for (int a = 0; a < 4; a++) bq[a] += wk * qk[a];
+        }
+        const float len = sqrtf(((bq[0] * bq[0] + bq[1] * bq[1]) + bq[2] * bq[2]) + bq[3] * bq[3]);
+        const float inv = 1.0f / len;                                           // operator/=(float4&, float)
+        for (int a = 0; a < 4; a++) bq[a] *= inv;
+        const Mat33 av = quat_to_rot(bq);
+        s.model.orient[i] = s.model.orient[i] * transpose(av);
+        s.model.shape[i] = mult_ABAt(av, s.model.shape[i]);
+        s.model.pos[i] = po;
+    }
+}
+
+}  // namespace orc

@@ -1,0 +1,321 @@
+"""ctypes binding of the C ABI in include/ssf.h.
+
+The same binding drives the product (libssf_hip.so, hand-written HIP for gfx950) and -- in tests
+and in bench.py's cpu_baseline leg only -- the CPU oracle (oracle/_build/libssf_oracle.so), which
+exports the identical ABI.  Names follow the reference's C++ surface
+(core/include/supersurfel_fusion/supersurfel_fusion.hpp:40-143): Fusion.process_frame ==
+SupersurfelFusion::processFrame, get_pose == getPose, get_model == getModel, ...
+"""
+import ctypes as C
+import os
+import numpy as np
+
+ICP_RECORD = 29
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "csrc", "libssf_hip.so")
+
+
+class SsfConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("cell_size", C.c_int), ("lambda_pos", C.c_float), ("lambda_bound", C.c_float),
+        ("lambda_size", C.c_float), ("lambda_disp", C.c_float), ("thresh_disp", C.c_float),
+        ("seg_iter", C.c_int), ("seg_use_ransac", C.c_int), ("nb_samples", C.c_int),
+        ("filter_iter", C.c_int), ("filter_alpha", C.c_float), ("filter_beta", C.c_float),
+        ("filter_threshold", C.c_float), ("range_min", C.c_float), ("range_max", C.c_float),
+        ("delta_t", C.c_int), ("conf_thresh", C.c_float), ("nb_supersurfels_max", C.c_int),
+        ("icp_iter", C.c_int), ("icp_cov_thresh", C.c_double),
+        ("rng_seed", C.c_uint64), ("icp_force_iters", C.c_int), ("device_id", C.c_int),
+        ("stream", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
+        ("shard_tile", C.c_float), ("profile", C.c_int),
+    ]
+
+
+class SsfSurfels(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("colors", C.c_void_p), ("stamps", C.c_void_p),
+                ("orientations", C.c_void_p), ("shapes", C.c_void_p), ("dims", C.c_void_p),
+                ("confidences", C.c_void_p)]
+
+
+class SsfFrameResult(C.Structure):
+    _fields_ = [("pose", C.c_float * 12), ("icp_valid", C.c_int), ("icp_iters", C.c_int),
+                ("n_model", C.c_int), ("n_visible", C.c_int), ("n_removed", C.c_int),
+                ("n_inserted", C.c_int), ("n_updated", C.c_int), ("stamp", C.c_int),
+                ("stage_ms", C.c_float * 3)]
+
+    def as_dict(self):
+        return dict(pose=np.array(self.pose[:], np.float32), icp_valid=self.icp_valid,
+                    icp_iters=self.icp_iters, n_model=self.n_model, n_visible=self.n_visible,
+                    n_removed=self.n_removed, n_inserted=self.n_inserted, n_updated=self.n_updated,
+                    stamp=self.stamp, stage_ms=list(self.stage_ms[:]))
+
+
+# every symbol include/ssf.h declares (tests check that each one is exported)
+ABI_SYMBOLS = [
+    "ssf_abi_version", "ssf_backend_name", "ssf_default_config", "ssf_create", "ssf_destroy",
+    "ssf_last_error", "ssf_process_frame", "ssf_process_frame_device", "ssf_stage_extract",
+    "ssf_debug_set_max_passes", "ssf_stage_set_shard", "ssf_stage_icp_begin",
+    "ssf_stage_icp_accumulate", "ssf_stage_icp_update", "ssf_stage_icp_end", "ssf_stage_match",
+    "ssf_stage_fuse", "ssf_get_pose", "ssf_set_pose", "ssf_get_counts", "ssf_get_model",
+    "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
+    "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
+    "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
+    "ssf_reset_kernel_times",
+]
+
+SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
+                 ("orientations", 9, np.float32), ("shapes", 6, np.float32),
+                 ("dims", 2, np.float32), ("confidences", 1, np.float32))
+
+
+class SsfError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded libssf_*.so."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise SsfError("shared library not found: %s (run __graft_entry__.build())" % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.ssf_backend_name.restype = C.c_char_p
+        L.ssf_last_error.restype = C.c_char_p
+        L.ssf_last_error.argtypes = [C.c_void_p]
+        L.ssf_default_config.argtypes = [C.POINTER(SsfConfig)]
+        L.ssf_create.argtypes = [C.POINTER(SsfConfig), C.POINTER(C.c_void_p)]
+        L.ssf_destroy.argtypes = [C.c_void_p]
+        L.ssf_destroy.restype = None
+        vp = C.c_void_p
+        L.ssf_process_frame.argtypes = [vp, vp, vp, vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_process_frame_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_stage_extract.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.ssf_debug_set_max_passes.argtypes = [vp, C.c_int]
+        L.ssf_stage_set_shard.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64]
+        L.ssf_stage_icp_begin.argtypes = [vp, vp]
+        L.ssf_stage_icp_accumulate.argtypes = [vp, vp]
+        L.ssf_stage_icp_update.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        L.ssf_stage_icp_end.argtypes = [vp, C.POINTER(C.c_int)]
+        L.ssf_stage_match.argtypes = [vp, vp, vp]
+        L.ssf_stage_fuse.argtypes = [vp, vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_get_pose.argtypes = [vp, vp]
+        L.ssf_set_pose.argtypes = [vp, vp]
+        L.ssf_get_counts.argtypes = [vp] + [C.POINTER(C.c_int)] * 4
+        L.ssf_get_model.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SsfSurfels)]
+        L.ssf_get_frame.argtypes = [vp, C.POINTER(SsfSurfels)]
+        L.ssf_set_model.argtypes = [vp, C.POINTER(SsfSurfels), C.c_int, C.c_int, C.c_int]
+        for nm in ("ssf_get_index_map", "ssf_get_boundary_map", "ssf_get_inlier_map",
+                   "ssf_get_plane_depth", "ssf_get_superpixels"):
+            getattr(L, nm).argtypes = [vp, vp]
+        L.ssf_get_model_device.argtypes = [vp, C.POINTER(SsfSurfels), C.POINTER(C.c_int)]
+        L.ssf_export_model_txt.argtypes = [vp, C.c_char_p]
+        L.ssf_apply_deformation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+        L.ssf_get_kernel_times.argtypes = [vp, vp, vp, vp, C.c_int]
+        L.ssf_reset_kernel_times.argtypes = [vp]
+
+    @property
+    def backend(self):
+        return self.lib.ssf_backend_name().decode()
+
+    def default_config(self, **kw):
+        cfg = SsfConfig()
+        self.lib.ssf_default_config(C.byref(cfg))
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise AttributeError("ssf_config has no field %r" % k)
+            setattr(cfg, k, v)
+        return cfg
+
+
+def load_product():
+    """Load the HIP product library.  Fails loudly when it has not been built; there is no
+    CPU fallback.  torch is imported first so that exactly one HIP runtime (the one torch
+    ships, SONAME libamdhip64.so.7) lives in the process."""
+    import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
+    return Library(PRODUCT_LIB)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _alloc_surfels(n):
+    arrs = {name: np.zeros((n, k) if k > 1 else (n,), dt) for name, k, dt in SURFEL_FIELDS}
+    st = SsfSurfels(*[arrs[name].ctypes.data_as(C.c_void_p) for name, _, _ in SURFEL_FIELDS])
+    return arrs, st
+
+
+class Fusion:
+    """Host-side mirror of supersurfel_fusion::SupersurfelFusion for the hot path."""
+
+    def __init__(self, library, cfg):
+        self.L = library
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = library.lib.ssf_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise SsfError("ssf_create failed (%d): %s" % (rc, library.lib.ssf_last_error(None).decode()))
+        self.W, self.H = cfg.width, cfg.height
+        self.S = self.counts()["n_superpixels"]
+
+    def close(self):
+        if self.h:
+            self.L.lib.ssf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise SsfError("%s failed (%d): %s" % (what, rc, self.L.lib.ssf_last_error(self.h).decode()))
+
+    # ---- whole frame -------------------------------------------------------------------------
+    def process_frame(self, rgb, depth, prior_pose=None, dynamic_mask=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        assert rgb.shape == (self.H, self.W, 3) and depth.shape == (self.H, self.W)
+        prior = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float32)
+        mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_process_frame(self.h, _ptr(rgb), _ptr(depth), _ptr(prior), _ptr(mask),
+                                              C.byref(res)), "ssf_process_frame")
+        return res.as_dict()
+
+    def process_frame_device(self, d_rgb_ptr, d_depth_ptr, prior_pose=None):
+        prior = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float32)
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_process_frame_device(self.h, C.c_void_p(d_rgb_ptr), C.c_void_p(d_depth_ptr),
+                                                     _ptr(prior), None, C.byref(res)),
+                 "ssf_process_frame_device")
+        return res
+
+    # ---- stage seams -------------------------------------------------------------------------
+    def stage_extract(self, rgb, depth, dynamic_mask=None, on_device=False):
+        if on_device:
+            rp, dp = C.c_void_p(rgb), C.c_void_p(depth)
+        else:
+            rgb = np.ascontiguousarray(rgb, np.uint8)
+            depth = np.ascontiguousarray(depth, np.float32)
+            rp, dp = _ptr(rgb), _ptr(depth)
+        mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
+        self._ck(self.L.lib.ssf_stage_extract(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_stage_extract")
+
+    def set_max_passes(self, n):
+        self._ck(self.L.lib.ssf_debug_set_max_passes(self.h, n), "ssf_debug_set_max_passes")
+
+    def set_shard(self, id_offset, global_n_model, global_n_visible):
+        self._ck(self.L.lib.ssf_stage_set_shard(self.h, id_offset, global_n_model, global_n_visible), "ssf_stage_set_shard")
+
+    def icp_begin(self, prior_pose=None):
+        prior = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float32)
+        self._ck(self.L.lib.ssf_stage_icp_begin(self.h, _ptr(prior)), "ssf_stage_icp_begin")
+
+    def icp_accumulate(self):
+        sums = np.zeros(ICP_RECORD, np.int64)
+        self._ck(self.L.lib.ssf_stage_icp_accumulate(self.h, _ptr(sums)), "ssf_stage_icp_accumulate")
+        return sums
+
+    def icp_update(self, sums):
+        sums = np.ascontiguousarray(sums, np.int64)
+        again = C.c_int(0)
+        self._ck(self.L.lib.ssf_stage_icp_update(self.h, _ptr(sums), C.byref(again)), "ssf_stage_icp_update")
+        return bool(again.value)
+
+    def icp_end(self):
+        valid = C.c_int(0)
+        self._ck(self.L.lib.ssf_stage_icp_end(self.h, C.byref(valid)), "ssf_stage_icp_end")
+        return bool(valid.value)
+
+    def match(self):
+        best = np.zeros(self.S, np.uint64)
+        matched = np.zeros(self.S, np.uint8)
+        self._ck(self.L.lib.ssf_stage_match(self.h, _ptr(best), _ptr(matched)), "ssf_stage_match")
+        return best, matched
+
+    def fuse(self, best, matched):
+        best = np.ascontiguousarray(best, np.uint64)
+        matched = np.ascontiguousarray(matched, np.uint8)
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_stage_fuse(self.h, _ptr(best), _ptr(matched), C.byref(res)), "ssf_stage_fuse")
+        return res.as_dict()
+
+    # ---- read back ---------------------------------------------------------------------------
+    def get_pose(self):
+        p = np.zeros(12, np.float32)
+        self._ck(self.L.lib.ssf_get_pose(self.h, _ptr(p)), "ssf_get_pose")
+        return p
+
+    def set_pose(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        self._ck(self.L.lib.ssf_set_pose(self.h, _ptr(p)), "ssf_set_pose")
+
+    def counts(self):
+        v = [C.c_int(0) for _ in range(4)]
+        self._ck(self.L.lib.ssf_get_counts(self.h, *[C.byref(x) for x in v]), "ssf_get_counts")
+        return dict(n_model=v[0].value, n_visible=v[1].value, stamp=v[2].value, n_superpixels=v[3].value)
+
+    def get_model(self, first=0, count=None):
+        if count is None:
+            count = self.counts()["n_model"] - first
+        arrs, st = _alloc_surfels(max(count, 0))
+        if count > 0:
+            self._ck(self.L.lib.ssf_get_model(self.h, first, count, C.byref(st)), "ssf_get_model")
+        return arrs
+
+    def get_frame(self):
+        arrs, st = _alloc_surfels(self.S)
+        self._ck(self.L.lib.ssf_get_frame(self.h, C.byref(st)), "ssf_get_frame")
+        return arrs
+
+    def set_model(self, arrs, n_visible, stamp):
+        n = len(arrs["confidences"])
+        keep = [np.ascontiguousarray(arrs[name], dt) for name, _, dt in SURFEL_FIELDS]
+        st = SsfSurfels(*[a.ctypes.data_as(C.c_void_p) for a in keep])
+        self._ck(self.L.lib.ssf_set_model(self.h, C.byref(st), n, n_visible, stamp), "ssf_set_model")
+
+    def _map(self, fn, dtype, shape):
+        out = np.zeros(shape, dtype)
+        self._ck(getattr(self.L.lib, fn)(self.h, _ptr(out)), fn)
+        return out
+
+    def index_map(self):
+        return self._map("ssf_get_index_map", np.int32, (self.H, self.W))
+
+    def boundary_map(self):
+        return self._map("ssf_get_boundary_map", np.int32, (self.H, self.W))
+
+    def inlier_map(self):
+        return self._map("ssf_get_inlier_map", np.uint8, (self.H, self.W))
+
+    def plane_depth(self):
+        return self._map("ssf_get_plane_depth", np.float32, (self.H, self.W))
+
+    def superpixels(self):
+        return self._map("ssf_get_superpixels", np.float32, (self.S, 9))
+
+    def export_model_txt(self, path):
+        self._ck(self.L.lib.ssf_export_model_txt(self.h, path.encode()), "ssf_export_model_txt")
+
+    def apply_deformation(self, node_pos, node_rot, node_trans, weights4, idx4):
+        a = [np.ascontiguousarray(node_pos, np.float32), np.ascontiguousarray(node_rot, np.float32),
+             np.ascontiguousarray(node_trans, np.float32), np.ascontiguousarray(weights4, np.float32),
+             np.ascontiguousarray(idx4, np.int32)]
+        self._ck(self.L.lib.ssf_apply_deformation(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), len(a[0]),
+                                                  _ptr(a[3]), _ptr(a[4])), "ssf_apply_deformation")
+
+    def kernel_times(self, max_k=64):
+        names = (C.c_char_p * max_k)()
+        ms = np.zeros(max_k, np.float64)
+        calls = np.zeros(max_k, np.int64)
+        n = self.L.lib.ssf_get_kernel_times(self.h, C.cast(names, C.c_void_p), _ptr(ms), _ptr(calls), max_k)
+        return {names[i].decode(): (float(ms[i]), int(calls[i])) for i in range(max(n, 0))}
+
+    def reset_kernel_times(self):
+        self.L.lib.ssf_reset_kernel_times(self.h)
