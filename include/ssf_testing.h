@@ -1,0 +1,26 @@
+/*
+ * ssf_testing.h -- test hooks exported by both libssf_hip.so and libssf_oracle.so next to the
+ * ABI of ssf.h.  They expose the dependency-free host solvers that replace the reference's Eigen
+ * calls inside the ICP loop (core/src/dense_registration.cu:367,377-378,384,394) and the pose
+ * re-normalisation (core/src/supersurfel_fusion.cu:324), so that tests can pin them against
+ * tests/golden/eigen_vectors.json (generated from the reference's vendored Eigen 3.3.7) on a box
+ * without a GPU.  Not part of the drop-in surface.
+ */
+#ifndef SSF_TESTING_H
+#define SSF_TESTING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* x = A^-1 b with the diagonally pivoted LDL^T of Eigen::LDLT; A 6x6 row-major symmetric. */
+int ssf_dbg_ldlt_solve6(const double* A36, const double* b6, double* x6);
+/* Ainv = PartialPivLU(A).inverse() */
+int ssf_dbg_lu_inverse6(const double* A36, double* Ainv36);
+/* R <- Quaternion(R).normalized().toRotationMatrix(), double / float */
+int ssf_dbg_renormalise_d(double* R9);
+int ssf_dbg_renormalise_f(float* R9);
+/* tf_iter (4x4 row-major) from the solved 6-vector X = (omega, tau), dense_registration.cu:369-384 */
+int ssf_dbg_gn_increment(const double* X6, double* tf16);
+#ifdef __cplusplus
+}
+#endif
+#endif

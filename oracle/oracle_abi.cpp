@@ -4,6 +4,7 @@
 // (tests, bench cpu_baseline leg) can drive the checker exactly like the HIP product.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -150,7 +151,10 @@ int ssf_set_pose(ssf_handle* h, const float* p) {
 }
 int ssf_get_counts(const ssf_handle* h, int* nm, int* nv, int* st, int* ns) {
     if (!h) return SSF_ERR_INVALID_ARG;
-    if (nm) *nm = h->s.n_model; if (nv) *nv = h->s.n_visible; if (st) *st = h->s.stamp; if (ns) *ns = h->s.S;
+    if (nm) *nm = h->s.n_model;
+    if (nv) *nv = h->s.n_visible;
+    if (st) *st = h->s.stamp;
+    if (ns) *ns = h->s.S;
     return SSF_OK;
 }
 static void copy_out(const Surfels& S, int first, int count, ssf_surfels* o) {
@@ -238,5 +242,31 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
     (void)h; (void)names; (void)ms; (void)calls; (void)max_k; return 0;
 }
 int ssf_reset_kernel_times(ssf_handle* h) { (void)h; return SSF_OK; }
+
+// test hooks of include/ssf_testing.h
+int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); return 0; }
+int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { lu_inverse6(A, Ainv); return 0; }
+int ssf_dbg_renormalise_d(double* R9) { quat_normalize_rot_d(R9); return 0; }
+int ssf_dbg_renormalise_f(float* R9) { quat_normalize_rot_f(R9); return 0; }
+int ssf_dbg_gn_increment(const double* X, double* tf) {
+    double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
+    const double nrm = std::sqrt((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+    const double angle = 0.5 * std::atan(nrm);
+    double Rr[9];
+    if (nrm == 0.0) { for (int i = 0; i < 9; i++) Rr[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    else { for (int i = 0; i < 3; i++) axis[i] /= nrm; angle_axis_to_rot_d(angle, axis, Rr); }
+    const double ca = std::cos(angle);
+    for (int i = 0; i < 3; i++) tran[i] *= ca;
+    double R9[9];
+    for (int i = 0; i < 16; i++) tf[i] = 0.0;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) R9[i * 3 + j] = (Rr[i * 3] * Rr[j] + Rr[i * 3 + 1] * Rr[3 + j]) + Rr[i * 3 + 2] * Rr[6 + j];
+        tf[i * 4 + 3] = (Rr[i * 3] * tran[0] + Rr[i * 3 + 1] * tran[1]) + Rr[i * 3 + 2] * tran[2];
+    }
+    quat_normalize_rot_d(R9);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tf[i * 4 + j] = R9[i * 3 + j];
+    tf[15] = 1.0;
+    return 0;
+}
 
 }  // extern "C"

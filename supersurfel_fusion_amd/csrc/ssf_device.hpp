@@ -1,0 +1,105 @@
+// ssf_device.hpp -- HBM layout of one handle and the kernel launch entry points.
+//
+// Layout (all device-resident, allocated once in ssf_create; P = W*H pixels, S superpixels,
+// N = nb_supersurfels_max):
+//   per-pixel maps   rgba u32[P] | disp f32[P] | label i32[P] x2 (ping-pong per relabelling pass)
+//                    inlier u8[P] | plane_depth f32[P]
+//   superpixel sums  9 x i32[S] (x,y,r,g,b,n,dx,dy,dn) + 6 x i64[S] (dxx,dyy,dxy | dxd,dyd,dd fixed
+//                    point 2^30): exact integers, updated with integer atomics only
+//   superpixel table SpRow[S] (48 B rows, 16 B aligned)
+//   supersurfels     structure of arrays, 3-float rows kept as separate streams so that a kernel
+//                    reads only what it needs (ICP: pos 12 + lab 12 + normal 12 B per surfel):
+//                    pos[3n] col[3n] lab[3n] stamps[2n] r0[3n] r1[3n] r2[3n] shape[6n] dims[2n] conf[n]
+//                    (r0,r1,r2 = rows of the reference's Mat33; r2 is the normal).  The model has
+//                    two such sets (ping-pong for the per-frame stable partition).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssf_math.hpp"
+
+namespace ssf {
+
+struct SurfelSoA {
+    float *pos, *col, *lab;
+    int32_t* stamps;
+    float *r0, *r1, *r2, *shape, *dims, *conf;
+};
+
+struct SpSums {
+    int32_t *sx, *sy, *sr, *sg, *sb, *n, *dx, *dy, *dn;
+    long long *dxx, *dyy, *dxy, *dxd, *dyd, *dd;
+};
+
+// device-side counters shared by the fuse kernels (no host round trip between them)
+struct Counters {
+    int n_model;      // rows in the model (after insert: includes the new rows)
+    int n_visible;
+    int n_inserted;
+    int n_updated;
+    int n_removed;
+    int n_state0, n_state1, n_state2;
+};
+
+struct Cam { float fx, fy, cx, cy; int W, H; };
+struct Rt { M3 R; V3 t; };
+
+struct SegParams {
+    int W, H, cell, gx, gy, S, nb_samples, min_size;
+    float lambda_pos, lambda_bound, lambda_size, lambda_disp, thresh_disp;
+    float filter_alpha, filter_beta, filter_threshold;
+    int filter_iter;
+    uint64_t seed;
+};
+
+struct FrameMaps {
+    uint32_t* rgba; float* disp; int32_t* label[2]; uint8_t* inlier; float* plane_depth;
+    SpSums sums; SpRow* sp; float4* samples; int32_t* sample_score; uint32_t* rng_counter;
+    long long* moments;   // 13 x i64 per superpixel
+    float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
+};
+
+// ---- extract stage (ssf_extract.hip) -----------------------------------------------------------
+void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m);
+void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, bool with_planes);
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int src, int ox, int oy, bool rgbd);
+void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur);
+void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac);
+void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m);
+void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur);
+void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
+                             float zmax, int stamp, const uint8_t* dynamic_mask);
+void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
+
+// ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
+void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                const int32_t* label, const float* plane_depth, Rt T, long long* sums29);
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                  const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
+                  unsigned long long* best, uint8_t* matched, int S);
+void launch_update(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                   int n_visible, const unsigned long long* best, const uint8_t* matched, int S, Counters* cnt);
+void launch_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, const uint8_t* matched,
+                   int S, int capacity, int rank, int nranks, float tile, Counters* cnt);
+void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
+                        int nranks, float tile, Counters* cnt);
+// classify + stable 3-way partition src -> dst; n_upper = host upper bound of cnt->n_model
+void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
+                             const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
+                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt);
+void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);
+void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
+                        const float* ntrans, const float* w4, const int32_t* idx4);
+
+// profiling hook: every launch_* brackets its kernels through these (ssf_host.hip)
+struct KernelTimer;
+KernelTimer* current_timer();
+void set_current_timer(KernelTimer* t);
+void timer_begin(KernelTimer* t, const char* name, hipStream_t st);
+void timer_end(KernelTimer* t, hipStream_t st);
+struct ScopedKernel {
+    KernelTimer* t; hipStream_t st;
+    ScopedKernel(const char* name, hipStream_t s) : t(current_timer()), st(s) { if (t) timer_begin(t, name, st); }
+    ~ScopedKernel() { if (t) timer_end(t, st); }
+};
+
+}  // namespace ssf

@@ -1,0 +1,602 @@
+// ssf_extract.hip -- "extract" stage for gfx950: RGB-D frame -> label map, slanted planes,
+// plane-rendered depth and the S frame supersurfels.
+//
+// What is computed follows the reference (TPS_RGBD::compute/filter/computeDepthImage,
+// core/src/TPS_RGBD.cu:101-525; generateSupersurfels, core/src/supersurfel_fusion.cu:551-593);
+// how is this build's own:
+//   * 64-wide wavefronts; every per-superpixel sum is an exact integer (int32 / int64 / fixed-point
+//     int64), built by wave-level aggregation by label (ballot + shuffle) and ONE integer atomic per
+//     (wave, label, term) -- no float atomics, bit-reproducible for any launch geometry.
+//   * a relabelling pass reads the previous label map through a 34x34 LDS tile (1-pixel halo) and
+//     writes the next map (ping-pong), so the cross-tile race of the reference cannot occur; the
+//     boundary count is derived from the tile, never stored.
+//   * the plane filter runs all its Jacobi sweeps in one single-workgroup launch.
+#include "ssf_device.hpp"
+
+namespace ssf {
+
+#define HIP_CHECK_LAUNCH() (void)hipGetLastError()
+
+// ---- wave64 helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void atomic_add_i64(long long* p, long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
+}
+// Iterate over the distinct labels held by the active lanes of a wave.  `body(l, in_group)` is
+// executed by ALL lanes (uniform control flow) once per distinct label.
+template <typename F>
+__device__ __forceinline__ void for_each_label(int label, bool active, F body) {
+    unsigned long long remaining = __ballot(active);
+    while (remaining) {
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int l = __shfl(label, leader, 64);
+        const bool in_group = active && (label == l);
+        const unsigned long long grp = __ballot(in_group);
+        body(l, in_group);
+        remaining &= ~grp;
+    }
+}
+
+// ---- ingest ------------------------------------------------------------------------------------
+// One workgroup per grid cell: RGB->RGBA, disparity = 1/depth, label = cell id, and the cell's
+// initial sums by an in-block reduction (depth2disp32F_kernel TPS_RGBD_kernels.cu:278-296,
+// initSuperpixelsRGBD_kernel :61-110).
+__global__ __launch_bounds__(256) void k_ingest(SegParams p, const uint8_t* __restrict__ rgb,
+                                                const float* __restrict__ depth, FrameMaps m) {
+    const int cell = blockIdx.x;
+    const int cx0 = (cell % p.gx) * p.cell, cy0 = (cell / p.gx) * p.cell;
+    const int w = min(p.cell, p.W - cx0), h = min(p.cell, p.H - cy0);
+    int sx = 0, sy = 0, sr = 0, sg = 0, sb = 0, n = 0;
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+        const int x = cx0 + i % w, y = cy0 + i / w;
+        const size_t q = (size_t)y * p.W + x;
+        const uint32_t r = rgb[3 * q], g = rgb[3 * q + 1], b = rgb[3 * q + 2];
+        m.rgba[q] = r | (g << 8) | (b << 16) | (255u << 24);
+        m.disp[q] = 1.f / depth[q];
+        m.label[0][q] = cell;
+        m.inlier[q] = 0;
+        sx += x; sy += y; sr += (int)r; sg += (int)g; sb += (int)b; n += 1;
+    }
+    __shared__ int red[4][6];
+    sx = wave_sum_i32(sx); sy = wave_sum_i32(sy); sr = wave_sum_i32(sr);
+    sg = wave_sum_i32(sg); sb = wave_sum_i32(sb); n = wave_sum_i32(n);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 0) { red[wv][0] = sx; red[wv][1] = sy; red[wv][2] = sr; red[wv][3] = sg; red[wv][4] = sb; red[wv][5] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t[6];
+        for (int j = 0; j < 6; j++) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+        SpSums& s = m.sums;
+        s.sx[cell] = t[0]; s.sy[cell] = t[1]; s.sr[cell] = t[2]; s.sg[cell] = t[3]; s.sb[cell] = t[4]; s.n[cell] = t[5];
+        s.dx[cell] = 0; s.dy[cell] = 0; s.dn[cell] = 0;
+        s.dxx[cell] = 0; s.dyy[cell] = 0; s.dxy[cell] = 0; s.dxd[cell] = 0; s.dyd[cell] = 0; s.dd[cell] = 0;
+        SpRow z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        m.sp[cell] = z;
+    }
+}
+
+// means (+ plane) of every superpixel: mergeTPSRGBCoeffs_kernel / mergeTPSRGBDCoeffs_kernel,
+// TPS_RGBD_kernels.cu:224-276
+__global__ void k_merge(SegParams p, FrameMaps m, int with_planes) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.S) return;
+    const SpSums& s = m.sums;
+    SpRow row = m.sp[k];
+    const float n = (float)s.n[k];
+    row.cx = (float)s.sx[k] / n; row.cy = (float)s.sy[k] / n;
+    row.r = (float)s.sr[k] / n; row.g = (float)s.sg[k] / n; row.b = (float)s.sb[k] / n;
+    row.size = n;
+    if (with_planes) {
+        const double inv = 1.0 / SSF_DISP_SCALE;
+        const float dx = (float)s.dx[k], dy = (float)s.dy[k], dn = (float)s.dn[k];
+        const float dxx = (float)s.dxx[k], dyy = (float)s.dyy[k], dxy = (float)s.dxy[k];
+        const float dxd = (float)((double)s.dxd[k] * inv), dyd = (float)((double)s.dyd[k] * inv);
+        const float dd = (float)((double)s.dd[k] * inv);
+        float ta, tb, tc;
+        if (!plane_solve(ta, tb, tc, dxx, dxy, dx, dxd, dxy, dyy, dy, dyd, dx, dy, dn, dd)) {
+            ta = 0.f; tb = 0.f; tc = __uint_as_float(0xFFE00000u);
+        }
+        row.ta = ta; row.tb = tb; row.tc = tc;
+    }
+    m.sp[k] = row;
+}
+
+// ---- relabelling pass --------------------------------------------------------------------------
+#define TILE 32
+#define TW (TILE + 2)
+
+__device__ __forceinline__ void load_label_tile(int* tile, const int32_t* __restrict__ src, int X0, int Y0, int W, int H) {
+    for (int i = threadIdx.x; i < TW * TW; i += blockDim.x) {
+        const int lx = i % TW, ly = i / TW;
+        const int x = X0 - 1 + lx, y = Y0 - 1 + ly;
+        tile[i] = (x >= 0 && x < W && y >= 0 && y < H) ? src[(size_t)y * W + x] : -1;
+    }
+}
+__device__ __forceinline__ int tile_boundary(const int* tile, int lx, int ly) {   // lx,ly in halo coordinates
+    const int own = tile[ly * TW + lx];
+    return (tile[(ly - 1) * TW + lx] != own) + (tile[ly * TW + lx - 1] != own) + (tile[ly * TW + lx + 1] != own) +
+           (tile[(ly + 1) * TW + lx] != own);
+}
+
+// the 9 inlier-only disparity sums of one pixel moved by `sign`
+__device__ __forceinline__ void disp_sums_add(const SpSums& s, int k, int x, int y, float d, int sign) {
+    atomicAdd(&s.dx[k], sign * x); atomicAdd(&s.dy[k], sign * y); atomicAdd(&s.dn[k], sign);
+    atomic_add_i64(&s.dxx[k], (long long)sign * x * x);
+    atomic_add_i64(&s.dyy[k], (long long)sign * y * y);
+    atomic_add_i64(&s.dxy[k], (long long)sign * x * y);
+    atomic_add_i64(&s.dxd[k], sign * fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    atomic_add_i64(&s.dyd[k], sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    atomic_add_i64(&s.dd[k], sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
+}
+
+// One pass (OX,OY) of the boundary relabelling: updateTPSRGB_kernel / updateTPSRGBD_kernel,
+// TPS_RGBD_kernels.cuh:235-651.  256 threads own the 256 pass pixels of a 32x32 tile.
+template <bool RGBD>
+__global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int src_buf, int OX, int OY) {
+    __shared__ int tile[TW * TW];
+    __shared__ int out[TILE * TILE];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const int32_t* __restrict__ src = m.label[src_buf];
+    int32_t* __restrict__ dst = m.label[src_buf ^ 1];
+    load_label_tile(tile, src, X0, Y0, p.W, p.H);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) out[i] = tile[(i / TILE + 1) * TW + (i % TILE) + 1];
+    __syncthreads();
+
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int raw_x = blockIdx.x * 16 + tx;
+    const int lx0 = 2 * tx + ((raw_x + OX) & 1), ly0 = 2 * ty + OY;           // tile-interior coordinates
+    const int x = X0 + lx0, y = Y0 + ly0;
+    if (x < p.W && y < p.H) {
+        const int lx = lx0 + 1, ly = ly0 + 1;                                 // halo coordinates
+        const size_t q = (size_t)y * p.W + x;
+        const int index = tile[ly * TW + lx];
+        int new_index = index;
+        const SpRow own = m.sp[index];
+        const int bounds = tile_boundary(tile, lx, ly);
+        float disp = 0.f, disp_energy = 0.f;
+        unsigned char prev_inlier = 0, inlier = 0xff;
+        if (RGBD) {
+            disp = m.disp[q];
+            prev_inlier = m.inlier[q];
+            const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
+            disp_energy = (dp - disp) * (dp - disp);
+            if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
+        }
+        bool eligible = bounds != 0;
+        if (eligible) {
+            // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
+            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+            bool prev = tile[(ly + oy[0]) * TW + lx + ox[0]] == index;
+            int jump = 0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const bool cur = tile[(ly + oy[k]) * TW + lx + ox[k]] == index;
+                if (prev != cur) { jump++; prev = cur; }
+            }
+            eligible = !(jump > 2);
+        }
+        if (eligible) {
+            const uint32_t px = m.rgba[q];
+            const float cr = (float)(px & 255u), cg = (float)((px >> 8) & 255u), cb = (float)((px >> 16) & 255u);
+            const float posx = (float)x, posy = (float)y;
+            const float size = own.size;
+            const float sc = size / (size - 1.f);
+            const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
+            const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
+            const float dsize = size - (float)p.min_size;
+            float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
+            if (RGBD) best = best + p.lambda_disp * disp_energy;
+            best = best - p.lambda_size * fminf(dsize, 0.f);
+            best = best + p.lambda_bound * (float)bounds;
+            const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
+            int nl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TW + lx + nx[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i_n = nl[k];
+                if (i_n == -1 || i_n == index) continue;
+                const SpRow nb = m.sp[i_n];
+                const float ndx = posx - nb.cx, ndy = posy - nb.cy;
+                const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
+                const float ndsize = (nb.size + 1.f) - (float)p.min_size;
+                float n_de = 0.f; unsigned char n_inlier = 0xff;
+                if (RGBD) {
+                    const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
+                    n_de = (dp - disp) * (dp - disp);
+                    if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+                }
+                const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
+                float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
+                if (RGBD) e = e + p.lambda_disp * n_de;
+                e = e - p.lambda_size * fminf(ndsize, 0.f);
+                e = e + p.lambda_bound * (float)b;
+                if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
+            }
+            if (new_index != index) {
+                out[ly0 * TILE + lx0] = new_index;
+                const SpSums& s = m.sums;
+                const int ir = (int)(px & 255u), ig = (int)((px >> 8) & 255u), ib = (int)((px >> 16) & 255u);
+                atomicAdd(&s.sx[index], -x); atomicAdd(&s.sy[index], -y); atomicAdd(&s.sr[index], -ir);
+                atomicAdd(&s.sg[index], -ig); atomicAdd(&s.sb[index], -ib); atomicAdd(&s.n[index], -1);
+                atomicAdd(&s.sx[new_index], x); atomicAdd(&s.sy[new_index], y); atomicAdd(&s.sr[new_index], ir);
+                atomicAdd(&s.sg[new_index], ig); atomicAdd(&s.sb[new_index], ib); atomicAdd(&s.n[new_index], 1);
+            }
+        }
+        if (RGBD) {
+            if (inlier && (!prev_inlier || index != new_index)) disp_sums_add(m.sums, new_index, x, y, disp, +1);
+            if (prev_inlier && (!inlier || (inlier && index != new_index))) disp_sums_add(m.sums, index, x, y, disp, -1);
+            if (inlier != prev_inlier) m.inlier[q] = inlier;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int xx = X0 + (i % TILE), yy = Y0 + (i / TILE);
+        if (xx < p.W && yy < p.H) dst[(size_t)yy * p.W + xx] = out[i];
+    }
+}
+
+// ---- RANSAC plane initialisation ---------------------------------------------------------------
+__device__ __forceinline__ size_t tex_index(float x, float y, int W, int H) {   // point sampling, clamp
+    const int ix = min(max((int)floorf(x), 0), W - 1), iy = min(max((int)floorf(y), 0), H - 1);
+    return (size_t)iy * W + ix;
+}
+// initSamples_kernel, TPS_RGBD_kernels.cu:324-401: one thread per (superpixel, sample)
+__global__ void k_init_samples(SegParams p, FrameMaps m, int cur) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)(p.S * p.nb_samples)) return;
+    const int index = (int)(idx / (uint32_t)p.nb_samples);
+    const int32_t* __restrict__ label = m.label[cur];
+    uint32_t ctr = m.rng_counter[idx];
+    const float radius = (float)p.cell / 2.f;
+    const float cx = m.sp[index].cx, cy = m.sp[index].cy;
+    float x = cx, y = cy;
+    int i = label[tex_index(x, y, p.W, p.H)];
+    int k = 0;
+    while (i != index && k++ < 10) {
+        const float u1 = rng_unit(rng_draw(p.seed, idx, ctr));
+        x = (float)((double)cx + ((double)radius * 2.) * (double)(u1 - 1.f));
+        const float u2 = rng_unit(rng_draw(p.seed, idx, ctr));
+        y = (float)((double)cy + ((double)radius * 2.) * (double)(u2 - 1.f));
+        i = label[tex_index(x, y, p.W, p.H)];
+    }
+    const float d0 = m.disp[tex_index(x, y, p.W, p.H)];
+    float px[3] = {x, x, x}, py[3] = {y, y, y}, pd[3] = {d0, d0, d0};
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        for (int w = 0; w < 10; w++) {
+            const int dir = (int)(rng_draw(p.seed, idx, ctr) & 3u);
+            const float ddx = (dir == 0) ? -1.f : ((dir == 2) ? 1.f : 0.f);
+            const float ddy = (dir == 1) ? -1.f : ((dir == 3) ? 1.f : 0.f);
+            const float nxp = x + ddx, nyp = y + ddy;
+            i = label[tex_index(x, y, p.W, p.H)];
+            if (i == index && nxp >= 0 && nxp < (float)p.W && nyp >= 0 && nyp < (float)p.H) {
+                x = nxp; y = nyp;
+                const float dd = m.disp[tex_index(x, y, p.W, p.H)];
+                if (isfinite(dd)) { px[j] = x; py[j] = y; pd[j] = dd; }
+            }
+        }
+    float a, b, c;
+    if (!plane_solve(a, b, c, px[0], py[0], 1.f, pd[0], px[1], py[1], 1.f, pd[1], px[2], py[2], 1.f, pd[2])) {
+        a = 0.f; b = 0.f; c = pd[2];
+    }
+    m.samples[idx] = make_float4(a, b, c, 0.f);
+    m.sample_score[idx] = 0;
+    m.rng_counter[idx] = ctr;
+}
+
+// evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores, one atomic per (wave,label,sample)
+__global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, int cur) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < p.W * p.H;
+    const int x = active ? q % p.W : 0, y = active ? q / p.W : 0;
+    const int label = active ? m.label[cur][q] : -1;
+    const float d = active ? m.disp[q] : 0.f;
+    const int ns = p.nb_samples;
+    for_each_label(label, active, [&](int l, bool in_group) {
+        for (int k0 = 0; k0 < ns; k0 += 64) {
+            int mine = 0;
+            for (int k = k0; k < min(ns, k0 + 64); k++) {
+                const float4 th = m.samples[(size_t)l * ns + k];
+                bool pass = false;
+                if (in_group && isfinite(th.z)) {
+                    const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
+                    const float dd = (d - dp) * (d - dp);
+                    pass = dd < p.thresh_disp;
+                }
+                const int cnt = __popcll(__ballot(pass));
+                if (lane_id() == k - k0) mine = cnt;
+            }
+            if (k0 + lane_id() < ns && mine) atomicAdd(&m.sample_score[(size_t)l * ns + k0 + lane_id()], mine);
+        }
+    });
+}
+
+// selectSamples_kernel, TPS_RGBD_kernels.cu:435-467
+__global__ void k_select_samples(SegParams p, FrameMaps m) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.S) return;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < p.nb_samples; k++) {
+        float4 th = m.samples[(size_t)idx * p.nb_samples + k];
+        th.w = (float)m.sample_score[(size_t)idx * p.nb_samples + k];
+        if (th.w > best.w) best = th;
+    }
+    SpRow row = m.sp[idx];
+    row.ta = best.x; row.tb = best.y; row.tc = best.z;
+    m.sp[idx] = row;
+    const SpSums& s = m.sums;
+    s.dx[idx] = 0; s.dy[idx] = 0; s.dn[idx] = 0;
+    s.dxx[idx] = 0; s.dyy[idx] = 0; s.dxy[idx] = 0; s.dxd[idx] = 0; s.dyd[idx] = 0; s.dd[idx] = 0;
+}
+
+// initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190)
+__global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int cur, int ransac) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < p.W * p.H;
+    const int x = active ? q % p.W : 0, y = active ? q / p.W : 0;
+    const int label = active ? m.label[cur][q] : -1;
+    const float d = active ? m.disp[q] : 0.f;
+    bool inl = false;
+    if (active && isfinite(d)) {
+        if (ransac) {
+            const SpRow sp = m.sp[label];
+            const float dp = (sp.ta * (float)x + sp.tb * (float)y) + sp.tc;
+            const float dd = (dp - d) * (dp - d);
+            inl = isfinite(dd) && dd < p.thresh_disp && dp > 0.f;
+        } else inl = true;
+    }
+    if (active) m.inlier[q] = inl ? 0xff : 0;
+    long long t[9];
+    t[0] = x; t[1] = y; t[2] = 1; t[3] = (long long)x * x; t[4] = (long long)y * y; t[5] = (long long)x * y;
+    t[6] = inl ? fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
+    t[7] = inl ? fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
+    t[8] = inl ? fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
+    const SpSums& s = m.sums;
+    for_each_label(label, inl, [&](int l, bool in_group) {
+        long long mine = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const long long v = wave_sum_i64(in_group ? t[j] : 0);
+            if (lane_id() == j) mine = v;
+        }
+        switch (lane_id()) {
+            case 0: atomicAdd(&s.dx[l], (int)mine); break;
+            case 1: atomicAdd(&s.dy[l], (int)mine); break;
+            case 2: atomicAdd(&s.dn[l], (int)mine); break;
+            case 3: atomic_add_i64(&s.dxx[l], mine); break;
+            case 4: atomic_add_i64(&s.dyy[l], mine); break;
+            case 5: atomic_add_i64(&s.dxy[l], mine); break;
+            case 6: atomic_add_i64(&s.dxd[l], mine); break;
+            case 7: atomic_add_i64(&s.dyd[l], mine); break;
+            case 8: atomic_add_i64(&s.dd[l], mine); break;
+            default: break;
+        }
+    });
+}
+
+// ---- plane filter: TPS_RGBD::filter, TPS_RGBD.cu:480-505; kernels TPS_RGBD_kernels.cu:510-614 ----
+// All sweeps in one single-workgroup launch; Jacobi (ping-pong X0/X1), the reference's
+// `x<gridSizeX` bound is kept and its out-of-range read of node S is skipped.
+__global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m) {
+    const int S = p.S;
+    float* X0 = m.filt; float* X1 = X0 + 3 * S; float* Z = X1 + 3 * S; float* px = Z + 3 * S; float* py = px + S;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        const SpRow sp = m.sp[i];
+        const float d0 = (sp.cx * sp.ta + sp.cy * sp.tb) + sp.tc;
+        X0[3 * i] = d0; X0[3 * i + 1] = sp.ta; X0[3 * i + 2] = sp.tb;
+        Z[3 * i] = d0; Z[3 * i + 1] = sp.ta; Z[3 * i + 2] = sp.tb;
+        px[i] = sp.cx; py[i] = sp.cy;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const float alpha = p.filter_alpha, beta = p.filter_beta, thr = p.filter_threshold;
+    float* Xa = X0; float* Xb = X1;
+    for (int it = 0; it < p.filter_iter; it++) {
+        for (int idx = threadIdx.x; idx < S; idx += blockDim.x) {
+            const int x = idx % p.gx, y = idx / p.gx;
+            Sym3 A = sym3(alpha, 0.f, 0.f, alpha, 0.f, alpha);
+            const V3 Xi = v3(Xa[3 * idx], Xa[3 * idx + 1], Xa[3 * idx + 2]);
+            V3 R = scale(alpha, v3(Z[3 * idx], Z[3 * idx + 1], Z[3 * idx + 2]));
+            const int v[4] = {-1, 0, 0, 1}, u[4] = {0, -1, 1, 0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int yy = y + v[j], xx = x + u[j];
+                if (yy >= 0 && yy < p.gy && xx >= 0 && x < p.gx) {
+                    const int nidx = yy * p.gx + xx;
+                    if (nidx >= S) continue;
+                    const V3 Xj = v3(Xa[3 * nidx], Xa[3 * nidx + 1], Xa[3 * nidx + 2]);
+                    const float dx = px[idx] - px[nidx], dy = py[idx] - py[nidx];
+                    const float dz = Xi.x - Xj.x;
+                    if (isfinite(dz) && dz * dz < thr * thr) {
+                        A.xx += beta * 2.f;
+                        A.xy += -beta * dx;
+                        A.xz += -beta * dy;
+                        A.yy += beta * (2.f + dx * dx);
+                        A.yz += beta * (dx * dy);
+                        A.zz += beta * (2.f + dy * dy);
+                        R.x += beta * ((2.f * Xj.x + dx * Xj.y) + dy * Xj.z);
+                        R.y += beta * (-dx * Xj.x + 2.f * Xj.y);
+                        R.z += beta * (-dy * Xj.x + 2.f * Xj.z);
+                    }
+                }
+            }
+            Sym3 A1;
+            V3 Xn = Xi;
+            if (sym_inverse(A, A1)) Xn = sym_mul(A1, R);
+            Xb[3 * idx] = Xn.x; Xb[3 * idx + 1] = Xn.y; Xb[3 * idx + 2] = Xn.z;
+        }
+        __threadfence_block();
+        __syncthreads();
+        float* t = Xa; Xa = Xb; Xb = t;
+    }
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        SpRow sp = m.sp[i];
+        const float X = Xa[3 * i], Y = Xa[3 * i + 1], Zz = Xa[3 * i + 2];
+        sp.ta = Y; sp.tb = Zz;
+        sp.tc = (X - sp.cx * Y) - sp.cy * Zz;
+        m.sp[i] = sp;
+    }
+}
+
+// ---- plane depth + supersurfel moments -----------------------------------------------------------
+// renderDepthImage_kernel (TPS_RGBD_kernels.cu:469-508) fused with computeSupersurfelCoeffs
+// (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
+// boundary test and the 13 moment sums (fixed point 2^24, exact).
+__global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m, int cur) {
+    __shared__ int tile[TW * TW];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    load_label_tile(tile, m.label[cur], X0, Y0, p.W, p.H);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {     // uniform trip count (4)
+        const int lx = i % TILE, ly = i / TILE;
+        const int x = X0 + lx, y = Y0 + ly;
+        const bool inside = x < p.W && y < p.H;
+        int label = -1; bool valid = false;
+        long long t[13];
+#pragma unroll
+        for (int j = 0; j < 13; j++) t[j] = 0;
+        if (inside) {
+            const size_t q = (size_t)y * p.W + x;
+            label = tile[(ly + 1) * TW + lx + 1];
+            const SpRow sp = m.sp[label];
+            const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
+            const float depth = 1.f / disp;
+            m.plane_depth[q] = depth;
+            const int bound = tile_boundary(tile, lx + 1, ly + 1);
+            if (m.inlier[q] && isfinite(depth) && depth > 0.0f && bound == 0) {
+                valid = true;
+                const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
+                const uint32_t px = m.rgba[q];
+                const V3 lab = rgb_to_lab(v3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)));
+                const Sym3 c = sym_outer(pos);
+                const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
+#pragma unroll
+                for (int j = 0; j < 12; j++) t[j] = fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM);
+                t[12] = 1;
+            }
+        }
+        for_each_label(label, valid, [&](int l, bool in_group) {
+            long long mine = 0;
+#pragma unroll
+            for (int j = 0; j < 13; j++) {
+                const long long v = wave_sum_i64(in_group ? t[j] : 0);
+                if (lane_id() == j) mine = v;
+            }
+            if (lane_id() < 13) atomic_add_i64(&m.moments[(size_t)l * 13 + lane_id()], mine);
+        });
+    }
+}
+
+// computeSupersurfels, supersurfel_fusion_kernels.cu:169-224 (+ the MOD mask hook)
+__global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp,
+                                   const uint8_t* __restrict__ dyn_mask) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.S) return;
+    const long long* a = &m.moments[(size_t)k * 13];
+    const double inv = 1.0 / SSF_MOM_SCALE;
+    float sum[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) sum[j] = (float)((double)a[j] * inv);
+    float conf = (float)a[12];
+    V3 pos = v3(sum[0], sum[1], sum[2]), col = v3(sum[3], sum[4], sum[5]);
+    Sym3 shape = sym3(sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
+    M3 vecs = m3(v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0));
+    float d0 = 0.f, d1 = 0.f; int s0 = 0, s1 = 0;
+    const float z = pos.z / conf;
+    if (isfinite(z) && conf > 100.0f && z > zmin && z < zmax) {
+        pos = v3(pos.x / conf, pos.y / conf, z);
+        col = lab_to_rgb(v3(col.x / conf, col.y / conf, col.z / conf));
+        shape = sym_sub(sym_div(shape, conf), sym_outer(pos));
+        V3 vals;
+        principal_frame(shape, vecs, vals);
+        d0 = vals.x; d1 = vals.y; s0 = stamp; s1 = stamp;
+        if (vals.x / vals.y > 50.0f) conf = -1.0f;
+    } else
+        conf = -1.0f;
+    if (dyn_mask && dyn_mask[k]) conf = -1.0f;
+    f.pos[3 * k] = pos.x; f.pos[3 * k + 1] = pos.y; f.pos[3 * k + 2] = pos.z;
+    f.col[3 * k] = col.x; f.col[3 * k + 1] = col.y; f.col[3 * k + 2] = col.z;
+    const V3 lab = rgb_to_lab(col);
+    f.lab[3 * k] = lab.x; f.lab[3 * k + 1] = lab.y; f.lab[3 * k + 2] = lab.z;
+    f.stamps[2 * k] = s0; f.stamps[2 * k + 1] = s1;
+    f.r0[3 * k] = vecs.r0.x; f.r0[3 * k + 1] = vecs.r0.y; f.r0[3 * k + 2] = vecs.r0.z;
+    f.r1[3 * k] = vecs.r1.x; f.r1[3 * k + 1] = vecs.r1.y; f.r1[3 * k + 2] = vecs.r1.z;
+    f.r2[3 * k] = vecs.r2.x; f.r2[3 * k + 1] = vecs.r2.y; f.r2[3 * k + 2] = vecs.r2.z;
+    f.shape[6 * k] = shape.xx; f.shape[6 * k + 1] = shape.xy; f.shape[6 * k + 2] = shape.xz;
+    f.shape[6 * k + 3] = shape.yy; f.shape[6 * k + 4] = shape.yz; f.shape[6 * k + 5] = shape.zz;
+    f.dims[2 * k] = d0; f.dims[2 * k + 1] = d1;
+    f.conf[k] = conf;
+}
+
+__global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t* __restrict__ label, int32_t* __restrict__ out) {
+    __shared__ int tile[TW * TW];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    load_label_tile(tile, label, X0, Y0, p.W, p.H);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        if (x < p.W && y < p.H) out[(size_t)y * p.W + x] = tile_boundary(tile, i % TILE + 1, i / TILE + 1);
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+static inline dim3 tile_grid(const SegParams& p) { return dim3((p.W + TILE - 1) / TILE, (p.H + TILE - 1) / TILE); }
+
+void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m) {
+    ScopedKernel sk("ingest", st);
+    hipLaunchKernelGGL(k_ingest, dim3(p.S), dim3(256), 0, st, p, rgb, depth, m);
+}
+void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, bool with_planes) {
+    ScopedKernel sk(with_planes ? "merge_rgbd" : "merge_rgb", st);
+    hipLaunchKernelGGL(k_merge, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m, with_planes ? 1 : 0);
+}
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int src, int ox, int oy, bool rgbd) {
+    ScopedKernel sk(rgbd ? "update_pass_rgbd" : "update_pass_rgb", st);
+    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, tile_grid(p), dim3(256), 0, st, p, m, src, ox, oy);
+    else hipLaunchKernelGGL(k_update_pass<false>, tile_grid(p), dim3(256), 0, st, p, m, src, ox, oy);
+}
+void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
+    const int P = p.W * p.H;
+    { ScopedKernel sk("init_samples", st);
+      hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, cur); }
+    { ScopedKernel sk("eval_samples", st);
+      hipLaunchKernelGGL(k_eval_samples, dim3((P + 255) / 256), dim3(256), 0, st, p, m, cur); }
+    { ScopedKernel sk("select_samples", st);
+      hipLaunchKernelGGL(k_select_samples, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m); }
+}
+void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac) {
+    ScopedKernel sk("init_disp", st);
+    const int P = p.W * p.H;
+    hipLaunchKernelGGL(k_init_disp, dim3((P + 255) / 256), dim3(256), 0, st, p, m, cur, ransac ? 1 : 0);
+}
+void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m) {
+    ScopedKernel sk("plane_filter", st);
+    hipLaunchKernelGGL(k_plane_filter, dim3(1), dim3(1024), 0, st, p, m);
+}
+void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur) {
+    (void)hipMemsetAsync(m.moments, 0, (size_t)p.S * 13 * sizeof(long long), st);
+    ScopedKernel sk("render_moments", st);
+    hipLaunchKernelGGL(k_render_moments, tile_grid(p), dim3(256), 0, st, p, cam, m, cur);
+}
+void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
+                             float zmax, int stamp, const uint8_t* dynamic_mask) {
+    ScopedKernel sk("finalize_surfels", st);
+    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 127) / 128), dim3(128), 0, st, p, m, frame, zmin, zmax, stamp, dynamic_mask);
+}
+void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out) {
+    hipLaunchKernelGGL(k_boundary_map, tile_grid(p), dim3(256), 0, st, p, label, out);
+}
+
+}  // namespace ssf

@@ -1,0 +1,801 @@
+// ssf_host.hip -- host side of the product library: handle, HBM allocation, the per-frame driver
+// (the C++ counterpart of SupersurfelFusion::processFrame, core/src/supersurfel_fusion.cu:166-530,
+// hot-path parts only), the host Gauss-Newton step of the ICP loop
+// (core/src/dense_registration.cu:324-421) and the C ABI of include/ssf.h.
+//
+// There is NO CPU fallback here: without a gfx950 device ssf_create fails with SSF_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+#include "../../include/ssf.h"
+#include "ssf_device.hpp"
+
+using namespace ssf;
+
+// ---- kernel timer (cfg.profile) -------------------------------------------------------------------
+namespace ssf {
+struct KernelTimer {
+    struct Rec { const char* name; hipEvent_t e0, e1; };
+    std::vector<Rec> open, pool_free;
+    std::vector<Rec> pending;
+    std::map<std::string, std::pair<double, long long>> acc;
+    const char* cur_name = nullptr; hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;
+};
+static thread_local KernelTimer* g_timer = nullptr;
+KernelTimer* current_timer() { return g_timer; }
+void set_current_timer(KernelTimer* t) { g_timer = t; }
+void timer_begin(KernelTimer* t, const char* name, hipStream_t st) {
+    KernelTimer::Rec r;
+    if (!t->pool_free.empty()) { r = t->pool_free.back(); t->pool_free.pop_back(); }
+    else { (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1); }
+    r.name = name;
+    (void)hipEventRecord(r.e0, st);
+    t->open.push_back(r);
+}
+void timer_end(KernelTimer* t, hipStream_t st) {
+    KernelTimer::Rec r = t->open.back(); t->open.pop_back();
+    (void)hipEventRecord(r.e1, st);
+    t->pending.push_back(r);
+}
+static void timer_collect(KernelTimer* t) {     // call after a stream sync
+    for (auto& r : t->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = t->acc[r.name]; a.first += ms; a.second += 1; }
+        t->pool_free.push_back(r);
+    }
+    t->pending.clear();
+}
+}  // namespace ssf
+
+// ---- host solvers: dependency-free counterparts of the reference's Eigen calls ---------------------
+// (LDLT with diagonal pivoting as Eigen::LDLT, partial-pivot LU inverse, Shoemake quaternion
+// re-normalisation, Rodrigues rotation; pinned against the reference's vendored Eigen by
+// tests/test_solvers.py through the ssf_dbg_* exports below.)
+namespace {
+
+void sym6_ldlt_solve(const double* A, const double* b, double* x) {
+    const int n = 6;
+    double L[36]; int piv[6]; double w[6];
+    std::memcpy(L, A, sizeof(L));
+    bool all_zero = false;
+    for (int k = 0; k < n; k++) {
+        int p = k; double pm = std::fabs(L[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (std::fabs(L[i * n + i]) > pm) { pm = std::fabs(L[i * n + i]); p = i; }
+        piv[k] = p;
+        if (p != k) {                       // symmetric row/column exchange on the lower triangle
+            for (int j = 0; j < k; j++) std::swap(L[k * n + j], L[p * n + j]);
+            for (int i = p + 1; i < n; i++) std::swap(L[i * n + k], L[i * n + p]);
+            std::swap(L[k * n + k], L[p * n + p]);
+            for (int i = k + 1; i < p; i++) std::swap(L[i * n + k], L[p * n + i]);
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; j++) w[j] = L[j * n + j] * L[k * n + j];
+            double s = 0.0;
+            for (int j = 0; j < k; j++) s += L[k * n + j] * w[j];
+            L[k * n + k] -= s;
+            for (int i = k + 1; i < n; i++) {
+                double s2 = 0.0;
+                for (int j = 0; j < k; j++) s2 += L[i * n + j] * w[j];
+                L[i * n + k] -= s2;
+            }
+        }
+        const double d = L[k * n + k];
+        const bool ok = std::fabs(d) > 0.0;
+        if (k == 0 && !ok) { for (int j = 0; j < n; j++) piv[j] = j; all_zero = true; break; }
+        if (ok) for (int i = k + 1; i < n; i++) L[i * n + k] /= d;
+    }
+    double y[6];
+    for (int i = 0; i < n; i++) y[i] = b[i];
+    for (int k = 0; k < n; k++) std::swap(y[k], y[piv[k]]);
+    if (!all_zero) for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= L[i * n + j] * y[j];
+    for (int i = 0; i < n; i++) { const double d = L[i * n + i]; y[i] = (std::fabs(d) > DBL_MIN) ? y[i] / d : 0.0; }
+    if (!all_zero) for (int i = n - 1; i >= 0; i--) for (int j = i + 1; j < n; j++) y[i] -= L[j * n + i] * y[j];
+    for (int k = n - 1; k >= 0; k--) std::swap(y[k], y[piv[k]]);
+    for (int i = 0; i < n; i++) x[i] = y[i];
+}
+
+void mat6_inverse_lu(const double* A, double* Ainv) {
+    const int n = 6;
+    double U[36]; int perm[6];
+    std::memcpy(U, A, sizeof(U));
+    for (int i = 0; i < n; i++) perm[i] = i;
+    for (int k = 0; k < n; k++) {
+        int p = k; double pm = std::fabs(U[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (std::fabs(U[i * n + k]) > pm) { pm = std::fabs(U[i * n + k]); p = i; }
+        if (p != k) { for (int j = 0; j < n; j++) std::swap(U[k * n + j], U[p * n + j]); std::swap(perm[k], perm[p]); }
+        for (int i = k + 1; i < n; i++) {
+            U[i * n + k] /= U[k * n + k];
+            for (int j = k + 1; j < n; j++) U[i * n + j] -= U[i * n + k] * U[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; c++) {
+        double y[6];
+        for (int i = 0; i < n; i++) y[i] = (perm[i] == c) ? 1.0 : 0.0;
+        for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) y[i] -= U[i * n + j] * y[j];
+        for (int i = n - 1; i >= 0; i--) { for (int j = i + 1; j < n; j++) y[i] -= U[i * n + j] * y[j]; y[i] /= U[i * n + i]; }
+        for (int i = 0; i < n; i++) Ainv[i * n + c] = y[i];
+    }
+}
+
+template <typename T>
+void renormalise_rotation(T* R) {       // Quaternion(R).normalized().toRotationMatrix()
+    T q[4];
+    T t = (R[0] + R[4]) + R[8];
+    if (t > T(0)) {
+        t = std::sqrt(t + T(1.0)); q[3] = T(0.5) * t; t = T(0.5) / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(((R[i * 4] - R[j * 4]) - R[k * 4]) + T(1.0));
+        q[i] = T(0.5) * t; t = T(0.5) / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+    const T z = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    if (z > T(0)) { const T nrm = std::sqrt(z); for (int a = 0; a < 4; a++) q[a] = q[a] / nrm; }
+    const T tx = T(2) * q[0], ty = T(2) * q[1], tz = T(2) * q[2];
+    const T twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const T txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const T tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = T(1) - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = T(1) - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = T(1) - (txx + tyy);
+}
+
+void rodrigues(double angle, const double* ax, double* R) {     // AngleAxisd::toRotationMatrix
+    const double s = std::sin(angle), c = std::cos(angle);
+    const double sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
+    const double ox = (1.0 - c) * ax[0], oy = (1.0 - c) * ax[1], oz = (1.0 - c) * ax[2];
+    double m;
+    m = ox * ax[1]; R[1] = m - sz; R[3] = m + sz;
+    m = ox * ax[2]; R[2] = m + sy; R[6] = m - sy;
+    m = oy * ax[2]; R[5] = m - sx; R[7] = m + sx;
+    R[0] = ox * ax[0] + c; R[4] = oy * ax[1] + c; R[8] = oz * ax[2] + c;
+}
+
+// one Gauss-Newton increment from the solved 6-vector: tf_iter (4x4, row-major)
+void gn_increment(const double* X, double* tf_iter) {
+    double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
+    const double nrm = std::sqrt((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+    const double angle = 0.5 * std::atan(nrm);
+    double Rr[9];
+    if (nrm == 0.0) { for (int i = 0; i < 9; i++) Rr[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    else { for (int i = 0; i < 3; i++) axis[i] /= nrm; rodrigues(angle, axis, Rr); }
+    const double ca = std::cos(angle);
+    for (int i = 0; i < 3; i++) tran[i] *= ca;
+    for (int i = 0; i < 16; i++) tf_iter[i] = 0.0;
+    double R9[9];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) R9[i * 3 + j] = (Rr[i * 3] * Rr[j] + Rr[i * 3 + 1] * Rr[3 + j]) + Rr[i * 3 + 2] * Rr[6 + j];
+        tf_iter[i * 4 + 3] = (Rr[i * 3] * tran[0] + Rr[i * 3 + 1] * tran[1]) + Rr[i * 3 + 2] * tran[2];
+    }
+    renormalise_rotation<double>(R9);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tf_iter[i * 4 + j] = R9[i * 3 + j];
+    tf_iter[15] = 1.0;
+}
+
+void mat4_lmul(const double* a, double* b) {      // b <- a * b
+    double r[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r[i * 4 + j] = ((a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j]) + a[i * 4 + 2] * b[8 + j]) + a[i * 4 + 3] * b[12 + j];
+    std::memcpy(b, r, sizeof(r));
+}
+
+}  // namespace
+
+// ---- handle -----------------------------------------------------------------------------------------
+struct IcpLoop {
+    bool active = false, valid = true, done = true;
+    int iter = 0;
+    double tf_inc[16], prev_error, JtJ[36];
+    M3 R_init; V3 t_init, t_inc_stale;
+};
+
+struct ssf_handle {
+    ssf_config cfg;
+    int S = 0, gx = 0, gy = 0;
+    std::string err;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    SegParams seg; Cam cam;
+    FrameMaps maps; int cur = 0;
+    SurfelSoA frame, model[2]; int mcur = 0;
+    std::vector<void*> allocs;
+    uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; uint8_t* d_mask = nullptr;
+    long long* d_icp = nullptr; unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
+    uint8_t* d_state = nullptr; uint32_t* d_block_counts = nullptr; Counters* d_cnt = nullptr;
+    int32_t* d_scratch_map = nullptr;
+    // pinned host mirrors
+    long long* h_icp = nullptr; Counters* h_cnt = nullptr;
+    int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
+    Rt pose;
+    IcpLoop icp;
+    long long id_offset = 0, global_n_model = -1, global_n_visible = -1;
+    bool have_frame = false;
+    int last_icp_valid = 0, last_icp_iters = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    KernelTimer timer;
+    std::vector<std::string> timer_names;
+};
+static std::string g_create_err;
+
+#define HCK(call)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return SSF_ERR_DEVICE;                                                                   \
+        }                                                                                            \
+    } while (0)
+
+template <typename T>
+static bool dalloc(ssf_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return true;
+}
+static bool alloc_surfels(ssf_handle* h, SurfelSoA& s, size_t n) {
+    return dalloc(h, &s.pos, 3 * n) && dalloc(h, &s.col, 3 * n) && dalloc(h, &s.lab, 3 * n) && dalloc(h, &s.stamps, 2 * n) &&
+           dalloc(h, &s.r0, 3 * n) && dalloc(h, &s.r1, 3 * n) && dalloc(h, &s.r2, 3 * n) && dalloc(h, &s.shape, 6 * n) &&
+           dalloc(h, &s.dims, 2 * n) && dalloc(h, &s.conf, n);
+}
+static void zero_surfels(ssf_handle* h, SurfelSoA& s, size_t n) {
+    (void)hipMemsetAsync(s.pos, 0, 12 * n, h->stream); (void)hipMemsetAsync(s.col, 0, 12 * n, h->stream);
+    (void)hipMemsetAsync(s.lab, 0, 12 * n, h->stream); (void)hipMemsetAsync(s.stamps, 0, 8 * n, h->stream);
+    (void)hipMemsetAsync(s.r0, 0, 12 * n, h->stream); (void)hipMemsetAsync(s.r1, 0, 12 * n, h->stream);
+    (void)hipMemsetAsync(s.r2, 0, 12 * n, h->stream); (void)hipMemsetAsync(s.shape, 0, 24 * n, h->stream);
+    (void)hipMemsetAsync(s.dims, 0, 8 * n, h->stream); (void)hipMemsetAsync(s.conf, 0, 4 * n, h->stream);
+}
+static Rt pose_from12(const float* p) {
+    Rt r; r.R = m3(v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), v3(p[6], p[7], p[8])); r.t = v3(p[9], p[10], p[11]); return r;
+}
+static void pose_to12(const Rt& r, float* p) {
+    p[0] = r.R.r0.x; p[1] = r.R.r0.y; p[2] = r.R.r0.z; p[3] = r.R.r1.x; p[4] = r.R.r1.y; p[5] = r.R.r1.z;
+    p[6] = r.R.r2.x; p[7] = r.R.r2.y; p[8] = r.R.r2.z; p[9] = r.t.x; p[10] = r.t.y; p[11] = r.t.z;
+}
+struct TimerScope {
+    ssf_handle* h;
+    explicit TimerScope(ssf_handle* hh) : h(hh) { set_current_timer(hh->cfg.profile ? &hh->timer : nullptr); }
+    ~TimerScope() { set_current_timer(nullptr); }
+};
+
+// ---- stages -----------------------------------------------------------------------------------------
+static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    const size_t P = (size_t)h->cfg.width * h->cfg.height;
+    const uint8_t* d_rgb = (const uint8_t*)rgb; const float* d_depth = (const float*)depth;
+    if (!on_device) {
+        HCK(hipMemcpyAsync(h->d_rgb_in, rgb, 3 * P, hipMemcpyHostToDevice, h->stream));
+        HCK(hipMemcpyAsync(h->d_depth_in, depth, 4 * P, hipMemcpyHostToDevice, h->stream));
+        d_rgb = h->d_rgb_in; d_depth = h->d_depth_in;
+    }
+    const uint8_t* d_mask = nullptr;
+    if (mask) { HCK(hipMemcpyAsync(h->d_mask, mask, h->S, hipMemcpyHostToDevice, h->stream)); d_mask = h->d_mask; }
+    const SegParams& p = h->seg;
+    hipStream_t st = h->stream;
+    launch_ingest(st, p, d_rgb, d_depth, h->maps);
+    launch_merge(st, p, h->maps, false);
+    int cur = 0, passes = 0;
+    const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
+    const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
+    for (int k = 0; k < h->cfg.seg_iter / 2; k++)
+        for (int q = 0; q < 4; q++) {
+            if (passes >= limit) break;
+            launch_update_pass(st, p, h->maps, cur, ox[q], oy[q], false); cur ^= 1;
+            launch_merge(st, p, h->maps, false); passes++;
+        }
+    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, cur); launch_init_disp(st, p, h->maps, cur, true); }
+    else launch_init_disp(st, p, h->maps, cur, false);
+    launch_merge(st, p, h->maps, true);
+    for (int k = h->cfg.seg_iter / 2; k < h->cfg.seg_iter; k++)
+        for (int q = 0; q < 4; q++) {
+            if (passes >= limit) break;
+            launch_update_pass(st, p, h->maps, cur, ox[q], oy[q], true); cur ^= 1;
+            launch_merge(st, p, h->maps, true); passes++;
+        }
+    h->cur = cur;
+    launch_plane_filter(st, p, h->maps);
+    launch_render_moments(st, p, h->cam, h->maps, cur);
+    launch_finalize_surfels(st, p, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask);
+    HCK(hipGetLastError());
+    h->have_frame = true;
+    return SSF_OK;
+}
+
+static void icp_begin(ssf_handle* h, const float* prior) {
+    if (prior) h->pose = pose_from12(prior);
+    IcpLoop& I = h->icp;
+    const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
+    I.active = nvis > 0 && h->cfg.icp_iter > 0;
+    I.valid = true; I.done = !I.active; I.iter = 0;
+    I.R_init = m3_transpose(h->pose.R);
+    I.t_init = negate(m3_mulv(I.R_init, h->pose.t));
+    for (int i = 0; i < 16; i++) I.tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 36; i++) I.JtJ[i] = 0.0;
+    I.prev_error = DBL_MAX;
+    I.t_inc_stale = v3(0, 0, 0);
+    h->last_icp_valid = 0; h->last_icp_iters = 0;
+}
+static void inc_to_float(const double* tf, M3& R, V3& t) {
+    R = m3(v3((float)tf[0], (float)tf[1], (float)tf[2]), v3((float)tf[4], (float)tf[5], (float)tf[6]),
+           v3((float)tf[8], (float)tf[9], (float)tf[10]));
+    t = v3((float)tf[3], (float)tf[7], (float)tf[11]);
+}
+// device accumulate; result left in d_icp (and copied to h_icp after a sync when to_host)
+static int icp_accumulate(ssf_handle* h, bool to_host) {
+    IcpLoop& I = h->icp;
+    M3 R_inc; V3 t_inc;
+    inc_to_float(I.tf_inc, R_inc, t_inc);
+    I.t_inc_stale = t_inc;
+    Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp);
+    if (to_host) {
+        HCK(hipMemcpyAsync(h->h_icp, h->d_icp, SSF_ICP_RECORD * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+        HCK(hipStreamSynchronize(h->stream));
+    }
+    return SSF_OK;
+}
+static void icp_update(ssf_handle* h, const int64_t* sums, int* again) {
+    IcpLoop& I = h->icp;
+    *again = 0;
+    if (!I.active || I.done) return;
+    I.iter++; h->last_icp_iters = I.iter;
+    static const int tri[6][6] = {{0, 1, 2, 3, 4, 5}, {1, 6, 7, 8, 9, 10}, {2, 7, 11, 12, 13, 14},
+                                  {3, 8, 12, 15, 16, 17}, {4, 9, 13, 16, 18, 19}, {5, 10, 14, 17, 19, 20}};
+    double Jtr[6];
+    for (int i = 0; i < 6; i++) {
+        for (int j = 0; j < 6; j++) I.JtJ[i * 6 + j] = (double)sums[tri[i][j]] / SSF_ICP_SCALE_JTJ;
+        Jtr[i] = (double)sums[21 + i] / SSF_ICP_SCALE_JTR;
+    }
+    const float r = (float)((double)sums[27] / SSF_ICP_SCALE_R);
+    const float inliers = (float)sums[28];
+    const double error = std::sqrt((double)(r / inliers));
+    if (inliers < 100.0f) { I.valid = false; I.done = true; return; }
+    double X[6], tf_iter[16];
+    sym6_ldlt_solve(I.JtJ, Jtr, X);
+    gn_increment(X, tf_iter);
+    mat4_lmul(tf_iter, I.tf_inc);
+    if (!h->cfg.icp_force_iters && error / I.prev_error > 0.9995) { I.done = true; return; }
+    I.prev_error = error;
+    if (I.iter >= h->cfg.icp_iter) { I.done = true; return; }
+    *again = 1;
+}
+static void icp_end(ssf_handle* h, int* valid) {
+    IcpLoop& I = h->icp;
+    *valid = 0;
+    if (!I.active) return;
+    bool ok = I.valid;
+    double cov[36];
+    mat6_inverse_lu(I.JtJ, cov);
+    for (int i = 0; i < 6; i++) if (cov[i * 6 + i] > h->cfg.icp_cov_thresh) { ok = false; break; }
+    if (ok) {
+        if (len3(I.t_inc_stale) > 0.2f) ok = false;
+        else {
+            M3 R_inc; V3 t_inc;
+            inc_to_float(I.tf_inc, R_inc, t_inc);
+            const M3 R_rel = m3_transpose(R_inc);
+            const V3 t_rel = negate(m3_mulv(R_rel, t_inc));
+            h->pose.t = add(m3_mulv(h->pose.R, t_rel), h->pose.t);
+            h->pose.R = m3_mul(h->pose.R, R_rel);
+            float R9[9] = {h->pose.R.r0.x, h->pose.R.r0.y, h->pose.R.r0.z, h->pose.R.r1.x, h->pose.R.r1.y, h->pose.R.r1.z,
+                           h->pose.R.r2.x, h->pose.R.r2.y, h->pose.R.r2.z};
+            renormalise_rotation<float>(R9);
+            h->pose.R = m3(v3(R9[0], R9[1], R9[2]), v3(R9[3], R9[4], R9[5]), v3(R9[6], R9[7], R9[8]));
+        }
+    }
+    *valid = ok ? 1 : 0;
+    h->last_icp_valid = *valid;
+    I.active = false;
+}
+
+static int do_match(ssf_handle* h) {
+    const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
+    const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
+    const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->frame, h->maps.label[h->cur], h->pose, h->cfg.range_min,
+                 h->cfg.range_max, h->id_offset, h->d_best, h->d_matched, h->S);
+    HCK(hipGetLastError());
+    return SSF_OK;
+}
+
+// update | insert | classify | reorder, all stream-ordered through the device-side counters
+static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
+    const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
+    const long long nvis_g = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
+    Counters c0; std::memset(&c0, 0, sizeof(c0));
+    c0.n_model = h->n_model; c0.n_visible = h->n_visible;
+    *h->h_cnt = c0;
+    HCK(hipMemcpyAsync(h->d_cnt, h->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+    SurfelSoA& M = h->model[h->mcur];
+    if (nmodel_g > 0) {
+        if (nvis_g > 0)
+            launch_update(h->stream, M, h->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->d_best, h->d_matched, h->S, h->d_cnt);
+        launch_insert(h->stream, M, h->frame, h->pose, h->stamp, h->d_matched, h->S, h->cfg.nb_supersurfels_max,
+                      h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
+        const int n_upper = std::min(h->n_model + h->S, h->cfg.nb_supersurfels_max);
+        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], n_upper, h->pose, h->maps.plane_depth, h->stamp,
+                                h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state,
+                                h->d_block_counts, h->d_cnt);
+        h->mcur ^= 1;
+    } else {
+        launch_first_frame(h->stream, M, h->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
+                           h->cfg.shard_tile, h->d_cnt);
+    }
+    HCK(hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HCK(hipStreamSynchronize(h->stream));
+    h->n_model = h->h_cnt->n_model; h->n_visible = h->h_cnt->n_visible;
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        pose_to12(h->pose, out->pose);
+        out->icp_valid = h->last_icp_valid; out->icp_iters = h->last_icp_iters;
+        out->n_model = h->n_model; out->n_visible = h->n_visible; out->n_removed = h->h_cnt->n_removed;
+        out->n_inserted = h->h_cnt->n_inserted; out->n_updated = h->h_cnt->n_updated; out->stamp = h->stamp;
+    }
+    h->stamp++;
+    h->global_n_model = -1; h->global_n_visible = -1;
+    h->have_frame = false;
+    if (h->cfg.profile) timer_collect(&h->timer);
+    return SSF_OK;
+}
+
+static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth, int on_device, const float* prior,
+                              const uint8_t* mask, ssf_frame_result* out) {
+    TimerScope ts(h);
+    HCK(hipEventRecord(h->ev[0], h->stream));
+    int rc = do_extract(h, rgb, depth, on_device, mask);
+    if (rc) return rc;
+    HCK(hipEventRecord(h->ev[1], h->stream));
+    icp_begin(h, prior);
+    int again = h->icp.active ? 1 : 0, valid = 0;
+    while (again) {
+        rc = icp_accumulate(h, true);
+        if (rc) return rc;
+        icp_update(h, (const int64_t*)h->h_icp, &again);
+    }
+    icp_end(h, &valid);
+    HCK(hipEventRecord(h->ev[2], h->stream));
+    rc = do_match(h);
+    if (rc) return rc;
+    ssf_frame_result r;
+    hipEvent_t e3 = h->ev[3];
+    // do_fuse synchronises the stream; record the closing event just before its final copy
+    rc = do_fuse(h, &r);
+    if (rc) return rc;
+    HCK(hipEventRecord(e3, h->stream));
+    HCK(hipEventSynchronize(e3));
+    float ms;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) r.stage_ms[0] = ms;
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) r.stage_ms[1] = ms;
+    if (hipEventElapsedTime(&ms, h->ev[2], e3) == hipSuccess) r.stage_ms[2] = ms;
+    if (out) *out = r;
+    return SSF_OK;
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------
+extern "C" {
+
+int ssf_abi_version(void) { return SSF_ABI_VERSION; }
+const char* ssf_backend_name(void) { return "hip-gfx950"; }
+
+void ssf_default_config(ssf_config* c) {       // default arguments of initialize, supersurfel_fusion.hpp:46-74
+    std::memset(c, 0, sizeof(*c));
+    c->width = 640; c->height = 480; c->fx = 525.f; c->fy = 525.f; c->cx = 319.5f; c->cy = 239.5f;
+    c->cell_size = 16; c->lambda_pos = 50.f; c->lambda_bound = 1000.f; c->lambda_size = 10000.f;
+    c->lambda_disp = 1e6f; c->thresh_disp = 1e-4f; c->seg_iter = 10; c->seg_use_ransac = 1;
+    c->nb_samples = 16; c->filter_iter = 4; c->filter_alpha = 0.1f; c->filter_beta = 1.0f;
+    c->filter_threshold = 0.05f; c->range_min = 0.2f; c->range_max = 5.0f; c->delta_t = 20;
+    c->conf_thresh = 2500.f; c->nb_supersurfels_max = 50000; c->icp_iter = 10; c->icp_cov_thresh = 0.04;
+    c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
+    c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
+}
+
+void ssf_destroy(ssf_handle* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->h_icp) (void)hipHostFree(h->h_icp);
+    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ssf_create(const ssf_config* cfg, ssf_handle** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return SSF_ERR_INVALID_ARG; }
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->cell_size <= 0 || cfg->nb_samples <= 0 || cfg->nb_samples > 64 ||
+        cfg->nb_supersurfels_max <= 0 || cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) {
+        g_create_err = "invalid configuration"; return SSF_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_err = "no HIP device: libssf_hip.so needs a gfx950 GPU (there is no CPU fallback)";
+        return SSF_ERR_NO_DEVICE;
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_create_err = "device_id out of range"; return SSF_ERR_INVALID_ARG; }
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { g_create_err = "hipSetDevice failed"; return SSF_ERR_DEVICE; }
+    ssf_handle* h = new (std::nothrow) ssf_handle();
+    if (!h) return SSF_ERR_DEVICE;
+    h->cfg = *cfg;
+    const int W = cfg->width, H = cfg->height, c = cfg->cell_size;
+    h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
+    if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
+    if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+    else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; } h->own_stream = true; }
+    SegParams& p = h->seg;
+    p.W = W; p.H = H; p.cell = c; p.gx = h->gx; p.gy = h->gy; p.S = h->S; p.nb_samples = cfg->nb_samples;
+    p.min_size = (int)((float)(c * c) / 4.f);                                   // TPS_RGBD.cu:198 (float -> int parameter)
+    p.lambda_pos = cfg->lambda_pos; p.lambda_bound = cfg->lambda_bound; p.lambda_size = cfg->lambda_size;
+    p.lambda_disp = cfg->lambda_disp; p.thresh_disp = cfg->thresh_disp;
+    p.filter_alpha = cfg->filter_alpha; p.filter_beta = cfg->filter_beta; p.filter_threshold = cfg->filter_threshold;
+    p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
+    h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
+    const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
+    FrameMaps& m = h->maps; SpSums& s = m.sums;
+    bool ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.label[1], P) &&
+              dalloc(h, &m.inlier, P) && dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) &&
+              dalloc(h, &m.sample_score, NS) && dalloc(h, &m.rng_counter, NS) && dalloc(h, &m.moments, 13 * S) &&
+              dalloc(h, &m.filt, 11 * S) && dalloc(h, &s.sx, S) && dalloc(h, &s.sy, S) && dalloc(h, &s.sr, S) &&
+              dalloc(h, &s.sg, S) && dalloc(h, &s.sb, S) && dalloc(h, &s.n, S) && dalloc(h, &s.dx, S) && dalloc(h, &s.dy, S) &&
+              dalloc(h, &s.dn, S) && dalloc(h, &s.dxx, S) && dalloc(h, &s.dyy, S) && dalloc(h, &s.dxy, S) &&
+              dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S) && alloc_surfels(h, h->frame, S) &&
+              alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && dalloc(h, &h->d_rgb_in, 3 * P) &&
+              dalloc(h, &h->d_depth_in, P) && dalloc(h, &h->d_mask, S) && dalloc(h, &h->d_icp, SSF_ICP_RECORD) &&
+              dalloc(h, &h->d_best, S) && dalloc(h, &h->d_matched, S) && dalloc(h, &h->d_state, N) &&
+              dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) && dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P);
+    ok = ok && hipHostMalloc((void**)&h->h_icp, SSF_ICP_RECORD * sizeof(long long)) == hipSuccess &&
+         hipHostMalloc((void**)&h->h_cnt, sizeof(Counters)) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    if (!ok) { g_create_err = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()); ssf_destroy(h); return SSF_ERR_DEVICE; }
+    (void)hipMemsetAsync(m.rng_counter, 0, NS * 4, h->stream);
+    (void)hipMemsetAsync(m.sample_score, 0, NS * 4, h->stream);
+    (void)hipMemsetAsync(m.inlier, 0, P, h->stream);
+    (void)hipMemsetAsync(m.plane_depth, 0, P * 4, h->stream);
+    (void)hipMemsetAsync(m.label[0], 0, P * 4, h->stream);
+    (void)hipMemsetAsync(m.label[1], 0, P * 4, h->stream);
+    zero_surfels(h, h->frame, S); zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = "initialisation failed"; ssf_destroy(h); return SSF_ERR_DEVICE; }
+    h->pose.R = m3_identity(); h->pose.t = v3(0, 0, 0);
+    *out = h;
+    return SSF_OK;
+}
+const char* ssf_last_error(const ssf_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, const float* prior, const uint8_t* mask, ssf_frame_result* out) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    return process_frame_impl(h, rgb, depth, 0, prior, mask, out);
+}
+int ssf_process_frame_device(ssf_handle* h, const void* rgb, const void* depth, const float* prior, const uint8_t* mask, ssf_frame_result* out) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    return process_frame_impl(h, rgb, depth, 1, prior, mask, out);
+}
+
+int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    TimerScope ts(h);
+    return do_extract(h, rgb, depth, on_device, mask);
+}
+int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->max_passes = n; return SSF_OK; }
+int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    h->id_offset = off; h->global_n_model = gm; h->global_n_visible = gv; return SSF_OK;
+}
+int ssf_stage_icp_begin(ssf_handle* h, const float* prior) {
+    if (!h || !h->have_frame) return SSF_ERR_STATE;
+    icp_begin(h, prior); return SSF_OK;
+}
+int ssf_stage_icp_accumulate(ssf_handle* h, int64_t* sums) {
+    if (!h || !sums) return SSF_ERR_INVALID_ARG;
+    TimerScope ts(h);
+    int rc = icp_accumulate(h, true);
+    if (rc) return rc;
+    std::memcpy(sums, h->h_icp, SSF_ICP_RECORD * sizeof(int64_t));
+    return SSF_OK;
+}
+int ssf_stage_icp_update(ssf_handle* h, const int64_t* sums, int* again) {
+    if (!h || !sums || !again) return SSF_ERR_INVALID_ARG;
+    icp_update(h, sums, again); return SSF_OK;
+}
+int ssf_stage_icp_end(ssf_handle* h, int* valid) {
+    if (!h || !valid) return SSF_ERR_INVALID_ARG;
+    icp_end(h, valid); return SSF_OK;
+}
+int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched) {
+    if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    int rc = do_match(h);
+    if (rc) return rc;
+    HCK(hipMemcpyAsync(best, h->d_best, (size_t)h->S * 8, hipMemcpyDeviceToHost, h->stream));
+    HCK(hipMemcpyAsync(matched, h->d_matched, (size_t)h->S, hipMemcpyDeviceToHost, h->stream));
+    HCK(hipStreamSynchronize(h->stream));
+    return SSF_OK;
+}
+int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
+    if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    HCK(hipMemcpyAsync(h->d_best, best, (size_t)h->S * 8, hipMemcpyHostToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->d_matched, matched, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+    return do_fuse(h, out);
+}
+
+int ssf_get_pose(const ssf_handle* h, float* p) { if (!h || !p) return SSF_ERR_INVALID_ARG; pose_to12(h->pose, p); return SSF_OK; }
+int ssf_set_pose(ssf_handle* h, const float* p) { if (!h || !p) return SSF_ERR_INVALID_ARG; h->pose = pose_from12(p); return SSF_OK; }
+int ssf_get_counts(const ssf_handle* h, int* nm, int* nv, int* st, int* ns) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (nm) *nm = h->n_model;
+    if (nv) *nv = h->n_visible;
+    if (st) *st = h->stamp;
+    if (ns) *ns = h->S;
+    return SSF_OK;
+}
+
+static int copy_out(ssf_handle* h, const SurfelSoA& s, int first, int count, ssf_surfels* o) {
+    if (count <= 0) return SSF_OK;
+    const size_t n = count, f = first;
+    hipStream_t st = h->stream;
+    if (o->positions) HCK(hipMemcpyAsync(o->positions, s.pos + 3 * f, 12 * n, hipMemcpyDeviceToHost, st));
+    if (o->colors) HCK(hipMemcpyAsync(o->colors, s.col + 3 * f, 12 * n, hipMemcpyDeviceToHost, st));
+    if (o->stamps) HCK(hipMemcpyAsync(o->stamps, s.stamps + 2 * f, 8 * n, hipMemcpyDeviceToHost, st));
+    if (o->shapes) HCK(hipMemcpyAsync(o->shapes, s.shape + 6 * f, 24 * n, hipMemcpyDeviceToHost, st));
+    if (o->dims) HCK(hipMemcpyAsync(o->dims, s.dims + 2 * f, 8 * n, hipMemcpyDeviceToHost, st));
+    if (o->confidences) HCK(hipMemcpyAsync(o->confidences, s.conf + f, 4 * n, hipMemcpyDeviceToHost, st));
+    std::vector<float> rows;
+    if (o->orientations) {
+        rows.resize(9 * n);
+        HCK(hipMemcpyAsync(rows.data(), s.r0 + 3 * f, 12 * n, hipMemcpyDeviceToHost, st));
+        HCK(hipMemcpyAsync(rows.data() + 3 * n, s.r1 + 3 * f, 12 * n, hipMemcpyDeviceToHost, st));
+        HCK(hipMemcpyAsync(rows.data() + 6 * n, s.r2 + 3 * f, 12 * n, hipMemcpyDeviceToHost, st));
+    }
+    HCK(hipStreamSynchronize(st));
+    if (o->orientations)
+        for (size_t i = 0; i < n; i++)
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) o->orientations[9 * i + 3 * r + c] = rows[(size_t)r * 3 * n + 3 * i + c];
+    return SSF_OK;
+}
+int ssf_get_model(ssf_handle* h, int first, int count, ssf_surfels* o) {
+    if (!h || !o || first < 0 || count < 0 || first + count > h->cfg.nb_supersurfels_max) return SSF_ERR_INVALID_ARG;
+    return copy_out(h, h->model[h->mcur], first, count, o);
+}
+int ssf_get_frame(ssf_handle* h, ssf_surfels* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_out(h, h->frame, 0, h->S, o); }
+int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, int stamp) {
+    if (!h || !in || n < 0 || n > h->cfg.nb_supersurfels_max || n_visible < 0 || n_visible > n) return SSF_ERR_INVALID_ARG;
+    if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
+    SurfelSoA& s = h->model[h->mcur];
+    hipStream_t st = h->stream;
+    const size_t N = n;
+    if (n > 0) {
+        std::vector<float> rows(9 * N);
+        for (size_t i = 0; i < N; i++)
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) rows[(size_t)r * 3 * N + 3 * i + c] = in->orientations[9 * i + 3 * r + c];
+        HCK(hipMemcpyAsync(s.pos, in->positions, 12 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.col, in->colors, 12 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.stamps, in->stamps, 8 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.shape, in->shapes, 24 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.dims, in->dims, 8 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.conf, in->confidences, 4 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.r0, rows.data(), 12 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.r1, rows.data() + 3 * N, 12 * N, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(s.r2, rows.data() + 6 * N, 12 * N, hipMemcpyHostToDevice, st));
+        launch_lab_refresh(st, s, n);
+        HCK(hipStreamSynchronize(st));
+    }
+    h->n_model = n; h->n_visible = n_visible; h->stamp = stamp;
+    return SSF_OK;
+}
+static int copy_map(ssf_handle* h, void* dst, const void* src, size_t bytes) {
+    HCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HCK(hipStreamSynchronize(h->stream));
+    return SSF_OK;
+}
+int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.label[h->cur], (size_t)h->cfg.width * h->cfg.height * 4); }
+int ssf_get_boundary_map(ssf_handle* h, int32_t* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    launch_boundary_map(h->stream, h->seg, h->maps.label[h->cur], h->d_scratch_map);
+    return copy_map(h, o, h->d_scratch_map, (size_t)h->cfg.width * h->cfg.height * 4);
+}
+int ssf_get_inlier_map(ssf_handle* h, uint8_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.inlier, (size_t)h->cfg.width * h->cfg.height); }
+int ssf_get_plane_depth(ssf_handle* h, float* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.plane_depth, (size_t)h->cfg.width * h->cfg.height * 4); }
+int ssf_get_superpixels(ssf_handle* h, float* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    std::vector<SpRow> rows(h->S);
+    int rc = copy_map(h, rows.data(), h->maps.sp, (size_t)h->S * sizeof(SpRow));
+    if (rc) return rc;
+    for (int k = 0; k < h->S; k++) {
+        const SpRow& r = rows[k];
+        const float v[9] = {r.cx, r.cy, r.r, r.g, r.b, r.ta, r.tb, r.tc, r.size};
+        std::memcpy(&o[9 * k], v, sizeof(v));
+    }
+    return SSF_OK;
+}
+int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    const SurfelSoA& s = h->model[h->mcur];
+    o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = s.r0; o->shapes = s.shape;
+    o->dims = s.dims; o->confidences = s.conf;     // orientations: r0 stream (r1, r2 follow the SoA layout of DESIGN.md)
+    if (n) *n = h->n_model;
+    return SSF_OK;
+}
+
+// exportModel, supersurfel_fusion.cu:595-633 (std::to_string == "%f"/"%d")
+int ssf_export_model_txt(ssf_handle* h, const char* path) {
+    if (!h || !path) return SSF_ERR_INVALID_ARG;
+    const int n = h->n_model;
+    std::vector<float> pos(3 * (size_t)n), col(3 * (size_t)n), ori(9 * (size_t)n), shp(6 * (size_t)n), dims(2 * (size_t)n), conf(n);
+    std::vector<int32_t> stamps(2 * (size_t)n);
+    ssf_surfels o = {pos.data(), col.data(), stamps.data(), ori.data(), shp.data(), dims.data(), conf.data()};
+    int rc = copy_out(h, h->model[h->mcur], 0, n, &o);
+    if (rc) return rc;
+    FILE* f = std::fopen(path, "w");
+    if (!f) { h->err = "cannot open file"; return SSF_ERR_IO; }
+    for (int i = 0; i < n; i++) {
+        if (!(conf[i] > h->cfg.conf_thresh)) continue;
+        std::fprintf(f, "%d %d %f\n", stamps[2 * i], stamps[2 * i + 1], conf[i]);
+        std::fprintf(f, "%f %f %f\n", pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        std::fprintf(f, "%f %f %f\n", col[3 * i], col[3 * i + 1], col[3 * i + 2]);
+        std::fprintf(f, "%f %f\n", dims[2 * i], dims[2 * i + 1]);
+        const float* q = &ori[9 * (size_t)i];
+        std::fprintf(f, "%f %f %f %f %f %f %f %f %f\n", q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+        const float* c = &shp[6 * (size_t)i];
+        std::fprintf(f, "%f %f %f %f %f %f\n\n", c[0], c[1], c[2], c[3], c[4], c[5]);
+    }
+    std::fclose(f);
+    return SSF_OK;
+}
+
+int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const float* nt, int m, const float* w4, const int32_t* idx4) {
+    if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
+    const size_t n = h->n_model;
+    if (n == 0) return SSF_OK;
+    float *d_np, *d_nr, *d_nt, *d_w; int32_t* d_i;
+    HCK(hipMalloc((void**)&d_np, 12 * (size_t)m)); HCK(hipMalloc((void**)&d_nr, 36 * (size_t)m)); HCK(hipMalloc((void**)&d_nt, 12 * (size_t)m));
+    HCK(hipMalloc((void**)&d_w, 16 * n)); HCK(hipMalloc((void**)&d_i, 16 * n));
+    hipStream_t st = h->stream;
+    HCK(hipMemcpyAsync(d_np, np, 12 * (size_t)m, hipMemcpyHostToDevice, st));
+    HCK(hipMemcpyAsync(d_nr, nr, 36 * (size_t)m, hipMemcpyHostToDevice, st));
+    HCK(hipMemcpyAsync(d_nt, nt, 12 * (size_t)m, hipMemcpyHostToDevice, st));
+    HCK(hipMemcpyAsync(d_w, w4, 16 * n, hipMemcpyHostToDevice, st));
+    HCK(hipMemcpyAsync(d_i, idx4, 16 * n, hipMemcpyHostToDevice, st));
+    { TimerScope ts(h); launch_deformation(st, h->model[h->mcur], (int)n, d_np, d_nr, d_nt, d_w, d_i); }
+    HCK(hipStreamSynchronize(st));
+    if (h->cfg.profile) timer_collect(&h->timer);
+    (void)hipFree(d_np); (void)hipFree(d_nr); (void)hipFree(d_nt); (void)hipFree(d_w); (void)hipFree(d_i);
+    return SSF_OK;
+}
+
+int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k) {
+    if (!h || !names || !ms || !calls) return 0;
+    h->timer_names.clear();
+    for (auto& kv : h->timer.acc) h->timer_names.push_back(kv.first);
+    int k = 0;
+    for (auto& nm : h->timer_names) {
+        if (k >= max_k) break;
+        names[k] = nm.c_str(); ms[k] = h->timer.acc[nm].first; calls[k] = h->timer.acc[nm].second; k++;
+    }
+    return k;
+}
+int ssf_reset_kernel_times(ssf_handle* h) { if (!h) return SSF_ERR_INVALID_ARG; h->timer.acc.clear(); return SSF_OK; }
+
+// ---- test hooks (include/ssf_testing.h): the host solvers, so they can be pinned on a CPU box ----------
+int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { sym6_ldlt_solve(A, b, x); return 0; }
+int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { mat6_inverse_lu(A, Ainv); return 0; }
+int ssf_dbg_renormalise_d(double* R9) { renormalise_rotation<double>(R9); return 0; }
+int ssf_dbg_renormalise_f(float* R9) { renormalise_rotation<float>(R9); return 0; }
+int ssf_dbg_gn_increment(const double* X6, double* tf16) { gn_increment(X6, tf16); return 0; }
+
+}  // extern "C"

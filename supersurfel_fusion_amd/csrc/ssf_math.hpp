@@ -1,0 +1,229 @@
+// ssf_math.hpp -- per-element arithmetic of the supersurfel hot path for gfx950 kernels.
+//
+// Everything here is `SSF_HD` (host + device) and uses only IEEE-754 +,-,*,/,sqrt, comparisons and
+// integer ops, in a fixed written order; the library is built with -ffp-contract=off and
+// -fhip-fp32-correctly-rounded-divide-sqrt, so results are bit-reproducible on host and device.
+// Reference semantics (what is computed) are cited per function, paths relative to
+// /root/reference/core; how it is computed (layout, fusion, exact integer sums) is this build's.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SSF_HD __host__ __device__ __forceinline__
+#else
+#define SSF_HD inline
+#endif
+
+namespace ssf {
+
+struct V3 { float x, y, z; };
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };   // symmetric 3x3 (Cov3, matrix_types.h:26-31)
+struct M3 { V3 r0, r1, r2; };                    // rows (Mat33, matrix_types.h:33-36)
+
+SSF_HD V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+SSF_HD V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SSF_HD V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SSF_HD V3 scale(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+SSF_HD V3 negate(V3 a) { return v3(-a.x, -a.y, -a.z); }
+SSF_HD float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }      // vector_math.cuh:235
+SSF_HD V3 cross3(V3 a, V3 b) {                                                     // vector_math.cuh:117
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+SSF_HD float len3(V3 a) { return sqrtf(dot3(a, a)); }
+// normalize with an exact reciprocal square root (the reference's rsqrtf is approximate on CUDA)
+SSF_HD V3 unit3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return v3(a.x * inv, a.y * inv, a.z * inv); }
+
+SSF_HD Sym3 sym3(float xx, float xy, float xz, float yy, float yz, float zz) {
+    Sym3 c; c.xx = xx; c.xy = xy; c.xz = xz; c.yy = yy; c.yz = yz; c.zz = zz; return c;
+}
+SSF_HD Sym3 sym_add(Sym3 a, Sym3 b) { return sym3(a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz); }
+SSF_HD Sym3 sym_sub(Sym3 a, Sym3 b) { return sym3(a.xx - b.xx, a.xy - b.xy, a.xz - b.xz, a.yy - b.yy, a.yz - b.yz, a.zz - b.zz); }
+SSF_HD Sym3 sym_scale(float s, Sym3 a) { return sym3(s * a.xx, s * a.xy, s * a.xz, s * a.yy, s * a.yz, s * a.zz); }
+SSF_HD Sym3 sym_div(Sym3 a, float s) { return sym3(a.xx / s, a.xy / s, a.xz / s, a.yy / s, a.yz / s, a.zz / s); }
+SSF_HD float sym_trace(Sym3 a) { return (a.xx + a.yy) + a.zz; }
+SSF_HD V3 sym_mul(Sym3 m, V3 b) {                                                  // matrix_math.cuh:164
+    return v3((m.xx * b.x + m.xy * b.y) + m.xz * b.z, (m.xy * b.x + m.yy * b.y) + m.yz * b.z,
+              (m.xz * b.x + m.yz * b.y) + m.zz * b.z);
+}
+SSF_HD Sym3 sym_square(Sym3 a) {                                                   // matrix_math.cuh:184
+    return sym3((a.xx * a.xx + a.xy * a.xy) + a.xz * a.xz, (a.xx * a.xy + a.xy * a.yy) + a.xz * a.yz,
+                (a.xx * a.xz + a.xy * a.yz) + a.xz * a.zz, (a.xy * a.xy + a.yy * a.yy) + a.yz * a.yz,
+                (a.xy * a.xz + a.yy * a.yz) + a.yz * a.zz, (a.xz * a.xz + a.yz * a.yz) + a.zz * a.zz);
+}
+SSF_HD Sym3 sym_outer(V3 v) { return sym3(v.x * v.x, v.x * v.y, v.x * v.z, v.y * v.y, v.y * v.z, v.z * v.z); }
+// closed-form inverse, |det| > 1e-9 compared in double (matrix_math.cuh:41-63)
+SSF_HD bool sym_inverse(Sym3 in, Sym3& out) {
+    out.xx = in.zz * in.yy - in.yz * in.yz;
+    out.xy = in.xz * in.yz - in.zz * in.xy;
+    out.xz = in.xy * in.yz - in.xz * in.yy;
+    out.yy = in.zz * in.xx - in.xz * in.xz;
+    out.yz = in.xy * in.xz - in.xx * in.yz;
+    out.zz = in.xx * in.yy - in.xy * in.xy;
+    float det = (in.xx * out.xx + in.xy * out.xy) + in.xz * out.xz;
+    if (fabs((double)det) > 1e-9) {
+        out.xx /= det; out.xy /= det; out.xz /= det; out.yy /= det; out.yz /= det; out.zz /= det;
+        return true;
+    }
+    return false;
+}
+
+SSF_HD M3 m3(V3 a, V3 b, V3 c) { M3 m; m.r0 = a; m.r1 = b; m.r2 = c; return m; }
+SSF_HD M3 m3_identity() { return m3(v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)); }
+SSF_HD M3 m3_transpose(M3 a) {
+    return m3(v3(a.r0.x, a.r1.x, a.r2.x), v3(a.r0.y, a.r1.y, a.r2.y), v3(a.r0.z, a.r1.z, a.r2.z));
+}
+SSF_HD V3 m3_mulv(M3 a, V3 b) { return v3(dot3(a.r0, b), dot3(a.r1, b), dot3(a.r2, b)); }   // matrix_math.cuh:484
+SSF_HD V3 row_mul(V3 a, M3 b) {                                                     // row vector * matrix
+    return v3((a.x * b.r0.x + a.y * b.r1.x) + a.z * b.r2.x, (a.x * b.r0.y + a.y * b.r1.y) + a.z * b.r2.y,
+              (a.x * b.r0.z + a.y * b.r1.z) + a.z * b.r2.z);
+}
+SSF_HD M3 m3_mul(M3 a, M3 b) { return m3(row_mul(a.r0, b), row_mul(a.r1, b), row_mul(a.r2, b)); }   // :381
+SSF_HD Sym3 rot_sym(M3 A, Sym3 B) {                                                 // mult_ABAt, :442
+    V3 b1 = v3(B.xx, B.xy, B.xz), b2 = v3(B.xy, B.yy, B.yz), b3 = v3(B.xz, B.yz, B.zz);
+    V3 t0 = v3(dot3(b1, A.r0), dot3(b2, A.r0), dot3(b3, A.r0));
+    V3 t1 = v3(dot3(b1, A.r1), dot3(b2, A.r1), dot3(b3, A.r1));
+    V3 t2 = v3(dot3(b1, A.r2), dot3(b2, A.r2), dot3(b3, A.r2));
+    return sym3(dot3(A.r0, t0), dot3(A.r0, t1), dot3(A.r0, t2), dot3(A.r1, t1), dot3(A.r1, t2), dot3(A.r2, t2));
+}
+
+// ---- specified roots: IEEE double ops only (see DESIGN.md "arithmetic spec") -----------------
+SSF_HD double bits_to_f64(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+SSF_HD uint64_t f64_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+SSF_HD double cbrt_spec(double a) {          // a > 0
+    double y = bits_to_f64(f64_to_bits(a) / 3 + 0x2A9F7893782DA1CEull);
+#pragma unroll
+    for (int i = 0; i < 6; i++) y = (2.0 * y + a / (y * y)) / 3.0;
+    return y;
+}
+SSF_HD double root5_spec(double a) {         // a > 0
+    double y = bits_to_f64(f64_to_bits(a) / 5 + 0x3325F8C2A7F1C29Aull);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { double y2 = y * y; y = (4.0 * y + a / (y2 * y2)) / 5.0; }
+    return y;
+}
+SSF_HD float pow24_spec(float x) { double a = (double)x, t = root5_spec(a); return (float)((a * a) * (t * t)); }
+SSF_HD float pow_inv24_spec(float x) {
+    double t = cbrt_spec(sqrt(sqrt((double)x)));
+    double t2 = t * t;
+    return (float)((t2 * t2) * t);
+}
+SSF_HD float cbrtf_spec(float x) { return (float)cbrt_spec((double)x); }
+
+// sRGB(0..255) -> CIE Lab, vector_math.cuh:566-585
+SSF_HD float srgb_expand(float c) { return (c > 0.04045f) ? pow24_spec((c + 0.055f) / 1.055f) : c / 12.92f; }
+SSF_HD float lab_f(float t) { return (t > 0.008856f) ? cbrtf_spec(t) : 7.787f * t + 16.0f / 116.0f; }
+SSF_HD V3 rgb_to_lab(V3 c) {
+    float r = srgb_expand(c.x / 255.0f), g = srgb_expand(c.y / 255.0f), b = srgb_expand(c.z / 255.0f);
+    float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
+    float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
+    float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;
+    x = lab_f(x); y = lab_f(y); z = lab_f(z);
+    return v3(116.0f * y - 16.0f, 500.0f * (x - y), 200.0f * (y - z));
+}
+// CIE Lab -> sRGB(0..255), vector_math.cuh:543-564 (its two double literals promote g and b)
+SSF_HD float lab_finv(float t) { float t3 = (t * t) * t; return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) / 7.787f; }
+SSF_HD float srgb_compress(float c) { return (c > 0.0031308f) ? (1.055f * pow_inv24_spec(c) - 0.055f) : 12.92f * c; }
+SSF_HD V3 lab_to_rgb(V3 c) {
+    float y = (c.x + 16.0f) / 116.0f;
+    float x = c.y / 500.0f + y;
+    float z = y - c.z / 200.0f;
+    x = 0.95047f * lab_finv(x); y = 1.0f * lab_finv(y); z = 1.08883f * lab_finv(z);
+    float r = (x * 3.2406f - y * 1.5372f) - z * 0.4986f;
+    float g = (float)(((double)(-x * 0.9689f) + (double)y * 1.8758) + (double)(z * 0.0415f));
+    float b = (float)((double)(x * 0.0557f - y * 0.2040f) + (double)z * 1.0570);
+    r = srgb_compress(r); g = srgb_compress(g); b = srgb_compress(b);
+    return v3(fmaxf(0.0f, fminf(1.0f, r)) * 255.0f, fmaxf(0.0f, fminf(1.0f, g)) * 255.0f,
+              fmaxf(0.0f, fminf(1.0f, b)) * 255.0f);
+}
+
+// principal frame by repeated squaring, supersurfel_fusion_kernels.cu:48-111
+SSF_HD V3 dominant_column(Sym3 M) {
+    float vmax = fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(M.xx, M.xy), M.xz), M.yy), M.yz), M.zz);
+    if (M.xx == vmax || M.xy == vmax || M.xz == vmax) return unit3(v3(M.xx, M.xy, M.xz));
+    if (M.yy == vmax || M.yz == vmax) return unit3(v3(M.xy, M.yy, M.yz));
+    return unit3(v3(M.xz, M.yz, M.zz));
+}
+SSF_HD float axis_eigenvalue(Sym3 A, V3 v) {
+    float emax = fmaxf(fmaxf(v.x, v.y), v.z);
+    if (v.x == emax) return ((A.xx * v.x + A.xy * v.y) + A.xz * v.z) / v.x;
+    if (v.y == emax) return ((A.xy * v.x + A.yy * v.y) + A.yz * v.z) / v.y;
+    return ((A.xz * v.x + A.yz * v.y) + A.zz * v.z) / v.z;
+}
+SSF_HD void principal_frame(Sym3 A, M3& vecs, V3& vals) {
+    Sym3 P = sym_div(A, sym_trace(A));
+    Sym3 Q = sym3(1.f - P.xx, -P.xy, -P.xz, 1.f - P.yy, -P.yz, 1.f - P.zz);
+    for (int i = 0; i < 10; ++i) {
+        P = sym_square(P); P = sym_div(P, sym_trace(P));
+        Q = sym_square(Q); Q = sym_div(Q, sym_trace(Q));
+    }
+    vecs.r0 = dominant_column(P);
+    vecs.r2 = dominant_column(Q);
+    vecs.r1 = cross3(vecs.r2, vecs.r0);
+    vals = v3(axis_eigenvalue(A, vecs.r0), axis_eigenvalue(A, vecs.r1), axis_eigenvalue(A, vecs.r2));
+}
+
+// 3x3 plane normal equations, TPS_RGBD_kernels.cu:27-59 (its guard only rejects -inf; kept)
+SSF_HD bool plane_solve(float& ta, float& tb, float& tc, float x1, float y1, float z1, float d1,
+                        float x2, float y2, float z2, float d2, float x3, float y3, float z3, float d3) {
+    const float eps = 1e-20f;
+    float denA = (x1 * z2 - x2 * z1) * (y2 * z3 - y3 * z2) - (x2 * z3 - x3 * z2) * (y1 * z2 - y2 * z1);
+    if (!isfinite(denA) && denA < eps) return false;
+    ta = ((z2 * d1 - z1 * d2) * (y2 * z3 - y3 * z2) - (z3 * d2 - z2 * d3) * (y1 * z2 - y2 * z1)) / denA;
+    float denB = y1 * z2 - y2 * z1;
+    if (denB > eps) tb = ((z2 * d1 - z1 * d2) - ta * (x1 * z2 - x2 * z1)) / denB;
+    else { denB = y2 * z3 - y3 * z2; tb = ((z3 * d2 - z2 * d3) - ta * (x2 * z3 - x3 * z2)) / denB; }
+    if (z1 > eps) tc = ((d1 - ta * x1) - tb * y1) / z1;
+    else if (z2 > eps) tc = ((d2 - ta * x2) - tb * y2) / z2;
+    else tc = ((d3 - ta * x3) - tb * y3) / z3;
+    return true;
+}
+
+// round half away from zero for |v| < 2^23, -1 when v cannot be a pixel coordinate
+SSF_HD int pixel_round(float v) {
+    if (!(fabsf(v) < 8388608.0f)) return -1;
+    float t = truncf(v);
+    if (fabsf(v - t) >= 0.5f) t += (v < 0.0f) ? -1.0f : 1.0f;
+    return (int)t;
+}
+
+// exact fixed-point terms (order-independent sums)
+SSF_HD long long fx64(double v, double scale, double lim) {
+    double t = v * scale;
+    if (!(t == t)) return 0;
+    if (t > lim) t = lim;
+    if (t < -lim) t = -lim;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2ll_rn(t);
+#else
+    return llrint(t);
+#endif
+}
+SSF_HD int fx32(float v, float scale) {
+    float t = rintf(v * scale);
+    if (!(t == t)) return 0;
+    if (t >= 2147483520.0f) return 2147483647;
+    if (t <= -2147483648.0f) return (int)0x80000000;
+    return (int)t;
+}
+#define SSF_DISP_SCALE 1073741824.0            /* 2^30 */
+#define SSF_DISP_LIM 4503599627370496.0        /* 2^52 */
+#define SSF_MOM_SCALE 16777216.0               /* 2^24 */
+#define SSF_MOM_LIM 1099511627776.0            /* 2^40 */
+
+// counter-based generator: splitmix64 finaliser over (seed, stream, counter)
+SSF_HD uint32_t rng_draw(uint64_t seed, uint32_t stream, uint32_t& counter) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((((uint64_t)stream) << 32) | (uint64_t)counter);
+    counter++;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+SSF_HD float rng_unit(uint32_t r) { return (float)((r >> 8) + 1u) * 5.9604644775390625e-8f; }   // (0,1]
+
+// superpixel table row: 12 floats, 48 B, 16-byte aligned (three dwordx4 gathers)
+struct __attribute__((aligned(16))) SpRow { float cx, cy, r, g, b, ta, tb, tc, size, pad0, pad1, pad2; };
+
+}  // namespace ssf

@@ -1,0 +1,494 @@
+// ssf_track_fuse.hip -- ICP normal-equation accumulation and the model fuse kernels for gfx950.
+//
+// What is computed follows the reference: computeSymmetricICPSystem
+// (core/include/supersurfel_fusion/dense_registration_kernels.cuh:175-291), findBestMatches /
+// updateSupersurfels / insertSupersurfels / filterModel (core/src/supersurfel_fusion_kernels.cu:
+// 348-467,522-682), thrust::sort_by_key over the model (core/src/supersurfel_fusion.cu:469-472) and
+// applyDeformation (core/src/deformation_graph_kernels.cu:27-73).  How:
+//   * ICP streams 36 B per visible supersurfel (pos, cached Lab, normal row) from separate SoA
+//     streams, accumulates the 29-value record per lane as exact int64 fixed point, reduces across
+//     the 64-lane wave with shuffles and issues 29 integer atomics per wave: bit-identical for any
+//     grid, block or rank decomposition (no float atomics, no 14.8 KB LDS tree).
+//   * association is one packed (dist_bits<<32 | id) 64-bit atomicMin per candidate: exact arg-min,
+//     ties to the lowest id.
+//   * insertion is an ordered block scan (ascending frame id), not atomic arrival order.
+//   * classify + stable 3-way partition replaces the radix sort: one pass computes the state and
+//     per-block histograms, a single-workgroup scan turns them into offsets, one pass scatters all
+//     ten SoA streams (116 B read + 116 B written per supersurfel) into the other model buffer.
+#include "ssf_device.hpp"
+
+namespace ssf {
+
+__device__ __forceinline__ int lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ long long wsum64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ V3 ld3(const float* __restrict__ p, size_t i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ void st3(float* __restrict__ p, size_t i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+__device__ __forceinline__ Sym3 ld6(const float* __restrict__ p, size_t i) {
+    return sym3(p[6 * i], p[6 * i + 1], p[6 * i + 2], p[6 * i + 3], p[6 * i + 4], p[6 * i + 5]);
+}
+__device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
+    p[6 * i] = c.xx; p[6 * i + 1] = c.xy; p[6 * i + 2] = c.xz; p[6 * i + 3] = c.yy; p[6 * i + 4] = c.yz; p[6 * i + 5] = c.zz;
+}
+
+// ---- ICP ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                                             const int32_t* __restrict__ label, const float* __restrict__ plane_depth,
+                                             Rt T, long long* __restrict__ sums) {
+    long long acc[29];
+#pragma unroll
+    for (int i = 0; i < 29; i++) acc[i] = 0;
+    const M3 R = T.R; const V3 t = T.t;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
+        const V3 ps = add(m3_mulv(R, ld3(model.pos, id)), t);
+        const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
+        const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
+        if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) continue;
+        const size_t q = (size_t)v * cam.W + u;
+        const int tid = label[q];
+        const float zt = plane_depth[q];
+        if (!(frame.conf[tid] > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;
+        const float dist_color = len3(sub(ld3(model.lab, id), ld3(frame.lab, tid)));
+        const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
+        const V3 nt = ld3(frame.r2, tid);
+        const V3 ns = unit3(m3_mulv(R, ld3(model.r2, id)));
+        if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) continue;
+        const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
+        const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
+        const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
+        const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++, k++) acc[k] += (long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[21 + i] += (long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f);
+        acc[27] += fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0);
+        acc[28] += 1;
+    }
+    long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < 29; i++) {
+        const long long s = wsum64(acc[i]);
+        if (lane() == i) mine = s;
+    }
+    if (lane() < 29 && mine != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[lane()]), (unsigned long long)mine);
+}
+
+// ---- association ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                                               const int32_t* __restrict__ label, Rt pose, float zmin, float zmax,
+                                               long long id_offset, unsigned long long* __restrict__ best,
+                                               uint8_t* __restrict__ matched) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_visible) return;
+    if (!(model.conf[id] > 0.0f)) return;
+    const M3 R = pose.R; const V3 t = pose.t;
+    const M3 Rt_ = m3_transpose(R);
+    const V3 tview = negate(m3_mulv(Rt_, t));
+    const V3 mp = ld3(model.pos, id);
+    const V3 pv = add(m3_mulv(Rt_, mp), tview);
+    if (!(pv.z > zmin && pv.z < zmax)) return;
+    const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
+    if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return;
+    const int f = label[(size_t)py * cam.W + px];
+    matched[f] = 1;
+    if (!(frame.conf[f] > 0.0f)) return;
+    const V3 fp = add(m3_mulv(R, ld3(frame.pos, f)), t);
+    const V3 fn = unit3(row_mul(ld3(frame.r2, f), Rt_));        // third row of frame_orientation * R^T
+    const V3 mn = unit3(ld3(model.r2, id));
+    const float dist = len3(sub(mp, fp));
+    const float lab_dist = len3(sub(ld3(model.lab, id), ld3(frame.lab, f)));
+    const float delta_norm = fabsf(dot3(mn, fn));
+    if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
+                                       (unsigned long long)(uint32_t)(id_offset + id);
+        atomicMin(&best[f], key);
+    }
+}
+
+// ---- update ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_update(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
+                                                int n_visible, const unsigned long long* __restrict__ best,
+                                                const uint8_t* __restrict__ matched, int S, Counters* cnt) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= S) return;
+    if (!matched[f] || best[f] == 0xFFFFFFFFFFFFFFFFull) return;
+    const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
+    if (local < 0 || local >= n_visible) return;
+    const size_t m = (size_t)local;
+    const M3 R = pose.R; const V3 t = pose.t;
+    const V3 model_position = ld3(M.pos, m);
+    const V3 frame_position = add(m3_mulv(R, ld3(F.pos, f)), t);
+    const Sym3 frame_shape = rot_sym(R, ld6(F.shape, f));
+    const Sym3 model_shape = ld6(M.shape, m);
+    const V3 frame_lab = ld3(F.lab, f), model_lab = ld3(M.lab, m);
+    const float m_conf = M.conf[m], f_conf = F.conf[f];
+    const float ratio = 1.0f / (m_conf + f_conf);
+    const V3 fused_color = lab_to_rgb(scale(ratio, add(scale(f_conf, frame_lab), scale(m_conf, model_lab))));
+    Sym3 f1, m1, fused_shape, fused_1;
+    V3 fused_position;
+    const float w = ratio * f_conf;
+    bool info = false;
+    if (sym_inverse(frame_shape, f1) && sym_inverse(model_shape, m1)) {
+        fused_1 = sym_add(sym_scale(w, f1), sym_scale(1.0f - w, m1));
+        if (sym_inverse(fused_1, fused_shape)) {
+            fused_position = sym_mul(fused_shape, add(sym_mul(sym_scale(w, f1), frame_position),
+                                                      sym_mul(sym_scale(1.0f - w, m1), model_position)));
+            info = true;
+        }
+    }
+    if (!info) {
+        fused_shape = sym_scale(ratio, sym_add(sym_scale(f_conf, frame_shape), sym_scale(m_conf, model_shape)));
+        fused_position = scale(ratio, add(scale(f_conf, frame_position), scale(m_conf, model_position)));
+    }
+    M3 vecs; V3 vals;
+    principal_frame(fused_shape, vecs, vals);
+    st3(M.pos, m, fused_position);
+    M.conf[m] = m_conf + f_conf;
+    st6(M.shape, m, fused_shape);
+    st3(M.r0, m, vecs.r0); st3(M.r1, m, vecs.r1); st3(M.r2, m, vecs.r2);
+    st3(M.col, m, fused_color);
+    st3(M.lab, m, rgb_to_lab(fused_color));
+    M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
+    M.stamps[2 * m + 1] = stamp;
+    atomicAdd(&cnt->n_updated, 1);
+}
+
+// spatial-tile owner of a frame supersurfel (multi-GPU sharding)
+__device__ __forceinline__ int shard_owner(const SurfelSoA& F, int f, const Rt& pose, int nranks, float tile) {
+    if (nranks <= 1) return 0;
+    if (!(F.conf[f] > 0.0f)) return f % nranks;
+    const V3 pw = add(m3_mulv(pose.R, ld3(F.pos, f)), pose.t);
+    const int ix = (int)floorf(pw.x / tile), iy = (int)floorf(pw.y / tile), iz = (int)floorf(pw.z / tile);
+    const uint32_t h = ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u);
+    return (int)(h % (uint32_t)nranks);
+}
+
+// ordered compaction helper: exclusive rank of `flag` among the block's threads (1024 threads)
+__device__ __forceinline__ int block_rank_1024(bool flag, int* wave_tot, int& block_total) {
+    const unsigned long long mask = __ballot(flag);
+    const int wv = threadIdx.x >> 6;
+    const int in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
+    if (lane() == 0) wave_tot[wv] = __popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; w++) { const int c = wave_tot[w]; if (w < wv) before += c; total += c; }
+    __syncthreads();
+    block_total = total;
+    return before + in_wave;
+}
+
+// insertSupersurfels (supersurfel_fusion_kernels.cu:348-395) in ascending frame id
+__global__ __launch_bounds__(1024) void k_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp,
+                                                 const uint8_t* __restrict__ matched, int S, int capacity, int rank,
+                                                 int nranks, float tile, Counters* cnt) {
+    __shared__ int wave_tot[16];
+    const int base = cnt->n_model;
+    __syncthreads();
+    const M3 R = pose.R; const V3 t = pose.t;
+    const M3 Rt_ = m3_transpose(R);
+    int running = 0;
+    for (int c0 = 0; c0 < S; c0 += 1024) {
+        const int f = c0 + threadIdx.x;
+        bool flag = false;
+        if (f < S) flag = (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
+        int total;
+        const int r = block_rank_1024(flag, wave_tot, total);
+        const int k = base + running + r;
+        if (flag && k < capacity) {
+            st3(M.pos, k, add(m3_mulv(R, ld3(F.pos, f)), t));
+            M.conf[k] = F.conf[f];
+            st3(M.col, k, ld3(F.col, f));
+            st3(M.lab, k, ld3(F.lab, f));
+            M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
+            M.dims[2 * k] = F.dims[2 * f]; M.dims[2 * k + 1] = F.dims[2 * f + 1];
+            st3(M.r0, k, row_mul(ld3(F.r0, f), Rt_));
+            st3(M.r1, k, row_mul(ld3(F.r1, f), Rt_));
+            st3(M.r2, k, row_mul(ld3(F.r2, f), Rt_));
+            st6(M.shape, k, rot_sym(R, ld6(F.shape, f)));
+        }
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        const int n_new = min(base + running, capacity);
+        cnt->n_inserted = n_new - base;
+        cnt->n_model = n_new;
+    }
+}
+
+// first frame: thrust::copy(frame -> model), supersurfel_fusion.cu:477-483 (owned rows only)
+__global__ __launch_bounds__(1024) void k_first_frame(SurfelSoA M, SurfelSoA F, Rt pose, int S, int capacity, int rank,
+                                                      int nranks, float tile, Counters* cnt) {
+    __shared__ int wave_tot[16];
+    int running = 0;
+    for (int c0 = 0; c0 < S; c0 += 1024) {
+        const int f = c0 + threadIdx.x;
+        const bool flag = (f < S) && shard_owner(F, f, pose, nranks, tile) == rank;
+        int total;
+        const int r = block_rank_1024(flag, wave_tot, total);
+        const int k = running + r;
+        if (flag && k < capacity) {
+            st3(M.pos, k, ld3(F.pos, f)); st3(M.col, k, ld3(F.col, f)); st3(M.lab, k, ld3(F.lab, f));
+            M.stamps[2 * k] = F.stamps[2 * f]; M.stamps[2 * k + 1] = F.stamps[2 * f + 1];
+            st3(M.r0, k, ld3(F.r0, f)); st3(M.r1, k, ld3(F.r1, f)); st3(M.r2, k, ld3(F.r2, f));
+            st6(M.shape, k, ld6(F.shape, f));
+            M.dims[2 * k] = F.dims[2 * f]; M.dims[2 * k + 1] = F.dims[2 * f + 1];
+            M.conf[k] = F.conf[f];
+        }
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        const int n = min(running, capacity);
+        cnt->n_model = n; cnt->n_visible = n; cnt->n_inserted = 0; cnt->n_removed = 0;
+    }
+}
+
+// ---- classify + stable partition -----------------------------------------------------------------
+// filterModel, supersurfel_fusion_kernels.cu:397-467 -> state byte + per-block 3-bin histogram
+__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA M, Rt pose, const float* __restrict__ plane_depth,
+                                                  int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
+                                                  uint8_t* __restrict__ state, uint32_t* __restrict__ block_counts,
+                                                  const Counters* __restrict__ cnt) {
+    __shared__ int hist[4][3];
+    const int n = cnt->n_model;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int st = 3;   // 3 = beyond the end
+    if (idx < n) {
+        st = 0;
+        const float conf = M.conf[idx];
+        const int time_diff = stamp - M.stamps[2 * idx + 1];
+        if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) {
+            M.conf[idx] = -1.0f; st = 2;
+        } else {
+            const M3 Rv = m3_transpose(pose.R);
+            const V3 tv = negate(m3_mulv(Rv, pose.t));
+            const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
+            if (p.z > zmin && p.z < zmax) {
+                const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
+                if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
+                    const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
+                    if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; st = 2; }
+                } else st = 1;
+            } else st = 1;
+        }
+        state[idx] = (uint8_t)st;
+    }
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int c = __popcll(__ballot(st == s));
+        if (lane() == 0) hist[wv][s] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) block_counts[3 * blockIdx.x + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+}
+
+// exclusive scan of the per-block histograms (single workgroup); totals -> counters
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ block_counts, int nblocks_upper, Counters* cnt) {
+    __shared__ uint32_t wtot[16][3];
+    __shared__ uint32_t run[3];
+    const int n = cnt->n_model;
+    const int nblocks = min(nblocks_upper, (n + 255) / 256);
+    if (threadIdx.x < 3) run[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        uint32_t c[3] = {0, 0, 0};
+        if (b < nblocks) { c[0] = block_counts[3 * b]; c[1] = block_counts[3 * b + 1]; c[2] = block_counts[3 * b + 2]; }
+        uint32_t incl[3];
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            uint32_t v = c[s];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
+            incl[s] = v;
+            if (lane() == 63) wtot[threadIdx.x >> 6][s] = v;
+        }
+        __syncthreads();
+        uint32_t before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+        for (int w = 0; w < 16; w++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) { const uint32_t t = wtot[w][s]; if (w < (int)(threadIdx.x >> 6)) before[s] += t; total[s] += t; }
+        if (b < nblocks)
+#pragma unroll
+            for (int s = 0; s < 3; s++) block_counts[3 * b + s] = run[s] + before[s] + incl[s] - c[s];
+        __syncthreads();
+        if (threadIdx.x < 3) run[threadIdx.x] += total[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt->n_state0 = (int)run[0]; cnt->n_state1 = (int)run[1]; cnt->n_state2 = (int)run[2];
+        cnt->n_visible = (int)run[0]; cnt->n_removed = (int)run[2];
+    }
+}
+
+// scatter every SoA stream of row i to its partitioned slot (stable within each state)
+__global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const uint8_t* __restrict__ state,
+                                                 const uint32_t* __restrict__ block_off, Counters* cnt) {
+    __shared__ int hist[4][3];
+    const int n = cnt->n_model;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int st = (i < n) ? (int)state[i] : 3;
+    const int wv = threadIdx.x >> 6;
+    int in_wave = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const unsigned long long mask = __ballot(st == s);
+        if (st == s) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
+        if (lane() == 0) hist[wv][s] = __popcll(mask);
+    }
+    __syncthreads();
+    if (i < n) {
+        int before = 0;
+        for (int w = 0; w < wv; w++) before += hist[w][st];
+        const int base = (st == 0) ? 0 : ((st == 1) ? cnt->n_state0 : cnt->n_state0 + cnt->n_state1);
+        const size_t j = (size_t)base + block_off[3 * blockIdx.x + st] + before + in_wave;
+        st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
+        B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
+        st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, ld3(A.r2, i));
+        st6(B.shape, j, ld6(A.shape, i));
+        B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
+        B.conf[j] = A.conf[i];
+    }
+}
+__global__ void k_finish_counts(Counters* cnt) {
+    cnt->n_model = cnt->n_model - cnt->n_state2;      // nbSupersurfels -= nbRemoved, supersurfel_fusion.cu:474
+}
+
+__global__ void k_lab_refresh(SurfelSoA s, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st3(s.lab, i, rgb_to_lab(ld3(s.col, i)));
+}
+
+// ---- deformation apply ("next" row) -----------------------------------------------------------------
+// rotMatToQuat matrix_math.cuh:529-618; quatToRotMat :512-527 (its wy = q.w*q.z is reproduced)
+__device__ __forceinline__ void rot_to_quat(M3 m, float* q) {
+    float s; const float tr = (m.r0.x + m.r1.y) + m.r2.z;
+    if (tr > 0) {
+        s = sqrtf(tr + 1); q[3] = 0.5f * s; s = 0.5f / s;
+        q[0] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.z - m.r2.x) * s; q[2] = (m.r1.x - m.r0.y) * s;
+    } else {
+        int i = 0;
+        if (m.r1.y > m.r0.x) i = 1;
+        if (m.r2.z > m.r0.x || m.r2.z > m.r1.y) i = 2;
+        if (i == 0) {
+            s = sqrtf(((1.0f + m.r0.x) - m.r1.y) - m.r2.z); q[0] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.y + m.r1.x) * s; q[2] = (m.r0.z + m.r2.x) * s;
+        } else if (i == 1) {
+            s = sqrtf(((1.0f + m.r1.y) - m.r0.x) - m.r2.z); q[1] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r0.z - m.r2.x) * s; q[0] = (m.r0.y + m.r1.x) * s; q[2] = (m.r1.z + m.r2.y) * s;
+        } else {
+            s = sqrtf(((1.0f + m.r2.z) - m.r0.x) - m.r1.y); q[2] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r1.x - m.r0.y) * s; q[0] = (m.r0.z + m.r2.x) * s; q[1] = (m.r1.z + m.r2.y) * s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const float* __restrict__ npos,
+                                                     const float* __restrict__ nrot, const float* __restrict__ ntrans,
+                                                     const float* __restrict__ w4, const int32_t* __restrict__ idx4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 pi = ld3(M.pos, i);
+    V3 po = v3(0, 0, 0);
+    float bq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int node = idx4[4 * i + k];
+        const float wk = w4[4 * i + k];
+        const V3 gk = ld3(npos, node), tk = ld3(ntrans, node);
+        const M3 Rk = m3(v3(nrot[9 * node], nrot[9 * node + 1], nrot[9 * node + 2]),
+                         v3(nrot[9 * node + 3], nrot[9 * node + 4], nrot[9 * node + 5]),
+                         v3(nrot[9 * node + 6], nrot[9 * node + 7], nrot[9 * node + 8]));
+        float qk[4]; rot_to_quat(Rk, qk);
+        po = add(po, scale(wk, add(add(m3_mulv(Rk, sub(pi, gk)), gk), tk)));
+#pragma unroll
+        for (int a = 0; a < 4; a++) bq[a] += wk * qk[a];
+    }
+    const float len = sqrtf(((bq[0] * bq[0] + bq[1] * bq[1]) + bq[2] * bq[2]) + bq[3] * bq[3]);
+    const float inv = 1.0f / len;
+#pragma unroll
+    for (int a = 0; a < 4; a++) bq[a] *= inv;
+    const float x2 = bq[0] * bq[0], y2 = bq[1] * bq[1], z2 = bq[2] * bq[2];
+    const float xy = bq[0] * bq[1], xz = bq[0] * bq[2], yz = bq[1] * bq[2];
+    const float wx = bq[3] * bq[0], wy = bq[3] * bq[2] /* sic, matrix_math.cuh:521 */, wz = bq[3] * bq[2];
+    const M3 av = m3(v3(1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy)),
+                     v3(2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx)),
+                     v3(2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)));
+    const M3 avT = m3_transpose(av);
+    st3(M.r0, i, row_mul(ld3(M.r0, i), avT));
+    st3(M.r1, i, row_mul(ld3(M.r1, i), avT));
+    st3(M.r2, i, row_mul(ld3(M.r2, i), avT));
+    st6(M.shape, i, rot_sym(av, ld6(M.shape, i)));
+    st3(M.pos, i, po);
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                const int32_t* label, const float* plane_depth, Rt T, long long* sums29) {
+    (void)hipMemsetAsync(sums29, 0, 29 * sizeof(long long), st);
+    if (n_visible <= 0) return;
+    ScopedKernel sk("icp_accumulate", st);
+    const int per_block = 256 * 4;       // 4 supersurfels per lane before the wave reduction
+    int grid = (n_visible + per_block - 1) / per_block;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, frame, label, plane_depth, T, sums29);
+}
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
+                  const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
+                  unsigned long long* best, uint8_t* matched, int S) {
+    (void)hipMemsetAsync(best, 0xFF, (size_t)S * 8, st);
+    (void)hipMemsetAsync(matched, 0, (size_t)S, st);
+    if (n_visible <= 0) return;
+    ScopedKernel sk("match", st);
+    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, frame, label,
+                       pose, zmin, zmax, id_offset, best, matched);
+}
+void launch_update(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                   int n_visible, const unsigned long long* best, const uint8_t* matched, int S, Counters* cnt) {
+    ScopedKernel sk("update", st);
+    hipLaunchKernelGGL(k_update, dim3((S + 127) / 128), dim3(128), 0, st, model, frame, pose, stamp, id_offset,
+                       n_visible, best, matched, S, cnt);
+}
+void launch_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, const uint8_t* matched,
+                   int S, int capacity, int rank, int nranks, float tile, Counters* cnt) {
+    ScopedKernel sk("insert", st);
+    hipLaunchKernelGGL(k_insert, dim3(1), dim3(1024), 0, st, model, frame, pose, stamp, matched, S, capacity, rank,
+                       nranks, tile, cnt);
+}
+void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
+                        int nranks, float tile, Counters* cnt) {
+    ScopedKernel sk("first_frame", st);
+    hipLaunchKernelGGL(k_first_frame, dim3(1), dim3(1024), 0, st, model, frame, pose, S, capacity, rank, nranks, tile, cnt);
+}
+void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
+                             const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
+                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt) {
+    const int nblocks = (n_upper + 255) / 256;
+    if (nblocks > 0) {
+        { ScopedKernel sk("classify", st);
+          hipLaunchKernelGGL(k_classify, dim3(nblocks), dim3(256), 0, st, cam, src, pose, plane_depth, stamp, delta_t,
+                             conf_thresh, zmin, zmax, state, block_counts, cnt); }
+        { ScopedKernel sk("scan_blocks", st);
+          hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nblocks, cnt); }
+        { ScopedKernel sk("reorder_scatter", st);
+          hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
+    }
+    hipLaunchKernelGGL(k_finish_counts, dim3(1), dim3(1), 0, st, cnt);
+}
+void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_lab_refresh, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
+}
+void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
+                        const float* ntrans, const float* w4, const int32_t* idx4) {
+    if (n <= 0) return;
+    ScopedKernel sk("apply_deformation", st);
+    hipLaunchKernelGGL(k_deformation, dim3((n + 255) / 256), dim3(256), 0, st, model, n, npos, nrot, ntrans, w4, idx4);
+}
+
+}  // namespace ssf
