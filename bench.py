@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of the supersurfel hot path (extract | ICP | fuse) on MI355X.
+
+Workload = the configuration BASELINE.json's metric is quoted on: a 640x480 synthetic RGB-D orbit
+against a map of ~1 M live supersurfels (seeded on the scene's surfaces, seed 1234), reference
+rgbd_benchmark parameters with sparse VO / MOD / loop closure off, ICP with
+the reference's own early stop (icp_iter = 10).  A "step" is one frame.  Frames are rendered before
+the timed region and are resident in HBM when it starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: launched by torch.distributed.run, one rank per GPU; the map is sharded by world-space
+  tile, the frame is replicated, ICP / association are exchanged over RCCL ("strong" scaling:
+  the total map size is fixed).
+
+Prints ONE JSON line (rank 0) with the contract keys plus "roofline" (dominant kernel, measured
+live with hipEvents on the library's stream) and "cpu_baseline" (the CPU oracle = a single-threaded
+port of the reference algorithm, timed on this box's host cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from supersurfel_fusion_amd import binding, sharded, synthetic  # noqa: E402
+
+W, H = 640, 480
+N_MODEL = 1000000
+PARAMS = dict(lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, thresh_disp=1e-4,
+              seg_iter=10, filter_iter=3, delta_t=20, conf_thresh=2560.0, icp_iter=10, icp_cov_thresh=0.05)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+# algorithmic bytes per unit of each kernel (DESIGN.md "Kernels")
+P = W * H
+ALGO_BYTES = {
+    "reorder_scatter": lambda c: 212.0 * c["n_model"],           # state 4 + row 104 read + row 104 written
+    "classify": lambda c: 28.0 * c["n_model"],                   # pos 12 + stamps 8 + conf 4 read, state 4 written
+    "icp_accumulate": lambda c: 36.0 * c["n_visible"] + 8.0 * P + 28.0 * c["S"],
+    "match": lambda c: 40.0 * c["n_visible"],
+    "update_pass_rgb": lambda c: 9.0 * P,
+    "update_pass_rgbd": lambda c: 14.0 * P,
+    "ingest": lambda c: 23.0 * P,
+    "init_disp": lambda c: 9.0 * P,
+    "eval_samples": lambda c: 8.0 * P,
+    "render_moments": lambda c: 25.0 * P,
+}
+
+
+def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False):
+    K = synthetic.intrinsics(W, H)
+    kw = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=cap,
+              rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0)
+    kw.update(PARAMS)
+    if stream is not None:
+        kw["stream"] = stream
+    return lib.default_config(**kw)
+
+
+def render_frames(n):
+    frames = []
+    for k in range(n):
+        R, t = synthetic.orbit_pose(k)
+        rgb, depth, _ = synthetic.render(R, t, W, H, noise=True, rng=np.random.default_rng(1000 + k))
+        frames.append((rgb, depth))
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded cpu_baseline sample (0 = skip)")
+    ap.add_argument("--profile-frames", type=int, default=8)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+
+    lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
+    K, Wm = a.steps, a.warmup
+    nf = K + Wm + a.profile_frames
+    frames = render_frames(nf)
+    d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
+
+    model, nvis = synthetic.seed_model_cam0(N_MODEL, W, H, stamp=30)
+    if world > 1:
+        own = synthetic.tile_owner(model["positions"], world, 0.5) == rank
+        vis = np.arange(N_MODEL) < nvis
+        nvis_local = int((own & vis).sum())
+        model_local = {k: v[own] for k, v in model.items()}
+    else:
+        model_local, nvis_local = model, nvis
+    n_local = len(model_local["confidences"])
+    cap = n_local + 65536
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp))
+    f.set_model(model_local, nvis_local, 30)
+    drv = sharded.ShardedFusion(f, device=dev) if world > 1 else None
+
+    def step(i):
+        if drv is not None:
+            return drv.process_frame(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), on_device=True)
+        return f.process_frame_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr()).as_dict()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(Wm):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    stage = np.zeros(3)
+    iters = []
+    last = None
+    for i in range(Wm, Wm + K):
+        last = step(i)
+        stage += np.array(last["stage_ms"])
+        iters.append(last["icp_iters"])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: per-kernel hipEvent times on the library's stream ----
+    f.set_profile(True); f.reset_kernel_times()
+    cnt_before = f.counts()
+    for i in range(Wm + K, Wm + K + a.profile_frames):
+        step(i)
+    torch.cuda.synchronize(dev)
+    kt = f.kernel_times()
+    f.set_profile(False)
+    counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S)
+    per_kernel = {}
+    for name, (ms, calls) in kt.items():
+        avg_us = 1000.0 * ms / max(calls, 1)
+        ent = dict(total_ms_per_frame=ms / a.profile_frames, launches_per_frame=calls / a.profile_frames, avg_us=avg_us)
+        if name in ALGO_BYTES:
+            by = ALGO_BYTES[name](counts)
+            ent["algo_bytes_per_launch"] = by
+            ent["achieved_GBs"] = by / (avg_us * 1e-6) / 1e9
+        per_kernel[name] = ent
+    dom = max(per_kernel, key=lambda n: per_kernel[n]["total_ms_per_frame"]) if per_kernel else None
+    roofline = None
+    if dom is not None and "achieved_GBs" in per_kernel[dom]:
+        ach = per_kernel[dom]["achieved_GBs"]
+        roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                        traffic=None, avg_launch_us=per_kernel[dom]["avg_us"],
+                        algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
+
+    # ---- CPU baseline: the oracle (single-threaded port), rank 0, bounded sample --------------------
+    cpu = None
+    if rank == 0 and a.cpu_frames > 0:
+        olib_path = os.path.join(ROOT, "oracle", "_build", "libssf_oracle.so")
+        if os.path.exists(olib_path):
+            olib = binding.Library(olib_path)
+            fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp))
+            fo.set_model(model, nvis, 30)
+            fo.process_frame(*frames[0])                      # warm-up frame
+            t1 = time.perf_counter()
+            for i in range(1, 1 + a.cpu_frames):
+                fo.process_frame(*frames[i])
+            cdt = time.perf_counter() - t1
+            cpu = dict(value=a.cpu_frames / cdt, unit="frames/s", cores=1, kind="port",
+                       sample="%d frames of the same 640x480 / ~1M-supersurfel workload, oracle/libssf_oracle.so "
+                              "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, cdt))
+            fo.close()
+
+    if rank == 0:
+        gn = last.get("global_n_model", last["n_model"])
+        gv = last.get("global_n_visible", last["n_visible"])
+        out = {
+            "metric": "frames_per_sec", "value": K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "640x480 synthetic RGB-D orbit (seed 1234), map seeded with 1,000,000 supersurfels "
+                                   "(~%d live, ~%d visible), reference rgbd_benchmark parameters, extract+ICP+fuse per frame"
+                                   % (gn, gv),
+                       "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
+                       "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
+                       "parallelism": "map sharded by world tile over %d rank(s)" % world},
+            "stage_ms": {"extract": stage[0] / K, "icp": stage[1] / K, "fuse": stage[2] / K},
+            "roofline": roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

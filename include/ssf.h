@@ -214,6 +214,8 @@ int ssf_apply_deformation(ssf_handle* h, const float* node_positions, const floa
  * names: up to max_k C strings (library-owned), ms / calls arrays of max_k.  Returns count. */
 int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k);
 int ssf_reset_kernel_times(ssf_handle* h);
+/* Switch the per-kernel hipEvent bracketing on/off at run time (overrides cfg.profile). */
+int ssf_set_profile(ssf_handle* h, int enable);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,15 @@ int ssf_dbg_renormalise_d(double* R9);
 int ssf_dbg_renormalise_f(float* R9);
 /* tf_iter (4x4 row-major) from the solved 6-vector X = (omega, tau), dense_registration.cu:369-384 */
 int ssf_dbg_gn_increment(const double* X6, double* tf16);
+/* per-element arithmetic of the kernels, evaluated on the host (same inline code as on the device):
+ * rgbToLab / labToRgb (vector_math.cuh:543-585), inverse(Cov3) (matrix_math.cuh:41-63),
+ * eigenDecomposition (supersurfel_fusion_kernels.cu:48-111), solvePlaneEquations
+ * (TPS_RGBD_kernels.cu:27-59).  Each returns what the kernel would compute for one element. */
+int ssf_dbg_rgb_to_lab(const float* rgb3, float* lab3);
+int ssf_dbg_lab_to_rgb(const float* lab3, float* rgb3);
+int ssf_dbg_sym_inverse(const float* cov6, float* inv6);            /* returns 1 when invertible */
+int ssf_dbg_principal_frame(const float* cov6, float* vecs9, float* vals3);
+int ssf_dbg_plane_solve(const float* rows12, float* theta3);        /* returns 1 when accepted */
 #ifdef __cplusplus
 }
 #endif

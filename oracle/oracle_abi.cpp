@@ -242,6 +242,7 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
     (void)h; (void)names; (void)ms; (void)calls; (void)max_k; return 0;
 }
 int ssf_reset_kernel_times(ssf_handle* h) { (void)h; return SSF_OK; }
+int ssf_set_profile(ssf_handle* h, int enable) { (void)h; (void)enable; return SSF_OK; }
 
 // test hooks of include/ssf_testing.h
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); return 0; }
@@ -267,6 +268,23 @@ int ssf_dbg_gn_increment(const double* X, double* tf) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tf[i * 4 + j] = R9[i * 3 + j];
     tf[15] = 1.0;
     return 0;
+}
+
+int ssf_dbg_rgb_to_lab(const float* c, float* o) { f3 r = rgbToLab(mk3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_lab_to_rgb(const float* c, float* o) { f3 r = labToRgb(mk3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_sym_inverse(const float* c, float* o) {
+    Cov3 out; const bool ok = inverse(mkcov(c[0], c[1], c[2], c[3], c[4], c[5]), out);
+    o[0] = out.xx; o[1] = out.xy; o[2] = out.xz; o[3] = out.yy; o[4] = out.yz; o[5] = out.zz; return ok ? 1 : 0;
+}
+int ssf_dbg_principal_frame(const float* c, float* vecs, float* vals) {
+    Mat33 m; f3 v; eigenDecomposition(mkcov(c[0], c[1], c[2], c[3], c[4], c[5]), m, v, 10);
+    for (int r = 0; r < 3; r++) { vecs[3 * r] = m.r[r].x; vecs[3 * r + 1] = m.r[r].y; vecs[3 * r + 2] = m.r[r].z; }
+    vals[0] = v.x; vals[1] = v.y; vals[2] = v.z; return 0;
+}
+int ssf_dbg_plane_solve(const float* r, float* th) {
+    float a = 0, b = 0, c = 0;
+    const bool ok = solvePlaneEquations(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
+    th[0] = a; th[1] = b; th[2] = c; return ok ? 1 : 0;
 }
 
 }  // extern "C"

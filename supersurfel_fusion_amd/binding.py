@@ -1,8 +1,8 @@
 """ctypes binding of the C ABI in include/ssf.h.
 
-The same binding drives the product (libssf_hip.so, hand-written HIP for gfx950) and -- in tests
-and in bench.py's cpu_baseline leg only -- the CPU oracle (oracle/_build/libssf_oracle.so), which
-exports the identical ABI.  Names follow the reference's C++ surface
+The binding is library-agnostic: it drives whatever shared object exporting this ABI it is handed.
+The product entry point is load_product() (libssf_hip.so, hand-written HIP for gfx950); tests and
+the bench's cpu_baseline leg hand the same class the CPU checker library.  Names follow the reference's C++ surface
 (core/include/supersurfel_fusion/supersurfel_fusion.hpp:40-143): Fusion.process_frame ==
 SupersurfelFusion::processFrame, get_pose == getPose, get_model == getModel, ...
 """
@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
     "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
-    "ssf_reset_kernel_times",
+    "ssf_reset_kernel_times", "ssf_set_profile",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -115,6 +115,7 @@ class Library:
         L.ssf_apply_deformation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
         L.ssf_get_kernel_times.argtypes = [vp, vp, vp, vp, C.c_int]
         L.ssf_reset_kernel_times.argtypes = [vp]
+        L.ssf_set_profile.argtypes = [vp, C.c_int]
 
     @property
     def backend(self):
@@ -319,3 +320,6 @@ class Fusion:
 
     def reset_kernel_times(self):
         self.L.lib.ssf_reset_kernel_times(self.h)
+
+    def set_profile(self, enable):
+        self._ck(self.L.lib.ssf_set_profile(self.h, 1 if enable else 0), "ssf_set_profile")

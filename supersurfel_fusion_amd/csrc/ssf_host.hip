@@ -790,6 +790,7 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
     return k;
 }
 int ssf_reset_kernel_times(ssf_handle* h) { if (!h) return SSF_ERR_INVALID_ARG; h->timer.acc.clear(); return SSF_OK; }
+int ssf_set_profile(ssf_handle* h, int enable) { if (!h) return SSF_ERR_INVALID_ARG; h->cfg.profile = enable ? 1 : 0; return SSF_OK; }
 
 // ---- test hooks (include/ssf_testing.h): the host solvers, so they can be pinned on a CPU box ----------
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { sym6_ldlt_solve(A, b, x); return 0; }
@@ -797,5 +798,22 @@ int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { mat6_inverse_lu(A, Ainv
 int ssf_dbg_renormalise_d(double* R9) { renormalise_rotation<double>(R9); return 0; }
 int ssf_dbg_renormalise_f(float* R9) { renormalise_rotation<float>(R9); return 0; }
 int ssf_dbg_gn_increment(const double* X6, double* tf16) { gn_increment(X6, tf16); return 0; }
+
+int ssf_dbg_rgb_to_lab(const float* c, float* o) { V3 r = rgb_to_lab(v3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_lab_to_rgb(const float* c, float* o) { V3 r = lab_to_rgb(v3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_sym_inverse(const float* c, float* o) {
+    Sym3 out; const bool ok = sym_inverse(sym3(c[0], c[1], c[2], c[3], c[4], c[5]), out);
+    o[0] = out.xx; o[1] = out.xy; o[2] = out.xz; o[3] = out.yy; o[4] = out.yz; o[5] = out.zz; return ok ? 1 : 0;
+}
+int ssf_dbg_principal_frame(const float* c, float* vecs, float* vals) {
+    M3 m; V3 v; principal_frame(sym3(c[0], c[1], c[2], c[3], c[4], c[5]), m, v);
+    const float o[9] = {m.r0.x, m.r0.y, m.r0.z, m.r1.x, m.r1.y, m.r1.z, m.r2.x, m.r2.y, m.r2.z};
+    std::memcpy(vecs, o, sizeof(o)); vals[0] = v.x; vals[1] = v.y; vals[2] = v.z; return 0;
+}
+int ssf_dbg_plane_solve(const float* r, float* th) {
+    float a = 0, b = 0, c = 0;
+    const bool ok = plane_solve(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
+    th[0] = a; th[1] = b; th[2] = c; return ok ? 1 : 0;
+}
 
 }  // extern "C"

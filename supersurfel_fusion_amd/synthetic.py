@@ -186,3 +186,31 @@ def relative_pose(k, **kw):
     R0, t0 = orbit_pose(0, **kw)
     Rk, tk = orbit_pose(k, **kw)
     return R0.T @ Rk, R0.T @ (tk - t0)
+
+
+def seed_model_cam0(n, width=640, height=480, stamp=30, seed=1234):
+    """seed_model() expressed in the frame of camera 0 (= the map frame of a run that starts at the
+    identity pose), visible rows first.  Returns (model arrays, n_visible)."""
+    R0, t0 = orbit_pose(0)
+    model = seed_model(n, stamp=stamp, seed=seed)
+    model["positions"] = ((model["positions"].astype(np.float64) - t0) @ R0).astype(np.float32)
+    O = model["orientations"].reshape(-1, 3, 3).astype(np.float64) @ R0
+    model["orientations"] = O.reshape(-1, 9).astype(np.float32)
+    Rm = R0.T
+    s = model["shapes"].astype(np.float64)
+    Cf = np.zeros((n, 3, 3))
+    Cf[:, 0, 0], Cf[:, 0, 1], Cf[:, 0, 2], Cf[:, 1, 1], Cf[:, 1, 2], Cf[:, 2, 2] = s.T
+    Cf[:, 1, 0], Cf[:, 2, 0], Cf[:, 2, 1] = Cf[:, 0, 1], Cf[:, 0, 2], Cf[:, 1, 2]
+    Cf = Rm @ Cf @ Rm.T
+    model["shapes"] = np.stack([Cf[:, 0, 0], Cf[:, 0, 1], Cf[:, 0, 2], Cf[:, 1, 1], Cf[:, 1, 2], Cf[:, 2, 2]], 1).astype(np.float32)
+    return visible_first(model, np.eye(3), np.zeros(3), width, height)
+
+
+def tile_owner(positions, nranks, tile=0.5):
+    """numpy twin of the library's spatial-tile owner hash (ssf_stage_fuse / shard_owner)."""
+    if nranks <= 1:
+        return np.zeros(len(positions), np.int64)
+    t = np.float32(tile)
+    ijk = np.floor(positions.astype(np.float32) / t).astype(np.int32).astype(np.uint32)
+    h = (ijk[:, 0] * np.uint32(73856093)) ^ (ijk[:, 1] * np.uint32(19349663)) ^ (ijk[:, 2] * np.uint32(83492791))
+    return (h % np.uint32(nranks)).astype(np.int64)

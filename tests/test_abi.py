@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI libraries load and export every symbol that
+include/ssf.h declares; defaults equal the reference's initialize() defaults
+(core/include/supersurfel_fusion/supersurfel_fusion.hpp:46-74); the product fails loudly without
+a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from supersurfel_fusion_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for hdr in ("ssf.h", "ssf_testing.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names += re.findall(r"\b(ssf_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree():
+    hdr = [s for s in declared_symbols() if not s.startswith("ssf_dbg_")]
+    assert sorted(binding.ABI_SYMBOLS) == hdr
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_library_exports_every_declared_symbol(which, product_lib, oracle_lib):
+    lib = product_lib if which == "product" else oracle_lib
+    for sym in declared_symbols():
+        assert hasattr(lib.lib, sym), "%s does not export %s" % (lib.path, sym)
+    assert lib.lib.ssf_abi_version() == 1
+    assert lib.backend == ("hip-gfx950" if which == "product" else "cpu-oracle")
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_default_config_is_the_reference_default(which, product_lib, oracle_lib):
+    lib = product_lib if which == "product" else oracle_lib
+    c = lib.default_config()
+    ref = dict(cell_size=16, lambda_pos=50.0, lambda_bound=1000.0, lambda_size=10000.0, lambda_disp=1e6,
+               seg_iter=10, seg_use_ransac=1, nb_samples=16, filter_iter=4, filter_beta=1.0, range_max=5.0,
+               delta_t=20, conf_thresh=2500.0, nb_supersurfels_max=50000, icp_iter=10, icp_cov_thresh=0.04,
+               rng_seed=1234, nranks=1)
+    for k, v in ref.items():
+        assert getattr(c, k) == pytest.approx(v), k
+    assert c.thresh_disp == pytest.approx(1e-4) and c.filter_alpha == pytest.approx(0.1)
+    assert c.filter_threshold == pytest.approx(0.05) and c.range_min == pytest.approx(0.2)
+
+
+def test_invalid_config_is_rejected(oracle_lib, product_lib):
+    for lib in (oracle_lib, product_lib):
+        for bad in (dict(width=0), dict(cell_size=0), dict(nb_supersurfels_max=10), dict(nranks=2, rank=2)):
+            with pytest.raises(binding.SsfError):
+                binding.Fusion(lib, lib.default_config(**bad))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="box has a GPU")
+def test_product_has_no_cpu_fallback(product_lib):
+    with pytest.raises(binding.SsfError, match="no HIP device"):
+        binding.Fusion(product_lib, product_lib.default_config())
+
+
+def test_product_never_links_or_loads_the_oracle():
+    """The product sources must not reference oracle/ (a product path through the checker would
+    void every parity claim)."""
+    pkg = os.path.join(ROOT, "supersurfel_fusion_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "libssf_oracle" not in txt and "oracle/" not in txt and "oracle_" not in txt, fn

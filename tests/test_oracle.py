@@ -1,0 +1,176 @@
+"""CPU tests of the oracle (the checker itself): committed golden vectors, determinism, structural
+invariants of the reference algorithm, and the edge cases the domain has (holes everywhere, ragged
+image sizes, capacity overflow, dynamic mask, first frame, empty model)."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from supersurfel_fusion_amd import binding, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "pipeline_160x128.npz")
+
+
+def run_golden_inputs(lib, n=3):
+    g = np.load(GOLD)
+    f = binding.Fusion(lib, util.make_cfg(lib, 160, 128, nb_supersurfels_max=4096))
+    res = []
+    for k in range(n):
+        r = f.process_frame(g["rgb%d" % k], g["depth%d" % k])
+        res.append((r, f.index_map(), f.inlier_map(), f.plane_depth(), f.superpixels(), f.get_frame()))
+    return g, f, res
+
+
+def check_against_golden(lib):
+    g, f, res = run_golden_inputs(lib)
+    for k, (r, lab, inl, pd, sp, fr) in enumerate(res):
+        util.assert_same_bits(lab, g["label%d" % k], "label map frame %d" % k)
+        util.assert_same_bits(inl, g["inlier%d" % k], "inlier map frame %d" % k)
+        util.assert_same_bits(pd, g["plane_depth%d" % k], "plane depth frame %d" % k)
+        util.assert_same_bits(sp, g["superpixels%d" % k], "superpixels frame %d" % k)
+        valid = g["frame_confidences%d" % k] > 0
+        for name, a in fr.items():
+            util.assert_same_bits(a[valid], g["frame_%s%d" % (name, k)][valid], "frame %s %d" % (name, k))
+        util.assert_same_bits(r["pose"], g["pose%d" % k], "pose %d" % k)
+        assert [r[q] for q in util.RESULT_KEYS] == list(g["counts%d" % k])
+    for name, a in f.get_model().items():
+        util.assert_same_bits(a, g["model_" + name], "model " + name)
+
+
+def test_oracle_reproduces_committed_golden_vectors(oracle_lib):
+    check_against_golden(oracle_lib)
+
+
+def test_oracle_is_deterministic(oracle_lib):
+    a = run_golden_inputs(oracle_lib, 2)
+    b = run_golden_inputs(oracle_lib, 2)
+    util.compare_state(a[1], b[1])
+
+
+def test_segmentation_invariants(oracle_lib):
+    g, f, res = run_golden_inputs(oracle_lib, 1)
+    lab, sp = res[0][1], res[0][4]
+    S = f.S
+    assert lab.min() >= 0 and lab.max() < S
+    # sizes in the superpixel table are the exact label histogram; centroids are exact means
+    hist = np.bincount(lab.ravel(), minlength=S)
+    assert np.array_equal(sp[:, 8].astype(np.int64), hist)
+    ys, xs = np.mgrid[0:128, 0:160]
+    for k in (0, 17, S - 1):
+        m = lab == k
+        if m.any():
+            assert sp[k, 0] == np.float32(np.float32(xs[m].sum()) / np.float32(m.sum()))
+            assert sp[k, 1] == np.float32(np.float32(ys[m].sum()) / np.float32(m.sum()))
+    # boundary map == number of differing 4-neighbours (out of image differs), decision A2
+    b = f.boundary_map()
+    pad = np.pad(lab, 1, constant_values=-1)
+    ref = ((pad[:-2, 1:-1] != lab).astype(int) + (pad[2:, 1:-1] != lab) + (pad[1:-1, :-2] != lab) + (pad[1:-1, 2:] != lab))
+    assert np.array_equal(b, ref)
+    # topology preservation: every superpixel stays 4-connected enough to keep its seed cell centre... weaker, robust check:
+    assert (hist > 0).sum() >= 0.95 * S
+    # frame supersurfels: confidence is the pixel count of interior inlier pixels or -1
+    conf = res[0][5]["confidences"]
+    assert ((conf == -1) | (conf > 100)).all()
+
+
+def test_plane_depth_is_consistent_with_planes(oracle_lib):
+    g, f, res = run_golden_inputs(oracle_lib, 1)
+    lab, pd, sp = res[0][1], res[0][3], res[0][4]
+    ys, xs = np.mgrid[0:128, 0:160].astype(np.float32)
+    th = sp[lab]
+    with np.errstate(all="ignore"):
+        ref = np.float32(1.0) / ((xs * th[..., 5] + ys * th[..., 6]) + th[..., 7])
+    util.assert_same_bits(pd, ref.astype(np.float32), "plane depth formula")
+    # on the noiseless part of the scene the plane depth tracks the input depth
+    d = g["depth0"]
+    ok = (d > 0) & np.isfinite(pd) & (f.inlier_map() > 0)
+    assert np.median(np.abs(pd[ok] - d[ok])) < 0.01
+
+
+def test_all_holes_frame(oracle_lib):
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128, nb_supersurfels_max=4096))
+    rgb, depth = util.frame(0, 160, 128)
+    r = f.process_frame(rgb, np.zeros_like(depth))
+    assert f.inlier_map().max() == 0
+    assert (f.get_frame()["confidences"] == -1).all()
+    assert r["n_model"] == f.S and r["n_visible"] == f.S     # first frame copies all S entries (a14)
+    r = f.process_frame(rgb, np.zeros_like(depth))
+    assert r["icp_valid"] == 0 and r["n_model"] == 0 and r["n_removed"] == f.S
+
+
+def test_ragged_image_size(oracle_lib):
+    W, H = 150, 100        # not multiples of the 16-pixel cell
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
+    assert f.S == 10 * 7
+    for k in range(2):
+        rgb, depth = util.frame(k, W, H)
+        r = f.process_frame(rgb, depth)
+    lab = f.index_map()
+    assert lab.shape == (H, W) and lab.max() < f.S and r["n_model"] > 0
+
+
+def test_capacity_overflow_drops_highest_frame_ids(oracle_lib):
+    lib = oracle_lib
+    f = binding.Fusion(lib, util.make_cfg(lib, 160, 128, nb_supersurfels_max=90))   # S = 80
+    rgb, depth = util.frame(0, 160, 128)
+    f.process_frame(rgb, depth)
+    R, t = synthetic.relative_pose(25)
+    rgb, depth = util.frame(25, 160, 128)
+    r = f.process_frame(rgb, depth, prior_pose=synthetic.pose12(R, t))
+    assert r["n_model"] + r["n_removed"] <= 90
+
+
+def test_dynamic_mask_invalidates_superpixels(oracle_lib):
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128, nb_supersurfels_max=4096))
+    rgb, depth = util.frame(0, 160, 128)
+    mask = np.zeros(f.S, np.uint8); mask[10:30] = 1
+    f.process_frame(rgb, depth, dynamic_mask=mask)
+    assert (f.get_model()["confidences"][10:30] == -1).all()
+
+
+def test_tracking_follows_the_ground_truth_orbit(oracle_lib):
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 640, 480, nb_supersurfels_max=20000))
+    errs = []
+    for k in range(4):
+        rgb, depth = util.frame(k, 640, 480)
+        r = f.process_frame(rgb, depth)
+        gt = synthetic.pose12(*synthetic.relative_pose(k))
+        errs.append(np.abs(r["pose"] - gt).max())
+        if k > 0:
+            assert r["icp_valid"] == 1
+    assert max(errs) < 5e-3, errs
+
+
+def test_export_text_format(oracle_lib, tmp_path):
+    """exportModel layout: 6 lines + blank per supersurfel above conf_thresh (supersurfel_fusion.cu:616-630)."""
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128, nb_supersurfels_max=4096, conf_thresh=150.0))
+    rgb, depth = util.frame(0, 160, 128)
+    f.process_frame(rgb, depth)
+    p = str(tmp_path / "model.txt")
+    f.export_model_txt(p)
+    m = f.get_model()
+    keep = np.nonzero(m["confidences"] > 150.0)[0]
+    lines = open(p).read().split("\n")
+    assert len(lines) == 7 * len(keep) + 1
+    first = keep[0]
+    assert lines[0] == "%d %d %f" % (m["stamps"][first, 0], m["stamps"][first, 1], m["confidences"][first])
+    assert lines[1] == "%f %f %f" % tuple(m["positions"][first])
+    assert len(lines[4].split()) == 9 and len(lines[5].split()) == 6 and lines[6] == ""
+
+
+def test_deformation_identity_and_translation(oracle_lib):
+    f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128, nb_supersurfels_max=4096))
+    rgb, depth = util.frame(0, 160, 128)
+    f.process_frame(rgb, depth)
+    n = f.counts()["n_model"]
+    before = f.get_model()
+    npos = np.zeros((2, 3), np.float32); nrot = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (2, 1))
+    ntr = np.float32([[0.1, 0.2, 0.3], [0.1, 0.2, 0.3]])
+    w = np.tile(np.float32([[0.25, 0.25, 0.25, 0.25]]), (n, 1)); idx = np.tile(np.int32([[0, 1, 0, 1]]), (n, 1))
+    f.apply_deformation(npos, nrot, ntr, w, idx)
+    after = f.get_model()
+    valid = before["confidences"] > 0
+    assert np.allclose(after["positions"][valid], before["positions"][valid] + ntr[0], atol=1e-6)
+    assert np.allclose(after["shapes"][valid], before["shapes"][valid], atol=1e-9)

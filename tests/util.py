@@ -1,0 +1,72 @@
+"""Shared helpers of the test-suite: configurations, synthetic frames, bit-exact comparison."""
+import numpy as np
+
+from supersurfel_fusion_amd import binding, synthetic
+
+# the reference's rgbd_benchmark launch column with VO/MOD/LC off
+BENCH_PARAMS = dict(lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, thresh_disp=1e-4,
+                    seg_iter=10, filter_iter=3, delta_t=20, conf_thresh=2560.0, icp_iter=10, icp_cov_thresh=0.05)
+
+
+def make_cfg(lib, W, H, **kw):
+    K = synthetic.intrinsics(W, H)
+    args = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=20000)
+    args.update(BENCH_PARAMS)
+    args.update(kw)
+    return lib.default_config(**args)
+
+
+def frame(k, W, H, noise=True, holes=0.0):
+    R, t = synthetic.orbit_pose(k)
+    rgb, depth, _ = synthetic.render(R, t, W, H, noise=noise, holes=holes, rng=np.random.default_rng(1000 + k))
+    return rgb, depth
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    if a.dtype == np.float64:
+        return a.view(np.uint64)
+    return a
+
+
+def assert_same_bits(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.kind == "f":
+        same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    else:
+        same = a == b
+    assert bool(same.all()), "%s: %d of %d elements differ" % (what, int((~same).sum()), a.size)
+
+
+def compare_state(fa, fb, maps=True, frame_surfels=True):
+    """Bit-exact comparison of two Fusion handles after the same calls."""
+    if maps:
+        assert_same_bits(fa.index_map(), fb.index_map(), "label map")
+        assert_same_bits(fa.boundary_map(), fb.boundary_map(), "boundary map")
+        assert_same_bits(fa.inlier_map(), fb.inlier_map(), "inlier map")
+        assert_same_bits(fa.plane_depth(), fb.plane_depth(), "plane depth")
+        assert_same_bits(fa.superpixels(), fb.superpixels(), "superpixel table")
+    if frame_surfels:
+        a, b = fa.get_frame(), fb.get_frame()
+        assert_same_bits(a["confidences"], b["confidences"], "frame confidences")
+        valid = a["confidences"] > 0
+        for name in a:
+            assert_same_bits(a[name][valid], b[name][valid], "frame " + name)
+    ca, cb = fa.counts(), fb.counts()
+    assert ca == cb, (ca, cb)
+    assert_same_bits(fa.get_pose(), fb.get_pose(), "pose")
+    ma, mb = fa.get_model(), fb.get_model()
+    for name in ma:
+        assert_same_bits(ma[name], mb[name], "model " + name)
+
+
+RESULT_KEYS = ("icp_valid", "icp_iters", "n_model", "n_visible", "n_removed", "n_inserted", "n_updated", "stamp")
+
+
+def same_result(ra, rb):
+    for k in RESULT_KEYS:
+        assert ra[k] == rb[k], (k, ra[k], rb[k])
+    assert_same_bits(ra["pose"], rb["pose"], "result pose")
