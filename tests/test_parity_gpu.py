@@ -136,7 +136,7 @@ def test_full_size_shard_additivity_of_icp_record(big, product_lib):
     """The ICP record over the whole visible set equals the exact integer sum of the records of
     two disjoint halves (what the multi-GPU SUM all-reduce relies on)."""
     f, nvis = big
-    assert nvis > 100000
+    assert nvis > 50000
     rgb, depth = util.frame(0, 640, 480)
     f.stage_extract(rgb, depth); f.icp_begin()
     whole = f.icp_accumulate()
