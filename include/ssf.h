@@ -103,7 +103,8 @@ typedef struct ssf_config {
     void* stream;              /* hipStream_t to launch on, NULL = library-owned stream */
     int   rank, nranks;        /* model shard of this handle; 0/1 = unsharded */
     float shard_tile;          /* world-space tile edge (m) hashed to the owning rank, 0.5 */
-    int   profile;             /* 1: bracket every kernel with hipEvents (ssf_get_kernel_times) */
+    int   profile;             /* 0: none (fastest); 2: stage_ms split (one event synchronise per frame);
+                                  1: additionally bracket every kernel with hipEvents (ssf_get_kernel_times) */
 } ssf_config;
 
 typedef struct ssf_handle ssf_handle;
@@ -132,7 +133,7 @@ typedef struct ssf_frame_result {
     int   n_inserted;
     int   n_updated;
     int   stamp;         /* stamp the frame was processed at */
-    float stage_ms[3];   /* extract | icp | fuse wall time on the library's stream */
+    float stage_ms[3];   /* extract | icp | fuse time on the library's stream (cfg.profile != 0, else 0) */
 } ssf_frame_result;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -214,7 +215,7 @@ int ssf_apply_deformation(ssf_handle* h, const float* node_positions, const floa
  * names: up to max_k C strings (library-owned), ms / calls arrays of max_k.  Returns count. */
 int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k);
 int ssf_reset_kernel_times(ssf_handle* h);
-/* Switch the per-kernel hipEvent bracketing on/off at run time (overrides cfg.profile). */
+/* Change cfg.profile at run time (0, 1 or 2). */
 int ssf_set_profile(ssf_handle* h, int enable);
 
 #ifdef __cplusplus

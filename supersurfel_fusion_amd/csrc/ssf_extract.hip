@@ -76,22 +76,22 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, const uint8_t* __re
     if (threadIdx.x == 0) {
         int t[6];
         for (int j = 0; j < 6; j++) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-        SpSums& s = m.sums;
-        s.sx[cell] = t[0]; s.sy[cell] = t[1]; s.sr[cell] = t[2]; s.sg[cell] = t[3]; s.sb[cell] = t[4]; s.n[cell] = t[5];
-        s.dx[cell] = 0; s.dy[cell] = 0; s.dn[cell] = 0;
-        s.dxx[cell] = 0; s.dyy[cell] = 0; s.dxy[cell] = 0; s.dxd[cell] = 0; s.dyd[cell] = 0; s.dd[cell] = 0;
+        for (int b = 0; b < 2; b++) {
+            SpSums& s = m.sums[b];
+            s.sx[cell] = t[0]; s.sy[cell] = t[1]; s.sr[cell] = t[2]; s.sg[cell] = t[3]; s.sb[cell] = t[4]; s.n[cell] = t[5];
+            s.dx[cell] = 0; s.dy[cell] = 0; s.dn[cell] = 0;
+            s.dxx[cell] = 0; s.dyy[cell] = 0; s.dxy[cell] = 0; s.dxd[cell] = 0; s.dyd[cell] = 0; s.dd[cell] = 0;
+        }
         SpRow z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         m.sp[cell] = z;
     }
 }
 
-// means (+ plane) of every superpixel: mergeTPSRGBCoeffs_kernel / mergeTPSRGBDCoeffs_kernel,
-// TPS_RGBD_kernels.cu:224-276
-__global__ void k_merge(SegParams p, FrameMaps m, int with_planes) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.S) return;
-    const SpSums& s = m.sums;
-    SpRow row = m.sp[k];
+// means (+ plane) of one superpixel from its exact sums: mergeTPSRGBCoeffs_kernel /
+// mergeTPSRGBDCoeffs_kernel, TPS_RGBD_kernels.cu:224-276.  `prev` supplies the plane that an RGB-only
+// merge leaves untouched.
+__device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with_planes, SpRow prev) {
+    SpRow row = prev;
     const float n = (float)s.n[k];
     row.cx = (float)s.sx[k] / n; row.cy = (float)s.sy[k] / n;
     row.r = (float)s.sr[k] / n; row.g = (float)s.sg[k] / n; row.b = (float)s.sb[k] / n;
@@ -108,7 +108,11 @@ __global__ void k_merge(SegParams p, FrameMaps m, int with_planes) {
         }
         row.ta = ta; row.tb = tb; row.tc = tc;
     }
-    m.sp[k] = row;
+    return row;
+}
+__global__ void k_merge(SegParams p, FrameMaps m, int true_buf, int with_planes) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p.S) m.sp[k] = row_from_sums(m.sums[true_buf], k, with_planes != 0, m.sp[k]);
 }
 
 // ---- relabelling pass --------------------------------------------------------------------------
@@ -138,112 +142,184 @@ __device__ __forceinline__ void disp_sums_add(const SpSums& s, int k, int x, int
     atomic_add_i64(&s.dyd[k], sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
     atomic_add_i64(&s.dd[k], sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
 }
+// the six colour/position sums of one pixel moved from superpixel a to b
+__device__ __forceinline__ void rgb_sums_move(const SpSums& s, int a, int b, int x, int y, int ir, int ig, int ib) {
+    atomicAdd(&s.sx[a], -x); atomicAdd(&s.sy[a], -y); atomicAdd(&s.sr[a], -ir);
+    atomicAdd(&s.sg[a], -ig); atomicAdd(&s.sb[a], -ib); atomicAdd(&s.n[a], -1);
+    atomicAdd(&s.sx[b], x); atomicAdd(&s.sy[b], y); atomicAdd(&s.sr[b], ir);
+    atomicAdd(&s.sg[b], ig); atomicAdd(&s.sb[b], ib); atomicAdd(&s.n[b], 1);
+}
+// all sum updates of one relabelled pixel (flags as in PassLog)
+__device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int to, int x, int y, uint32_t rgbf, float d) {
+    const unsigned flags = rgbf >> 24;
+    if (flags & 1u) rgb_sums_move(s, from, to, x, y, (int)(rgbf & 255u), (int)((rgbf >> 8) & 255u), (int)((rgbf >> 16) & 255u));
+    if (flags & 2u) disp_sums_add(s, to, x, y, d, +1);
+    if (flags & 4u) disp_sums_add(s, from, x, y, d, -1);
+}
 
 // One pass (OX,OY) of the boundary relabelling: updateTPSRGB_kernel / updateTPSRGBD_kernel,
 // TPS_RGBD_kernels.cuh:235-651.  256 threads own the 256 pass pixels of a 32x32 tile.
+//
+// No merge launch between passes.  The exact sums are double buffered: pass k builds the superpixel
+// rows (means, plane) it needs straight from sums[k&1], which nothing writes during the pass, and
+// applies its relabelling deltas to sums[(k+1)&1] together with the replayed log of pass k-1 (the
+// deltas that buffer is still missing).  Integer adds commute, so the lagging buffer catches up
+// exactly.  The rows of the superpixels around the tile (a window of grid cells) are computed by
+// the first threads of the workgroup into LDS while the label tile is being staged; the energy
+// then reads rows from LDS.  Labels that have drifted out of the window take an exact slow path.
+#define WIN_MAX 144
 template <bool RGBD>
-__global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int src_buf, int OX, int OY) {
+__global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     __shared__ int tile[TW * TW];
-    __shared__ int out[TILE * TILE];
+    __shared__ SpRow w_row[WIN_MAX];
+    __shared__ unsigned int s_nlog;
+    const bool odd = (pass & 1) != 0;
+    const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
+    const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    const int32_t* __restrict__ src = m.label[src_buf];
-    int32_t* __restrict__ dst = m.label[src_buf ^ 1];
-    load_label_tile(tile, src, X0, Y0, p.W, p.H);
-    __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) out[i] = tile[(i / TILE + 1) * TW + (i % TILE) + 1];
-    __syncthreads();
-
+    const int32_t* __restrict__ src = odd ? m.label[1] : m.label[0];
+    int32_t* __restrict__ dst = odd ? m.label[0] : m.label[1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int raw_x = blockIdx.x * 16 + tx;
     const int lx0 = 2 * tx + ((raw_x + OX) & 1), ly0 = 2 * ty + OY;           // tile-interior coordinates
     const int x = X0 + lx0, y = Y0 + ly0;
-    if (x < p.W && y < p.H) {
-        const int lx = lx0 + 1, ly = ly0 + 1;                                 // halo coordinates
-        const size_t q = (size_t)y * p.W + x;
-        const int index = tile[ly * TW + lx];
-        int new_index = index;
-        const SpRow own = m.sp[index];
-        const int bounds = tile_boundary(tile, lx, ly);
-        float disp = 0.f, disp_energy = 0.f;
-        unsigned char prev_inlier = 0, inlier = 0xff;
+    const bool in_image = x < p.W && y < p.H;
+    const size_t q = in_image ? (size_t)y * p.W + x : 0;
+    // operands that do not depend on the label tile: in flight while the tile is staged
+    const uint32_t px = m.rgba[q];
+    float disp = 0.f; unsigned char prev_inlier = 0;
+    if (RGBD) { disp = m.disp[q]; prev_inlier = m.inlier[q]; }
+    // window of grid cells around the tile whose superpixel rows are cached in LDS
+    int margin = 2;
+    const int tcx0 = X0 / p.cell, tcy0 = Y0 / p.cell;
+    const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
+    while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
+    const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
+    const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
+    const bool window_ok = nwx * nwy <= WIN_MAX;
+    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (window_ok && !(dbg & 1))
+        for (int i = threadIdx.x; i < nwx * nwy; i += blockDim.x) {
+            const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
+            if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) w_row[i] = row_from_sums(sr, cy * p.gx + cx, RGBD, zero_row);
+        }
+    // this tile's log entry of the previous pass: requested now, replayed at the very end
+    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lp = (pass + 2) % 3, lc = pass % 3;
+    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
+    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
+    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
+    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
+    const int4 prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
+    const float prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
+    if (threadIdx.x == 0) s_nlog = 0;
+    if (!(dbg & 32)) load_label_tile(tile, src, X0, Y0, p.W, p.H);
+    __syncthreads();
+    // pixels that are not in this pass keep their label: copy them to the next map now
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int cx = i % TILE, cy = i / TILE;
+        const bool in_pass = ((cy & 1) == OY) && ((cx & 1) == ((blockIdx.x * 16 + (cx >> 1) + OX) & 1));
+        const int xx = X0 + cx, yy = Y0 + cy;
+        if (!in_pass && xx < p.W && yy < p.H && !(dbg & 16)) dst[(size_t)yy * p.W + xx] = tile[(cy + 1) * TW + cx + 1];
+    }
+    const float inv_gx = 1.0f / (float)p.gx;
+    auto row_of = [&](int l) -> SpRow {
+        const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
+        const int wx = (l - cyl * p.gx) - wcx0, wy = cyl - wcy0;
+        if (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) return w_row[wy * nwx + wx];
+        return row_from_sums(sr, l, RGBD, zero_row);          // drifted out of the window: exact slow path
+    };
+    if (dbg & 2) return;
+    const int lx = lx0 + 1, ly = ly0 + 1;                                     // halo coordinates
+    const int index = in_image ? tile[ly * TW + lx] : 0;
+    int new_index = index;
+    const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
+    int nl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TW + lx + nx[k]];
+    const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
+    bool eligible = in_image && bounds != 0 && !(dbg & 4);
+    if (eligible) {
+        // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
+        const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+        bool prev = tile[(ly + oy[0]) * TW + lx + ox[0]] == index;
+        int jump = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+            const bool cur = tile[(ly + oy[k]) * TW + lx + ox[k]] == index;
+            if (prev != cur) { jump++; prev = cur; }
+        }
+        eligible = !(jump > 2);
+    }
+    SpRow own = zero_row;
+    if (in_image && (RGBD || eligible)) own = row_of(index);
+    float disp_energy = 0.f;
+    unsigned char inlier = 0xff;
+    if (RGBD && in_image) {
+        const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
+        disp_energy = (dp - disp) * (dp - disp);
+        if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
+    }
+    if (eligible) {
+        const float cr = (float)(px & 255u), cg = (float)((px >> 8) & 255u), cb = (float)((px >> 16) & 255u);
+        const float posx = (float)x, posy = (float)y;
+        const float size = own.size;
+        const float sc = size / (size - 1.f);
+        const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
+        const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
+        const float dsize = size - (float)p.min_size;
+        float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
+        if (RGBD) best = best + p.lambda_disp * disp_energy;
+        best = best - p.lambda_size * fminf(dsize, 0.f);
+        best = best + p.lambda_bound * (float)bounds;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i_n = nl[k];
+            if (i_n == -1 || i_n == index) continue;
+            const SpRow nb = row_of(i_n);
+            const float ndx = posx - nb.cx, ndy = posy - nb.cy;
+            const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
+            const float ndsize = (nb.size + 1.f) - (float)p.min_size;
+            float n_de = 0.f; unsigned char n_inlier = 0xff;
+            if (RGBD) {
+                const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
+                n_de = (dp - disp) * (dp - disp);
+                if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+            }
+            const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
+            float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
+            if (RGBD) e = e + p.lambda_disp * n_de;
+            e = e - p.lambda_size * fminf(ndsize, 0.f);
+            e = e + p.lambda_bound * (float)b;
+            if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
+        }
+    }
+    unsigned flags = 0u;
+    if (in_image) {
+        dst[q] = new_index;
+        flags = (new_index != index) ? 1u : 0u;
         if (RGBD) {
-            disp = m.disp[q];
-            prev_inlier = m.inlier[q];
-            const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-            disp_energy = (dp - disp) * (dp - disp);
-            if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
-        }
-        bool eligible = bounds != 0;
-        if (eligible) {
-            // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
-            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-            bool prev = tile[(ly + oy[0]) * TW + lx + ox[0]] == index;
-            int jump = 0;
-#pragma unroll
-            for (int k = 1; k < 8; k++) {
-                const bool cur = tile[(ly + oy[k]) * TW + lx + ox[k]] == index;
-                if (prev != cur) { jump++; prev = cur; }
-            }
-            eligible = !(jump > 2);
-        }
-        if (eligible) {
-            const uint32_t px = m.rgba[q];
-            const float cr = (float)(px & 255u), cg = (float)((px >> 8) & 255u), cb = (float)((px >> 16) & 255u);
-            const float posx = (float)x, posy = (float)y;
-            const float size = own.size;
-            const float sc = size / (size - 1.f);
-            const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
-            const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
-            const float dsize = size - (float)p.min_size;
-            float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
-            if (RGBD) best = best + p.lambda_disp * disp_energy;
-            best = best - p.lambda_size * fminf(dsize, 0.f);
-            best = best + p.lambda_bound * (float)bounds;
-            const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-            int nl[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TW + lx + nx[k]];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i_n = nl[k];
-                if (i_n == -1 || i_n == index) continue;
-                const SpRow nb = m.sp[i_n];
-                const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-                const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-                const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-                float n_de = 0.f; unsigned char n_inlier = 0xff;
-                if (RGBD) {
-                    const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
-                    n_de = (dp - disp) * (dp - disp);
-                    if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
-                }
-                const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-                float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-                if (RGBD) e = e + p.lambda_disp * n_de;
-                e = e - p.lambda_size * fminf(ndsize, 0.f);
-                e = e + p.lambda_bound * (float)b;
-                if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
-            }
-            if (new_index != index) {
-                out[ly0 * TILE + lx0] = new_index;
-                const SpSums& s = m.sums;
-                const int ir = (int)(px & 255u), ig = (int)((px >> 8) & 255u), ib = (int)((px >> 16) & 255u);
-                atomicAdd(&s.sx[index], -x); atomicAdd(&s.sy[index], -y); atomicAdd(&s.sr[index], -ir);
-                atomicAdd(&s.sg[index], -ig); atomicAdd(&s.sb[index], -ib); atomicAdd(&s.n[index], -1);
-                atomicAdd(&s.sx[new_index], x); atomicAdd(&s.sy[new_index], y); atomicAdd(&s.sr[new_index], ir);
-                atomicAdd(&s.sg[new_index], ig); atomicAdd(&s.sb[new_index], ib); atomicAdd(&s.n[new_index], 1);
-            }
-        }
-        if (RGBD) {
-            if (inlier && (!prev_inlier || index != new_index)) disp_sums_add(m.sums, new_index, x, y, disp, +1);
-            if (prev_inlier && (!inlier || (inlier && index != new_index))) disp_sums_add(m.sums, index, x, y, disp, -1);
+            if (inlier && (!prev_inlier || index != new_index)) flags |= 2u;
+            if (prev_inlier && (!inlier || (inlier && index != new_index))) flags |= 4u;
             if (inlier != prev_inlier) m.inlier[q] = inlier;
         }
     }
+    if (flags) {
+        const uint32_t rgbf = (px & 0x00FFFFFFu) | (flags << 24);
+        apply_pixel_delta(sw, index, new_index, x, y, rgbf, disp);
+        int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
+        float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
+        const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < 256 by construction
+        cent[(size_t)tile_id * 256 + slot] = make_int4(index, new_index, x | (y << 16), (int)rgbf);
+        cdis[(size_t)tile_id * 256 + slot] = disp;
+    }
+    // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
+    if (threadIdx.x < n_prev && !(dbg & 8))
+        apply_pixel_delta(sw, prev_ent.x, prev_ent.y, prev_ent.z & 0xFFFF, (prev_ent.z >> 16) & 0xFFFF, (uint32_t)prev_ent.w, prev_disp);
     __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
-        const int xx = X0 + (i % TILE), yy = Y0 + (i / TILE);
-        if (xx < p.W && yy < p.H) dst[(size_t)yy * p.W + xx] = out[i];
+    if (threadIdx.x == 0) {
+        unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+        ccnt[tile_id] = s_nlog;
     }
 }
 
@@ -296,30 +372,31 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int cur) {
     m.rng_counter[idx] = ctr;
 }
 
-// evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores, one atomic per (wave,label,sample)
+// evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores, one atomic per (wave,label,sample).
+// Lane k fetches sample k of the label once; the plane is then broadcast lane-to-lane.
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, int cur) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = q < p.W * p.H;
     const int x = active ? q % p.W : 0, y = active ? q / p.W : 0;
     const int label = active ? m.label[cur][q] : -1;
     const float d = active ? m.disp[q] : 0.f;
-    const int ns = p.nb_samples;
+    const int ns = p.nb_samples;                      // <= 64 (checked in ssf_create)
     for_each_label(label, active, [&](int l, bool in_group) {
-        for (int k0 = 0; k0 < ns; k0 += 64) {
-            int mine = 0;
-            for (int k = k0; k < min(ns, k0 + 64); k++) {
-                const float4 th = m.samples[(size_t)l * ns + k];
-                bool pass = false;
-                if (in_group && isfinite(th.z)) {
-                    const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
-                    const float dd = (d - dp) * (d - dp);
-                    pass = dd < p.thresh_disp;
-                }
-                const int cnt = __popcll(__ballot(pass));
-                if (lane_id() == k - k0) mine = cnt;
+        float4 mine_th = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_id() < ns) mine_th = m.samples[(size_t)l * ns + lane_id()];
+        int mine = 0;
+        for (int k = 0; k < ns; k++) {
+            const float ta = __shfl(mine_th.x, k, 64), tb = __shfl(mine_th.y, k, 64), tc = __shfl(mine_th.z, k, 64);
+            bool pass = false;
+            if (in_group && isfinite(tc)) {
+                const float dp = (ta * (float)x + tb * (float)y) + tc;
+                const float dd = (d - dp) * (d - dp);
+                pass = dd < p.thresh_disp;
             }
-            if (k0 + lane_id() < ns && mine) atomicAdd(&m.sample_score[(size_t)l * ns + k0 + lane_id()], mine);
+            const int cnt = __popcll(__ballot(pass));
+            if (lane_id() == k) mine = cnt;
         }
+        if (lane_id() < ns && mine) atomicAdd(&m.sample_score[(size_t)l * ns + lane_id()], mine);
     });
 }
 
@@ -336,9 +413,11 @@ __global__ void k_select_samples(SegParams p, FrameMaps m) {
     SpRow row = m.sp[idx];
     row.ta = best.x; row.tb = best.y; row.tc = best.z;
     m.sp[idx] = row;
-    const SpSums& s = m.sums;
-    s.dx[idx] = 0; s.dy[idx] = 0; s.dn[idx] = 0;
-    s.dxx[idx] = 0; s.dyy[idx] = 0; s.dxy[idx] = 0; s.dxd[idx] = 0; s.dyd[idx] = 0; s.dd[idx] = 0;
+    for (int b = 0; b < 2; b++) {
+        const SpSums& s = m.sums[b];
+        s.dx[idx] = 0; s.dy[idx] = 0; s.dn[idx] = 0;
+        s.dxx[idx] = 0; s.dyy[idx] = 0; s.dxy[idx] = 0; s.dxd[idx] = 0; s.dyd[idx] = 0; s.dd[idx] = 0;
+    }
 }
 
 // initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190)
@@ -363,15 +442,15 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
     t[6] = inl ? fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
     t[7] = inl ? fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
     t[8] = inl ? fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
-    const SpSums& s = m.sums;
     for_each_label(label, inl, [&](int l, bool in_group) {
         long long mine = 0;
 #pragma unroll
         for (int j = 0; j < 9; j++) {
             const long long v = wave_sum_i64(in_group ? t[j] : 0);
-            if (lane_id() == j) mine = v;
+            if (lane_id() == j || lane_id() == j + 16) mine = v;
         }
-        switch (lane_id()) {
+        const SpSums s = ((lane_id() >> 4) & 1) ? m.sums[1] : m.sums[0];   // lanes 0-8 feed buffer 0, lanes 16-24 buffer 1
+        if (lane_id() < 32) switch (lane_id() & 15) {
             case 0: atomicAdd(&s.dx[l], (int)mine); break;
             case 1: atomicAdd(&s.dy[l], (int)mine); break;
             case 2: atomicAdd(&s.dn[l], (int)mine); break;
@@ -479,7 +558,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
                 valid = true;
                 const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
                 const uint32_t px = m.rgba[q];
-                const V3 lab = rgb_to_lab(v3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)));
+                const V3 lab = rgb8_to_lab(m.srgb_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
                 const Sym3 c = sym_outer(pos);
                 const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
 #pragma unroll
@@ -558,14 +637,14 @@ void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const
     ScopedKernel sk("ingest", st);
     hipLaunchKernelGGL(k_ingest, dim3(p.S), dim3(256), 0, st, p, rgb, depth, m);
 }
-void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, bool with_planes) {
+void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf, bool with_planes) {
     ScopedKernel sk(with_planes ? "merge_rgbd" : "merge_rgb", st);
-    hipLaunchKernelGGL(k_merge, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m, with_planes ? 1 : 0);
+    hipLaunchKernelGGL(k_merge, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m, true_buf, with_planes ? 1 : 0);
 }
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int src, int ox, int oy, bool rgbd) {
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg) {
     ScopedKernel sk(rgbd ? "update_pass_rgbd" : "update_pass_rgb", st);
-    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, tile_grid(p), dim3(256), 0, st, p, m, src, ox, oy);
-    else hipLaunchKernelGGL(k_update_pass<false>, tile_grid(p), dim3(256), 0, st, p, m, src, ox, oy);
+    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, tile_grid(p), dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    else hipLaunchKernelGGL(k_update_pass<false>, tile_grid(p), dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
 void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
     const int P = p.W * p.H;

@@ -216,7 +216,12 @@ struct ssf_handle {
     long long* d_icp = nullptr; unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_state = nullptr; uint32_t* d_block_counts = nullptr; Counters* d_cnt = nullptr;
     int32_t* d_scratch_map = nullptr;
-    // pinned host mirrors
+    long long* d_icp_replicas = nullptr; unsigned int* d_tickets = nullptr; float* d_srgb_lut = nullptr;
+    // host-mapped mailbox (fine-grained): results the host waits for are polled, not synchronised on
+    Mailbox* mb_host = nullptr; Mailbox* mb_dev = nullptr;
+    unsigned long long icp_seq = 0, cnt_seq = 0;
+    hipGraph_t seg_graph = nullptr; hipGraphExec_t seg_exec = nullptr; int seg_graph_cur = 0; bool graph_failed = false;
+    long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
     int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
     Rt pose;
@@ -238,6 +243,27 @@ static std::string g_create_err;
             return SSF_ERR_DEVICE;                                                                   \
         }                                                                                            \
     } while (0)
+
+// Wait until the device has published sequence number `want` into the host-mapped mailbox word.
+// Bounded: falls back to a stream synchronise (and reports a device error) after ~5 s.
+static int wait_seq(ssf_handle* h, const volatile unsigned long long* word, unsigned long long want) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long spins = 0;
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0xFFFF) == 0) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                hipError_t e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) { h->err = std::string("device error while waiting: ") + hipGetErrorString(e); return SSF_ERR_DEVICE; }
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return SSF_OK;
+                h->err = "mailbox sequence number never arrived"; return SSF_ERR_DEVICE;
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return SSF_OK;
+}
 
 template <typename T>
 static bool dalloc(ssf_handle* h, T** p, size_t count) {
@@ -268,11 +294,42 @@ static void pose_to12(const Rt& r, float* p) {
 }
 struct TimerScope {
     ssf_handle* h;
-    explicit TimerScope(ssf_handle* hh) : h(hh) { set_current_timer(hh->cfg.profile ? &hh->timer : nullptr); }
+    explicit TimerScope(ssf_handle* hh) : h(hh) { set_current_timer(hh->cfg.profile == 1 ? &hh->timer : nullptr); }
     ~TimerScope() { set_current_timer(nullptr); }
 };
 
 // ---- stages -----------------------------------------------------------------------------------------
+// the segmentation chain between ingest and finalize: fixed topology and arguments per handle.
+// Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
+// kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
+// only materialised where a later stage wants it: before RANSAC and before the plane filter.
+static int enqueue_segmentation(ssf_handle* h, int* cur_out) {
+    const SegParams& p = h->seg;
+    hipStream_t st = h->stream;
+    int k = 0;
+    const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
+    const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
+    for (int it = 0; it < h->cfg.seg_iter / 2; it++)
+        for (int q = 0; q < 4; q++) {
+            if (k >= limit) break;
+            launch_update_pass(st, p, h->maps, k, ox[q], oy[q], false); k++;
+        }
+    launch_merge(st, p, h->maps, k & 1, false);           // sums[k&1] holds the exact sums after k passes
+    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, k & 1); launch_init_disp(st, p, h->maps, k & 1, true); }
+    else launch_init_disp(st, p, h->maps, k & 1, false);
+    if (k >= limit || h->cfg.seg_iter - h->cfg.seg_iter / 2 <= 0) launch_merge(st, p, h->maps, k & 1, true);
+    for (int it = h->cfg.seg_iter / 2; it < h->cfg.seg_iter; it++)
+        for (int q = 0; q < 4; q++) {
+            if (k >= limit) break;
+            launch_update_pass(st, p, h->maps, k, ox[q], oy[q], true); k++;
+        }
+    launch_merge(st, p, h->maps, k & 1, true);
+    launch_plane_filter(st, p, h->maps);
+    launch_render_moments(st, p, h->cam, h->maps, k & 1);
+    *cur_out = k & 1;
+    return SSF_OK;
+}
+
 static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     const size_t P = (size_t)h->cfg.width * h->cfg.height;
     const uint8_t* d_rgb = (const uint8_t*)rgb; const float* d_depth = (const float*)depth;
@@ -283,32 +340,28 @@ static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
     }
     const uint8_t* d_mask = nullptr;
     if (mask) { HCK(hipMemcpyAsync(h->d_mask, mask, h->S, hipMemcpyHostToDevice, h->stream)); d_mask = h->d_mask; }
-    const SegParams& p = h->seg;
     hipStream_t st = h->stream;
-    launch_ingest(st, p, d_rgb, d_depth, h->maps);
-    launch_merge(st, p, h->maps, false);
-    int cur = 0, passes = 0;
-    const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
-    const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
-    for (int k = 0; k < h->cfg.seg_iter / 2; k++)
-        for (int q = 0; q < 4; q++) {
-            if (passes >= limit) break;
-            launch_update_pass(st, p, h->maps, cur, ox[q], oy[q], false); cur ^= 1;
-            launch_merge(st, p, h->maps, false); passes++;
+    launch_ingest(st, h->seg, d_rgb, d_depth, h->maps);
+    // ~85 short dependent kernels: replayed as one captured hipGraph (launch-bound inner loop);
+    // eager when kernels are individually timed or the pass count is being bisected
+    const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
+    int cur = 0;
+    if (use_graph) {
+        if (!h->seg_exec) {
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                enqueue_segmentation(h, &h->seg_graph_cur);
+                ok = hipStreamEndCapture(st, &h->seg_graph) == hipSuccess && h->seg_graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&h->seg_exec, h->seg_graph, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) { h->graph_failed = true; h->seg_exec = nullptr; (void)hipGetLastError(); }
         }
-    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, cur); launch_init_disp(st, p, h->maps, cur, true); }
-    else launch_init_disp(st, p, h->maps, cur, false);
-    launch_merge(st, p, h->maps, true);
-    for (int k = h->cfg.seg_iter / 2; k < h->cfg.seg_iter; k++)
-        for (int q = 0; q < 4; q++) {
-            if (passes >= limit) break;
-            launch_update_pass(st, p, h->maps, cur, ox[q], oy[q], true); cur ^= 1;
-            launch_merge(st, p, h->maps, true); passes++;
-        }
+        if (h->seg_exec) { HCK(hipGraphLaunch(h->seg_exec, st)); cur = h->seg_graph_cur; }
+        else enqueue_segmentation(h, &cur);
+    } else
+        enqueue_segmentation(h, &cur);
     h->cur = cur;
-    launch_plane_filter(st, p, h->maps);
-    launch_render_moments(st, p, h->cam, h->maps, cur);
-    launch_finalize_surfels(st, p, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask);
+    launch_finalize_surfels(st, h->seg, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask);
     HCK(hipGetLastError());
     h->have_frame = true;
     return SSF_OK;
@@ -333,17 +386,22 @@ static void inc_to_float(const double* tf, M3& R, V3& t) {
            v3((float)tf[8], (float)tf[9], (float)tf[10]));
     t = v3((float)tf[3], (float)tf[7], (float)tf[11]);
 }
-// device accumulate; result left in d_icp (and copied to h_icp after a sync when to_host)
+// device accumulate; the record lands in d_icp and in the mailbox (h_icp points at the mailbox copy)
 static int icp_accumulate(ssf_handle* h, bool to_host) {
     IcpLoop& I = h->icp;
     M3 R_inc; V3 t_inc;
     inc_to_float(I.tf_inc, R_inc, t_inc);
     I.t_inc_stale = t_inc;
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp);
+    const unsigned long long seq = ++h->icp_seq;
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T,
+               h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, seq);
+    HCK(hipGetLastError());
     if (to_host) {
-        HCK(hipMemcpyAsync(h->h_icp, h->d_icp, SSF_ICP_RECORD * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-        HCK(hipStreamSynchronize(h->stream));
+        int rc = wait_seq(h, &h->mb_host->icp_seq, seq);
+        if (rc) return rc;
+        for (int i = 0; i < SSF_ICP_RECORD; i++) h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
+        h->h_icp = h->h_icp_local;
     }
     return SSF_OK;
 }
@@ -410,15 +468,13 @@ static int do_match(ssf_handle* h) {
     return SSF_OK;
 }
 
-// update | insert | classify | reorder, all stream-ordered through the device-side counters
+// update | insert | classify | reorder, all stream-ordered through the device-side counters; the
+// final counters come back through the mailbox (no D2H copy, no stream synchronise)
 static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis_g = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
-    Counters c0; std::memset(&c0, 0, sizeof(c0));
-    c0.n_model = h->n_model; c0.n_visible = h->n_visible;
-    *h->h_cnt = c0;
-    HCK(hipMemcpyAsync(h->d_cnt, h->h_cnt, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
     SurfelSoA& M = h->model[h->mcur];
+    int shrink = 0;
     if (nmodel_g > 0) {
         if (nvis_g > 0)
             launch_update(h->stream, M, h->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->d_best, h->d_matched, h->S, h->d_cnt);
@@ -429,34 +485,40 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
                                 h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state,
                                 h->d_block_counts, h->d_cnt);
         h->mcur ^= 1;
+        shrink = 1;
     } else {
         launch_first_frame(h->stream, M, h->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
     }
-    HCK(hipMemcpyAsync(h->h_cnt, h->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
-    HCK(hipStreamSynchronize(h->stream));
-    h->n_model = h->h_cnt->n_model; h->n_visible = h->h_cnt->n_visible;
+    const unsigned long long seq = ++h->cnt_seq;
+    launch_publish_counts(h->stream, h->d_cnt, shrink, h->mb_dev, seq);
+    HCK(hipGetLastError());
+    int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
+    if (rc) return rc;
+    const Counters c = *const_cast<const Counters*>(&h->mb_host->cnt);
+    h->n_model = c.n_model; h->n_visible = c.n_visible;
     if (out) {
         std::memset(out, 0, sizeof(*out));
         pose_to12(h->pose, out->pose);
         out->icp_valid = h->last_icp_valid; out->icp_iters = h->last_icp_iters;
-        out->n_model = h->n_model; out->n_visible = h->n_visible; out->n_removed = h->h_cnt->n_removed;
-        out->n_inserted = h->h_cnt->n_inserted; out->n_updated = h->h_cnt->n_updated; out->stamp = h->stamp;
+        out->n_model = h->n_model; out->n_visible = h->n_visible; out->n_removed = c.n_removed;
+        out->n_inserted = c.n_inserted; out->n_updated = c.n_updated; out->stamp = h->stamp;
     }
     h->stamp++;
     h->global_n_model = -1; h->global_n_visible = -1;
     h->have_frame = false;
-    if (h->cfg.profile) timer_collect(&h->timer);
+    if (h->cfg.profile == 1) { HCK(hipStreamSynchronize(h->stream)); timer_collect(&h->timer); }
     return SSF_OK;
 }
 
 static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth, int on_device, const float* prior,
                               const uint8_t* mask, ssf_frame_result* out) {
     TimerScope ts(h);
-    HCK(hipEventRecord(h->ev[0], h->stream));
+    const bool timing = h->cfg.profile != 0;       // stage split costs an event synchronise: opt-in
+    if (timing) HCK(hipEventRecord(h->ev[0], h->stream));
     int rc = do_extract(h, rgb, depth, on_device, mask);
     if (rc) return rc;
-    HCK(hipEventRecord(h->ev[1], h->stream));
+    if (timing) HCK(hipEventRecord(h->ev[1], h->stream));
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
     while (again) {
@@ -465,20 +527,20 @@ static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth,
         icp_update(h, (const int64_t*)h->h_icp, &again);
     }
     icp_end(h, &valid);
-    HCK(hipEventRecord(h->ev[2], h->stream));
+    if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
     rc = do_match(h);
     if (rc) return rc;
     ssf_frame_result r;
-    hipEvent_t e3 = h->ev[3];
-    // do_fuse synchronises the stream; record the closing event just before its final copy
     rc = do_fuse(h, &r);
     if (rc) return rc;
-    HCK(hipEventRecord(e3, h->stream));
-    HCK(hipEventSynchronize(e3));
-    float ms;
-    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) r.stage_ms[0] = ms;
-    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) r.stage_ms[1] = ms;
-    if (hipEventElapsedTime(&ms, h->ev[2], e3) == hipSuccess) r.stage_ms[2] = ms;
+    if (timing) {
+        HCK(hipEventRecord(h->ev[3], h->stream));
+        HCK(hipEventSynchronize(h->ev[3]));
+        float ms;
+        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) r.stage_ms[0] = ms;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) r.stage_ms[1] = ms;
+        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) r.stage_ms[2] = ms;
+    }
     if (out) *out = r;
     return SSF_OK;
 }
@@ -504,9 +566,10 @@ void ssf_default_config(ssf_config* c) {       // default arguments of initializ
 void ssf_destroy(ssf_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->seg_exec) (void)hipGraphExecDestroy(h->seg_exec);
+    if (h->seg_graph) (void)hipGraphDestroy(h->seg_graph);
     for (void* p : h->allocs) (void)hipFree(p);
-    if (h->h_icp) (void)hipHostFree(h->h_icp);
-    if (h->h_cnt) (void)hipHostFree(h->h_cnt);
+    if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -543,22 +606,43 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
-    FrameMaps& m = h->maps; SpSums& s = m.sums;
+    FrameMaps& m = h->maps; SpSums& s = m.sums[0]; SpSums& s2 = m.sums[1];
+    const size_t NT = (size_t)((W + 31) / 32) * ((H + 31) / 32);   // relabelling tiles
     bool ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.label[1], P) &&
               dalloc(h, &m.inlier, P) && dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) &&
               dalloc(h, &m.sample_score, NS) && dalloc(h, &m.rng_counter, NS) && dalloc(h, &m.moments, 13 * S) &&
               dalloc(h, &m.filt, 11 * S) && dalloc(h, &s.sx, S) && dalloc(h, &s.sy, S) && dalloc(h, &s.sr, S) &&
               dalloc(h, &s.sg, S) && dalloc(h, &s.sb, S) && dalloc(h, &s.n, S) && dalloc(h, &s.dx, S) && dalloc(h, &s.dy, S) &&
               dalloc(h, &s.dn, S) && dalloc(h, &s.dxx, S) && dalloc(h, &s.dyy, S) && dalloc(h, &s.dxy, S) &&
-              dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S) && alloc_surfels(h, h->frame, S) &&
+              dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S) && dalloc(h, &s2.sx, S) && dalloc(h, &s2.sy, S) &&
+              dalloc(h, &s2.sr, S) && dalloc(h, &s2.sg, S) && dalloc(h, &s2.sb, S) && dalloc(h, &s2.n, S) && dalloc(h, &s2.dx, S) &&
+              dalloc(h, &s2.dy, S) && dalloc(h, &s2.dn, S) && dalloc(h, &s2.dxx, S) && dalloc(h, &s2.dyy, S) && dalloc(h, &s2.dxy, S) &&
+              dalloc(h, &s2.dxd, S) && dalloc(h, &s2.dyd, S) && dalloc(h, &s2.dd, S) && dalloc(h, &m.log.ent[0], NT * 256) &&
+              dalloc(h, &m.log.ent[1], NT * 256) && dalloc(h, &m.log.ent[2], NT * 256) && dalloc(h, &m.log.disp[0], NT * 256) &&
+              dalloc(h, &m.log.disp[1], NT * 256) && dalloc(h, &m.log.disp[2], NT * 256) && dalloc(h, &m.log.count[0], NT) &&
+              dalloc(h, &m.log.count[1], NT) && dalloc(h, &m.log.count[2], NT) &&
+              alloc_surfels(h, h->frame, S) &&
               alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && dalloc(h, &h->d_rgb_in, 3 * P) &&
               dalloc(h, &h->d_depth_in, P) && dalloc(h, &h->d_mask, S) && dalloc(h, &h->d_icp, SSF_ICP_RECORD) &&
               dalloc(h, &h->d_best, S) && dalloc(h, &h->d_matched, S) && dalloc(h, &h->d_state, N) &&
-              dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) && dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P);
-    ok = ok && hipHostMalloc((void**)&h->h_icp, SSF_ICP_RECORD * sizeof(long long)) == hipSuccess &&
-         hipHostMalloc((void**)&h->h_cnt, sizeof(Counters)) == hipSuccess;
+              dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) && dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) &&
+              dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32) && dalloc(h, &h->d_tickets, 4) && dalloc(h, &h->d_srgb_lut, 256);
+    if (ok) {
+        ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
+             hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;
+        if (ok) { std::memset(h->mb_host, 0, sizeof(Mailbox)); ok = hipHostGetDevicePointer((void**)&h->mb_dev, h->mb_host, 0) == hipSuccess; }
+    }
     for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     if (!ok) { g_create_err = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()); ssf_destroy(h); return SSF_ERR_DEVICE; }
+    {   // gamma-expansion table for 8-bit colours, built with the same inline function the kernels use
+        float lut[256];
+        for (int c8 = 0; c8 < 256; c8++) lut[c8] = srgb_expand((float)c8 / 255.0f);
+        (void)hipMemcpy(h->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
+        m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
+    }
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->stream);
     (void)hipMemsetAsync(m.rng_counter, 0, NS * 4, h->stream);
     (void)hipMemsetAsync(m.sample_score, 0, NS * 4, h->stream);
     (void)hipMemsetAsync(m.inlier, 0, P, h->stream);
@@ -696,6 +780,8 @@ int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, in
         HCK(hipStreamSynchronize(st));
     }
     h->n_model = n; h->n_visible = n_visible; h->stamp = stamp;
+    Counters c; std::memset(&c, 0, sizeof(c)); c.n_model = n; c.n_visible = n_visible;
+    HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
     return SSF_OK;
 }
 static int copy_map(ssf_handle* h, void* dst, const void* src, size_t bytes) {
@@ -773,7 +859,7 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     HCK(hipMemcpyAsync(d_i, idx4, 16 * n, hipMemcpyHostToDevice, st));
     { TimerScope ts(h); launch_deformation(st, h->model[h->mcur], (int)n, d_np, d_nr, d_nt, d_w, d_i); }
     HCK(hipStreamSynchronize(st));
-    if (h->cfg.profile) timer_collect(&h->timer);
+    if (h->cfg.profile == 1) timer_collect(&h->timer);
     (void)hipFree(d_np); (void)hipFree(d_nr); (void)hipFree(d_nt); (void)hipFree(d_w); (void)hipFree(d_i);
     return SSF_OK;
 }
@@ -790,7 +876,41 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
     return k;
 }
 int ssf_reset_kernel_times(ssf_handle* h) { if (!h) return SSF_ERR_INVALID_ARG; h->timer.acc.clear(); return SSF_OK; }
-int ssf_set_profile(ssf_handle* h, int enable) { if (!h) return SSF_ERR_INVALID_ARG; h->cfg.profile = enable ? 1 : 0; return SSF_OK; }
+int ssf_set_profile(ssf_handle* h, int enable) { if (!h) return SSF_ERR_INVALID_ARG; h->cfg.profile = enable; return SSF_OK; }
+
+// ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
+// (bit0: skip the per-surfel math, bit1: skip the wave reduction, bit2: skip ticket + tail)
+double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
+    if (!h || !h->have_frame) return -1.0;
+    Rt T; T.R = m3_transpose(h->pose.R); T.t = negate(m3_mulv(T.R, h->pose.t));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    (void)hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    (void)hipEventRecord(e1, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 1000.0 * ms / reps;
+}
+
+// ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
+double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg) {
+    if (!h) return -1.0;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};
+    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->maps, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    (void)hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->maps, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    (void)hipEventRecord(e1, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 1000.0 * ms / reps;
+}
 
 // ---- test hooks (include/ssf_testing.h): the host solvers, so they can be pinned on a CPU box ----------
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { sym6_ldlt_solve(A, b, x); return 0; }

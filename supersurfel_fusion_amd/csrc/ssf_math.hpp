@@ -94,13 +94,13 @@ SSF_HD uint64_t f64_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b;
 SSF_HD double cbrt_spec(double a) {          // a > 0
     double y = bits_to_f64(f64_to_bits(a) / 3 + 0x2A9F7893782DA1CEull);
 #pragma unroll
-    for (int i = 0; i < 6; i++) y = (2.0 * y + a / (y * y)) / 3.0;
+    for (int i = 0; i < 4; i++) y = (2.0 * y + a / (y * y)) / 3.0;
     return y;
 }
 SSF_HD double root5_spec(double a) {         // a > 0
     double y = bits_to_f64(f64_to_bits(a) / 5 + 0x3325F8C2A7F1C29Aull);
 #pragma unroll
-    for (int i = 0; i < 7; i++) { double y2 = y * y; y = (4.0 * y + a / (y2 * y2)) / 5.0; }
+    for (int i = 0; i < 5; i++) { double y2 = y * y; y = (4.0 * y + a / (y2 * y2)) / 5.0; }
     return y;
 }
 SSF_HD float pow24_spec(float x) { double a = (double)x, t = root5_spec(a); return (float)((a * a) * (t * t)); }
@@ -116,6 +116,16 @@ SSF_HD float srgb_expand(float c) { return (c > 0.04045f) ? pow24_spec((c + 0.05
 SSF_HD float lab_f(float t) { return (t > 0.008856f) ? cbrtf_spec(t) : 7.787f * t + 16.0f / 116.0f; }
 SSF_HD V3 rgb_to_lab(V3 c) {
     float r = srgb_expand(c.x / 255.0f), g = srgb_expand(c.y / 255.0f), b = srgb_expand(c.z / 255.0f);
+    float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
+    float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
+    float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;
+    x = lab_f(x); y = lab_f(y); z = lab_f(z);
+    return v3(116.0f * y - 16.0f, 500.0f * (x - y), 200.0f * (y - z));
+}
+// same conversion for 8-bit colours: the gamma expansion of the 256 possible channel values comes
+// from a table built on the host with srgb_expand itself (identical bits), the rest is unchanged
+SSF_HD V3 rgb8_to_lab(const float* __restrict__ expand_lut, unsigned r8, unsigned g8, unsigned b8) {
+    const float r = expand_lut[r8], g = expand_lut[g8], b = expand_lut[b8];
     float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
     float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
     float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;

@@ -15,6 +15,7 @@
 //   * classify + stable 3-way partition replaces the radix sort: one pass computes the state and
 //     per-block histograms, a single-workgroup scan turns them into offsets, one pass scatters all
 //     ten SoA streams (116 B read + 116 B written per supersurfel) into the other model buffer.
+#include <stdlib.h>
 #include "ssf_device.hpp"
 
 namespace ssf {
@@ -35,15 +36,25 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 }
 
 // ---- ICP ---------------------------------------------------------------------------------------
+// One supersurfel per lane.  An inlier adds its 29 fixed-point terms with LDS integer atomics into a
+// 29 x 16 table of the workgroup (lane & 15 spreads the same-address traffic); 29 threads fold the
+// table and issue one global integer atomic each into one of SSF_ICP_REPLICAS replica records; the
+// workgroup that arrives last sums the replicas (agent-scope loads), leaves them zeroed for the next
+// launch and publishes the record to device memory and to the host-mapped mailbox.  All adds are
+// integer, so the record is independent of every one of these decompositions.
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                                              const int32_t* __restrict__ label, const float* __restrict__ plane_depth,
-                                             Rt T, long long* __restrict__ sums) {
-    long long acc[29];
-#pragma unroll
-    for (int i = 0; i < 29; i++) acc[i] = 0;
+                                             Rt T, long long* __restrict__ replicas, unsigned int* ticket,
+                                             long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
+    __shared__ int s_last;
+    __shared__ unsigned long long red[32 * 16];
+    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) red[i] = 0ull;
+    __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
+    const int slot = lane() & 15;
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
         const V3 ps = add(m3_mulv(R, ld3(model.pos, id)), t);
+        if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * 16 + slot], 1ull); continue; }
         const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
         const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
         if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) continue;
@@ -60,23 +71,66 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
         const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
         const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+        if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) atomicAdd(&red[slot], 1ull); continue; }
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = i; j < 6; j++, k++) acc[k] += (long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f);
+            for (int j = i; j < 6; j++, k++)
+                atomicAdd(&red[k * 16 + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
 #pragma unroll
-        for (int i = 0; i < 6; i++) acc[21 + i] += (long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f);
-        acc[27] += fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0);
-        acc[28] += 1;
+        for (int i = 0; i < 6; i++)
+            atomicAdd(&red[(21 + i) * 16 + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
+        atomicAdd(&red[27 * 16 + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+        atomicAdd(&red[28 * 16 + slot], 1ull);
     }
-    long long mine = 0;
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        unsigned long long tot = 0;
 #pragma unroll
-    for (int i = 0; i < 29; i++) {
-        const long long s = wsum64(acc[i]);
-        if (lane() == i) mine = s;
+        for (int sidx = 0; sidx < 16; sidx++) tot += red[threadIdx.x * 16 + sidx];
+        long long* rep = replicas + (size_t)(blockIdx.x % SSF_ICP_REPLICAS) * 32;
+        if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&rep[threadIdx.x]), tot);
     }
-    if (lane() < 29 && mine != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[lane()]), (unsigned long long)mine);
+    if (dbg & 4) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1 : 0;
+        if (s_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (s_last) {
+        // 32 x 32 replica words: every thread fetches 4 independent words (one round trip), LDS column sums
+        __shared__ long long part[SSF_ICP_REPLICAS * 32];
+        long long v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = __hip_atomic_load(&replicas[threadIdx.x + 256 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            part[threadIdx.x + 256 * j] = v[j];
+            __hip_atomic_store(&replicas[threadIdx.x + 256 * j], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            if (threadIdx.x < 29) {
+                long long tot = 0;
+                for (int r = 0; r < SSF_ICP_REPLICAS; r++) tot += part[r * 32 + threadIdx.x];
+                sums[threadIdx.x] = tot;
+                __hip_atomic_store(&mb->icp[threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // system scope
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- association ---------------------------------------------------------------------------------
@@ -356,8 +410,21 @@ __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const
         B.conf[j] = A.conf[i];
     }
 }
-__global__ void k_finish_counts(Counters* cnt) {
-    cnt->n_model = cnt->n_model - cnt->n_state2;      // nbSupersurfels -= nbRemoved, supersurfel_fusion.cu:474
+// end of the fuse stage: nbSupersurfels -= nbRemoved (supersurfel_fusion.cu:474), publish the
+// counters to the host-mapped mailbox, reset the per-frame ones for the next frame
+__global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+    Counters c = *cnt;
+    if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
+    Counters next = c;
+    next.n_inserted = 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
+    *cnt = next;
+    int* dst = reinterpret_cast<int*>(&mb->cnt);
+    const int* src = reinterpret_cast<const int*>(&c);
+    for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_lab_refresh(SurfelSoA s, int n) {
@@ -429,14 +496,18 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
 
 // ---- launchers -----------------------------------------------------------------------------------
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                const int32_t* label, const float* plane_depth, Rt T, long long* sums29) {
-    (void)hipMemsetAsync(sums29, 0, 29 * sizeof(long long), st);
-    if (n_visible <= 0) return;
+                const int32_t* label, const float* plane_depth, Rt T, long long* replicas, unsigned int* ticket,
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg) {
     ScopedKernel sk("icp_accumulate", st);
-    const int per_block = 256 * 4;       // 4 supersurfels per lane before the wave reduction
+    static int per_lane = 0;             // supersurfels per lane before the wave reduction
+    if (!per_lane) { const char* e = getenv("SSF_ICP_PER_LANE"); per_lane = e ? atoi(e) : 1; if (per_lane < 1) per_lane = 1; }
+    const int per_block = 256 * per_lane;
     int grid = (n_visible + per_block - 1) / per_block;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, frame, label, plane_depth, T, sums29);
+    if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
+    if (grid > 2048) grid = 2048;
+    const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
+    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, frame, label, plane_depth, T, replicas,
+                       ticket, sums29, mb, seq, dbg);
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                   const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
@@ -478,7 +549,9 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, Surf
         { ScopedKernel sk("reorder_scatter", st);
           hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
     }
-    hipLaunchKernelGGL(k_finish_counts, dim3(1), dim3(1), 0, st, cnt);
+}
+void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+    hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, st, cnt, shrink_by_removed, mb, seq);
 }
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n) {
     if (n <= 0) return;

@@ -1,0 +1,16 @@
+"""Ablation timing of the ICP accumulate kernel (back-to-back launches, hipEvents)."""
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import util
+from supersurfel_fusion_amd import binding, synthetic
+lib = binding.load_product()
+lib.lib.ssf_dbg_time_icp.restype = C.c_double
+lib.lib.ssf_dbg_time_icp.argtypes = [C.c_void_p, C.c_int, C.c_int]
+f = binding.Fusion(lib, util.make_cfg(lib, 640, 480, nb_supersurfels_max=1100000))
+model, nvis = synthetic.seed_model_cam0(1000000, 640, 480)
+f.set_model(model, nvis, 30)
+rgb, depth = util.frame(0, 640, 480)
+f.stage_extract(rgb, depth); f.icp_begin()
+names = {0: "full", 4: "no tail", 6: "no accumulation, no tail", 7: "loads only"}
+print("per_lane", os.environ.get("SSF_ICP_PER_LANE"), "nvis", nvis, {names[d]: "%.1f us" % lib.lib.ssf_dbg_time_icp(f.h, 200, d) for d in (0, 4, 6, 7)})
