@@ -112,12 +112,17 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
 }
 __global__ void k_merge(SegParams p, FrameMaps m, int true_buf, int with_planes) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < p.S) m.sp[k] = row_from_sums(m.sums[true_buf], k, with_planes != 0, m.sp[k]);
+    if (k >= p.S) return;
+    m.sp[k] = row_from_sums(true_buf ? m.sums[1] : m.sums[0], k, with_planes != 0, m.sp[k]);
+#pragma unroll
+    for (int j = 0; j < 13; j++) m.moments[(size_t)k * 13 + j] = 0;     // accumulators of k_render_moments
 }
 
 // ---- relabelling pass --------------------------------------------------------------------------
 #define TILE 32
 #define TW (TILE + 2)
+#define WIN_MAX 144
+static inline dim3 tile_grid(const SegParams& p) { return dim3((p.W + TILE - 1) / TILE, (p.H + TILE - 1) / TILE); }
 
 __device__ __forceinline__ void load_label_tile(int* tile, const int32_t* __restrict__ src, int X0, int Y0, int W, int H) {
     for (int i = threadIdx.x; i < TW * TW; i += blockDim.x) {
@@ -131,6 +136,35 @@ __device__ __forceinline__ int tile_boundary(const int* tile, int lx, int ly) { 
     return (tile[(ly - 1) * TW + lx] != own) + (tile[ly * TW + lx - 1] != own) + (tile[ly * TW + lx + 1] != own) +
            (tile[(ly + 1) * TW + lx] != own);
 }
+
+// Window of grid cells around a 32x32 tile.  Superpixels stay close to their seed cell, so per-tile
+// LDS tables indexed by window cell serve (almost) every label of the tile; a label that drifted out
+// of the window takes an exact global-memory slow path.
+struct CellWindow {
+    int cx0, cy0, nwx, nwy, gx; float inv_gx; bool ok;
+    __device__ __forceinline__ void init(const SegParams& p, int X0, int Y0, int max_entries) {
+        int margin = 2;
+        const int tcx0 = X0 / p.cell, tcy0 = Y0 / p.cell;
+        const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
+        while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > max_entries) margin--;
+        cx0 = tcx0 - margin; cy0 = tcy0 - margin;
+        nwx = tcx1 - tcx0 + 1 + 2 * margin; nwy = tcy1 - tcy0 + 1 + 2 * margin;
+        ok = nwx * nwy <= max_entries; gx = p.gx; inv_gx = 1.0f / (float)p.gx;
+    }
+    __device__ __forceinline__ int size() const { return ok ? nwx * nwy : 0; }
+    // window slot of a label, -1 when outside
+    __device__ __forceinline__ int slot(int l) const {
+        const int cyl = (int)(((float)l + 0.5f) * inv_gx);            // l / gx, exact for l < 2^20
+        const int wx = (l - cyl * gx) - cx0, wy = cyl - cy0;
+        return (ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
+    }
+    // label of window slot i, -1 when the cell is outside the grid
+    __device__ __forceinline__ int label_of(int i, int gy) const {
+        const int cx = cx0 + i % nwx, cy = cy0 + i / nwx;
+        return (cx >= 0 && cx < gx && cy >= 0 && cy < gy) ? cy * gx + cx : -1;
+    }
+};
+__device__ __forceinline__ void lds_add_i64(unsigned long long* p, long long v) { atomicAdd(p, (unsigned long long)v); }
 
 // the 9 inlier-only disparity sums of one pixel moved by `sign`
 __device__ __forceinline__ void disp_sums_add(const SpSums& s, int k, int x, int y, float d, int sign) {
@@ -160,6 +194,14 @@ __device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int
 // One pass (OX,OY) of the boundary relabelling: updateTPSRGB_kernel / updateTPSRGBD_kernel,
 // TPS_RGBD_kernels.cuh:235-651.  256 threads own the 256 pass pixels of a 32x32 tile.
 //
+// Labels are updated IN PLACE.  A pass touches rows y = OY (mod 2) and columns x = 0,3 (mod 4) for
+// OX = 0 or x = 1,2 (mod 4) for OX = 1, i.e. horizontally adjacent PAIRS of pixels; everything else a
+// pass pixel looks at (rows y-1, y+1, the outer neighbours of its pair) is not modified in this pass.
+// The tile grid is shifted so that a pair never straddles two tiles (X0 = 2 mod 4 for OX = 0): a
+// workgroup snapshots its tile + halo into LDS, decides from the snapshot, and is the only writer of
+// the pass pixels it read -- exactly the "all reads before any write" schedule of the oracle (A1)
+// without a second label map or a copy of the untouched pixels.
+//
 // No merge launch between passes.  The exact sums are double buffered: pass k builds the superpixel
 // rows (means, plane) it needs straight from sums[k&1], which nothing writes during the pass, and
 // applies its relabelling deltas to sums[(k+1)&1] together with the replayed log of pass k-1 (the
@@ -167,7 +209,6 @@ __device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int
 // exactly.  The rows of the superpixels around the tile (a window of grid cells) are computed by
 // the first threads of the workgroup into LDS while the label tile is being staged; the energy
 // then reads rows from LDS.  Labels that have drifted out of the window take an exact slow path.
-#define WIN_MAX 144
 template <bool RGBD>
 __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     __shared__ int tile[TW * TW];
@@ -176,14 +217,12 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    const int32_t* __restrict__ src = odd ? m.label[1] : m.label[0];
-    int32_t* __restrict__ dst = odd ? m.label[0] : m.label[1];
+    const int X0 = blockIdx.x * TILE - (OX ? 0 : 30), Y0 = blockIdx.y * TILE;  // OX = 0: tiles start at 2 (mod 4)
+    int32_t* __restrict__ lab = m.label[0];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int raw_x = blockIdx.x * 16 + tx;
-    const int lx0 = 2 * tx + ((raw_x + OX) & 1), ly0 = 2 * ty + OY;           // tile-interior coordinates
+    const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;          // pass pixels: local columns 4j+1, 4j+2
     const int x = X0 + lx0, y = Y0 + ly0;
-    const bool in_image = x < p.W && y < p.H;
+    const bool in_image = x >= 0 && x < p.W && y < p.H;
     const size_t q = in_image ? (size_t)y * p.W + x : 0;
     // operands that do not depend on the label tile: in flight while the tile is staged
     const uint32_t px = m.rgba[q];
@@ -191,7 +230,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     if (RGBD) { disp = m.disp[q]; prev_inlier = m.inlier[q]; }
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
-    const int tcx0 = X0 / p.cell, tcy0 = Y0 / p.cell;
+    const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
     const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
     while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
     const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
@@ -213,15 +252,8 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const int4 prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
     const float prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
     if (threadIdx.x == 0) s_nlog = 0;
-    if (!(dbg & 32)) load_label_tile(tile, src, X0, Y0, p.W, p.H);
+    if (!(dbg & 32)) load_label_tile(tile, lab, X0, Y0, p.W, p.H);
     __syncthreads();
-    // pixels that are not in this pass keep their label: copy them to the next map now
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
-        const int cx = i % TILE, cy = i / TILE;
-        const bool in_pass = ((cy & 1) == OY) && ((cx & 1) == ((blockIdx.x * 16 + (cx >> 1) + OX) & 1));
-        const int xx = X0 + cx, yy = Y0 + cy;
-        if (!in_pass && xx < p.W && yy < p.H && !(dbg & 16)) dst[(size_t)yy * p.W + xx] = tile[(cy + 1) * TW + cx + 1];
-    }
     const float inv_gx = 1.0f / (float)p.gx;
     auto row_of = [&](int l) -> SpRow {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
@@ -296,7 +328,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     }
     unsigned flags = 0u;
     if (in_image) {
-        dst[q] = new_index;
+        if (new_index != index) lab[q] = new_index;
         flags = (new_index != index) ? 1u : 0u;
         if (RGBD) {
             if (inlier && (!prev_inlier || index != new_index)) flags |= 2u;
@@ -333,7 +365,7 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int cur) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(p.S * p.nb_samples)) return;
     const int index = (int)(idx / (uint32_t)p.nb_samples);
-    const int32_t* __restrict__ label = m.label[cur];
+    const int32_t* __restrict__ label = m.label[0];
     uint32_t ctr = m.rng_counter[idx];
     const float radius = (float)p.cell / 2.f;
     const float cx = m.sp[index].cx, cy = m.sp[index].cy;
@@ -372,32 +404,48 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int cur) {
     m.rng_counter[idx] = ctr;
 }
 
-// evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores, one atomic per (wave,label,sample).
-// Lane k fetches sample k of the label once; the plane is then broadcast lane-to-lane.
+// evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores.  Tile kernel: the candidate
+// planes of the window's superpixels are staged in LDS, every pixel tests its label's planes and
+// counts with LDS integer atomics; the tile flushes non-zero counts with one global atomic each.
+#define EVAL_WIN 64
+#define EVAL_NS 16
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, int cur) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = q < p.W * p.H;
-    const int x = active ? q % p.W : 0, y = active ? q / p.W : 0;
-    const int label = active ? m.label[cur][q] : -1;
-    const float d = active ? m.disp[q] : 0.f;
-    const int ns = p.nb_samples;                      // <= 64 (checked in ssf_create)
-    for_each_label(label, active, [&](int l, bool in_group) {
-        float4 mine_th = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane_id() < ns) mine_th = m.samples[(size_t)l * ns + lane_id()];
-        int mine = 0;
+    __shared__ float4 w_plane[EVAL_WIN * EVAL_NS];
+    __shared__ int w_cnt[EVAL_WIN * EVAL_NS];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const int ns = p.nb_samples;
+    CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? EVAL_WIN : 0);
+    const int32_t* __restrict__ label = m.label[0];
+    for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
+        const int l = win.label_of(i / ns, p.gy);
+        w_plane[i] = l >= 0 ? m.samples[(size_t)l * ns + i % ns] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        if (x >= p.W || y >= p.H) continue;
+        const size_t q = (size_t)y * p.W + x;
+        const int l = label[q];
+        const float d = m.disp[q];
+        const int ws = win.slot(l);
         for (int k = 0; k < ns; k++) {
-            const float ta = __shfl(mine_th.x, k, 64), tb = __shfl(mine_th.y, k, 64), tc = __shfl(mine_th.z, k, 64);
-            bool pass = false;
-            if (in_group && isfinite(tc)) {
-                const float dp = (ta * (float)x + tb * (float)y) + tc;
+            const float4 th = ws >= 0 ? w_plane[ws * ns + k] : m.samples[(size_t)l * ns + k];
+            if (isfinite(th.z)) {
+                const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
                 const float dd = (d - dp) * (d - dp);
-                pass = dd < p.thresh_disp;
+                if (dd < p.thresh_disp) {
+                    if (ws >= 0) atomicAdd(&w_cnt[ws * ns + k], 1);
+                    else atomicAdd(&m.sample_score[(size_t)l * ns + k], 1);
+                }
             }
-            const int cnt = __popcll(__ballot(pass));
-            if (lane_id() == k) mine = cnt;
         }
-        if (lane_id() < ns && mine) atomicAdd(&m.sample_score[(size_t)l * ns + lane_id()], mine);
-    });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
+        const int c = w_cnt[i];
+        if (c) atomicAdd(&m.sample_score[(size_t)win.label_of(i / ns, p.gy) * ns + i % ns], c);
+    }
 }
 
 // selectSamples_kernel, TPS_RGBD_kernels.cu:435-467
@@ -420,57 +468,79 @@ __global__ void k_select_samples(SegParams p, FrameMaps m) {
     }
 }
 
-// initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190)
+// initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190).  Tile kernel:
+// the 9 exact integer sums of every inlier go into LDS accumulators of the window's superpixels and
+// are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
 __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int cur, int ransac) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = q < p.W * p.H;
-    const int x = active ? q % p.W : 0, y = active ? q / p.W : 0;
-    const int label = active ? m.label[cur][q] : -1;
-    const float d = active ? m.disp[q] : 0.f;
-    bool inl = false;
-    if (active && isfinite(d)) {
-        if (ransac) {
-            const SpRow sp = m.sp[label];
-            const float dp = (sp.ta * (float)x + sp.tb * (float)y) + sp.tc;
-            const float dd = (dp - d) * (dp - d);
-            inl = isfinite(dd) && dd < p.thresh_disp && dp > 0.f;
-        } else inl = true;
+    __shared__ unsigned long long w_acc[WIN_MAX * 9];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    CellWindow win; win.init(p, X0, Y0, WIN_MAX);
+    const int32_t* __restrict__ label = m.label[0];
+    for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) w_acc[i] = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        if (x >= p.W || y >= p.H) continue;
+        const size_t q = (size_t)y * p.W + x;
+        const int l = label[q];
+        const float d = m.disp[q];
+        bool inl = false;
+        if (isfinite(d)) {
+            if (ransac) {
+                const SpRow sp = m.sp[l];
+                const float dp = (sp.ta * (float)x + sp.tb * (float)y) + sp.tc;
+                const float dd = (dp - d) * (dp - d);
+                inl = isfinite(dd) && dd < p.thresh_disp && dp > 0.f;
+            } else inl = true;
+        }
+        m.inlier[q] = inl ? 0xff : 0;
+        if (!inl) continue;
+        const long long t6 = fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM);
+        const long long t7 = fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM);
+        const long long t8 = fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM);
+        const int ws = win.slot(l);
+        if (ws >= 0) {
+            unsigned long long* a = &w_acc[ws * 9];
+            lds_add_i64(&a[0], x); lds_add_i64(&a[1], y); lds_add_i64(&a[2], 1);
+            lds_add_i64(&a[3], (long long)x * x); lds_add_i64(&a[4], (long long)y * y); lds_add_i64(&a[5], (long long)x * y);
+            lds_add_i64(&a[6], t6); lds_add_i64(&a[7], t7); lds_add_i64(&a[8], t8);
+        } else {
+            disp_sums_add(m.sums[0], l, x, y, d, +1);
+            disp_sums_add(m.sums[1], l, x, y, d, +1);
+        }
     }
-    if (active) m.inlier[q] = inl ? 0xff : 0;
-    long long t[9];
-    t[0] = x; t[1] = y; t[2] = 1; t[3] = (long long)x * x; t[4] = (long long)y * y; t[5] = (long long)x * y;
-    t[6] = inl ? fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
-    t[7] = inl ? fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
-    t[8] = inl ? fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM) : 0;
-    for_each_label(label, inl, [&](int l, bool in_group) {
-        long long mine = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++) {
-            const long long v = wave_sum_i64(in_group ? t[j] : 0);
-            if (lane_id() == j || lane_id() == j + 16) mine = v;
+    __syncthreads();
+    for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) {
+        const long long v = (long long)w_acc[i];
+        if (v == 0) continue;
+        const int l = win.label_of(i / 9, p.gy), j = i % 9;
+        for (int b = 0; b < 2; b++) {
+            const SpSums s = b ? m.sums[1] : m.sums[0];
+            switch (j) {
+                case 0: atomicAdd(&s.dx[l], (int)v); break;
+                case 1: atomicAdd(&s.dy[l], (int)v); break;
+                case 2: atomicAdd(&s.dn[l], (int)v); break;
+                case 3: atomic_add_i64(&s.dxx[l], v); break;
+                case 4: atomic_add_i64(&s.dyy[l], v); break;
+                case 5: atomic_add_i64(&s.dxy[l], v); break;
+                case 6: atomic_add_i64(&s.dxd[l], v); break;
+                case 7: atomic_add_i64(&s.dyd[l], v); break;
+                default: atomic_add_i64(&s.dd[l], v); break;
+            }
         }
-        const SpSums s = ((lane_id() >> 4) & 1) ? m.sums[1] : m.sums[0];   // lanes 0-8 feed buffer 0, lanes 16-24 buffer 1
-        if (lane_id() < 32) switch (lane_id() & 15) {
-            case 0: atomicAdd(&s.dx[l], (int)mine); break;
-            case 1: atomicAdd(&s.dy[l], (int)mine); break;
-            case 2: atomicAdd(&s.dn[l], (int)mine); break;
-            case 3: atomic_add_i64(&s.dxx[l], mine); break;
-            case 4: atomic_add_i64(&s.dyy[l], mine); break;
-            case 5: atomic_add_i64(&s.dxy[l], mine); break;
-            case 6: atomic_add_i64(&s.dxd[l], mine); break;
-            case 7: atomic_add_i64(&s.dyd[l], mine); break;
-            case 8: atomic_add_i64(&s.dd[l], mine); break;
-            default: break;
-        }
-    });
+    }
 }
 
 // ---- plane filter: TPS_RGBD::filter, TPS_RGBD.cu:480-505; kernels TPS_RGBD_kernels.cu:510-614 ----
 // All sweeps in one single-workgroup launch; Jacobi (ping-pong X0/X1), the reference's
-// `x<gridSizeX` bound is kept and its out-of-range read of node S is skipped.
+// `x<gridSizeX` bound is kept and its out-of-range read of node S is skipped.  The 11 floats per node
+// live in LDS when S fits (dynamic LDS, 44 B per node), otherwise in the global scratch.
+extern __shared__ __attribute__((aligned(16))) float filt_lds[];
+template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m) {
     const int S = p.S;
-    float* X0 = m.filt; float* X1 = X0 + 3 * S; float* Z = X1 + 3 * S; float* px = Z + 3 * S; float* py = px + S;
+    float* base = IN_LDS ? filt_lds : m.filt;
+    float* X0 = base; float* X1 = X0 + 3 * S; float* Z = X1 + 3 * S; float* px = Z + 3 * S; float* py = px + S;
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
         const SpRow sp = m.sp[i];
         const float d0 = (sp.cx * sp.ta + sp.cy * sp.tb) + sp.tc;
@@ -478,7 +548,7 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m)
         Z[3 * i] = d0; Z[3 * i + 1] = sp.ta; Z[3 * i + 2] = sp.tb;
         px[i] = sp.cx; py[i] = sp.cy;
     }
-    __threadfence_block();
+    if (!IN_LDS) __threadfence_block();
     __syncthreads();
     const float alpha = p.filter_alpha, beta = p.filter_beta, thr = p.filter_threshold;
     float* Xa = X0; float* Xb = X1;
@@ -516,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m)
             if (sym_inverse(A, A1)) Xn = sym_mul(A1, R);
             Xb[3 * idx] = Xn.x; Xb[3 * idx + 1] = Xn.y; Xb[3 * idx + 2] = Xn.z;
         }
-        __threadfence_block();
+        if (!IN_LDS) __threadfence_block();
         __syncthreads();
         float* t = Xa; Xa = Xb; Xb = t;
     }
@@ -532,57 +602,63 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m)
 // ---- plane depth + supersurfel moments -----------------------------------------------------------
 // renderDepthImage_kernel (TPS_RGBD_kernels.cu:469-508) fused with computeSupersurfelCoeffs
 // (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
-// boundary test and the 13 moment sums (fixed point 2^24, exact).
+// boundary test and the 13 moment sums (fixed point 2^24, exact), which are accumulated with LDS
+// integer atomics per window superpixel and flushed once per tile.
 __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m, int cur) {
     __shared__ int tile[TW * TW];
+    __shared__ SpRow w_row[WIN_MAX];
+    __shared__ unsigned long long w_acc[WIN_MAX * 13];
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    load_label_tile(tile, m.label[cur], X0, Y0, p.W, p.H);
+    CellWindow win; win.init(p, X0, Y0, WIN_MAX);
+    for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
+        const int l = win.label_of(i, p.gy);
+        if (l >= 0) w_row[i] = m.sp[l];
+    }
+    for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) w_acc[i] = 0ull;
+    load_label_tile(tile, m.label[0], X0, Y0, p.W, p.H);
     __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {     // uniform trip count (4)
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
         const int lx = i % TILE, ly = i / TILE;
         const int x = X0 + lx, y = Y0 + ly;
-        const bool inside = x < p.W && y < p.H;
-        int label = -1; bool valid = false;
-        long long t[13];
+        if (x >= p.W || y >= p.H) continue;
+        const size_t q = (size_t)y * p.W + x;
+        const int label = tile[(ly + 1) * TW + lx + 1];
+        const int ws = win.slot(label);
+        const SpRow sp = ws >= 0 ? w_row[ws] : m.sp[label];
+        const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
+        const float depth = 1.f / disp;
+        m.plane_depth[q] = depth;
+        const int bound = tile_boundary(tile, lx + 1, ly + 1);
+        if (!(m.inlier[q] && isfinite(depth) && depth > 0.0f && bound == 0)) continue;
+        const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
+        const uint32_t px = m.rgba[q];
+        const V3 lab = rgb8_to_lab(m.srgb_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
+        const Sym3 c = sym_outer(pos);
+        const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
+        if (ws >= 0) {
 #pragma unroll
-        for (int j = 0; j < 13; j++) t[j] = 0;
-        if (inside) {
-            const size_t q = (size_t)y * p.W + x;
-            label = tile[(ly + 1) * TW + lx + 1];
-            const SpRow sp = m.sp[label];
-            const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
-            const float depth = 1.f / disp;
-            m.plane_depth[q] = depth;
-            const int bound = tile_boundary(tile, lx + 1, ly + 1);
-            if (m.inlier[q] && isfinite(depth) && depth > 0.0f && bound == 0) {
-                valid = true;
-                const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
-                const uint32_t px = m.rgba[q];
-                const V3 lab = rgb8_to_lab(m.srgb_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
-                const Sym3 c = sym_outer(pos);
-                const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
+            for (int j = 0; j < 12; j++) lds_add_i64(&w_acc[ws * 13 + j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
+            lds_add_i64(&w_acc[ws * 13 + 12], 1);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 12; j++) t[j] = fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM);
-                t[12] = 1;
-            }
+            for (int j = 0; j < 12; j++) atomic_add_i64(&m.moments[(size_t)label * 13 + j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
+            atomic_add_i64(&m.moments[(size_t)label * 13 + 12], 1);
         }
-        for_each_label(label, valid, [&](int l, bool in_group) {
-            long long mine = 0;
-#pragma unroll
-            for (int j = 0; j < 13; j++) {
-                const long long v = wave_sum_i64(in_group ? t[j] : 0);
-                if (lane_id() == j) mine = v;
-            }
-            if (lane_id() < 13) atomic_add_i64(&m.moments[(size_t)l * 13 + lane_id()], mine);
-        });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) {
+        const long long v = (long long)w_acc[i];
+        if (v != 0) atomic_add_i64(&m.moments[(size_t)win.label_of(i / 13, p.gy) * 13 + i % 13], v);
     }
 }
 
 // computeSupersurfels, supersurfel_fusion_kernels.cu:169-224 (+ the MOD mask hook)
 __global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp,
-                                   const uint8_t* __restrict__ dyn_mask) {
+                                   const uint8_t* __restrict__ dyn_mask, unsigned long long* __restrict__ best,
+                                   uint8_t* __restrict__ matched) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.S) return;
+    best[k] = 0xFFFFFFFFFFFFFFFFull; matched[k] = 0;         // association tables of this frame (findBestMatches init)
     const long long* a = &m.moments[(size_t)k * 13];
     const double inv = 1.0 / SSF_MOM_SCALE;
     float sum[12];
@@ -631,7 +707,6 @@ __global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-static inline dim3 tile_grid(const SegParams& p) { return dim3((p.W + TILE - 1) / TILE, (p.H + TILE - 1) / TILE); }
 
 void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m) {
     ScopedKernel sk("ingest", st);
@@ -643,36 +718,41 @@ void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf
 }
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg) {
     ScopedKernel sk(rgbd ? "update_pass_rgbd" : "update_pass_rgb", st);
-    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, tile_grid(p), dim3(256), 0, st, p, m, k, ox, oy, dbg);
-    else hipLaunchKernelGGL(k_update_pass<false>, tile_grid(p), dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    // OX = 0: tiles shifted left by 30: [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
+    // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.
+    dim3 grid = tile_grid(p);
+    grid.x = (p.W + 30 + TILE - 1) / TILE;
+    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    else hipLaunchKernelGGL(k_update_pass<false>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
 void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
-    const int P = p.W * p.H;
     { ScopedKernel sk("init_samples", st);
       hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, cur); }
     { ScopedKernel sk("eval_samples", st);
-      hipLaunchKernelGGL(k_eval_samples, dim3((P + 255) / 256), dim3(256), 0, st, p, m, cur); }
+      hipLaunchKernelGGL(k_eval_samples, tile_grid(p), dim3(256), 0, st, p, m, cur); }
     { ScopedKernel sk("select_samples", st);
       hipLaunchKernelGGL(k_select_samples, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m); }
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac) {
     ScopedKernel sk("init_disp", st);
-    const int P = p.W * p.H;
-    hipLaunchKernelGGL(k_init_disp, dim3((P + 255) / 256), dim3(256), 0, st, p, m, cur, ransac ? 1 : 0);
+    hipLaunchKernelGGL(k_init_disp, tile_grid(p), dim3(256), 0, st, p, m, cur, ransac ? 1 : 0);
 }
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m) {
     ScopedKernel sk("plane_filter", st);
-    hipLaunchKernelGGL(k_plane_filter, dim3(1), dim3(1024), 0, st, p, m);
+    const size_t lds = (size_t)p.S * 11 * sizeof(float);
+    const int threads = p.S >= 1024 ? 1024 : ((p.S + 63) / 64) * 64;
+    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(1), dim3(threads), lds, st, p, m);
+    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(1), dim3(1024), 0, st, p, m);
 }
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur) {
-    (void)hipMemsetAsync(m.moments, 0, (size_t)p.S * 13 * sizeof(long long), st);
     ScopedKernel sk("render_moments", st);
     hipLaunchKernelGGL(k_render_moments, tile_grid(p), dim3(256), 0, st, p, cam, m, cur);
 }
 void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
-                             float zmax, int stamp, const uint8_t* dynamic_mask) {
+                             float zmax, int stamp, const uint8_t* dynamic_mask, unsigned long long* best, uint8_t* matched) {
     ScopedKernel sk("finalize_surfels", st);
-    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 127) / 128), dim3(128), 0, st, p, m, frame, zmin, zmax, stamp, dynamic_mask);
+    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 63) / 64), dim3(64), 0, st, p, m, frame, zmin, zmax, stamp, dynamic_mask,
+                       best, matched);
 }
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out) {
     hipLaunchKernelGGL(k_boundary_map, tile_grid(p), dim3(256), 0, st, p, label, out);

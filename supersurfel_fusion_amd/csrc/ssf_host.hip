@@ -315,8 +315,8 @@ static int enqueue_segmentation(ssf_handle* h, int* cur_out) {
             launch_update_pass(st, p, h->maps, k, ox[q], oy[q], false); k++;
         }
     launch_merge(st, p, h->maps, k & 1, false);           // sums[k&1] holds the exact sums after k passes
-    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, k & 1); launch_init_disp(st, p, h->maps, k & 1, true); }
-    else launch_init_disp(st, p, h->maps, k & 1, false);
+    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, 0); launch_init_disp(st, p, h->maps, 0, true); }
+    else launch_init_disp(st, p, h->maps, 0, false);
     if (k >= limit || h->cfg.seg_iter - h->cfg.seg_iter / 2 <= 0) launch_merge(st, p, h->maps, k & 1, true);
     for (int it = h->cfg.seg_iter / 2; it < h->cfg.seg_iter; it++)
         for (int q = 0; q < 4; q++) {
@@ -325,8 +325,8 @@ static int enqueue_segmentation(ssf_handle* h, int* cur_out) {
         }
     launch_merge(st, p, h->maps, k & 1, true);
     launch_plane_filter(st, p, h->maps);
-    launch_render_moments(st, p, h->cam, h->maps, k & 1);
-    *cur_out = k & 1;
+    launch_render_moments(st, p, h->cam, h->maps, 0);
+    *cur_out = 0;                                          // labels are relabelled in place (single map)
     return SSF_OK;
 }
 
@@ -361,7 +361,7 @@ static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
     } else
         enqueue_segmentation(h, &cur);
     h->cur = cur;
-    launch_finalize_surfels(st, h->seg, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask);
+    launch_finalize_surfels(st, h->seg, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask, h->d_best, h->d_matched);
     HCK(hipGetLastError());
     h->have_frame = true;
     return SSF_OK;
@@ -607,7 +607,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
     FrameMaps& m = h->maps; SpSums& s = m.sums[0]; SpSums& s2 = m.sums[1];
-    const size_t NT = (size_t)((W + 31) / 32) * ((H + 31) / 32);   // relabelling tiles
+    const size_t NT = (size_t)((W + 30 + 31) / 32) * ((H + 31) / 32);   // relabelling tiles (shifted grid has one more column)
     bool ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.label[1], P) &&
               dalloc(h, &m.inlier, P) && dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) &&
               dalloc(h, &m.sample_score, NS) && dalloc(h, &m.rng_counter, NS) && dalloc(h, &m.moments, 13 * S) &&

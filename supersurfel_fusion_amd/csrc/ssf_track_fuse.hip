@@ -512,8 +512,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                   const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S) {
-    (void)hipMemsetAsync(best, 0xFF, (size_t)S * 8, st);
-    (void)hipMemsetAsync(matched, 0, (size_t)S, st);
+    (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, frame, label,
