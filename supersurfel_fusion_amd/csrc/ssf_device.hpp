@@ -75,10 +75,14 @@ struct FrameMaps {
 // Host-mapped (fine-grained, coherent) mailbox: the last workgroup of the ICP reduction and of the
 // fuse stage publish their small results here and then store a sequence number; the host polls the
 // sequence number instead of paying a DMA copy + hipStreamSynchronize per ICP iteration / frame.
+// Each record carries a checksum (sum of the payload words + sequence number) so that the host can
+// detect a torn read without the device paying a system-scope cache write-back per publication.
 struct Mailbox {
     long long icp[29];
+    unsigned long long icp_check;
     unsigned long long icp_seq;
     Counters cnt;
+    unsigned long long cnt_check;
     unsigned long long cnt_seq;
 };
 #define SSF_ICP_REPLICAS 32

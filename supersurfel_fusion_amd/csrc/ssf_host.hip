@@ -400,7 +400,15 @@ static int icp_accumulate(ssf_handle* h, bool to_host) {
     if (to_host) {
         int rc = wait_seq(h, &h->mb_host->icp_seq, seq);
         if (rc) return rc;
-        for (int i = 0; i < SSF_ICP_RECORD; i++) h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
+        for (int attempt = 0;; attempt++) {          // checksum guards against a torn record
+            unsigned long long check = seq;
+            for (int i = 0; i < SSF_ICP_RECORD; i++) {
+                h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
+                check += (unsigned long long)h->h_icp_local[i];
+            }
+            if (check == __atomic_load_n(&h->mb_host->icp_check, __ATOMIC_ACQUIRE)) break;
+            if (attempt > 100000) { h->err = "ICP mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
+        }
         h->h_icp = h->h_icp_local;
     }
     return SSF_OK;
@@ -495,7 +503,18 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     HCK(hipGetLastError());
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
     if (rc) return rc;
-    const Counters c = *const_cast<const Counters*>(&h->mb_host->cnt);
+    Counters c;
+    for (int attempt = 0;; attempt++) {
+        unsigned long long check = seq;
+        const int* srcw = reinterpret_cast<const int*>(&h->mb_host->cnt);
+        int* dstw = reinterpret_cast<int*>(&c);
+        for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) {
+            dstw[i] = __atomic_load_n(&srcw[i], __ATOMIC_RELAXED);
+            check += (unsigned long long)(unsigned int)dstw[i];
+        }
+        if (check == __atomic_load_n(&h->mb_host->cnt_check, __ATOMIC_ACQUIRE)) break;
+        if (attempt > 100000) { h->err = "counter mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
+    }
     h->n_model = c.n_model; h->n_visible = c.n_visible;
     if (out) {
         std::memset(out, 0, sizeof(*out));

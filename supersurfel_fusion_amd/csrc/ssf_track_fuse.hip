@@ -95,15 +95,14 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     if (dbg & 4) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // The replica updates above are device-scope atomic RMWs and have completed (vmcnt(0) + barrier)
+    // before this workgroup takes its ticket; the last workgroup reads them back with device-scope
+    // atomic loads.  Everything exchanged between workgroups is an atomic at the coherence point, so
+    // no cache write-back / invalidate fence is needed.
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1) ? 1 : 0;
-        if (s_last) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_last) {
@@ -119,16 +118,16 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         }
         __syncthreads();
         if (threadIdx.x < 64) {
+            long long tot = 0;
             if (threadIdx.x < 29) {
-                long long tot = 0;
                 for (int r = 0; r < SSF_ICP_REPLICAS; r++) tot += part[r * 32 + threadIdx.x];
                 sums[threadIdx.x] = tot;
                 __hip_atomic_store(&mb->icp[threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // system scope
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long check = (unsigned long long)wsum64(tot) + seq;
+            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // payload write-through stores acknowledged
+            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -420,11 +419,14 @@ __global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* 
     *cnt = next;
     int* dst = reinterpret_cast<int*>(&mb->cnt);
     const int* src = reinterpret_cast<const int*>(&c);
-    for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long check = seq;
+    for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) {
+        __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        check += (unsigned long long)(unsigned int)src[i];
+    }
+    __hip_atomic_store(&mb->cnt_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // payload write-through stores acknowledged
+    __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_lab_refresh(SurfelSoA s, int n) {
