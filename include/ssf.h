@@ -103,6 +103,11 @@ typedef struct ssf_config {
     void* stream;              /* hipStream_t to launch on, NULL = library-owned stream */
     int   rank, nranks;        /* model shard of this handle; 0/1 = unsharded */
     float shard_tile;          /* world-space tile edge (m) hashed to the owning rank, 0.5 */
+    int   depth_prefilter;     /* 1: run the bilateral depth pre-filter inside process_frame, as the reference's
+                                  processFrame does (supersurfel_fusion.cu:180); 0 (default): the caller passes
+                                  the depth it wants segmented */
+    float prefilter_sigma_color;   /* 0.03 m  */
+    float prefilter_sigma_space;   /* 4.5 px  */
     int   profile;             /* 0: none (fastest); 2: stage_ms split (one event synchronise per frame);
                                   1: additionally bracket every kernel with hipEvents (ssf_get_kernel_times) */
 } ssf_config;
@@ -202,6 +207,12 @@ int ssf_get_superpixels(ssf_handle* h, float* out /* 9*S */);
 /* Device-resident views (product only; valid until the next call on the handle). */
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_model);
 int ssf_export_model_txt(ssf_handle* h, const char* path);
+
+/* ---- "next" row: depth pre-filter ----------------------------------------------------------- */
+/* Out-of-place restatement of cv::cuda::bilateralFilter(depth, depth, -1, sigma_color, sigma_space)
+ * (supersurfel_fusion.cu:180; OpenCV 3.4 cudaimgproc, third party): kernel radius = round(1.5 *
+ * sigma_space), circular support, BORDER_REFLECT_101.  depth_in / depth_out: H*W float32. */
+int ssf_bilateral_filter(ssf_handle* h, const void* depth_in, void* depth_out, int on_device);
 
 /* ---- "next" row: loop-closure deformation apply ---------------------------------------------- */
 /* nodes: positions 3*m, rotations 9*m (row-major), translations 3*m; per model surfel 4 weights

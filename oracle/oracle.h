@@ -100,6 +100,7 @@ struct State {
 // oracle_extract.cpp
 void extract(State& s, const uint8_t* rgb, const float* depth, const uint8_t* dynamic_mask);
 int  boundary_at(const State& s, const std::vector<int32_t>& lab, int x, int y);
+void bilateral_filter(const float* in, float* out, int W, int H, float sigma_color, float sigma_space);
 // oracle_track_fuse.cpp
 void icp_begin(State& s, const float* prior);
 void icp_accumulate(State& s, int64_t* sums);

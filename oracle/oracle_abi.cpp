@@ -36,6 +36,7 @@ void ssf_default_config(ssf_config* c) {      // supersurfel_fusion.hpp:46-74 de
     c->conf_thresh = 2500.f; c->nb_supersurfels_max = 50000; c->icp_iter = 10; c->icp_cov_thresh = 0.04;
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
+    c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
 }
 
 int ssf_create(const ssf_config* cfg, ssf_handle** out) {
@@ -237,6 +238,12 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
                           const float* w4, const int32_t* idx4) {
     if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
     apply_deformation(h->s, np, nr, nt, m, w4, idx4); return SSF_OK;
+}
+int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device) {
+    (void)on_device;
+    if (!h || !in || !out) return SSF_ERR_INVALID_ARG;
+    bilateral_filter((const float*)in, (float*)out, h->s.W, h->s.H, h->s.cfg.prefilter_sigma_color, h->s.cfg.prefilter_sigma_space);
+    return SSF_OK;
 }
 int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k) {
     (void)h; (void)names; (void)ms; (void)calls; (void)max_k; return 0;

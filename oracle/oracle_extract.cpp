@@ -407,9 +407,49 @@ static void generate_supersurfels(State& s) {
     }
 }
 
+// Depth pre-filter: cv::cuda::bilateralFilter(depth, depth, -1, 0.03, 4.5), supersurfel_fusion.cu:180.
+// OpenCV (3.4, cudaimgproc/src/cuda/bilateral_filter.cu) is a third-party dependency that is not
+// vendored by the reference: its published algorithm is restated here -- radius = round(1.5 sigma_s),
+// taps inside the circle of that radius in row-major order, weight = exp(-d2/(2 sigma_s^2) -
+// dv^2/(2 sigma_c^2)), BORDER_REFLECT_101, result = sum(w v)/sum(w) -- out of place (the reference's
+// in-place call races with itself).  PARITY UNPINNED (no OpenCV here, no reference vector).
+static inline int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
+    return i;
+}
+void bilateral_filter(const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
+    int radius = (int)std::lrint((double)sigma_space * 1.5);
+    if (radius < 1) radius = 1;
+    const float r2 = (float)(radius * radius);
+    const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float center = in[(size_t)y * W + x];
+            float sum1 = 0.f, sum2 = 0.f;
+            for (int cy = y - radius; cy <= y + radius; cy++)
+                for (int cx = x - radius; cx <= x + radius; cx++) {
+                    const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+                    if (space2 > r2) continue;
+                    const float v = in[(size_t)reflect101(cy, H) * W + reflect101(cx, W)];
+                    const float dv = fabsf(v - center);
+                    const float w = spec_exp_neg(space2 * ss + (dv * dv) * sc);
+                    sum1 = sum1 + w * v;
+                    sum2 = sum2 + w;
+                }
+            out[(size_t)y * W + x] = sum1 / sum2;
+        }
+}
+
 void extract(State& s, const uint8_t* rgb, const float* depth, const uint8_t* dynamic_mask) {
     const ssf_config& c = s.cfg;
     const int W = s.W, H = s.H;
+    std::vector<float> filtered;
+    if (c.depth_prefilter) {                                                    // supersurfel_fusion.cu:180
+        filtered.resize((size_t)W * H);
+        bilateral_filter(depth, filtered.data(), W, H, c.prefilter_sigma_color, c.prefilter_sigma_space);
+        depth = filtered.data();
+    }
     // ingest: cvtColor BGR2BGRA keeps channel order (TPS_RGBD.cu:136), depth2disp32F_kernel
     // (TPS_RGBD_kernels.cu:278-296), initSuperpixelsRGBD_kernel (:61-110)
     for (int k = 0; k < s.S; k++) { SpSums z{}; s.sums[k] = z; Superpixel zs{}; s.sp[k] = zs; }

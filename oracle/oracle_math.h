@@ -149,6 +149,21 @@ static inline float spec_pow_inv24(float x) {
 }
 static inline float spec_cbrtf(float x) { return (float)spec_cbrt((double)x); }
 
+// exp(x) for x <= 0 as a specified sequence of IEEE double operations (libm/OCML exp are not
+// bit-reproducible across platforms): x = k ln2 + r, degree-11 Taylor polynomial in r, exact 2^k.
+static inline float spec_exp_neg(float x) {
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 0.0f) x = 0.0f;
+    const double xd = (double)x;
+    const double kf = std::rint(xd * 1.4426950408889634);
+    const double r = xd - kf * 0.6931471805599453;
+    double p = 1.0;
+    for (int i = 11; i >= 1; i--) p = 1.0 + (r / (double)i) * p;
+    const uint64_t bits = (uint64_t)(1023 + (int)kf) << 52;
+    double two_k; std::memcpy(&two_k, &bits, 8);
+    return (float)(p * two_k);
+}
+
 // vector_math.cuh:566-585
 static inline f3 rgbToLab(f3 c) {
     float r = c.x / 255.0f, g = c.y / 255.0f, b = c.z / 255.0f;

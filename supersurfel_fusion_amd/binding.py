@@ -28,7 +28,8 @@ class SsfConfig(C.Structure):
         ("icp_iter", C.c_int), ("icp_cov_thresh", C.c_double),
         ("rng_seed", C.c_uint64), ("icp_force_iters", C.c_int), ("device_id", C.c_int),
         ("stream", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
-        ("shard_tile", C.c_float), ("profile", C.c_int),
+        ("shard_tile", C.c_float), ("depth_prefilter", C.c_int), ("prefilter_sigma_color", C.c_float),
+        ("prefilter_sigma_space", C.c_float), ("profile", C.c_int),
     ]
 
 
@@ -61,7 +62,7 @@ ABI_SYMBOLS = [
     "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
     "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
-    "ssf_reset_kernel_times", "ssf_set_profile",
+    "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -116,6 +117,7 @@ class Library:
         L.ssf_get_kernel_times.argtypes = [vp, vp, vp, vp, C.c_int]
         L.ssf_reset_kernel_times.argtypes = [vp]
         L.ssf_set_profile.argtypes = [vp, C.c_int]
+        L.ssf_bilateral_filter.argtypes = [vp, vp, vp, C.c_int]
 
     @property
     def backend(self):
@@ -310,6 +312,12 @@ class Fusion:
              np.ascontiguousarray(idx4, np.int32)]
         self._ck(self.L.lib.ssf_apply_deformation(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), len(a[0]),
                                                   _ptr(a[3]), _ptr(a[4])), "ssf_apply_deformation")
+
+    def bilateral_filter(self, depth):
+        depth = np.ascontiguousarray(depth, np.float32)
+        out = np.zeros_like(depth)
+        self._ck(self.L.lib.ssf_bilateral_filter(self.h, _ptr(depth), _ptr(out), 0), "ssf_bilateral_filter")
+        return out
 
     def kernel_times(self, max_k=64):
         names = (C.c_char_p * max_k)()

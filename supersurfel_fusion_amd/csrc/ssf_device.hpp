@@ -98,6 +98,7 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m);
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur);
 void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
                              float zmax, int stamp, const uint8_t* dynamic_mask, unsigned long long* best, uint8_t* matched);
+void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space);
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
 
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------

@@ -706,6 +706,58 @@ __global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t
     }
 }
 
+// ---- depth pre-filter ("next" row f3) ---------------------------------------------------------------
+// Out-of-place restatement of cv::cuda::bilateralFilter(depth, depth, -1, sigma_color, sigma_space)
+// (supersurfel_fusion.cu:180; OpenCV cudaimgproc is third party, algorithm as published): circular
+// support of radius round(1.5 sigma_space), BORDER_REFLECT_101, taps in row-major order.  The tile and
+// its halo are staged in LDS once; every pixel then reads its (2r+1)^2 window from LDS.
+#define BIL_RMAX 16
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
+    return i;
+}
+__global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ in, float* __restrict__ out, int W, int H,
+                                                   int radius, float ss, float sc) {
+    __shared__ float tile[(TILE + 2 * BIL_RMAX) * (TILE + 2 * BIL_RMAX)];
+    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    const int tw = TILE + 2 * radius;
+    const bool staged = radius <= BIL_RMAX;
+    if (staged)
+        for (int i = threadIdx.x; i < tw * tw; i += blockDim.x) {
+            const int gx = reflect101(X0 - radius + i % tw, W), gy = reflect101(Y0 - radius + i / tw, H);
+            tile[i] = in[(size_t)gy * W + gx];
+        }
+    __syncthreads();
+    const float r2 = (float)(radius * radius);
+    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+        const int lx = i % TILE, ly = i / TILE;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (x >= W || y >= H) continue;
+        const float center = staged ? tile[(ly + radius) * tw + lx + radius] : in[(size_t)y * W + x];
+        float sum1 = 0.f, sum2 = 0.f;
+        for (int dy = -radius; dy <= radius; dy++)
+            for (int dx = -radius; dx <= radius; dx++) {
+                const float space2 = (float)(dx * dx + dy * dy);
+                if (space2 > r2) continue;
+                const float v = staged ? tile[(ly + radius + dy) * tw + lx + radius + dx]
+                                       : in[(size_t)reflect101(y + dy, H) * W + reflect101(x + dx, W)];
+                const float dv = fabsf(v - center);
+                const float w = exp_neg_spec(space2 * ss + (dv * dv) * sc);
+                sum1 = sum1 + w * v;
+                sum2 = sum2 + w;
+            }
+        out[(size_t)y * W + x] = sum1 / sum2;
+    }
+}
+void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
+    ScopedKernel sk("bilateral_prefilter", st);
+    int radius = (int)lrint((double)sigma_space * 1.5);
+    if (radius < 1) radius = 1;
+    const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
+    hipLaunchKernelGGL(k_bilateral, dim3((W + TILE - 1) / TILE, (H + TILE - 1) / TILE), dim3(256), 0, st, in, out, W, H, radius, ss, sc);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 
 void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m) {

@@ -111,6 +111,19 @@ SSF_HD float pow_inv24_spec(float x) {
 }
 SSF_HD float cbrtf_spec(float x) { return (float)cbrt_spec((double)x); }
 
+// exp(x), x <= 0: k = rint(x / ln2), r = x - k ln2, degree-11 Taylor in r (Horner, double), exact 2^k
+SSF_HD float exp_neg_spec(float x) {
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 0.0f) x = 0.0f;
+    const double xd = (double)x;
+    const double kf = rint(xd * 1.4426950408889634);
+    const double r = xd - kf * 0.6931471805599453;
+    double p = 1.0;
+#pragma unroll
+    for (int i = 11; i >= 1; i--) p = 1.0 + (r / (double)i) * p;
+    return (float)(p * bits_to_f64((uint64_t)(1023 + (int)kf) << 52));
+}
+
 // sRGB(0..255) -> CIE Lab, vector_math.cuh:566-585
 SSF_HD float srgb_expand(float c) { return (c > 0.04045f) ? pow24_spec((c + 0.055f) / 1.055f) : c / 12.92f; }
 SSF_HD float lab_f(float t) { return (t > 0.008856f) ? cbrtf_spec(t) : 7.787f * t + 16.0f / 116.0f; }
