@@ -169,8 +169,15 @@ def main():
     roofline = None
     if dom is not None and "achieved_GBs" in per_kernel[dom]:
         ach = per_kernel[dom]["achieved_GBs"]
+        # HBM traffic of the kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KB; separate rocprofv3
+        # --pmc passes of this same command, recorded in profiles/pmc_r01.json -- bench.py cannot run the
+        # profiler on itself)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=None, avg_launch_us=per_kernel[dom]["avg_us"],
+                        traffic=traffic, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
 
     # ---- CPU baseline: the oracle (single-threaded port), rank 0, bounded sample --------------------

@@ -191,6 +191,41 @@ __device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int
     if (flags & 4u) disp_sums_add(s, from, x, y, d, -1);
 }
 
+// Field order of the per-window-superpixel LDS accumulators of a pass (15 exact integer sums).
+enum { F_SX, F_SY, F_SR, F_SG, F_SB, F_N, F_DX, F_DY, F_DN, F_DXX, F_DYY, F_DXY, F_DXD, F_DYD, F_DD, F_COUNT };
+__device__ __forceinline__ void lds_rgb(unsigned long long* a, int sign, int x, int y, uint32_t rgbf) {
+    lds_add_i64(&a[F_SX], sign * x); lds_add_i64(&a[F_SY], sign * y);
+    lds_add_i64(&a[F_SR], sign * (int)(rgbf & 255u)); lds_add_i64(&a[F_SG], sign * (int)((rgbf >> 8) & 255u));
+    lds_add_i64(&a[F_SB], sign * (int)((rgbf >> 16) & 255u)); lds_add_i64(&a[F_N], sign);
+}
+__device__ __forceinline__ void lds_disp(unsigned long long* a, int sign, int x, int y, float d) {
+    lds_add_i64(&a[F_DX], sign * x); lds_add_i64(&a[F_DY], sign * y); lds_add_i64(&a[F_DN], sign);
+    lds_add_i64(&a[F_DXX], (long long)sign * x * x); lds_add_i64(&a[F_DYY], (long long)sign * y * y);
+    lds_add_i64(&a[F_DXY], (long long)sign * x * y);
+    lds_add_i64(&a[F_DXD], sign * fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    lds_add_i64(&a[F_DYD], sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    lds_add_i64(&a[F_DD], sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
+}
+__device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, long long v) {
+    switch (field) {
+        case F_SX: atomicAdd(&s.sx[l], (int)v); break;
+        case F_SY: atomicAdd(&s.sy[l], (int)v); break;
+        case F_SR: atomicAdd(&s.sr[l], (int)v); break;
+        case F_SG: atomicAdd(&s.sg[l], (int)v); break;
+        case F_SB: atomicAdd(&s.sb[l], (int)v); break;
+        case F_N: atomicAdd(&s.n[l], (int)v); break;
+        case F_DX: atomicAdd(&s.dx[l], (int)v); break;
+        case F_DY: atomicAdd(&s.dy[l], (int)v); break;
+        case F_DN: atomicAdd(&s.dn[l], (int)v); break;
+        case F_DXX: atomic_add_i64(&s.dxx[l], v); break;
+        case F_DYY: atomic_add_i64(&s.dyy[l], v); break;
+        case F_DXY: atomic_add_i64(&s.dxy[l], v); break;
+        case F_DXD: atomic_add_i64(&s.dxd[l], v); break;
+        case F_DYD: atomic_add_i64(&s.dyd[l], v); break;
+        default: atomic_add_i64(&s.dd[l], v); break;
+    }
+}
+
 // One pass (OX,OY) of the boundary relabelling: updateTPSRGB_kernel / updateTPSRGBD_kernel,
 // TPS_RGBD_kernels.cuh:235-651.  256 threads own the 256 pass pixels of a 32x32 tile.
 //
@@ -213,6 +248,7 @@ template <bool RGBD>
 __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     __shared__ int tile[TW * TW];
     __shared__ SpRow w_row[WIN_MAX];
+    __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];   // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
@@ -252,14 +288,37 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const int4 prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
     const float prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
     if (threadIdx.x == 0) s_nlog = 0;
+    if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
     if (!(dbg & 32)) load_label_tile(tile, lab, X0, Y0, p.W, p.H);
     __syncthreads();
     const float inv_gx = 1.0f / (float)p.gx;
-    auto row_of = [&](int l) -> SpRow {
+    auto slot_of = [&](int l) -> int {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
         const int wx = (l - cyl * p.gx) - wcx0, wy = cyl - wcy0;
-        if (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) return w_row[wy * nwx + wx];
+        return (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
+    };
+    auto row_of = [&](int l) -> SpRow {
+        const int ws = slot_of(l);
+        if (ws >= 0) return w_row[ws];
         return row_from_sums(sr, l, RGBD, zero_row);          // drifted out of the window: exact slow path
+    };
+    // sum deltas of one relabelled pixel: LDS accumulators of the window, global atomics outside it
+    auto add_delta = [&](int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {
+        const unsigned fl = rgbf >> 24;
+        const int wf = slot_of(from), wt = slot_of(to);
+        if (fl & 1u) {
+            if (wf >= 0) lds_rgb(&w_acc[wf * F_COUNT], -1, px_x, px_y, rgbf);
+            if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
+            if (wf < 0 || wt < 0) {
+                const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
+                if (wf < 0) { atomicAdd(&sw.sx[from], -px_x); atomicAdd(&sw.sy[from], -px_y); atomicAdd(&sw.sr[from], -ir);
+                              atomicAdd(&sw.sg[from], -ig); atomicAdd(&sw.sb[from], -ib); atomicAdd(&sw.n[from], -1); }
+                if (wt < 0) { atomicAdd(&sw.sx[to], px_x); atomicAdd(&sw.sy[to], px_y); atomicAdd(&sw.sr[to], ir);
+                              atomicAdd(&sw.sg[to], ig); atomicAdd(&sw.sb[to], ib); atomicAdd(&sw.n[to], 1); }
+            }
+        }
+        if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
+        if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
     };
     if (dbg & 2) return;
     const int lx = lx0 + 1, ly = ly0 + 1;                                     // halo coordinates
@@ -338,7 +397,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     }
     if (flags) {
         const uint32_t rgbf = (px & 0x00FFFFFFu) | (flags << 24);
-        apply_pixel_delta(sw, index, new_index, x, y, rgbf, disp);
+        add_delta(index, new_index, x, y, rgbf, disp);
         int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
         float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
         const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < 256 by construction
@@ -347,8 +406,15 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     }
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
     if (threadIdx.x < n_prev && !(dbg & 8))
-        apply_pixel_delta(sw, prev_ent.x, prev_ent.y, prev_ent.z & 0xFFFF, (prev_ent.z >> 16) & 0xFFFF, (uint32_t)prev_ent.w, prev_disp);
+        add_delta(prev_ent.x, prev_ent.y, prev_ent.z & 0xFFFF, (prev_ent.z >> 16) & 0xFFFF, (uint32_t)prev_ent.w, prev_disp);
     __syncthreads();
+    if (window_ok)
+        for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) {
+            const long long v = (long long)w_acc[i];
+            if (v == 0) continue;
+            const int wi = i / F_COUNT;
+            flush_field(sw, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i % F_COUNT, v);
+        }
     if (threadIdx.x == 0) {
         unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
         ccnt[tile_id] = s_nlog;
