@@ -38,6 +38,7 @@ struct Counters {
     int n_updated;
     int n_removed;
     int n_state0, n_state1, n_state2;
+    int part_n, part_s0, part_s1;   // frozen inputs of the scatter (rows to move, sizes of the first two classes)
 };
 
 struct Cam { float fx, fy, cx, cy; int W, H; };
@@ -109,16 +110,18 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                   const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S);
-void launch_update(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
-                   int n_visible, const unsigned long long* best, const uint8_t* matched, int S, Counters* cnt);
-void launch_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, const uint8_t* matched,
-                   int S, int capacity, int rank, int nranks, float tile, Counters* cnt);
+// update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
+// (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)
+void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                          int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
+                          int capacity, int rank, int nranks, float tile, Counters* cnt);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // classify + stable 3-way partition src -> dst; n_upper = host upper bound of cnt->n_model
 void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
                              const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
-                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt);
+                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
+                             unsigned long long seq);
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);

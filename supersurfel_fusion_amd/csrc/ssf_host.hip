@@ -486,24 +486,23 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis_g = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     SurfelSoA& M = h->model[h->mcur];
-    int shrink = 0;
+    const unsigned long long seq = ++h->cnt_seq;
     if (nmodel_g > 0) {
-        if (nvis_g > 0)
-            launch_update(h->stream, M, h->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->d_best, h->d_matched, h->S, h->d_cnt);
-        launch_insert(h->stream, M, h->frame, h->pose, h->stamp, h->d_matched, h->S, h->cfg.nb_supersurfels_max,
-                      h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
-        const int n_upper = std::min(h->n_model + h->S, h->cfg.nb_supersurfels_max);
+        launch_update_insert(h->stream, M, h->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->d_best, h->d_matched, h->S,
+                             nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
+        const int n_upper = std::max(1, std::min(h->n_model + h->S, h->cfg.nb_supersurfels_max));
+        // classify | scan (publishes the counters) | scatter: the host continues once the counters arrive,
+        // the scatter of this frame overlaps the host-side launch work of the next one (stream order keeps
+        // every later reader of the model behind it)
         launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], n_upper, h->pose, h->maps.plane_depth, h->stamp,
                                 h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state,
-                                h->d_block_counts, h->d_cnt);
+                                h->d_block_counts, h->d_cnt, h->mb_dev, seq);
         h->mcur ^= 1;
-        shrink = 1;
     } else {
         launch_first_frame(h->stream, M, h->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
+        launch_publish_counts(h->stream, h->d_cnt, 0, h->mb_dev, seq);
     }
-    const unsigned long long seq = ++h->cnt_seq;
-    launch_publish_counts(h->stream, h->d_cnt, shrink, h->mb_dev, seq);
     HCK(hipGetLastError());
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
     if (rc) return rc;

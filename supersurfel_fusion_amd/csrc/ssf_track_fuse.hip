@@ -165,10 +165,9 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
 }
 
 // ---- update ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_update(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
-                                                int n_visible, const unsigned long long* __restrict__ best,
-                                                const uint8_t* __restrict__ matched, int S, Counters* cnt) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
+                                           int n_visible, const unsigned long long* __restrict__ best,
+                                           const uint8_t* __restrict__ matched, int S, Counters* cnt, int f) {
     if (f >= S) return;
     if (!matched[f] || best[f] == 0xFFFFFFFFFFFFFFFFull) return;
     const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
@@ -222,31 +221,30 @@ __device__ __forceinline__ int shard_owner(const SurfelSoA& F, int f, const Rt& 
     return (int)(h % (uint32_t)nranks);
 }
 
-// ordered compaction helper: exclusive rank of `flag` among the block's threads (1024 threads)
+// ordered compaction helper: exclusive rank of `flag` among the block's threads (blockDim <= 1024)
 __device__ __forceinline__ int block_rank_1024(bool flag, int* wave_tot, int& block_total) {
     const unsigned long long mask = __ballot(flag);
-    const int wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
     if (lane() == 0) wave_tot[wv] = __popcll(mask);
     __syncthreads();
     int before = 0, total = 0;
-    for (int w = 0; w < 16; w++) { const int c = wave_tot[w]; if (w < wv) before += c; total += c; }
+    for (int w = 0; w < nw; w++) { const int c = wave_tot[w]; if (w < wv) before += c; total += c; }
     __syncthreads();
     block_total = total;
     return before + in_wave;
 }
 
 // insertSupersurfels (supersurfel_fusion_kernels.cu:348-395) in ascending frame id
-__global__ __launch_bounds__(1024) void k_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp,
-                                                 const uint8_t* __restrict__ matched, int S, int capacity, int rank,
-                                                 int nranks, float tile, Counters* cnt) {
-    __shared__ int wave_tot[16];
+__device__ __forceinline__ void insert_all(SurfelSoA M, SurfelSoA F, Rt pose, int stamp,
+                                           const uint8_t* __restrict__ matched, int S, int capacity, int rank,
+                                           int nranks, float tile, Counters* cnt, int* wave_tot) {
     const int base = cnt->n_model;
     __syncthreads();
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
     int running = 0;
-    for (int c0 = 0; c0 < S; c0 += 1024) {
+    for (int c0 = 0; c0 < S; c0 += blockDim.x) {
         const int f = c0 + threadIdx.x;
         bool flag = false;
         if (f < S) flag = (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
@@ -272,6 +270,15 @@ __global__ __launch_bounds__(1024) void k_insert(SurfelSoA M, SurfelSoA F, Rt po
         cnt->n_inserted = n_new - base;
         cnt->n_model = n_new;
     }
+}
+// update (blocks 0 .. gridDim-2, one frame supersurfel per thread) | insert (last block)
+__global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
+                                                       int n_visible, const unsigned long long* __restrict__ best,
+                                                       const uint8_t* __restrict__ matched, int S, int do_update, int capacity,
+                                                       int rank, int nranks, float tile, Counters* cnt) {
+    __shared__ int wave_tot[16];
+    if (blockIdx.x == gridDim.x - 1) insert_all(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot);
+    else if (do_update) update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // first frame: thrust::copy(frame -> model), supersurfel_fusion.cu:477-483 (owned rows only)
@@ -342,7 +349,9 @@ __global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA M, Rt pose,
 }
 
 // exclusive scan of the per-block histograms (single workgroup); totals -> counters
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ block_counts, int nblocks_upper, Counters* cnt) {
+__device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ block_counts, int nblocks_upper, Counters* cnt,
+                                                      Mailbox* mb, unsigned long long seq) {
     __shared__ uint32_t wtot[16][3];
     __shared__ uint32_t run[3];
     const int n = cnt->n_model;
@@ -377,6 +386,10 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ blo
     if (threadIdx.x == 0) {
         cnt->n_state0 = (int)run[0]; cnt->n_state1 = (int)run[1]; cnt->n_state2 = (int)run[2];
         cnt->n_visible = (int)run[0]; cnt->n_removed = (int)run[2];
+        cnt->part_n = n; cnt->part_s0 = (int)run[0]; cnt->part_s1 = (int)run[1];     // what the scatter needs
+        // the frame's counters are final here: publish them now, the host overlaps its next launches
+        // with the scatter that follows in the stream
+        publish_counters(cnt, 1, mb, seq);
     }
 }
 
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ blo
 __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const uint8_t* __restrict__ state,
                                                  const uint32_t* __restrict__ block_off, Counters* cnt) {
     __shared__ int hist[4][3];
-    const int n = cnt->n_model;
+    const int n = cnt->part_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int st = (i < n) ? (int)state[i] : 3;
     const int wv = threadIdx.x >> 6;
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const
     if (i < n) {
         int before = 0;
         for (int w = 0; w < wv; w++) before += hist[w][st];
-        const int base = (st == 0) ? 0 : ((st == 1) ? cnt->n_state0 : cnt->n_state0 + cnt->n_state1);
+        const int base = (st == 0) ? 0 : ((st == 1) ? cnt->part_s0 : cnt->part_s0 + cnt->part_s1);
         const size_t j = (size_t)base + block_off[3 * blockIdx.x + st] + before + in_wave;
         st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
         B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const
 }
 // end of the fuse stage: nbSupersurfels -= nbRemoved (supersurfel_fusion.cu:474), publish the
 // counters to the host-mapped mailbox, reset the per-frame ones for the next frame
-__global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+__device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
     Counters c = *cnt;
     if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
     Counters next = c;
@@ -427,6 +440,9 @@ __global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* 
     __hip_atomic_store(&mb->cnt_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // payload write-through stores acknowledged
     __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+    publish_counters(cnt, shrink_by_removed, mb, seq);
 }
 
 __global__ void k_lab_refresh(SurfelSoA s, int n) {
@@ -520,17 +536,12 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, frame, label,
                        pose, zmin, zmax, id_offset, best, matched);
 }
-void launch_update(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
-                   int n_visible, const unsigned long long* best, const uint8_t* matched, int S, Counters* cnt) {
-    ScopedKernel sk("update", st);
-    hipLaunchKernelGGL(k_update, dim3((S + 127) / 128), dim3(128), 0, st, model, frame, pose, stamp, id_offset,
-                       n_visible, best, matched, S, cnt);
-}
-void launch_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, const uint8_t* matched,
-                   int S, int capacity, int rank, int nranks, float tile, Counters* cnt) {
-    ScopedKernel sk("insert", st);
-    hipLaunchKernelGGL(k_insert, dim3(1), dim3(1024), 0, st, model, frame, pose, stamp, matched, S, capacity, rank,
-                       nranks, tile, cnt);
+void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                          int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
+                          int capacity, int rank, int nranks, float tile, Counters* cnt) {
+    ScopedKernel sk("update_insert", st);
+    hipLaunchKernelGGL(k_update_insert, dim3((S + 255) / 256 + 1), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
+                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {
@@ -539,14 +550,15 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 }
 void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
                              const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
-                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt) {
+                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
+                             unsigned long long seq) {
     const int nblocks = (n_upper + 255) / 256;
-    if (nblocks > 0) {
+    {
         { ScopedKernel sk("classify", st);
           hipLaunchKernelGGL(k_classify, dim3(nblocks), dim3(256), 0, st, cam, src, pose, plane_depth, stamp, delta_t,
                              conf_thresh, zmin, zmax, state, block_counts, cnt); }
         { ScopedKernel sk("scan_blocks", st);
-          hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nblocks, cnt); }
+          hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nblocks, cnt, mb, seq); }
         { ScopedKernel sk("reorder_scatter", st);
           hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
     }
