@@ -11,6 +11,8 @@
 //     writes the next map (ping-pong), so the cross-tile race of the reference cannot occur; the
 //     boundary count is derived from the tile, never stored.
 //   * the plane filter runs all its Jacobi sweeps in one single-workgroup launch.
+#include <stdio.h>
+#include <stdlib.h>
 #include "ssf_device.hpp"
 
 namespace ssf {
@@ -427,14 +429,17 @@ __device__ __forceinline__ size_t tex_index(float x, float y, int W, int H) {   
     return (size_t)iy * W + ix;
 }
 // initSamples_kernel, TPS_RGBD_kernels.cu:324-401: one thread per (superpixel, sample)
-__global__ void k_init_samples(SegParams p, FrameMaps m, int cur) {
+__global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(p.S * p.nb_samples)) return;
     const int index = (int)(idx / (uint32_t)p.nb_samples);
     const int32_t* __restrict__ label = m.label[0];
     uint32_t ctr = m.rng_counter[idx];
     const float radius = (float)p.cell / 2.f;
-    const float cx = m.sp[index].cx, cy = m.sp[index].cy;
+    // centroid = mergeTPSRGBCoeffs of this superpixel, straight from the exact sums
+    const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
+    const float nn = (float)sm.n[index];
+    const float cx = (float)sm.sx[index] / nn, cy = (float)sm.sy[index] / nn;
     float x = cx, y = cy;
     int i = label[tex_index(x, y, p.W, p.H)];
     int k = 0;
@@ -514,24 +519,18 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, 
     }
 }
 
-// selectSamples_kernel, TPS_RGBD_kernels.cu:435-467
-__global__ void k_select_samples(SegParams p, FrameMaps m) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.S) return;
+// selectSamples_kernel, TPS_RGBD_kernels.cu:435-467: first sample with the strictly largest score
+// (all-zero scores -> theta = 0).  Evaluated where it is consumed (k_init_disp) instead of in a launch
+// of its own; the disparity sums it zeroes in the reference are still zero here (nothing has
+// accumulated into them since ingest).
+__device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int ns) {
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < p.nb_samples; k++) {
-        float4 th = m.samples[(size_t)idx * p.nb_samples + k];
-        th.w = (float)m.sample_score[(size_t)idx * p.nb_samples + k];
+    for (int k = 0; k < ns; k++) {
+        float4 th = m.samples[(size_t)l * ns + k];
+        th.w = (float)m.sample_score[(size_t)l * ns + k];
         if (th.w > best.w) best = th;
     }
-    SpRow row = m.sp[idx];
-    row.ta = best.x; row.tb = best.y; row.tc = best.z;
-    m.sp[idx] = row;
-    for (int b = 0; b < 2; b++) {
-        const SpSums& s = m.sums[b];
-        s.dx[idx] = 0; s.dy[idx] = 0; s.dn[idx] = 0;
-        s.dxx[idx] = 0; s.dyy[idx] = 0; s.dxy[idx] = 0; s.dxd[idx] = 0; s.dyd[idx] = 0; s.dd[idx] = 0;
-    }
+    return best;
 }
 
 // initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190).  Tile kernel:
@@ -539,10 +538,16 @@ __global__ void k_select_samples(SegParams p, FrameMaps m) {
 // are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
 __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int cur, int ransac) {
     __shared__ unsigned long long w_acc[WIN_MAX * 9];
+    __shared__ float4 w_theta[WIN_MAX];
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
     const int32_t* __restrict__ label = m.label[0];
     for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) w_acc[i] = 0ull;
+    if (ransac)
+        for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
+            const int l = win.label_of(i, p.gy);
+            if (l >= 0) w_theta[i] = select_sample(m, l, p.nb_samples);
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
         const int x = X0 + i % TILE, y = Y0 + i / TILE;
@@ -553,8 +558,9 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
         bool inl = false;
         if (isfinite(d)) {
             if (ransac) {
-                const SpRow sp = m.sp[l];
-                const float dp = (sp.ta * (float)x + sp.tb * (float)y) + sp.tc;
+                const int wsl = win.slot(l);
+                const float4 th = wsl >= 0 ? w_theta[wsl] : select_sample(m, l, p.nb_samples);
+                const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
                 const float dd = (dp - d) * (dp - d);
                 inl = isfinite(dd) && dd < p.thresh_disp && dp > 0.f;
             } else inl = true;
@@ -603,12 +609,18 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
 // live in LDS when S fits (dynamic LDS, 44 B per node), otherwise in the global scratch.
 extern __shared__ __attribute__((aligned(16))) float filt_lds[];
 template <bool IN_LDS>
-__global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m) {
+__global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m, int true_buf) {
     const int S = p.S;
     float* base = IN_LDS ? filt_lds : m.filt;
     float* X0 = base; float* X1 = X0 + 3 * S; float* Z = X1 + 3 * S; float* px = Z + 3 * S; float* py = px + S;
+    const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
+    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-        const SpRow sp = m.sp[i];
+        // the final merge (mergeTPSRGBDCoeffs_kernel) of superpixel i, then its filter state
+        const SpRow sp = row_from_sums(sm, i, true, zero_row);
+        m.sp[i] = sp;
+#pragma unroll
+        for (int j = 0; j < 13; j++) m.moments[(size_t)i * 13 + j] = 0;     // accumulators of k_render_moments
         const float d0 = (sp.cx * sp.ta + sp.cy * sp.tb) + sp.tc;
         X0[3 * i] = d0; X0[3 * i + 1] = sp.ta; X0[3 * i + 2] = sp.tb;
         Z[3 * i] = d0; Z[3 * i + 1] = sp.ta; Z[3 * i + 2] = sp.tb;
@@ -835,7 +847,14 @@ void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf
     hipLaunchKernelGGL(k_merge, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m, true_buf, with_planes ? 1 : 0);
 }
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg) {
-    ScopedKernel sk(rgbd ? "update_pass_rgbd" : "update_pass_rgb", st);
+    static const char* per_pass_names[64] = {nullptr};
+    static int per_pass = -1;
+    if (per_pass < 0) {
+        per_pass = getenv("SSF_PROFILE_PER_PASS") ? 1 : 0;
+        static char buf[64][16];
+        for (int i = 0; i < 64; i++) { snprintf(buf[i], 16, "pass_%02d", i); per_pass_names[i] = buf[i]; }
+    }
+    ScopedKernel sk(per_pass ? per_pass_names[k & 63] : (rgbd ? "update_pass_rgbd" : "update_pass_rgb"), st);
     // OX = 0: tiles shifted left by 30: [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
     // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.
     dim3 grid = tile_grid(p);
@@ -843,24 +862,22 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k,
     if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
     else hipLaunchKernelGGL(k_update_pass<false>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
-void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
+void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, int true_buf) {
     { ScopedKernel sk("init_samples", st);
-      hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, cur); }
+      hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, true_buf); }
     { ScopedKernel sk("eval_samples", st);
       hipLaunchKernelGGL(k_eval_samples, tile_grid(p), dim3(256), 0, st, p, m, cur); }
-    { ScopedKernel sk("select_samples", st);
-      hipLaunchKernelGGL(k_select_samples, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m); }
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac) {
     ScopedKernel sk("init_disp", st);
     hipLaunchKernelGGL(k_init_disp, tile_grid(p), dim3(256), 0, st, p, m, cur, ransac ? 1 : 0);
 }
-void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m) {
+void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf) {
     ScopedKernel sk("plane_filter", st);
     const size_t lds = (size_t)p.S * 11 * sizeof(float);
     const int threads = p.S >= 1024 ? 1024 : ((p.S + 63) / 64) * 64;
-    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(1), dim3(threads), lds, st, p, m);
-    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(1), dim3(1024), 0, st, p, m);
+    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(1), dim3(threads), lds, st, p, m, true_buf);
+    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(1), dim3(1024), 0, st, p, m, true_buf);
 }
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur) {
     ScopedKernel sk("render_moments", st);

@@ -314,17 +314,15 @@ static int enqueue_segmentation(ssf_handle* h, int* cur_out) {
             if (k >= limit) break;
             launch_update_pass(st, p, h->maps, k, ox[q], oy[q], false); k++;
         }
-    launch_merge(st, p, h->maps, k & 1, false);           // sums[k&1] holds the exact sums after k passes
-    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, 0); launch_init_disp(st, p, h->maps, 0, true); }
+    // sums[k&1] holds the exact sums after k passes; RANSAC and the inlier initialisation read them directly
+    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, 0, k & 1); launch_init_disp(st, p, h->maps, 0, true); }
     else launch_init_disp(st, p, h->maps, 0, false);
-    if (k >= limit || h->cfg.seg_iter - h->cfg.seg_iter / 2 <= 0) launch_merge(st, p, h->maps, k & 1, true);
     for (int it = h->cfg.seg_iter / 2; it < h->cfg.seg_iter; it++)
         for (int q = 0; q < 4; q++) {
             if (k >= limit) break;
             launch_update_pass(st, p, h->maps, k, ox[q], oy[q], true); k++;
         }
-    launch_merge(st, p, h->maps, k & 1, true);
-    launch_plane_filter(st, p, h->maps);
+    launch_plane_filter(st, p, h->maps, k & 1);             // final merge (table + planes) + smoothing sweeps
     launch_render_moments(st, p, h->cam, h->maps, 0);
     *cur_out = 0;                                          // labels are relabelled in place (single map)
     return SSF_OK;
