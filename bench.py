@@ -53,10 +53,10 @@ ALGO_BYTES = {
 }
 
 
-def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False):
+def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0):
     K = synthetic.intrinsics(W, H)
     kw = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=cap,
-              rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0)
+              rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0, pipeline_depth=pipeline_depth)
     kw.update(PARAMS)
     if stream is not None:
         kw["stream"] = stream
@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=8)
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="frames the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,7 +97,7 @@ def main():
 
     lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
     K, Wm = a.steps, a.warmup
-    nf = K + Wm + a.profile_frames + 2
+    nf = K + Wm + 2 * a.profile_frames + 2
     frames = render_frames(nf)
     d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
@@ -111,7 +113,8 @@ def main():
     n_local = len(model_local["confidences"])
     cap = n_local + 65536
     stream = torch.cuda.current_stream(dev).cuda_stream
-    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp))
+    depth = a.pipeline_depth if world == 1 else 0
+    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth))
     f.set_model(model_local, nvis_local, 30)
     drv = sharded.ShardedFusion(f, device=dev) if world > 1 else None
 
@@ -125,17 +128,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(Wm):
-        step(i)
+    def run(first, count):
+        """Process frames [first, first + count): every frame's extract, ICP and fusion complete inside."""
+        res = []
+        if depth == 0:
+            for i in range(first, first + count):
+                res.append(step(i))
+            return res
+        nsub = first
+        for i in range(first, first + count):
+            while nsub < first + count and f.pending_frames() < depth + 1:
+                f.submit_frame(d_rgb[nsub].data_ptr(), d_depth[nsub].data_ptr(), on_device=True)
+                nsub += 1
+            res.append(f.process_submitted().as_dict())
+        return res
+
+    run(0, Wm)
     barrier()
     t0 = time.perf_counter()
-    iters = []
-    last = None
-    for i in range(Wm, Wm + K):
-        last = step(i)
-        iters.append(last["icp_iters"])
+    results = run(Wm, K)
     barrier()
     dt = time.perf_counter() - t0
+    iters = [r["icp_iters"] for r in results]
+    last = results[-1]
+    # strictly sequential latency of the same frames on the same handle (one frame in flight)
+    nseq = a.profile_frames
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(Wm + K, Wm + K + nseq):
+        step(i)
+    barrier()
+    seq_ms = 1000.0 * (time.perf_counter() - t1) / max(nseq, 1)
+    base = Wm + K + nseq
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -145,12 +169,12 @@ def main():
     stage = np.zeros(3)
     ns = max(a.profile_frames // 2, 1)
     f.set_profile(2)                                  # stage split only (one event synchronise per frame)
-    for i in range(Wm + K, Wm + K + ns):
+    for i in range(base, base + ns):
         stage += np.array(step(i)["stage_ms"]) / ns
     f.set_profile(1); f.reset_kernel_times()          # per-kernel hipEvent brackets
     cnt_before = f.counts()
     npk = max(a.profile_frames - ns, 1)
-    for i in range(Wm + K + ns, Wm + K + ns + npk):
+    for i in range(base + ns, base + ns + npk):
         step(i)
     torch.cuda.synchronize(dev)
     kt = f.kernel_times()
@@ -210,7 +234,9 @@ def main():
                                    % (gn, gv),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
-                       "parallelism": "map sharded by world tile over %d rank(s)" % world},
+                       "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
+                                      "ahead of ICP/fusion on its own HIP streams" % (world, depth + 1 if depth else 0)},
+            "pipeline_depth": depth, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }

@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define SSF_ABI_VERSION 1
+#define SSF_ABI_VERSION 2
+#define SSF_MAX_PIPELINE_DEPTH 3
 
 typedef enum ssf_status {
     SSF_OK = 0,
@@ -110,6 +111,13 @@ typedef struct ssf_config {
     float prefilter_sigma_space;   /* 4.5 px  */
     int   profile;             /* 0: none (fastest); 2: stage_ms split (one event synchronise per frame);
                                   1: additionally bracket every kernel with hipEvents (ssf_get_kernel_times) */
+    int   pipeline_depth;      /* 0 (default): frames are processed strictly one after the other, as the reference
+                                  does.  d > 0: ssf_submit_frame may run the extract stage of up to d + 1 frames
+                                  ahead of ICP/fusion on separate HIP streams (replay / offline mapping: raises
+                                  throughput, results are bit-identical to the sequential order).  Clamped to
+                                  0..SSF_MAX_PIPELINE_DEPTH; 2 is the measured optimum on MI355X: the command
+                                  processor serves 4 hardware queues concurrently = the track stream + 3
+                                  extract streams, a 5th active queue halves the throughput. */
 } ssf_config;
 
 typedef struct ssf_handle ssf_handle;
@@ -164,6 +172,23 @@ int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth_m,
 int ssf_process_frame_device(ssf_handle* h, const void* d_rgb, const void* d_depth_m,
                              const float* prior_pose, const uint8_t* dynamic_mask,
                              ssf_frame_result* out);
+
+/* ---- pipelined form (cfg.pipeline_depth > 0 to gain anything; valid with 0 too) ------------- */
+/* The extract stage (segmentation -> frame supersurfels) of a frame depends on no earlier frame
+ * except through the RANSAC draw counters, while ICP/fusion of frame k needs the map after frame
+ * k-1.  ssf_submit_frame enqueues the extract stage of the NEXT frame asynchronously (its own HIP
+ * stream; returns without waiting) and ssf_process_submitted runs ICP + association + fusion of the
+ * OLDEST submitted frame and returns its result, exactly what ssf_process_frame would have
+ * returned.  At most pipeline_depth + 1 frames may be pending (SSF_ERR_STATE beyond that).
+ * Device input buffers (on_device = 1) must stay valid until the frame has been processed.  The
+ * per-frame getters below refer to the last processed frame and are invalidated by the next
+ * ssf_submit_frame once the pipeline wraps around (always valid with pipeline_depth = 0).
+ * Replaces the loop body of the replay node (supersurfel_fusion_rgbd_benchmark_node.cpp, one
+ * processFrame per image pair) when frames are available ahead of time. */
+int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth_m, int on_device,
+                     const uint8_t* dynamic_mask);
+int ssf_process_submitted(ssf_handle* h, const float* prior_pose, ssf_frame_result* out);
+int ssf_pending_frames(const ssf_handle* h);
 
 /* ---- stage seams (used by the sharded multi-GPU driver and by the parity tests) ------------- */
 /* extract: ingest + TPS segmentation + plane filter + plane depth + frame supersurfels. */

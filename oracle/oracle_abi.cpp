@@ -7,13 +7,16 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <vector>
 #include <new>
 #include <string>
 #include "oracle.h"
 
 using namespace orc;
 
-struct ssf_handle { State s; };
+struct PendingFrame { std::vector<uint8_t> rgb; std::vector<float> depth; std::vector<uint8_t> mask; bool has_mask; };
+struct ssf_handle { State s; std::deque<PendingFrame> pending; };
 static std::string g_create_err;
 
 static void pose_to12(const Pose& p, float* o) {
@@ -37,6 +40,7 @@ void ssf_default_config(ssf_config* c) {      // supersurfel_fusion.hpp:46-74 de
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
     c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
+    c->pipeline_depth = 0;
 }
 
 int ssf_create(const ssf_config* cfg, ssf_handle** out) {
@@ -139,6 +143,29 @@ int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, con
     if (out) *out = r;
     return SSF_OK;
 }
+// the pipelined form is, by definition, the sequential order: the checker queues copies of the inputs
+int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int /*on_device*/, const uint8_t* mask) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    const int depth_max = h->s.cfg.pipeline_depth < 0 ? 0 : (h->s.cfg.pipeline_depth > SSF_MAX_PIPELINE_DEPTH ? SSF_MAX_PIPELINE_DEPTH : h->s.cfg.pipeline_depth);
+    if ((int)h->pending.size() >= depth_max + 1) return SSF_ERR_STATE;
+    const size_t P = (size_t)h->s.W * h->s.H;
+    PendingFrame f;
+    f.rgb.assign((const uint8_t*)rgb, (const uint8_t*)rgb + 3 * P);
+    f.depth.assign((const float*)depth, (const float*)depth + P);
+    f.has_mask = mask != nullptr;
+    if (mask) f.mask.assign(mask, mask + h->s.S);
+    h->pending.push_back(std::move(f));
+    return SSF_OK;
+}
+int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* out) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (h->pending.empty()) return SSF_ERR_STATE;
+    PendingFrame f = std::move(h->pending.front());
+    h->pending.pop_front();
+    return ssf_process_frame(h, f.rgb.data(), f.depth.data(), prior, f.has_mask ? f.mask.data() : nullptr, out);
+}
+int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
+
 int ssf_process_frame_device(ssf_handle* h, const void* rgb, const void* depth, const float* prior,
                              const uint8_t* mask, ssf_frame_result* out) {
     return ssf_process_frame(h, (const uint8_t*)rgb, (const float*)depth, prior, mask, out);

@@ -29,7 +29,7 @@ class SsfConfig(C.Structure):
         ("rng_seed", C.c_uint64), ("icp_force_iters", C.c_int), ("device_id", C.c_int),
         ("stream", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
         ("shard_tile", C.c_float), ("depth_prefilter", C.c_int), ("prefilter_sigma_color", C.c_float),
-        ("prefilter_sigma_space", C.c_float), ("profile", C.c_int),
+        ("prefilter_sigma_space", C.c_float), ("profile", C.c_int), ("pipeline_depth", C.c_int),
     ]
 
 
@@ -62,7 +62,8 @@ ABI_SYMBOLS = [
     "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
     "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
-    "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter",
+    "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
+    "ssf_process_submitted", "ssf_pending_frames",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -118,6 +119,9 @@ class Library:
         L.ssf_reset_kernel_times.argtypes = [vp]
         L.ssf_set_profile.argtypes = [vp, C.c_int]
         L.ssf_bilateral_filter.argtypes = [vp, vp, vp, C.c_int]
+        L.ssf_submit_frame.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.ssf_process_submitted.argtypes = [vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_pending_frames.argtypes = [vp]
 
     @property
     def backend(self):
@@ -198,6 +202,30 @@ class Fusion:
                                                      _ptr(prior), None, C.byref(res)),
                  "ssf_process_frame_device")
         return res
+
+    # ---- pipelined form ----------------------------------------------------------------------
+    def submit_frame(self, rgb, depth, dynamic_mask=None, on_device=False):
+        """Enqueue the extract stage of the next frame (asynchronous).  With on_device=True rgb and
+        depth are device addresses that must stay valid until the frame has been processed."""
+        if on_device:
+            rp, dp = C.c_void_p(rgb), C.c_void_p(depth)
+        else:
+            rgb = np.ascontiguousarray(rgb, np.uint8)
+            depth = np.ascontiguousarray(depth, np.float32)
+            assert rgb.shape == (self.H, self.W, 3) and depth.shape == (self.H, self.W)
+            rp, dp = _ptr(rgb), _ptr(depth)
+        mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
+        self._ck(self.L.lib.ssf_submit_frame(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_submit_frame")
+
+    def process_submitted(self, prior_pose=None):
+        """ICP + association + fusion of the oldest submitted frame; returns its SsfFrameResult."""
+        prior = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float32)
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_process_submitted(self.h, _ptr(prior), C.byref(res)), "ssf_process_submitted")
+        return res
+
+    def pending_frames(self):
+        return int(self.L.lib.ssf_pending_frames(self.h))
 
     # ---- stage seams -------------------------------------------------------------------------
     def stage_extract(self, rgb, depth, dynamic_mask=None, on_device=False):

@@ -93,7 +93,8 @@ void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const
 void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf, bool with_planes);
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg = 0);
-void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, int true_buf);
+void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf);
+void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int cur);
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac);
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf);   // includes the final merge
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur);

@@ -862,11 +862,13 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k,
     if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
     else hipLaunchKernelGGL(k_update_pass<false>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
-void launch_ransac(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, int true_buf) {
-    { ScopedKernel sk("init_samples", st);
-      hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, true_buf); }
-    { ScopedKernel sk("eval_samples", st);
-      hipLaunchKernelGGL(k_eval_samples, tile_grid(p), dim3(256), 0, st, p, m, cur); }
+void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf) {
+    ScopedKernel sk("init_samples", st);
+    hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, true_buf);
+}
+void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
+    ScopedKernel sk("eval_samples", st);
+    hipLaunchKernelGGL(k_eval_samples, tile_grid(p), dim3(256), 0, st, p, m, cur);
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac) {
     ScopedKernel sk("init_disp", st);

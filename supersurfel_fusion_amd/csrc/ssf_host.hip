@@ -7,8 +7,10 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <deque>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -203,24 +205,42 @@ struct IcpLoop {
     M3 R_init; V3 t_init, t_inc_stale;
 };
 
+// Everything one frame's extract stage owns.  With pipeline_depth > 0 there are pipeline_depth + 1 of
+// these, each on its own stream: the extract of frames k+1.. runs while the track/fuse chain (h->stream)
+// consumes frame k.  The only cross-frame state of extract is the RANSAC draw counters (chained by ev_rng).
+struct ExtractCtx {
+    FrameMaps maps;
+    SurfelSoA frame;
+    unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
+    uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    hipEvent_t ev_done = nullptr, ev_rng = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    bool consumed_valid = false, timed = false;
+    hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t exec[2] = {nullptr, nullptr};
+    int stamp = 0;
+};
+
 struct ssf_handle {
     ssf_config cfg;
     int S = 0, gx = 0, gy = 0;
     std::string err;
     hipStream_t stream = nullptr; bool own_stream = false;
     SegParams seg; Cam cam;
-    FrameMaps maps; int cur = 0;
-    SurfelSoA frame, model[2]; int mcur = 0;
+    std::vector<ExtractCtx> ctx; int next_ctx = 0;
+    std::deque<int> pending;                      // submitted, not yet processed (oldest first)
+    ExtractCtx* cc = nullptr;                     // the frame the track/fuse chain is working on (or last worked on)
+    ExtractCtx* rng_tail = nullptr;               // last context that advanced the RANSAC draw counters
+    SurfelSoA model[2]; int mcur = 0;
     std::vector<void*> allocs;
-    uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
-    long long* d_icp = nullptr; unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
+    float* d_bf_in = nullptr; float* d_bf_out = nullptr;
+    long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; uint32_t* d_block_counts = nullptr; Counters* d_cnt = nullptr;
     int32_t* d_scratch_map = nullptr;
     long long* d_icp_replicas = nullptr; unsigned int* d_tickets = nullptr; float* d_srgb_lut = nullptr;
     // host-mapped mailbox (fine-grained): results the host waits for are polled, not synchronised on
     Mailbox* mb_host = nullptr; Mailbox* mb_dev = nullptr;
     unsigned long long icp_seq = 0, cnt_seq = 0;
-    hipGraph_t seg_graph = nullptr; hipGraphExec_t seg_exec = nullptr; int seg_graph_cur = 0; bool graph_failed = false;
+    bool graph_failed = false;
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
     int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
@@ -232,6 +252,7 @@ struct ssf_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     KernelTimer timer;
     std::vector<std::string> timer_names;
+    double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // debug: submit | icp loop | match+fuse | frames | extract ready at activation | first icp iteration
 };
 static std::string g_create_err;
 
@@ -299,74 +320,115 @@ struct TimerScope {
 };
 
 // ---- stages -----------------------------------------------------------------------------------------
-// the segmentation chain between ingest and finalize: fixed topology and arguments per handle.
+// the segmentation chain between ingest and finalize: fixed topology and arguments per context.
 // Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
 // kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
-// only materialised where a later stage wants it: before RANSAC and before the plane filter.
-static int enqueue_segmentation(ssf_handle* h, int* cur_out) {
+// only materialised where a later stage wants it: before the plane filter.
+enum { SEG_RGB = 1, SEG_SAMPLES = 2, SEG_REST = 4, SEG_ALL = 7 };
+static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, int parts) {
     const SegParams& p = h->seg;
-    hipStream_t st = h->stream;
-    int k = 0;
+    hipStream_t st = c.stream;
     const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
-    for (int it = 0; it < h->cfg.seg_iter / 2; it++)
-        for (int q = 0; q < 4; q++) {
-            if (k >= limit) break;
-            launch_update_pass(st, p, h->maps, k, ox[q], oy[q], false); k++;
+    const int k1 = std::min(4 * (h->cfg.seg_iter / 2), limit), k2 = std::min(4 * h->cfg.seg_iter, std::max(limit, k1));
+    if (parts & SEG_RGB)
+        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, k, ox[k & 3], oy[k & 3], false);
+    // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
+    if ((parts & SEG_SAMPLES) && h->cfg.seg_use_ransac) launch_init_samples(st, p, c.maps, k1 & 1);
+    if (parts & SEG_REST) {
+        if (h->cfg.seg_use_ransac) { launch_eval_samples(st, p, c.maps, 0); launch_init_disp(st, p, c.maps, 0, true); }
+        else launch_init_disp(st, p, c.maps, 0, false);
+        int k = k1;
+        for (; k < k2 && k1 < limit; k++) launch_update_pass(st, p, c.maps, k, ox[k & 3], oy[k & 3], true);
+        launch_plane_filter(st, p, c.maps, k & 1);             // final merge (table + planes) + smoothing sweeps
+        launch_render_moments(st, p, h->cam, c.maps, 0);
+    }
+}
+// ~45 short dependent kernels: replayed as captured hipGraphs (launch-bound inner loop); eager when
+// kernels are individually timed or the pass count is being bisected
+static int run_segmentation(ssf_handle* h, ExtractCtx& c, int slot, int parts) {
+    const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
+    if (use_graph) {
+        if (!c.exec[slot]) {
+            bool ok = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                enqueue_segmentation(h, c, parts);
+                ok = hipStreamEndCapture(c.stream, &c.graph[slot]) == hipSuccess && c.graph[slot] != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&c.exec[slot], c.graph[slot], nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) { h->graph_failed = true; c.exec[slot] = nullptr; (void)hipGetLastError(); }
         }
-    // sums[k&1] holds the exact sums after k passes; RANSAC and the inlier initialisation read them directly
-    if (h->cfg.seg_use_ransac) { launch_ransac(st, p, h->maps, 0, k & 1); launch_init_disp(st, p, h->maps, 0, true); }
-    else launch_init_disp(st, p, h->maps, 0, false);
-    for (int it = h->cfg.seg_iter / 2; it < h->cfg.seg_iter; it++)
-        for (int q = 0; q < 4; q++) {
-            if (k >= limit) break;
-            launch_update_pass(st, p, h->maps, k, ox[q], oy[q], true); k++;
-        }
-    launch_plane_filter(st, p, h->maps, k & 1);             // final merge (table + planes) + smoothing sweeps
-    launch_render_moments(st, p, h->cam, h->maps, 0);
-    *cur_out = 0;                                          // labels are relabelled in place (single map)
+        if (c.exec[slot]) { HCK(hipGraphLaunch(c.exec[slot], c.stream)); return SSF_OK; }
+    }
+    enqueue_segmentation(h, c, parts);
     return SSF_OK;
 }
 
-static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+// Enqueue the extract stage of one frame into the next context (asynchronous; nothing is waited for).
+static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    const int nctx = (int)h->ctx.size();
+    if ((int)h->pending.size() >= nctx) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
+    const int ci = h->next_ctx;
+    ExtractCtx& c = h->ctx[ci];
+    hipStream_t st = c.stream;
+    const bool multi = nctx > 1;
+    // the track/fuse chain must be done with the frame this context held before it is overwritten
+    if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
+    c.stamp = h->stamp + (int)h->pending.size();
+    c.timed = h->cfg.profile != 0;
+    if (c.timed) HCK(hipEventRecord(c.ev_t0, st));
     const size_t P = (size_t)h->cfg.width * h->cfg.height;
     const uint8_t* d_rgb = (const uint8_t*)rgb; const float* d_depth = (const float*)depth;
     if (!on_device) {
-        HCK(hipMemcpyAsync(h->d_rgb_in, rgb, 3 * P, hipMemcpyHostToDevice, h->stream));
-        HCK(hipMemcpyAsync(h->d_depth_in, depth, 4 * P, hipMemcpyHostToDevice, h->stream));
-        d_rgb = h->d_rgb_in; d_depth = h->d_depth_in;
+        HCK(hipMemcpyAsync(c.d_rgb_in, rgb, 3 * P, hipMemcpyHostToDevice, st));
+        HCK(hipMemcpyAsync(c.d_depth_in, depth, 4 * P, hipMemcpyHostToDevice, st));
+        d_rgb = c.d_rgb_in; d_depth = c.d_depth_in;
     }
     const uint8_t* d_mask = nullptr;
-    if (mask) { HCK(hipMemcpyAsync(h->d_mask, mask, h->S, hipMemcpyHostToDevice, h->stream)); d_mask = h->d_mask; }
-    hipStream_t st = h->stream;
+    if (mask) { HCK(hipMemcpyAsync(c.d_mask, mask, h->S, hipMemcpyHostToDevice, st)); d_mask = c.d_mask; }
     if (h->cfg.depth_prefilter) {                                          // supersurfel_fusion.cu:180
-        launch_bilateral(st, d_depth, h->d_depth_filt, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
-        d_depth = h->d_depth_filt;
+        launch_bilateral(st, d_depth, c.d_depth_filt, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
+        d_depth = c.d_depth_filt;
     }
-    launch_ingest(st, h->seg, d_rgb, d_depth, h->maps);
-    // ~85 short dependent kernels: replayed as one captured hipGraph (launch-bound inner loop);
-    // eager when kernels are individually timed or the pass count is being bisected
-    const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
-    int cur = 0;
-    if (use_graph) {
-        if (!h->seg_exec) {
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                enqueue_segmentation(h, &h->seg_graph_cur);
-                ok = hipStreamEndCapture(st, &h->seg_graph) == hipSuccess && h->seg_graph != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&h->seg_exec, h->seg_graph, nullptr, nullptr, 0) == hipSuccess;
-            if (!ok) { h->graph_failed = true; h->seg_exec = nullptr; (void)hipGetLastError(); }
+    launch_ingest(st, h->seg, d_rgb, d_depth, c.maps);
+    int rc;
+    if (!multi) rc = run_segmentation(h, c, 0, SEG_ALL);
+    else {
+        // the RANSAC draw counters carry over from frame to frame: init_samples of this frame runs after
+        // init_samples of the previous one (which lives on another stream), everything else is independent
+        rc = run_segmentation(h, c, 0, SEG_RGB);
+        if (!rc && h->cfg.seg_use_ransac) {
+            if (h->rng_tail && h->rng_tail != &c) HCK(hipStreamWaitEvent(st, h->rng_tail->ev_rng, 0));
+            enqueue_segmentation(h, c, SEG_SAMPLES);
+            HCK(hipEventRecord(c.ev_rng, st));
+            h->rng_tail = &c;
         }
-        if (h->seg_exec) { HCK(hipGraphLaunch(h->seg_exec, st)); cur = h->seg_graph_cur; }
-        else enqueue_segmentation(h, &cur);
-    } else
-        enqueue_segmentation(h, &cur);
-    h->cur = cur;
-    launch_finalize_surfels(st, h->seg, h->maps, h->frame, h->cfg.range_min, h->cfg.range_max, h->stamp, d_mask, h->d_best, h->d_matched);
+        if (!rc) rc = run_segmentation(h, c, 1, SEG_REST);
+    }
+    if (rc) return rc;
+    launch_finalize_surfels(st, h->seg, c.maps, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp, d_mask, c.d_best, c.d_matched);
     HCK(hipGetLastError());
+    if (c.timed) HCK(hipEventRecord(c.ev_t1, st));
+    if (multi) HCK(hipEventRecord(c.ev_done, st));
+    h->pending.push_back(ci);
+    h->next_ctx = (ci + 1) % nctx;
+    return SSF_OK;
+}
+// Make the oldest submitted frame the one the track/fuse chain works on.
+static int activate_oldest(ssf_handle* h) {
+    if (h->pending.empty()) { h->err = "no submitted frame"; return SSF_ERR_STATE; }
+    ExtractCtx& c = h->ctx[h->pending.front()];
+    h->pending.pop_front();
+    if (h->ctx.size() > 1) HCK(hipStreamWaitEvent(h->stream, c.ev_done, 0));
+    if (c.stamp != h->stamp) { h->err = "submitted frame is out of sequence (model stamp changed while frames were pending)"; return SSF_ERR_STATE; }
+    h->cc = &c;
     h->have_frame = true;
     return SSF_OK;
+}
+static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    int rc = submit_extract(h, rgb, depth, on_device, mask);
+    return rc ? rc : activate_oldest(h);
 }
 
 static void icp_begin(ssf_handle* h, const float* prior) {
@@ -396,7 +458,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host) {
     I.t_inc_stale = t_inc;
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     const unsigned long long seq = ++h->icp_seq;
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T,
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T,
                h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, seq);
     HCK(hipGetLastError());
     if (to_host) {
@@ -472,8 +534,8 @@ static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->frame, h->maps.label[h->cur], h->pose, h->cfg.range_min,
-                 h->cfg.range_max, h->id_offset, h->d_best, h->d_matched, h->S);
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->frame, h->cc->maps.label[0], h->pose, h->cfg.range_min,
+                 h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->S);
     HCK(hipGetLastError());
     return SSF_OK;
 }
@@ -486,22 +548,23 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     SurfelSoA& M = h->model[h->mcur];
     const unsigned long long seq = ++h->cnt_seq;
     if (nmodel_g > 0) {
-        launch_update_insert(h->stream, M, h->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->d_best, h->d_matched, h->S,
+        launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
                              nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
         const int n_upper = std::max(1, std::min(h->n_model + h->S, h->cfg.nb_supersurfels_max));
         // classify | scan (publishes the counters) | scatter: the host continues once the counters arrive,
         // the scatter of this frame overlaps the host-side launch work of the next one (stream order keeps
         // every later reader of the model behind it)
-        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], n_upper, h->pose, h->maps.plane_depth, h->stamp,
+        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], n_upper, h->pose, h->cc->maps.plane_depth, h->stamp,
                                 h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state,
                                 h->d_block_counts, h->d_cnt, h->mb_dev, seq);
         h->mcur ^= 1;
     } else {
-        launch_first_frame(h->stream, M, h->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
+        launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
         launch_publish_counts(h->stream, h->d_cnt, 0, h->mb_dev, seq);
     }
     HCK(hipGetLastError());
+    if (h->ctx.size() > 1) { HCK(hipEventRecord(h->cc->ev_consumed, h->stream)); h->cc->consumed_valid = true; }
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
     if (rc) return rc;
     Counters c;
@@ -531,38 +594,51 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     return SSF_OK;
 }
 
-static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth, int on_device, const float* prior,
-                              const uint8_t* mask, ssf_frame_result* out) {
+// ICP + association + fusion of the oldest submitted frame, on the track stream
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* out) {
     TimerScope ts(h);
-    const bool timing = h->cfg.profile != 0;       // stage split costs an event synchronise: opt-in
-    if (timing) HCK(hipEventRecord(h->ev[0], h->stream));
-    int rc = do_extract(h, rgb, depth, on_device, mask);
+    int rc = activate_oldest(h);
     if (rc) return rc;
+    const double t_a = now_us();
+    if (h->ctx.size() > 1 && hipEventQuery(h->cc->ev_done) == hipSuccess) h->host_us[4] += 1;
+    bool first_it = true;
+    const bool timing = h->cfg.profile != 0 && h->cc->timed;     // stage split costs an event synchronise: opt-in
     if (timing) HCK(hipEventRecord(h->ev[1], h->stream));
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
     while (again) {
         rc = icp_accumulate(h, true);
         if (rc) return rc;
+        if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
         icp_update(h, (const int64_t*)h->h_icp, &again);
     }
     icp_end(h, &valid);
+    const double t_b = now_us();
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
     rc = do_match(h);
     if (rc) return rc;
     ssf_frame_result r;
     rc = do_fuse(h, &r);
     if (rc) return rc;
+    h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
     if (timing) {
         HCK(hipEventRecord(h->ev[3], h->stream));
         HCK(hipEventSynchronize(h->ev[3]));
         float ms;
-        if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) r.stage_ms[0] = ms;
+        if (hipEventElapsedTime(&ms, h->cc->ev_t0, h->cc->ev_t1) == hipSuccess) r.stage_ms[0] = ms;
         if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) r.stage_ms[1] = ms;
         if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) r.stage_ms[2] = ms;
     }
     if (out) *out = r;
     return SSF_OK;
+}
+static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth, int on_device, const float* prior,
+                              const uint8_t* mask, ssf_frame_result* out) {
+    if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline: use ssf_process_submitted"; return SSF_ERR_STATE; }
+    int rc;
+    { TimerScope ts(h); rc = submit_extract(h, rgb, depth, on_device, mask); }
+    return rc ? rc : process_oldest(h, prior, out);
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------------
@@ -582,13 +658,19 @@ void ssf_default_config(ssf_config* c) {       // default arguments of initializ
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
     c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
+    c->pipeline_depth = 0;
 }
 
 void ssf_destroy(ssf_handle* h) {
     if (!h) return;
+    for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->seg_exec) (void)hipGraphExecDestroy(h->seg_exec);
-    if (h->seg_graph) (void)hipGraphDestroy(h->seg_graph);
+    for (auto& c : h->ctx) {
+        for (int i = 0; i < 2; i++) { if (c.exec[i]) (void)hipGraphExecDestroy(c.exec[i]); if (c.graph[i]) (void)hipGraphDestroy(c.graph[i]); }
+        hipEvent_t evs[5] = {c.ev_done, c.ev_rng, c.ev_consumed, c.ev_t0, c.ev_t1};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+    }
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -627,27 +709,47 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
-    FrameMaps& m = h->maps; SpSums& s = m.sums[0]; SpSums& s2 = m.sums[1];
     const size_t NT = (size_t)((W + 30 + 31) / 32) * ((H + 31) / 32);   // relabelling tiles (shifted grid has one more column)
-    bool ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.label[1], P) &&
-              dalloc(h, &m.inlier, P) && dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) &&
-              dalloc(h, &m.sample_score, NS) && dalloc(h, &m.rng_counter, NS) && dalloc(h, &m.moments, 13 * S) &&
-              dalloc(h, &m.filt, 11 * S) && dalloc(h, &s.sx, S) && dalloc(h, &s.sy, S) && dalloc(h, &s.sr, S) &&
-              dalloc(h, &s.sg, S) && dalloc(h, &s.sb, S) && dalloc(h, &s.n, S) && dalloc(h, &s.dx, S) && dalloc(h, &s.dy, S) &&
-              dalloc(h, &s.dn, S) && dalloc(h, &s.dxx, S) && dalloc(h, &s.dyy, S) && dalloc(h, &s.dxy, S) &&
-              dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S) && dalloc(h, &s2.sx, S) && dalloc(h, &s2.sy, S) &&
-              dalloc(h, &s2.sr, S) && dalloc(h, &s2.sg, S) && dalloc(h, &s2.sb, S) && dalloc(h, &s2.n, S) && dalloc(h, &s2.dx, S) &&
-              dalloc(h, &s2.dy, S) && dalloc(h, &s2.dn, S) && dalloc(h, &s2.dxx, S) && dalloc(h, &s2.dyy, S) && dalloc(h, &s2.dxy, S) &&
-              dalloc(h, &s2.dxd, S) && dalloc(h, &s2.dyd, S) && dalloc(h, &s2.dd, S) && dalloc(h, &m.log.ent[0], NT * 256) &&
-              dalloc(h, &m.log.ent[1], NT * 256) && dalloc(h, &m.log.ent[2], NT * 256) && dalloc(h, &m.log.disp[0], NT * 256) &&
-              dalloc(h, &m.log.disp[1], NT * 256) && dalloc(h, &m.log.disp[2], NT * 256) && dalloc(h, &m.log.count[0], NT) &&
-              dalloc(h, &m.log.count[1], NT) && dalloc(h, &m.log.count[2], NT) &&
-              alloc_surfels(h, h->frame, S) &&
-              alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && dalloc(h, &h->d_rgb_in, 3 * P) &&
-              dalloc(h, &h->d_depth_in, P) && dalloc(h, &h->d_depth_filt, P) && dalloc(h, &h->d_mask, S) && dalloc(h, &h->d_icp, SSF_ICP_RECORD) &&
-              dalloc(h, &h->d_best, S) && dalloc(h, &h->d_matched, S) && dalloc(h, &h->d_state, N) &&
-              dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) && dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) &&
-              dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32) && dalloc(h, &h->d_tickets, 4) && dalloc(h, &h->d_srgb_lut, 256);
+    const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
+    h->ctx.resize(nctx);
+    uint32_t* d_rng = nullptr;
+    bool ok = dalloc(h, &d_rng, NS) && dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 4);
+    for (int ci = 0; ci < nctx && ok; ci++) {
+        ExtractCtx& c = h->ctx[ci];
+        FrameMaps& m = c.maps;
+        ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.inlier, P) &&
+             dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) && dalloc(h, &m.sample_score, NS) &&
+             dalloc(h, &m.moments, 13 * S) && dalloc(h, &m.filt, 11 * S);
+        m.label[1] = m.label[0];                                        // labels are relabelled in place (single map)
+        for (int b = 0; b < 2 && ok; b++) {
+            SpSums& s = m.sums[b];
+            ok = dalloc(h, &s.sx, S) && dalloc(h, &s.sy, S) && dalloc(h, &s.sr, S) && dalloc(h, &s.sg, S) && dalloc(h, &s.sb, S) &&
+                 dalloc(h, &s.n, S) && dalloc(h, &s.dx, S) && dalloc(h, &s.dy, S) && dalloc(h, &s.dn, S) && dalloc(h, &s.dxx, S) &&
+                 dalloc(h, &s.dyy, S) && dalloc(h, &s.dxy, S) && dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S);
+        }
+        for (int b = 0; b < 3 && ok; b++)
+            ok = dalloc(h, &m.log.ent[b], NT * 256) && dalloc(h, &m.log.disp[b], NT * 256) && dalloc(h, &m.log.count[b], NT);
+        ok = ok && alloc_surfels(h, c.frame, S) && dalloc(h, &c.d_best, S) && dalloc(h, &c.d_matched, S) && dalloc(h, &c.d_rgb_in, 3 * P) &&
+             dalloc(h, &c.d_depth_in, P) && dalloc(h, &c.d_depth_filt, P) && dalloc(h, &c.d_mask, S);
+        m.rng_counter = d_rng; m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
+        if (!ok) break;
+        if (nctx == 1) c.stream = h->stream;                            // sequential: extract shares the track stream
+        else {
+            // low priority: the track chain (ICP -> fuse, on h->stream) is the critical path, and the
+            // runtime keeps a separate pool of hardware queues per priority, so every context gets a
+            // queue of its own instead of sharing one with the track stream (head-of-line blocking)
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) == hipSuccess; c.own_stream = ok;
+        }
+        ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_rng, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreate(&c.ev_t0) == hipSuccess && hipEventCreate(&c.ev_t1) == hipSuccess;
+    }
+    ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
+         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) &&
+         dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
              hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;
@@ -659,19 +761,21 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         float lut[256];
         for (int c8 = 0; c8 < 256; c8++) lut[c8] = srgb_expand((float)c8 / 255.0f);
         (void)hipMemcpy(h->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
-        m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
     }
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->stream);
-    (void)hipMemsetAsync(m.rng_counter, 0, NS * 4, h->stream);
-    (void)hipMemsetAsync(m.sample_score, 0, NS * 4, h->stream);
-    (void)hipMemsetAsync(m.inlier, 0, P, h->stream);
-    (void)hipMemsetAsync(m.plane_depth, 0, P * 4, h->stream);
-    (void)hipMemsetAsync(m.label[0], 0, P * 4, h->stream);
-    (void)hipMemsetAsync(m.label[1], 0, P * 4, h->stream);
-    zero_surfels(h, h->frame, S); zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
+    (void)hipMemsetAsync(d_rng, 0, NS * 4, h->stream);
+    for (auto& c : h->ctx) {
+        (void)hipMemsetAsync(c.maps.sample_score, 0, NS * 4, h->stream);
+        (void)hipMemsetAsync(c.maps.inlier, 0, P, h->stream);
+        (void)hipMemsetAsync(c.maps.plane_depth, 0, P * 4, h->stream);
+        (void)hipMemsetAsync(c.maps.label[0], 0, P * 4, h->stream);
+        zero_surfels(h, c.frame, S);
+    }
+    zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = "initialisation failed"; ssf_destroy(h); return SSF_ERR_DEVICE; }
+    h->cc = &h->ctx[0];
     h->pose.R = m3_identity(); h->pose.t = v3(0, 0, 0);
     *out = h;
     return SSF_OK;
@@ -686,6 +790,21 @@ int ssf_process_frame_device(ssf_handle* h, const void* rgb, const void* depth, 
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
     return process_frame_impl(h, rgb, depth, 1, prior, mask, out);
 }
+
+// pipelined form: extract of future frames runs ahead on its own stream(s)
+int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    TimerScope ts(h);
+    const double t0 = now_us();
+    int rc = submit_extract(h, rgb, depth, on_device, mask);
+    h->host_us[0] += now_us() - t0;
+    return rc;
+}
+int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* out) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    return process_oldest(h, prior, out);
+}
+int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
 
 int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
@@ -723,8 +842,8 @@ int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched) {
     TimerScope ts(h);
     int rc = do_match(h);
     if (rc) return rc;
-    HCK(hipMemcpyAsync(best, h->d_best, (size_t)h->S * 8, hipMemcpyDeviceToHost, h->stream));
-    HCK(hipMemcpyAsync(matched, h->d_matched, (size_t)h->S, hipMemcpyDeviceToHost, h->stream));
+    HCK(hipMemcpyAsync(best, h->cc->d_best, (size_t)h->S * 8, hipMemcpyDeviceToHost, h->stream));
+    HCK(hipMemcpyAsync(matched, h->cc->d_matched, (size_t)h->S, hipMemcpyDeviceToHost, h->stream));
     HCK(hipStreamSynchronize(h->stream));
     return SSF_OK;
 }
@@ -732,8 +851,8 @@ int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, 
     if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
     if (!h->have_frame) return SSF_ERR_STATE;
     TimerScope ts(h);
-    HCK(hipMemcpyAsync(h->d_best, best, (size_t)h->S * 8, hipMemcpyHostToDevice, h->stream));
-    HCK(hipMemcpyAsync(h->d_matched, matched, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->cc->d_best, best, (size_t)h->S * 8, hipMemcpyHostToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->cc->d_matched, matched, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
     return do_fuse(h, out);
 }
 
@@ -776,10 +895,11 @@ int ssf_get_model(ssf_handle* h, int first, int count, ssf_surfels* o) {
     if (!h || !o || first < 0 || count < 0 || first + count > h->cfg.nb_supersurfels_max) return SSF_ERR_INVALID_ARG;
     return copy_out(h, h->model[h->mcur], first, count, o);
 }
-int ssf_get_frame(ssf_handle* h, ssf_surfels* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_out(h, h->frame, 0, h->S, o); }
+int ssf_get_frame(ssf_handle* h, ssf_surfels* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_out(h, h->cc->frame, 0, h->S, o); }
 int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, int stamp) {
     if (!h || !in || n < 0 || n > h->cfg.nb_supersurfels_max || n_visible < 0 || n_visible > n) return SSF_ERR_INVALID_ARG;
     if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
     SurfelSoA& s = h->model[h->mcur];
     hipStream_t st = h->stream;
     const size_t N = n;
@@ -810,18 +930,18 @@ static int copy_map(ssf_handle* h, void* dst, const void* src, size_t bytes) {
     HCK(hipStreamSynchronize(h->stream));
     return SSF_OK;
 }
-int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.label[h->cur], (size_t)h->cfg.width * h->cfg.height * 4); }
+int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.label[0], (size_t)h->cfg.width * h->cfg.height * 4); }
 int ssf_get_boundary_map(ssf_handle* h, int32_t* o) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    launch_boundary_map(h->stream, h->seg, h->maps.label[h->cur], h->d_scratch_map);
+    launch_boundary_map(h->stream, h->seg, h->cc->maps.label[0], h->d_scratch_map);
     return copy_map(h, o, h->d_scratch_map, (size_t)h->cfg.width * h->cfg.height * 4);
 }
-int ssf_get_inlier_map(ssf_handle* h, uint8_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.inlier, (size_t)h->cfg.width * h->cfg.height); }
-int ssf_get_plane_depth(ssf_handle* h, float* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->maps.plane_depth, (size_t)h->cfg.width * h->cfg.height * 4); }
+int ssf_get_inlier_map(ssf_handle* h, uint8_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.inlier, (size_t)h->cfg.width * h->cfg.height); }
+int ssf_get_plane_depth(ssf_handle* h, float* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.plane_depth, (size_t)h->cfg.width * h->cfg.height * 4); }
 int ssf_get_superpixels(ssf_handle* h, float* o) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
     std::vector<SpRow> rows(h->S);
-    int rc = copy_map(h, rows.data(), h->maps.sp, (size_t)h->S * sizeof(SpRow));
+    int rc = copy_map(h, rows.data(), h->cc->maps.sp, (size_t)h->S * sizeof(SpRow));
     if (rc) return rc;
     for (int k = 0; k < h->S; k++) {
         const SpRow& r = rows[k];
@@ -889,7 +1009,7 @@ int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device
     if (!h || !in || !out) return SSF_ERR_INVALID_ARG;
     const size_t P = (size_t)h->cfg.width * h->cfg.height;
     const float* d_in = (const float*)in; float* d_out = (float*)out;
-    if (!on_device) { HCK(hipMemcpyAsync(h->d_depth_in, in, 4 * P, hipMemcpyHostToDevice, h->stream)); d_in = h->d_depth_in; d_out = h->d_depth_filt; }
+    if (!on_device) { HCK(hipMemcpyAsync(h->d_bf_in, in, 4 * P, hipMemcpyHostToDevice, h->stream)); d_in = h->d_bf_in; d_out = h->d_bf_out; }
     { TimerScope ts(h); launch_bilateral(h->stream, d_in, d_out, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space); }
     if (!on_device) HCK(hipMemcpyAsync(out, d_out, 4 * P, hipMemcpyDeviceToHost, h->stream));
     HCK(hipStreamSynchronize(h->stream));
@@ -909,15 +1029,22 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
 int ssf_reset_kernel_times(ssf_handle* h) { if (!h) return SSF_ERR_INVALID_ARG; h->timer.acc.clear(); return SSF_OK; }
 int ssf_set_profile(ssf_handle* h, int enable) { if (!h) return SSF_ERR_INVALID_ARG; h->cfg.profile = enable; return SSF_OK; }
 
+// host-side time split of the pipelined loop (tools/pipeline_probe.py); reset on read
+int ssf_dbg_host_times(ssf_handle* h, double* out8) {
+    if (!h || !out8) return SSF_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; i++) { out8[i] = h->host_us[i]; h->host_us[i] = 0; }
+    return SSF_OK;
+}
+
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
 // (bit0: skip the per-surfel math, bit1: skip the wave reduction, bit2: skip ticket + tail)
 double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     if (!h || !h->have_frame) return -1.0;
     Rt T; T.R = m3_transpose(h->pose.R); T.t = negate(m3_mulv(T.R, h->pose.t));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->frame, h->maps.label[h->cur], h->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -933,9 +1060,9 @@ double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg) {
     if (!h) return -1.0;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};
-    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->maps, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->maps, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

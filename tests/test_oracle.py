@@ -174,3 +174,23 @@ def test_deformation_identity_and_translation(oracle_lib):
     valid = before["confidences"] > 0
     assert np.allclose(after["positions"][valid], before["positions"][valid] + ntr[0], atol=1e-6)
     assert np.allclose(after["shapes"][valid], before["shapes"][valid], atol=1e-9)
+
+
+def test_submit_process_is_the_sequential_order(oracle_lib):
+    """The pipelined entry points are defined as the sequential order (checker side)."""
+    W, H = 160, 128
+    fa = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    fb = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, pipeline_depth=2))
+    frames = [util.frame(k, W, H) for k in range(4)]
+    want = [fa.process_frame(*fr) for fr in frames]
+    for fr in frames[:3]:
+        fb.submit_frame(*fr)
+    with pytest.raises(binding.SsfError):
+        fb.submit_frame(*frames[3])
+    got = [fb.process_submitted().as_dict()]
+    fb.submit_frame(*frames[3])
+    while fb.pending_frames():
+        got.append(fb.process_submitted().as_dict())
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fa, fb)

@@ -182,3 +182,40 @@ def test_full_size_determinism_and_partition_properties(product_lib):
         assert int((np.diff(o) < 0).sum()) <= 3
     new = ids[ids < 1000]
     assert set(np.unique(new)) <= {30, 31}
+
+
+@pytest.mark.parametrize("depth_ahead", [1, 2, 3])
+def test_pipelined_equals_sequential_bit_exact(depth_ahead, oracle_lib, product_lib):
+    """ssf_submit_frame / ssf_process_submitted with extract running `depth_ahead` frames ahead on
+    its own streams: every per-frame result and the final map equal the oracle's sequential run
+    (the RANSAC draw counters are the only cross-frame state of extract and are event-chained)."""
+    W, H, nf = 320, 240, 9
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead))
+    frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
+    want = [fo.process_frame(*fr) for fr in frames]
+    got = []
+    nsub = 0
+    for k in range(nf):
+        while nsub < nf and fh.pending_frames() < depth_ahead + 1:
+            fh.submit_frame(*frames[nsub]); nsub += 1
+        got.append(fh.process_submitted().as_dict())
+    assert fh.pending_frames() == 0
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)            # maps / frame supersurfels of the last frame + pose + whole model
+
+
+def test_pipeline_full_and_empty_are_errors(product_lib):
+    W, H = 160, 128
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=1))
+    rgb, depth = util.frame(0, W, H)
+    with pytest.raises(binding.SsfError):
+        fh.process_submitted()
+    fh.submit_frame(rgb, depth); fh.submit_frame(rgb, depth)
+    with pytest.raises(binding.SsfError):
+        fh.submit_frame(rgb, depth)
+    with pytest.raises(binding.SsfError):      # the whole-frame call may not jump the queue
+        fh.process_frame(rgb, depth)
+    fh.process_submitted(); fh.process_submitted()
+    fh.process_frame(rgb, depth)
