@@ -40,23 +40,24 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 # algorithmic bytes per unit of each kernel (DESIGN.md "Kernels")
 P = W * H
 ALGO_BYTES = {
-    "reorder_scatter": lambda c: 212.0 * c["n_model"],           # state 4 + row 104 read + row 104 written
+    "reorder_scatter": lambda c: 209.0 * c["n_model"],           # state 1 + row 104 read + row 104 written
     "classify": lambda c: 28.0 * c["n_model"],                   # pos 12 + stamps 8 + conf 4 read, state 4 written
     "icp_accumulate": lambda c: 36.0 * c["n_visible"] + 8.0 * P + 28.0 * c["S"],
     "match": lambda c: 40.0 * c["n_visible"],
-    "update_pass_rgb": lambda c: 9.0 * P,
-    "update_pass_rgbd": lambda c: 14.0 * P,
-    "ingest": lambda c: 23.0 * P,
-    "init_disp": lambda c: 9.0 * P,
-    "eval_samples": lambda c: 8.0 * P,
-    "render_moments": lambda c: 25.0 * P,
+    "update_pass_rgb": lambda c: c["batch"] * 9.0 * P,
+    "update_pass_rgbd": lambda c: c["batch"] * 14.0 * P,
+    "ingest": lambda c: c["batch"] * 23.0 * P,
+    "init_disp": lambda c: c["batch"] * 9.0 * P,
+    "eval_samples": lambda c: c["batch"] * 8.0 * P,
+    "render_moments": lambda c: c["batch"] * 25.0 * P,
 }
 
 
-def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0):
+def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1):
     K = synthetic.intrinsics(W, H)
     kw = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=cap,
-              rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0, pipeline_depth=pipeline_depth)
+              rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0, pipeline_depth=pipeline_depth,
+              extract_batch=extract_batch)
     kw.update(PARAMS)
     if stream is not None:
         kw["stream"] = stream
@@ -81,7 +82,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="frames the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
+                    help="batches the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
+    ap.add_argument("--extract-batch", type=int, default=1, help="frames per extract launch chain")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +99,7 @@ def main():
 
     lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
     K, Wm = a.steps, a.warmup
-    nf = K + Wm + 2 * a.profile_frames + 2
+    nf = K + Wm + a.profile_frames + 2 * (a.profile_frames + a.extract_batch) + 2
     frames = render_frames(nf)
     d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
@@ -114,7 +116,8 @@ def main():
     cap = n_local + 65536
     stream = torch.cuda.current_stream(dev).cuda_stream
     depth = a.pipeline_depth if world == 1 else 0
-    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth))
+    batch = a.extract_batch if world == 1 else 1
+    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch))
     f.set_model(model_local, nvis_local, 30)
     drv = sharded.ShardedFusion(f, device=dev) if world > 1 else None
 
@@ -128,16 +131,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    cap_frames = f.pipeline_capacity()
+
     def run(first, count):
         """Process frames [first, first + count): every frame's extract, ICP and fusion complete inside."""
         res = []
-        if depth == 0:
+        if depth == 0 and batch == 1:
             for i in range(first, first + count):
                 res.append(step(i))
             return res
         nsub = first
         for i in range(first, first + count):
-            while nsub < first + count and f.pending_frames() < depth + 1:
+            while nsub < first + count and f.can_submit():
                 f.submit_frame(d_rgb[nsub].data_ptr(), d_depth[nsub].data_ptr(), on_device=True)
                 nsub += 1
             res.append(f.process_submitted().as_dict())
@@ -166,20 +171,19 @@ def main():
         dt = float(tt.item())
 
     # ---- roofline of the dominant kernel: per-kernel hipEvent times on the library's stream ----
+    # (same submission pattern as the timed region: batched / pipelined when configured)
     stage = np.zeros(3)
-    ns = max(a.profile_frames // 2, 1)
+    ns = npk = -(-max(a.profile_frames // 2, 1) // batch) * batch     # whole batches
     f.set_profile(2)                                  # stage split only (one event synchronise per frame)
-    for i in range(base, base + ns):
-        stage += np.array(step(i)["stage_ms"]) / ns
+    for r in run(base, ns):
+        stage += np.array(r["stage_ms"]) / ns
     f.set_profile(1); f.reset_kernel_times()          # per-kernel hipEvent brackets
     cnt_before = f.counts()
-    npk = max(a.profile_frames - ns, 1)
-    for i in range(base + ns, base + ns + npk):
-        step(i)
+    run(base + ns, npk)
     torch.cuda.synchronize(dev)
     kt = f.kernel_times()
     f.set_profile(0)
-    counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S)
+    counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S, batch=batch)
     per_kernel = {}
     for name, (ms, calls) in kt.items():
         avg_us = 1000.0 * ms / max(calls, 1)
@@ -236,7 +240,7 @@ def main():
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams" % (world, depth + 1 if depth else 0)},
-            "pipeline_depth": depth, "sequential_ms_per_frame": seq_ms,
+            "pipeline_depth": depth, "extract_batch": batch, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }

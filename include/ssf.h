@@ -44,6 +44,7 @@ extern "C" {
 
 #define SSF_ABI_VERSION 2
 #define SSF_MAX_PIPELINE_DEPTH 3
+#define SSF_MAX_EXTRACT_BATCH 8
 
 typedef enum ssf_status {
     SSF_OK = 0,
@@ -118,6 +119,10 @@ typedef struct ssf_config {
                                   0..SSF_MAX_PIPELINE_DEPTH; 2 is the measured optimum on MI355X: the command
                                   processor serves 4 hardware queues concurrently = the track stream + 3
                                   extract streams, a 5th active queue halves the throughput. */
+    int   extract_batch;       /* 1 (default).  b > 1: the extract stage of b submitted frames runs as ONE chain of
+                                  launches (every kernel relabels the tiles of all b frames; the passes are
+                                  launch-latency bound, so b frames cost little more than one).  Only the
+                                  submit/process form batches; 1..SSF_MAX_EXTRACT_BATCH. */
 } ssf_config;
 
 typedef struct ssf_handle ssf_handle;
@@ -179,7 +184,9 @@ int ssf_process_frame_device(ssf_handle* h, const void* d_rgb, const void* d_dep
  * k-1.  ssf_submit_frame enqueues the extract stage of the NEXT frame asynchronously (its own HIP
  * stream; returns without waiting) and ssf_process_submitted runs ICP + association + fusion of the
  * OLDEST submitted frame and returns its result, exactly what ssf_process_frame would have
- * returned.  At most pipeline_depth + 1 frames may be pending (SSF_ERR_STATE beyond that).
+ * returned.  At most ssf_pipeline_capacity() frames may be pending (SSF_ERR_STATE beyond that).
+ * With extract_batch = b the launches happen once b frames have been submitted (or when the
+ * first of them is asked for by ssf_process_submitted).
  * Device input buffers (on_device = 1) must stay valid until the frame has been processed.  The
  * per-frame getters below refer to the last processed frame and are invalidated by the next
  * ssf_submit_frame once the pipeline wraps around (always valid with pipeline_depth = 0).
@@ -189,6 +196,11 @@ int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth_m, int on
                      const uint8_t* dynamic_mask);
 int ssf_process_submitted(ssf_handle* h, const float* prior_pose, ssf_frame_result* out);
 int ssf_pending_frames(const ssf_handle* h);
+/* Frames that can be pending at once: (pipeline_depth + 1) * extract_batch. */
+int ssf_pipeline_capacity(const ssf_handle* h);
+/* 1 when ssf_submit_frame would accept a frame now (a batch context is open or free), else 0:
+ * a batch whose frames are still being consumed keeps its context until the last one is fused. */
+int ssf_can_submit(const ssf_handle* h);
 
 /* ---- stage seams (used by the sharded multi-GPU driver and by the parity tests) ------------- */
 /* extract: ingest + TPS segmentation + plane filter + plane depth + frame supersurfels. */

@@ -17,7 +17,12 @@
 //       out-of-range read of the very last node is skipped
 //   A13 association = exact arg-min of dist, ties -> lowest global id (packed u64 min)
 //   A14 insertion order = ascending frame id; overflow drops the highest ids
-//   cuRAND -> counter-based splitmix64 stream per (superpixel, sample), counters persist
+//   cuRAND -> counter-based splitmix64 stream per (superpixel, sample).  The reference's XORWOW state
+//       persists and advances by a data-dependent number of draws per frame; here the draws of
+//       frame number e (frames extracted so far by this handle) use counters e*64 .. e*64+63 (a frame
+//       consumes at most 20 + 30 draws per stream), i.e. a fixed skip-ahead per frame: every frame
+//       still gets fresh draws of the same stream, and frames no longer depend on one another, so
+//       their extraction can be batched / pipelined
 #pragma once
 #include <cstdint>
 #include <string>
@@ -82,7 +87,7 @@ struct State {
     std::vector<SpSums> sums;
     std::vector<Superpixel> sp;
     std::vector<float> samples;        // 4 per (superpixel, sample): a, b, c, score
-    std::vector<uint32_t> rng_counter; // per (superpixel, sample)
+    uint32_t extract_ordinal = 0;      // frames extracted so far: the RNG epoch of the next frame
     int max_passes = 0;
     Surfels frame, model;
     // rgbToLab(colour) caches: a pure function of the stored colour, refreshed whenever a colour is

@@ -40,7 +40,7 @@ void ssf_default_config(ssf_config* c) {      // supersurfel_fusion.hpp:46-74 de
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
     c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
-    c->pipeline_depth = 0;
+    c->pipeline_depth = 0; c->extract_batch = 1;
 }
 
 int ssf_create(const ssf_config* cfg, ssf_handle** out) {
@@ -63,7 +63,6 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     s.label.assign(P, 0); s.label_tmp.assign(P, 0); s.inlier.assign(P, 0);
     s.sums.resize(s.S); s.sp.resize(s.S);
     s.samples.assign((size_t)s.S * cfg->nb_samples * 4, 0.f);
-    s.rng_counter.assign((size_t)s.S * cfg->nb_samples, 0u);
     s.frame.resize(s.S); s.frame.zero(s.S); s.frame_lab.assign(s.S, mk3(0, 0, 0));
     s.model.resize(cfg->nb_supersurfels_max); s.model.zero(cfg->nb_supersurfels_max);
     s.model_lab.assign(cfg->nb_supersurfels_max, mk3(0, 0, 0));
@@ -143,11 +142,17 @@ int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, con
     if (out) *out = r;
     return SSF_OK;
 }
+int ssf_pipeline_capacity(const ssf_handle* h) {
+    if (!h) return 0;
+    const int d = h->s.cfg.pipeline_depth, b = h->s.cfg.extract_batch;
+    return ((d < 0 ? 0 : (d > SSF_MAX_PIPELINE_DEPTH ? SSF_MAX_PIPELINE_DEPTH : d)) + 1) *
+           (b < 1 ? 1 : (b > SSF_MAX_EXTRACT_BATCH ? SSF_MAX_EXTRACT_BATCH : b));
+}
+int ssf_can_submit(const ssf_handle* h) { return (h && (int)h->pending.size() < ssf_pipeline_capacity(h)) ? 1 : 0; }
 // the pipelined form is, by definition, the sequential order: the checker queues copies of the inputs
 int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int /*on_device*/, const uint8_t* mask) {
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
-    const int depth_max = h->s.cfg.pipeline_depth < 0 ? 0 : (h->s.cfg.pipeline_depth > SSF_MAX_PIPELINE_DEPTH ? SSF_MAX_PIPELINE_DEPTH : h->s.cfg.pipeline_depth);
-    if ((int)h->pending.size() >= depth_max + 1) return SSF_ERR_STATE;
+    if ((int)h->pending.size() >= ssf_pipeline_capacity(h)) return SSF_ERR_STATE;
     const size_t P = (size_t)h->s.W * h->s.H;
     PendingFrame f;
     f.rgb.assign((const uint8_t*)rgb, (const uint8_t*)rgb + 3 * P);

@@ -202,7 +202,7 @@ static void init_samples(State& s) {
     for (int index = 0; index < s.S; index++)
         for (int t = 0; t < ns; t++) {
             const uint32_t idx = (uint32_t)(index * ns + t);
-            uint32_t ctr = s.rng_counter[idx];
+            uint32_t ctr = s.extract_ordinal * 64u;                              // epoch of this frame (oracle.h)
             const float cx = s.sp[index].cx, cy = s.sp[index].cy;
             float x = cx, y = cy;
             int i = s.label[tex_idx(s, x, y)];
@@ -234,7 +234,6 @@ static void init_samples(State& s) {
             }
             float* smp = &s.samples[4 * (size_t)idx];
             smp[0] = a; smp[1] = b; smp[2] = cc; smp[3] = 0.f;
-            s.rng_counter[idx] = ctr;                                           // state persists (:400)
         }
 }
 
@@ -442,6 +441,7 @@ void bilateral_filter(const float* in, float* out, int W, int H, float sigma_col
 }
 
 void extract(State& s, const uint8_t* rgb, const float* depth, const uint8_t* dynamic_mask) {
+    struct Epoch { State& st; ~Epoch() { st.extract_ordinal++; } } epoch_guard{s};   // next frame, next RNG epoch
     const ssf_config& c = s.cfg;
     const int W = s.W, H = s.H;
     std::vector<float> filtered;

@@ -29,7 +29,7 @@ class SsfConfig(C.Structure):
         ("rng_seed", C.c_uint64), ("icp_force_iters", C.c_int), ("device_id", C.c_int),
         ("stream", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int),
         ("shard_tile", C.c_float), ("depth_prefilter", C.c_int), ("prefilter_sigma_color", C.c_float),
-        ("prefilter_sigma_space", C.c_float), ("profile", C.c_int), ("pipeline_depth", C.c_int),
+        ("prefilter_sigma_space", C.c_float), ("profile", C.c_int), ("pipeline_depth", C.c_int), ("extract_batch", C.c_int),
     ]
 
 
@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
-    "ssf_process_submitted", "ssf_pending_frames",
+    "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -122,6 +122,8 @@ class Library:
         L.ssf_submit_frame.argtypes = [vp, vp, vp, C.c_int, vp]
         L.ssf_process_submitted.argtypes = [vp, vp, C.POINTER(SsfFrameResult)]
         L.ssf_pending_frames.argtypes = [vp]
+        L.ssf_pipeline_capacity.argtypes = [vp]
+        L.ssf_can_submit.argtypes = [vp]
 
     @property
     def backend(self):
@@ -226,6 +228,12 @@ class Fusion:
 
     def pending_frames(self):
         return int(self.L.lib.ssf_pending_frames(self.h))
+
+    def can_submit(self):
+        return bool(self.L.lib.ssf_can_submit(self.h))
+
+    def pipeline_capacity(self):
+        return int(self.L.lib.ssf_pipeline_capacity(self.h))
 
     # ---- stage seams -------------------------------------------------------------------------
     def stage_extract(self, rgb, depth, dynamic_mask=None, on_device=False):

@@ -66,12 +66,60 @@ struct FrameMaps {
     uint32_t* rgba; float* disp; int32_t* label[2]; uint8_t* inlier; float* plane_depth;
     // Exact sums, double buffered: relabelling pass k reads sums[k & 1] (quiescent: nothing writes it
     // during the pass) and applies its own deltas plus the log of pass k-1 to sums[(k + 1) & 1].
-    SpSums sums[2]; PassLog log; SpRow* sp; float4* samples; int32_t* sample_score; uint32_t* rng_counter;
+    SpSums sums[2]; PassLog log; SpRow* sp; float4* samples; int32_t* sample_score;
+    uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
     unsigned int* ticket; // arrival counter of the relabelling pass (last workgroup runs the merge)
     const float* srgb_lut; // srgb_expand(c/255) for c = 0..255, built on the host with the same function
+    size_t slab;          // bytes between the working sets of consecutive frames of a batch (see batch_slot)
 };
+
+// Frame batching: an extract context holds up to SSF_MAX_BATCH frames whose working sets are carved
+// identically out of consecutive slabs, so frame b of a batch lives at (every pointer) + b * slab.
+// The extract kernels take the batch index from the grid (blockIdx.z, or .y for 1-D kernels): one
+// launch relabels the tiles of all frames of the batch.  srgb_lut / ticket are shared.
+#define SSF_MAX_BATCH 8
+template <typename T> SSF_HD T* slab_shift(T* p, size_t off) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
+}
+SSF_HD SpSums batch_slot(SpSums s, size_t o) {
+    s.sx = slab_shift(s.sx, o); s.sy = slab_shift(s.sy, o); s.sr = slab_shift(s.sr, o); s.sg = slab_shift(s.sg, o);
+    s.sb = slab_shift(s.sb, o); s.n = slab_shift(s.n, o); s.dx = slab_shift(s.dx, o); s.dy = slab_shift(s.dy, o);
+    s.dn = slab_shift(s.dn, o); s.dxx = slab_shift(s.dxx, o); s.dyy = slab_shift(s.dyy, o); s.dxy = slab_shift(s.dxy, o);
+    s.dxd = slab_shift(s.dxd, o); s.dyd = slab_shift(s.dyd, o); s.dd = slab_shift(s.dd, o);
+    return s;
+}
+SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
+    const size_t o = (size_t)b * m.slab;
+    m.rgba = slab_shift(m.rgba, o); m.disp = slab_shift(m.disp, o); m.label[0] = slab_shift(m.label[0], o);
+    m.label[1] = slab_shift(m.label[1], o); m.inlier = slab_shift(m.inlier, o); m.plane_depth = slab_shift(m.plane_depth, o);
+    m.sums[0] = batch_slot(m.sums[0], o); m.sums[1] = batch_slot(m.sums[1], o);
+    for (int i = 0; i < 3; i++) {
+        m.log.ent[i] = slab_shift(m.log.ent[i], o); m.log.disp[i] = slab_shift(m.log.disp[i], o);
+        m.log.count[i] = slab_shift(m.log.count[i], o);
+    }
+    m.sp = slab_shift(m.sp, o); m.samples = slab_shift(m.samples, o); m.sample_score = slab_shift(m.sample_score, o);
+    m.moments = slab_shift(m.moments, o); m.filt = slab_shift(m.filt, o); m.epoch = slab_shift(m.epoch, o);
+    return m;
+}
+SSF_HD SurfelSoA batch_slot(SurfelSoA s, size_t o) {
+    s.pos = slab_shift(s.pos, o); s.col = slab_shift(s.col, o); s.lab = slab_shift(s.lab, o); s.stamps = slab_shift(s.stamps, o);
+    s.r0 = slab_shift(s.r0, o); s.r1 = slab_shift(s.r1, o); s.r2 = slab_shift(s.r2, o); s.shape = slab_shift(s.shape, o);
+    s.dims = slab_shift(s.dims, o); s.conf = slab_shift(s.conf, o);
+    return s;
+}
+// caller-side inputs of the frames of one batch
+struct BatchIn {
+    const uint8_t* rgb[SSF_MAX_BATCH];
+    const float* depth[SSF_MAX_BATCH];
+};
+template <typename T> SSF_HD T batch_pick(const T* arr, int b) {     // uniform select chain (no dynamic kernarg indexing)
+    T v = arr[0];
+#pragma unroll
+    for (int i = 1; i < SSF_MAX_BATCH; i++) v = (b == i) ? arr[i] : v;
+    return v;
+}
 
 // Host-mapped (fine-grained, coherent) mailbox: the last workgroup of the ICP reduction and of the
 // fuse stage publish their small results here and then store a sequence number; the host polls the
@@ -89,17 +137,20 @@ struct Mailbox {
 #define SSF_ICP_REPLICAS 32
 
 // ---- extract stage (ssf_extract.hip) -----------------------------------------------------------
-void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m);
-void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf, bool with_planes);
+// every extract launch processes the nb frames of a batch (m, frame, best, matched, dynamic_mask = slot 0)
+// frame k of the batch is frame number epoch0 + k of this handle (keys its RANSAC draws)
+void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameMaps& m, int nb, uint32_t epoch0);
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg = 0);
-void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf);
-void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int cur);
-void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac);
-void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf);   // includes the final merge
-void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur);
-void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
-                             float zmax, int stamp, const uint8_t* dynamic_mask, unsigned long long* best, uint8_t* matched);
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0);
+void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);
+void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb);
+void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac);
+void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);   // includes the final merge
+void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb);
+// frame k of the batch gets stamp stamp0 + k; bit k of mask_bits: dynamic_mask slot k is valid
+void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, float zmin,
+                             float zmax, int stamp0, const uint8_t* dynamic_mask, unsigned mask_bits,
+                             unsigned long long* best, uint8_t* matched);
 void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space);
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
 

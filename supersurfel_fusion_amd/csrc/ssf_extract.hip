@@ -53,9 +53,12 @@ __device__ __forceinline__ void for_each_label(int label, bool active, F body) {
 // One workgroup per grid cell: RGB->RGBA, disparity = 1/depth, label = cell id, and the cell's
 // initial sums by an in-block reduction (depth2disp32F_kernel TPS_RGBD_kernels.cu:278-296,
 // initSuperpixelsRGBD_kernel :61-110).
-__global__ __launch_bounds__(256) void k_ingest(SegParams p, const uint8_t* __restrict__ rgb,
-                                                const float* __restrict__ depth, FrameMaps m) {
+__global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMaps m, uint32_t epoch0) {
+    const uint8_t* __restrict__ rgb = batch_pick(in.rgb, (int)blockIdx.y);
+    const float* __restrict__ depth = batch_pick(in.depth, (int)blockIdx.y);
+    m = batch_slot(m, blockIdx.y);
     const int cell = blockIdx.x;
+    if (cell == 0 && threadIdx.x == 0) m.epoch[0] = epoch0 + blockIdx.y;
     const int cx0 = (cell % p.gx) * p.cell, cy0 = (cell / p.gx) * p.cell;
     const int w = min(p.cell, p.W - cx0), h = min(p.cell, p.H - cy0);
     int sx = 0, sy = 0, sr = 0, sg = 0, sb = 0, n = 0;
@@ -112,14 +115,6 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
     }
     return row;
 }
-__global__ void k_merge(SegParams p, FrameMaps m, int true_buf, int with_planes) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.S) return;
-    m.sp[k] = row_from_sums(true_buf ? m.sums[1] : m.sums[0], k, with_planes != 0, m.sp[k]);
-#pragma unroll
-    for (int j = 0; j < 13; j++) m.moments[(size_t)k * 13 + j] = 0;     // accumulators of k_render_moments
-}
-
 // ---- relabelling pass --------------------------------------------------------------------------
 #define TILE 32
 #define TW (TILE + 2)
@@ -252,6 +247,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];   // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
+    m = batch_slot(m, blockIdx.z);
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
@@ -433,46 +429,49 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(p.S * p.nb_samples)) return;
     const int index = (int)(idx / (uint32_t)p.nb_samples);
-    const int32_t* __restrict__ label = m.label[0];
-    uint32_t ctr = m.rng_counter[idx];
+    m = batch_slot(m, blockIdx.y);
+    // draws of frame number e use counters e*64 .. e*64+63 of stream idx (a frame needs at most 50)
+    uint32_t ctr = m.epoch[0] * 64u;
     const float radius = (float)p.cell / 2.f;
-    // centroid = mergeTPSRGBCoeffs of this superpixel, straight from the exact sums
-    const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
-    const float nn = (float)sm.n[index];
-    const float cx = (float)sm.sx[index] / nn, cy = (float)sm.sy[index] / nn;
-    float x = cx, y = cy;
-    int i = label[tex_index(x, y, p.W, p.H)];
-    int k = 0;
-    while (i != index && k++ < 10) {
-        const float u1 = rng_unit(rng_draw(p.seed, idx, ctr));
-        x = (float)((double)cx + ((double)radius * 2.) * (double)(u1 - 1.f));
-        const float u2 = rng_unit(rng_draw(p.seed, idx, ctr));
-        y = (float)((double)cy + ((double)radius * 2.) * (double)(u2 - 1.f));
-        i = label[tex_index(x, y, p.W, p.H)];
-    }
-    const float d0 = m.disp[tex_index(x, y, p.W, p.H)];
-    float px[3] = {x, x, x}, py[3] = {y, y, y}, pd[3] = {d0, d0, d0};
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-        for (int w = 0; w < 10; w++) {
-            const int dir = (int)(rng_draw(p.seed, idx, ctr) & 3u);
-            const float ddx = (dir == 0) ? -1.f : ((dir == 2) ? 1.f : 0.f);
-            const float ddy = (dir == 1) ? -1.f : ((dir == 3) ? 1.f : 0.f);
-            const float nxp = x + ddx, nyp = y + ddy;
+    {
+        const int32_t* __restrict__ label = m.label[0];
+        // centroid = mergeTPSRGBCoeffs of this superpixel, straight from the exact sums
+        const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
+        const float nn = (float)sm.n[index];
+        const float cx = (float)sm.sx[index] / nn, cy = (float)sm.sy[index] / nn;
+        float x = cx, y = cy;
+        int i = label[tex_index(x, y, p.W, p.H)];
+        int k = 0;
+        while (i != index && k++ < 10) {
+            const float u1 = rng_unit(rng_draw(p.seed, idx, ctr));
+            x = (float)((double)cx + ((double)radius * 2.) * (double)(u1 - 1.f));
+            const float u2 = rng_unit(rng_draw(p.seed, idx, ctr));
+            y = (float)((double)cy + ((double)radius * 2.) * (double)(u2 - 1.f));
             i = label[tex_index(x, y, p.W, p.H)];
-            if (i == index && nxp >= 0 && nxp < (float)p.W && nyp >= 0 && nyp < (float)p.H) {
-                x = nxp; y = nyp;
-                const float dd = m.disp[tex_index(x, y, p.W, p.H)];
-                if (isfinite(dd)) { px[j] = x; py[j] = y; pd[j] = dd; }
-            }
         }
-    float a, b, c;
-    if (!plane_solve(a, b, c, px[0], py[0], 1.f, pd[0], px[1], py[1], 1.f, pd[1], px[2], py[2], 1.f, pd[2])) {
-        a = 0.f; b = 0.f; c = pd[2];
+        const float d0 = m.disp[tex_index(x, y, p.W, p.H)];
+        float px[3] = {x, x, x}, py[3] = {y, y, y}, pd[3] = {d0, d0, d0};
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            for (int w = 0; w < 10; w++) {
+                const int dir = (int)(rng_draw(p.seed, idx, ctr) & 3u);
+                const float ddx = (dir == 0) ? -1.f : ((dir == 2) ? 1.f : 0.f);
+                const float ddy = (dir == 1) ? -1.f : ((dir == 3) ? 1.f : 0.f);
+                const float nxp = x + ddx, nyp = y + ddy;
+                i = label[tex_index(x, y, p.W, p.H)];
+                if (i == index && nxp >= 0 && nxp < (float)p.W && nyp >= 0 && nyp < (float)p.H) {
+                    x = nxp; y = nyp;
+                    const float dd = m.disp[tex_index(x, y, p.W, p.H)];
+                    if (isfinite(dd)) { px[j] = x; py[j] = y; pd[j] = dd; }
+                }
+            }
+        float a, b, c;
+        if (!plane_solve(a, b, c, px[0], py[0], 1.f, pd[0], px[1], py[1], 1.f, pd[1], px[2], py[2], 1.f, pd[2])) {
+            a = 0.f; b = 0.f; c = pd[2];
+        }
+        m.samples[idx] = make_float4(a, b, c, 0.f);
+        m.sample_score[idx] = 0;
     }
-    m.samples[idx] = make_float4(a, b, c, 0.f);
-    m.sample_score[idx] = 0;
-    m.rng_counter[idx] = ctr;
 }
 
 // evalSamples_kernel, TPS_RGBD_kernels.cu:403-433: integer scores.  Tile kernel: the candidate
@@ -480,9 +479,10 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
 // counts with LDS integer atomics; the tile flushes non-zero counts with one global atomic each.
 #define EVAL_WIN 64
 #define EVAL_NS 16
-__global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, int cur) {
+__global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
     __shared__ float4 w_plane[EVAL_WIN * EVAL_NS];
     __shared__ int w_cnt[EVAL_WIN * EVAL_NS];
+    m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const int ns = p.nb_samples;
     CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? EVAL_WIN : 0);
@@ -536,9 +536,10 @@ __device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int n
 // initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190).  Tile kernel:
 // the 9 exact integer sums of every inlier go into LDS accumulators of the window's superpixels and
 // are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
-__global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int cur, int ransac) {
+__global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int ransac) {
     __shared__ unsigned long long w_acc[WIN_MAX * 9];
     __shared__ float4 w_theta[WIN_MAX];
+    m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
     const int32_t* __restrict__ label = m.label[0];
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
 extern __shared__ __attribute__((aligned(16))) float filt_lds[];
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m, int true_buf) {
+    m = batch_slot(m, blockIdx.x);                     // one workgroup per frame of the batch
     const int S = p.S;
     float* base = IN_LDS ? filt_lds : m.filt;
     float* X0 = base; float* X1 = X0 + 3 * S; float* Z = X1 + 3 * S; float* px = Z + 3 * S; float* py = px + S;
@@ -682,10 +684,11 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m,
 // (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
 // boundary test and the 13 moment sums (fixed point 2^24, exact), which are accumulated with LDS
 // integer atomics per window superpixel and flushed once per tile.
-__global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m, int cur) {
+__global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m) {
     __shared__ int tile[TW * TW];
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ unsigned long long w_acc[WIN_MAX * 13];
+    m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
     for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
@@ -731,11 +734,17 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
 }
 
 // computeSupersurfels, supersurfel_fusion_kernels.cu:169-224 (+ the MOD mask hook)
-__global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp,
-                                   const uint8_t* __restrict__ dyn_mask, unsigned long long* __restrict__ best,
-                                   uint8_t* __restrict__ matched) {
+__global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp0,
+                                   const uint8_t* __restrict__ dyn_mask, unsigned mask_bits,
+                                   unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.S) return;
+    const int fb = blockIdx.y;
+    const size_t off = (size_t)fb * m.slab;
+    m = batch_slot(m, fb); f = batch_slot(f, off);
+    best = slab_shift(best, off); matched = slab_shift(matched, off);
+    dyn_mask = ((mask_bits >> fb) & 1u) ? slab_shift(dyn_mask, off) : nullptr;
+    const int stamp = stamp0 + fb;
     best[k] = 0xFFFFFFFFFFFFFFFFull; matched[k] = 0;         // association tables of this frame (findBestMatches init)
     const long long* a = &m.moments[(size_t)k * 13];
     const double inv = 1.0 / SSF_MOM_SCALE;
@@ -838,15 +847,11 @@ void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H,
 
 // ---- launchers -----------------------------------------------------------------------------------
 
-void launch_ingest(hipStream_t st, const SegParams& p, const uint8_t* rgb, const float* depth, FrameMaps& m) {
+void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameMaps& m, int nb, uint32_t epoch0) {
     ScopedKernel sk("ingest", st);
-    hipLaunchKernelGGL(k_ingest, dim3(p.S), dim3(256), 0, st, p, rgb, depth, m);
+    hipLaunchKernelGGL(k_ingest, dim3(p.S, nb), dim3(256), 0, st, p, in, m, epoch0);
 }
-void launch_merge(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf, bool with_planes) {
-    ScopedKernel sk(with_planes ? "merge_rgbd" : "merge_rgb", st);
-    hipLaunchKernelGGL(k_merge, dim3((p.S + 255) / 256), dim3(256), 0, st, p, m, true_buf, with_planes ? 1 : 0);
-}
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k, int ox, int oy, bool rgbd, int dbg) {
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
     static const char* per_pass_names[64] = {nullptr};
     static int per_pass = -1;
     if (per_pass < 0) {
@@ -859,37 +864,40 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int k,
     // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.
     dim3 grid = tile_grid(p);
     grid.x = (p.W + 30 + TILE - 1) / TILE;
+    grid.z = nb;
     if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
     else hipLaunchKernelGGL(k_update_pass<false>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
-void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf) {
+void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);
-    hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256), dim3(256), 0, st, p, m, true_buf);
+    hipLaunchKernelGGL(k_init_samples, dim3((p.S * p.nb_samples + 255) / 256, nb), dim3(256), 0, st, p, m, true_buf);
 }
-void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int cur) {
+static inline dim3 batch_tile_grid(const SegParams& p, int nb) { dim3 g = tile_grid(p); g.z = nb; return g; }
+void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb) {
     ScopedKernel sk("eval_samples", st);
-    hipLaunchKernelGGL(k_eval_samples, tile_grid(p), dim3(256), 0, st, p, m, cur);
+    hipLaunchKernelGGL(k_eval_samples, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
 }
-void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int cur, bool ransac) {
+void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac) {
     ScopedKernel sk("init_disp", st);
-    hipLaunchKernelGGL(k_init_disp, tile_grid(p), dim3(256), 0, st, p, m, cur, ransac ? 1 : 0);
+    hipLaunchKernelGGL(k_init_disp, batch_tile_grid(p, nb), dim3(256), 0, st, p, m, ransac ? 1 : 0);
 }
-void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int true_buf) {
+void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("plane_filter", st);
     const size_t lds = (size_t)p.S * 11 * sizeof(float);
     const int threads = p.S >= 1024 ? 1024 : ((p.S + 63) / 64) * 64;
-    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(1), dim3(threads), lds, st, p, m, true_buf);
-    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(1), dim3(1024), 0, st, p, m, true_buf);
+    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(nb), dim3(threads), lds, st, p, m, true_buf);
+    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(nb), dim3(1024), 0, st, p, m, true_buf);
 }
-void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int cur) {
+void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb) {
     ScopedKernel sk("render_moments", st);
-    hipLaunchKernelGGL(k_render_moments, tile_grid(p), dim3(256), 0, st, p, cam, m, cur);
+    hipLaunchKernelGGL(k_render_moments, batch_tile_grid(p, nb), dim3(256), 0, st, p, cam, m);
 }
-void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, SurfelSoA frame, float zmin,
-                             float zmax, int stamp, const uint8_t* dynamic_mask, unsigned long long* best, uint8_t* matched) {
+void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, float zmin,
+                             float zmax, int stamp0, const uint8_t* dynamic_mask, unsigned mask_bits,
+                             unsigned long long* best, uint8_t* matched) {
     ScopedKernel sk("finalize_surfels", st);
-    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 63) / 64), dim3(64), 0, st, p, m, frame, zmin, zmax, stamp, dynamic_mask,
-                       best, matched);
+    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 63) / 64, nb), dim3(64), 0, st, p, m, frame, zmin, zmax, stamp0,
+                       dynamic_mask, mask_bits, best, matched);
 }
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out) {
     hipLaunchKernelGGL(k_boundary_map, tile_grid(p), dim3(256), 0, st, p, label, out);

@@ -15,6 +15,8 @@
 #include <map>
 #include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 #include "../../include/ssf.h"
 #include "ssf_device.hpp"
@@ -205,19 +207,30 @@ struct IcpLoop {
     M3 R_init; V3 t_init, t_inc_stale;
 };
 
-// Everything one frame's extract stage owns.  With pipeline_depth > 0 there are pipeline_depth + 1 of
-// these, each on its own stream: the extract of frames k+1.. runs while the track/fuse chain (h->stream)
-// consumes frame k.  The only cross-frame state of extract is the RANSAC draw counters (chained by ev_rng).
+// Everything the extract stage of one BATCH of frames owns (cfg.extract_batch frames, slot b of every
+// buffer at + b * slab bytes).  With pipeline_depth > 0 there are pipeline_depth + 1 of these, each on
+// its own stream: the extract of later batches runs while the track/fuse chain (h->stream) consumes the
+// frames of an earlier one.  Extract has no cross-frame state (the RANSAC draws are keyed by the frame
+// number), so batches are independent of one another.
 struct ExtractCtx {
-    FrameMaps maps;
+    FrameMaps maps;                               // slot 0; maps.slab = bytes to the next slot
     SurfelSoA frame;
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
     hipStream_t stream = nullptr; bool own_stream = false;
-    hipEvent_t ev_done = nullptr, ev_rng = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_done = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool consumed_valid = false, timed = false;
-    hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t exec[2] = {nullptr, nullptr};
-    int stamp = 0;
+    hipGraph_t graph[SSF_MAX_BATCH + 1] = {}; hipGraphExec_t exec[SSF_MAX_BATCH + 1] = {};
+    // batch state: open (count > 0, !launched) -> in flight (launched, inflight > 0) -> free
+    int count = 0, inflight = 0, stamp0 = 0, nb_launched = 1; bool launched = false, waited = false;
+    uint32_t epoch0 = 0;
+    BatchIn in = {}; unsigned mask_bits = 0;
+};
+// the frame the track/fuse chain works on: slot views into its context
+struct ActiveFrame {
+    FrameMaps maps; SurfelSoA frame;
+    unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
+    ExtractCtx* ctx = nullptr; int slot = 0;
 };
 
 struct ssf_handle {
@@ -226,10 +239,10 @@ struct ssf_handle {
     std::string err;
     hipStream_t stream = nullptr; bool own_stream = false;
     SegParams seg; Cam cam;
-    std::vector<ExtractCtx> ctx; int next_ctx = 0;
-    std::deque<int> pending;                      // submitted, not yet processed (oldest first)
-    ExtractCtx* cc = nullptr;                     // the frame the track/fuse chain is working on (or last worked on)
-    ExtractCtx* rng_tail = nullptr;               // last context that advanced the RANSAC draw counters
+    std::vector<ExtractCtx> ctx; int open_ctx = 0, batch = 1;
+    std::deque<std::pair<int, int>> pending;      // (context, slot) submitted, not yet processed (oldest first)
+    ActiveFrame active; ActiveFrame* cc = &active; // the frame the track/fuse chain is working on (or last worked on)
+    uint32_t extract_ordinal = 0;                 // frames submitted so far = RNG epoch of the next frame
     SurfelSoA model[2]; int mcur = 0;
     std::vector<void*> allocs;
     float* d_bf_in = nullptr; float* d_bf_out = nullptr;
@@ -324,110 +337,129 @@ struct TimerScope {
 // Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
 // kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
 // only materialised where a later stage wants it: before the plane filter.
-enum { SEG_RGB = 1, SEG_SAMPLES = 2, SEG_REST = 4, SEG_ALL = 7 };
-static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, int parts) {
+static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c) {
     const SegParams& p = h->seg;
     hipStream_t st = c.stream;
+    const int nb = c.count;
     const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
     const int k1 = std::min(4 * (h->cfg.seg_iter / 2), limit), k2 = std::min(4 * h->cfg.seg_iter, std::max(limit, k1));
-    if (parts & SEG_RGB)
-        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, k, ox[k & 3], oy[k & 3], false);
+    for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false);
     // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
-    if ((parts & SEG_SAMPLES) && h->cfg.seg_use_ransac) launch_init_samples(st, p, c.maps, k1 & 1);
-    if (parts & SEG_REST) {
-        if (h->cfg.seg_use_ransac) { launch_eval_samples(st, p, c.maps, 0); launch_init_disp(st, p, c.maps, 0, true); }
-        else launch_init_disp(st, p, c.maps, 0, false);
-        int k = k1;
-        for (; k < k2 && k1 < limit; k++) launch_update_pass(st, p, c.maps, k, ox[k & 3], oy[k & 3], true);
-        launch_plane_filter(st, p, c.maps, k & 1);             // final merge (table + planes) + smoothing sweeps
-        launch_render_moments(st, p, h->cam, c.maps, 0);
-    }
+    if (h->cfg.seg_use_ransac) {
+        launch_init_samples(st, p, c.maps, nb, k1 & 1);
+        launch_eval_samples(st, p, c.maps, nb);
+        launch_init_disp(st, p, c.maps, nb, true);
+    } else launch_init_disp(st, p, c.maps, nb, false);
+    int k = k1;
+    for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true);
+    launch_plane_filter(st, p, c.maps, nb, k & 1);             // final merge (table + planes) + smoothing sweeps
+    launch_render_moments(st, p, h->cam, c.maps, nb);
 }
-// ~45 short dependent kernels: replayed as captured hipGraphs (launch-bound inner loop); eager when
-// kernels are individually timed or the pass count is being bisected
-static int run_segmentation(ssf_handle* h, ExtractCtx& c, int slot, int parts) {
+// ~45 short dependent kernels: replayed as one captured hipGraph (launch-bound inner loop), one graph per
+// batch size; eager when kernels are individually timed or the pass count is being bisected
+static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
     const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
     if (use_graph) {
-        if (!c.exec[slot]) {
+        hipGraphExec_t& ex = c.exec[c.count];
+        if (!ex) {
             bool ok = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                enqueue_segmentation(h, c, parts);
-                ok = hipStreamEndCapture(c.stream, &c.graph[slot]) == hipSuccess && c.graph[slot] != nullptr;
+                enqueue_segmentation(h, c);
+                ok = hipStreamEndCapture(c.stream, &c.graph[c.count]) == hipSuccess && c.graph[c.count] != nullptr;
             }
-            if (ok) ok = hipGraphInstantiate(&c.exec[slot], c.graph[slot], nullptr, nullptr, 0) == hipSuccess;
-            if (!ok) { h->graph_failed = true; c.exec[slot] = nullptr; (void)hipGetLastError(); }
+            if (ok) ok = hipGraphInstantiate(&ex, c.graph[c.count], nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) { h->graph_failed = true; ex = nullptr; (void)hipGetLastError(); }
         }
-        if (c.exec[slot]) { HCK(hipGraphLaunch(c.exec[slot], c.stream)); return SSF_OK; }
+        if (ex) { HCK(hipGraphLaunch(ex, c.stream)); return SSF_OK; }
     }
-    enqueue_segmentation(h, c, parts);
+    enqueue_segmentation(h, c);
     return SSF_OK;
 }
 
-// Enqueue the extract stage of one frame into the next context (asynchronous; nothing is waited for).
-static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
-    const int nctx = (int)h->ctx.size();
-    if ((int)h->pending.size() >= nctx) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
-    const int ci = h->next_ctx;
-    ExtractCtx& c = h->ctx[ci];
+// Launch the extract stage of the open batch of context c (asynchronous; nothing is waited for).
+static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     hipStream_t st = c.stream;
-    const bool multi = nctx > 1;
-    // the track/fuse chain must be done with the frame this context held before it is overwritten
+    const bool multi = h->ctx.size() > 1;
+    const int nb = c.count;
+    // the track/fuse chain must be done with the frames this context held before they are overwritten
     if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
-    c.stamp = h->stamp + (int)h->pending.size();
     c.timed = h->cfg.profile != 0;
     if (c.timed) HCK(hipEventRecord(c.ev_t0, st));
-    const size_t P = (size_t)h->cfg.width * h->cfg.height;
-    const uint8_t* d_rgb = (const uint8_t*)rgb; const float* d_depth = (const float*)depth;
-    if (!on_device) {
-        HCK(hipMemcpyAsync(c.d_rgb_in, rgb, 3 * P, hipMemcpyHostToDevice, st));
-        HCK(hipMemcpyAsync(c.d_depth_in, depth, 4 * P, hipMemcpyHostToDevice, st));
-        d_rgb = c.d_rgb_in; d_depth = c.d_depth_in;
-    }
-    const uint8_t* d_mask = nullptr;
-    if (mask) { HCK(hipMemcpyAsync(c.d_mask, mask, h->S, hipMemcpyHostToDevice, st)); d_mask = c.d_mask; }
     if (h->cfg.depth_prefilter) {                                          // supersurfel_fusion.cu:180
-        launch_bilateral(st, d_depth, c.d_depth_filt, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
-        d_depth = c.d_depth_filt;
-    }
-    launch_ingest(st, h->seg, d_rgb, d_depth, c.maps);
-    int rc;
-    if (!multi) rc = run_segmentation(h, c, 0, SEG_ALL);
-    else {
-        // the RANSAC draw counters carry over from frame to frame: init_samples of this frame runs after
-        // init_samples of the previous one (which lives on another stream), everything else is independent
-        rc = run_segmentation(h, c, 0, SEG_RGB);
-        if (!rc && h->cfg.seg_use_ransac) {
-            if (h->rng_tail && h->rng_tail != &c) HCK(hipStreamWaitEvent(st, h->rng_tail->ev_rng, 0));
-            enqueue_segmentation(h, c, SEG_SAMPLES);
-            HCK(hipEventRecord(c.ev_rng, st));
-            h->rng_tail = &c;
+        for (int b = 0; b < nb; b++) {
+            float* out = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
+            launch_bilateral(st, c.in.depth[b], out, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
+            c.in.depth[b] = out;
         }
-        if (!rc) rc = run_segmentation(h, c, 1, SEG_REST);
     }
+    launch_ingest(st, h->seg, c.in, c.maps, nb, c.epoch0);
+    int rc = run_segmentation(h, c);
     if (rc) return rc;
-    launch_finalize_surfels(st, h->seg, c.maps, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp, d_mask, c.d_best, c.d_matched);
+    launch_finalize_surfels(st, h->seg, c.maps, nb, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp0, c.d_mask, c.mask_bits,
+                            c.d_best, c.d_matched);
     HCK(hipGetLastError());
     if (c.timed) HCK(hipEventRecord(c.ev_t1, st));
     if (multi) HCK(hipEventRecord(c.ev_done, st));
-    h->pending.push_back(ci);
-    h->next_ctx = (ci + 1) % nctx;
+    c.launched = true; c.waited = false; c.inflight = nb; c.nb_launched = nb;
+    h->open_ctx = (int)((&c - h->ctx.data() + 1) % (ptrdiff_t)h->ctx.size());
+    return SSF_OK;
+}
+// Add one frame to the open batch; the batch is launched when it is full (or when its first frame is needed).
+static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
+    ExtractCtx& c = h->ctx[h->open_ctx];
+    if (c.launched) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
+    const int b = c.count;
+    if (b == 0) { c.stamp0 = h->stamp + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal; }
+    h->extract_ordinal++;
+    const size_t P = (size_t)h->cfg.width * h->cfg.height, off = (size_t)b * c.maps.slab;
+    c.in.rgb[b] = (const uint8_t*)rgb; c.in.depth[b] = (const float*)depth;
+    if (!on_device) {
+        uint8_t* drgb = slab_shift(c.d_rgb_in, off); float* ddep = slab_shift(c.d_depth_in, off);
+        HCK(hipMemcpyAsync(drgb, rgb, 3 * P, hipMemcpyHostToDevice, c.stream));
+        HCK(hipMemcpyAsync(ddep, depth, 4 * P, hipMemcpyHostToDevice, c.stream));
+        c.in.rgb[b] = drgb; c.in.depth[b] = ddep;
+    }
+    if (mask) { HCK(hipMemcpyAsync(slab_shift(c.d_mask, off), mask, h->S, hipMemcpyHostToDevice, c.stream)); c.mask_bits |= 1u << b; }
+    c.count = b + 1;
+    h->pending.push_back(std::make_pair(h->open_ctx, b));
+    if (c.count == h->batch) return launch_batch(h, c);
+    return SSF_OK;
+}
+// the frame held by h->active will not be fused (or has been): its slot is free again
+static int retire_active(ssf_handle* h) {
+    ExtractCtx* c = h->active.ctx;
+    if (!c || !h->have_frame) return SSF_OK;
+    h->have_frame = false;
+    if (--c->inflight == 0) {
+        if (h->ctx.size() > 1) { HCK(hipEventRecord(c->ev_consumed, h->stream)); c->consumed_valid = true; }
+        c->launched = false; c->count = 0;
+    }
     return SSF_OK;
 }
 // Make the oldest submitted frame the one the track/fuse chain works on.
 static int activate_oldest(ssf_handle* h) {
     if (h->pending.empty()) { h->err = "no submitted frame"; return SSF_ERR_STATE; }
-    ExtractCtx& c = h->ctx[h->pending.front()];
+    int rc = retire_active(h);                    // an activated frame that was never fused is dropped
+    if (rc) return rc;
+    const std::pair<int, int> fr = h->pending.front();
+    ExtractCtx& c = h->ctx[fr.first];
+    if (!c.launched) { rc = launch_batch(h, c); if (rc) return rc; }
     h->pending.pop_front();
-    if (h->ctx.size() > 1) HCK(hipStreamWaitEvent(h->stream, c.ev_done, 0));
-    if (c.stamp != h->stamp) { h->err = "submitted frame is out of sequence (model stamp changed while frames were pending)"; return SSF_ERR_STATE; }
-    h->cc = &c;
+    if (h->ctx.size() > 1 && !c.waited) { HCK(hipStreamWaitEvent(h->stream, c.ev_done, 0)); c.waited = true; }
+    if (c.stamp0 + fr.second != h->stamp) { h->err = "submitted frame is out of sequence (model stamp changed while frames were pending)"; return SSF_ERR_STATE; }
+    const size_t off = (size_t)fr.second * c.maps.slab;
+    ActiveFrame& a = h->active;
+    a.maps = batch_slot(c.maps, fr.second); a.frame = batch_slot(c.frame, off);
+    a.d_best = slab_shift(c.d_best, off); a.d_matched = slab_shift(c.d_matched, off);
+    a.ctx = &c; a.slot = fr.second;
     h->have_frame = true;
     return SSF_OK;
 }
 static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
-    int rc = submit_extract(h, rgb, depth, on_device, mask);
+    int rc = retire_active(h);
+    if (!rc) rc = submit_extract(h, rgb, depth, on_device, mask);
     return rc ? rc : activate_oldest(h);
 }
 
@@ -559,12 +591,12 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
                                 h->d_block_counts, h->d_cnt, h->mb_dev, seq);
         h->mcur ^= 1;
     } else {
-        launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
+            launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
         launch_publish_counts(h->stream, h->d_cnt, 0, h->mb_dev, seq);
     }
     HCK(hipGetLastError());
-    if (h->ctx.size() > 1) { HCK(hipEventRecord(h->cc->ev_consumed, h->stream)); h->cc->consumed_valid = true; }
+    { int rr = retire_active(h); if (rr) return rr; }     // last reader of this frame's buffers is enqueued
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
     if (rc) return rc;
     Counters c;
@@ -589,7 +621,6 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     }
     h->stamp++;
     h->global_n_model = -1; h->global_n_visible = -1;
-    h->have_frame = false;
     if (h->cfg.profile == 1) { HCK(hipStreamSynchronize(h->stream)); timer_collect(&h->timer); }
     return SSF_OK;
 }
@@ -601,9 +632,9 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     int rc = activate_oldest(h);
     if (rc) return rc;
     const double t_a = now_us();
-    if (h->ctx.size() > 1 && hipEventQuery(h->cc->ev_done) == hipSuccess) h->host_us[4] += 1;
+    if (h->ctx.size() > 1 && hipEventQuery(h->cc->ctx->ev_done) == hipSuccess) h->host_us[4] += 1;
     bool first_it = true;
-    const bool timing = h->cfg.profile != 0 && h->cc->timed;     // stage split costs an event synchronise: opt-in
+    const bool timing = h->cfg.profile != 0 && h->cc->ctx->timed;     // stage split costs an event synchronise: opt-in
     if (timing) HCK(hipEventRecord(h->ev[1], h->stream));
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
@@ -626,7 +657,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         HCK(hipEventRecord(h->ev[3], h->stream));
         HCK(hipEventSynchronize(h->ev[3]));
         float ms;
-        if (hipEventElapsedTime(&ms, h->cc->ev_t0, h->cc->ev_t1) == hipSuccess) r.stage_ms[0] = ms;
+        ExtractCtx* ec = h->cc->ctx;      // extract time of the batch this frame came in, per frame
+        if (hipEventElapsedTime(&ms, ec->ev_t0, ec->ev_t1) == hipSuccess) r.stage_ms[0] = ms / (float)ec->nb_launched;
         if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) r.stage_ms[1] = ms;
         if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) r.stage_ms[2] = ms;
     }
@@ -658,7 +690,7 @@ void ssf_default_config(ssf_config* c) {       // default arguments of initializ
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
     c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
-    c->pipeline_depth = 0;
+    c->pipeline_depth = 0; c->extract_batch = 1;
 }
 
 void ssf_destroy(ssf_handle* h) {
@@ -666,8 +698,8 @@ void ssf_destroy(ssf_handle* h) {
     for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& c : h->ctx) {
-        for (int i = 0; i < 2; i++) { if (c.exec[i]) (void)hipGraphExecDestroy(c.exec[i]); if (c.graph[i]) (void)hipGraphDestroy(c.graph[i]); }
-        hipEvent_t evs[5] = {c.ev_done, c.ev_rng, c.ev_consumed, c.ev_t0, c.ev_t1};
+        for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
+        hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
         if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     }
@@ -711,28 +743,46 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
     const size_t NT = (size_t)((W + 30 + 31) / 32) * ((H + 31) / 32);   // relabelling tiles (shifted grid has one more column)
     const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
+    h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
-    uint32_t* d_rng = nullptr;
-    bool ok = dalloc(h, &d_rng, NS) && dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 4);
+    bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 4);
+    // working set of one frame, carved out of a slab (256 B aligned pieces); a context owns `batch` slabs
+    auto carve = [&](ExtractCtx& c, char* base) -> size_t {
+        size_t off = 0;
+        auto take = [&](auto*& ptr, size_t count) {
+            using T = typename std::remove_reference<decltype(*ptr)>::type;
+            off = (off + 255) & ~(size_t)255;
+            ptr = reinterpret_cast<T*>(base + off);
+            off += std::max<size_t>(count, 1) * sizeof(T);
+        };
+        FrameMaps& m = c.maps;
+        take(m.rgba, P); take(m.disp, P); take(m.label[0], P); take(m.inlier, P); take(m.plane_depth, P);
+        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1);
+        m.label[1] = m.label[0];                                        // labels are relabelled in place (single map)
+        for (int b = 0; b < 2; b++) {
+            SpSums& q = m.sums[b];
+            take(q.sx, S); take(q.sy, S); take(q.sr, S); take(q.sg, S); take(q.sb, S); take(q.n, S); take(q.dx, S); take(q.dy, S);
+            take(q.dn, S); take(q.dxx, S); take(q.dyy, S); take(q.dxy, S); take(q.dxd, S); take(q.dyd, S); take(q.dd, S);
+        }
+        for (int b = 0; b < 3; b++) { take(m.log.ent[b], NT * 256); take(m.log.disp[b], NT * 256); take(m.log.count[b], NT); }
+        SurfelSoA& f = c.frame;
+        take(f.pos, 3 * S); take(f.col, 3 * S); take(f.lab, 3 * S); take(f.stamps, 2 * S); take(f.r0, 3 * S); take(f.r1, 3 * S);
+        take(f.r2, 3 * S); take(f.shape, 6 * S); take(f.dims, 2 * S); take(f.conf, S);
+        take(c.d_best, S); take(c.d_matched, S); take(c.d_rgb_in, 3 * P); take(c.d_depth_in, P); take(c.d_depth_filt, P); take(c.d_mask, S);
+        return (off + 255) & ~(size_t)255;
+    };
+    size_t slab_bytes = 0;
     for (int ci = 0; ci < nctx && ok; ci++) {
         ExtractCtx& c = h->ctx[ci];
-        FrameMaps& m = c.maps;
-        ok = dalloc(h, &m.rgba, P) && dalloc(h, &m.disp, P) && dalloc(h, &m.label[0], P) && dalloc(h, &m.inlier, P) &&
-             dalloc(h, &m.plane_depth, P) && dalloc(h, &m.sp, S) && dalloc(h, &m.samples, NS) && dalloc(h, &m.sample_score, NS) &&
-             dalloc(h, &m.moments, 13 * S) && dalloc(h, &m.filt, 11 * S);
-        m.label[1] = m.label[0];                                        // labels are relabelled in place (single map)
-        for (int b = 0; b < 2 && ok; b++) {
-            SpSums& s = m.sums[b];
-            ok = dalloc(h, &s.sx, S) && dalloc(h, &s.sy, S) && dalloc(h, &s.sr, S) && dalloc(h, &s.sg, S) && dalloc(h, &s.sb, S) &&
-                 dalloc(h, &s.n, S) && dalloc(h, &s.dx, S) && dalloc(h, &s.dy, S) && dalloc(h, &s.dn, S) && dalloc(h, &s.dxx, S) &&
-                 dalloc(h, &s.dyy, S) && dalloc(h, &s.dxy, S) && dalloc(h, &s.dxd, S) && dalloc(h, &s.dyd, S) && dalloc(h, &s.dd, S);
-        }
-        for (int b = 0; b < 3 && ok; b++)
-            ok = dalloc(h, &m.log.ent[b], NT * 256) && dalloc(h, &m.log.disp[b], NT * 256) && dalloc(h, &m.log.count[b], NT);
-        ok = ok && alloc_surfels(h, c.frame, S) && dalloc(h, &c.d_best, S) && dalloc(h, &c.d_matched, S) && dalloc(h, &c.d_rgb_in, 3 * P) &&
-             dalloc(h, &c.d_depth_in, P) && dalloc(h, &c.d_depth_filt, P) && dalloc(h, &c.d_mask, S);
-        m.rng_counter = d_rng; m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
+        slab_bytes = carve(c, nullptr);
+        char* base = nullptr;
+        ok = dalloc(h, &base, slab_bytes * h->batch);
         if (!ok) break;
+        (void)carve(c, base);
+        FrameMaps& m = c.maps;
+        m.slab = slab_bytes;
+        m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
+        (void)hipMemsetAsync(base, 0, slab_bytes * h->batch, h->stream);
         if (nctx == 1) c.stream = h->stream;                            // sequential: extract shares the track stream
         else {
             // low priority: the track chain (ICP -> fuse, on h->stream) is the critical path, and the
@@ -743,7 +793,6 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) == hipSuccess; c.own_stream = ok;
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c.ev_rng, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
              hipEventCreate(&c.ev_t0) == hipSuccess && hipEventCreate(&c.ev_t1) == hipSuccess;
     }
@@ -765,17 +814,13 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->stream);
-    (void)hipMemsetAsync(d_rng, 0, NS * 4, h->stream);
-    for (auto& c : h->ctx) {
-        (void)hipMemsetAsync(c.maps.sample_score, 0, NS * 4, h->stream);
-        (void)hipMemsetAsync(c.maps.inlier, 0, P, h->stream);
-        (void)hipMemsetAsync(c.maps.plane_depth, 0, P * 4, h->stream);
-        (void)hipMemsetAsync(c.maps.label[0], 0, P * 4, h->stream);
-        zero_surfels(h, c.frame, S);
-    }
     zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = "initialisation failed"; ssf_destroy(h); return SSF_ERR_DEVICE; }
-    h->cc = &h->ctx[0];
+    {   // getters before the first frame see slot 0 of context 0 (zeroed)
+        ExtractCtx& c0 = h->ctx[0];
+        h->active.maps = c0.maps; h->active.frame = c0.frame; h->active.d_best = c0.d_best; h->active.d_matched = c0.d_matched;
+        h->active.ctx = &c0; h->active.slot = 0;
+    }
     h->pose.R = m3_identity(); h->pose.t = v3(0, 0, 0);
     *out = h;
     return SSF_OK;
@@ -805,6 +850,8 @@ int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* o
     return process_oldest(h, prior, out);
 }
 int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
+int ssf_pipeline_capacity(const ssf_handle* h) { return h ? (int)h->ctx.size() * h->batch : 0; }
+int ssf_can_submit(const ssf_handle* h) { return (h && !h->ctx[h->open_ctx].launched) ? 1 : 0; }
 
 int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
@@ -1060,9 +1107,9 @@ double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg) {
     if (!h) return -1.0;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};
-    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 1, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 1, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -393,9 +393,10 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ blo
     }
 }
 
-// scatter every SoA stream of row i to its partitioned slot (stable within each state)
+// scatter every SoA stream of row i to its partitioned slot (stable within each state).  Removed rows
+// (state 2) are not moved: they would land beyond the new row count, where nothing reads them.
 __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const uint8_t* __restrict__ state,
-                                                 const uint32_t* __restrict__ block_off, Counters* cnt) {
+                                                 const uint32_t* __restrict__ block_off, const Counters* __restrict__ cnt) {
     __shared__ int hist[4][3];
     const int n = cnt->part_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,10 +410,10 @@ __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const
         if (lane() == 0) hist[wv][s] = __popcll(mask);
     }
     __syncthreads();
-    if (i < n) {
+    if (i < n && st < 2) {
         int before = 0;
         for (int w = 0; w < wv; w++) before += hist[w][st];
-        const int base = (st == 0) ? 0 : ((st == 1) ? cnt->part_s0 : cnt->part_s0 + cnt->part_s1);
+        const int base = (st == 0) ? 0 : cnt->part_s0;
         const size_t j = (size_t)base + block_off[3 * blockIdx.x + st] + before + in_wave;
         st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
         B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];

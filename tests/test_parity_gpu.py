@@ -184,21 +184,26 @@ def test_full_size_determinism_and_partition_properties(product_lib):
     assert set(np.unique(new)) <= {30, 31}
 
 
-@pytest.mark.parametrize("depth_ahead", [1, 2, 3])
-def test_pipelined_equals_sequential_bit_exact(depth_ahead, oracle_lib, product_lib):
-    """ssf_submit_frame / ssf_process_submitted with extract running `depth_ahead` frames ahead on
-    its own streams: every per-frame result and the final map equal the oracle's sequential run
-    (the RANSAC draw counters are the only cross-frame state of extract and are event-chained)."""
-    W, H, nf = 320, 240, 9
+@pytest.mark.parametrize("depth_ahead,batch", [(1, 1), (2, 1), (3, 1), (0, 3), (1, 2), (2, 4), (1, 8)])
+def test_pipelined_equals_sequential_bit_exact(depth_ahead, batch, oracle_lib, product_lib):
+    """ssf_submit_frame / ssf_process_submitted with extract running ahead on its own streams and
+    `batch` frames per launch chain: every per-frame result and the final map equal the oracle's
+    sequential run (the RANSAC draw counters are the only cross-frame state of extract; they are
+    chained inside a batch by the kernel and between batches by events).  11 frames: the last
+    batch is a partial one."""
+    W, H, nf = 320, 240, 11
     fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
-    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+    assert fh.pipeline_capacity() == (depth_ahead + 1) * batch
     frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
-    want = [fo.process_frame(*fr) for fr in frames]
+    mask = np.zeros(fo.S, np.uint8); mask[7:19] = 1
+    masks = [mask if k in (2, 5) else None for k in range(nf)]
+    want = [fo.process_frame(fr[0], fr[1], dynamic_mask=mk) for fr, mk in zip(frames, masks)]
     got = []
     nsub = 0
     for k in range(nf):
-        while nsub < nf and fh.pending_frames() < depth_ahead + 1:
-            fh.submit_frame(*frames[nsub]); nsub += 1
+        while nsub < nf and fh.can_submit():
+            fh.submit_frame(frames[nsub][0], frames[nsub][1], dynamic_mask=masks[nsub]); nsub += 1
         got.append(fh.process_submitted().as_dict())
     assert fh.pending_frames() == 0
     for a, b in zip(want, got):
