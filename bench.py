@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default: keep stdout for the one JSON line
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -76,14 +77,20 @@ def render_frames(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--rendered-frames", type=int, default=64,
+                    help="distinct orbit frames rendered; the sequence sweeps them back and forth (consecutive frames stay 1 degree apart)")
     ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
-    ap.add_argument("--extract-batch", type=int, default=1, help="frames per extract launch chain")
+    ap.add_argument("--extract-batch", type=int, default=4, help="frames per extract launch chain")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU exchanges (collectives included) even on one rank: exercises the N > 1 code path")
+    ap.add_argument("--py-driver", action="store_true",
+                    help="N > 1 through supersurfel_fusion_amd/sharded.py (torch.distributed collectives) instead of native RCCL")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,10 +106,20 @@ def main():
 
     lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
     K, Wm = a.steps, a.warmup
-    nf = K + Wm + a.profile_frames + 2 * (a.profile_frames + a.extract_batch) + 2
-    frames = render_frames(nf)
-    d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
-    d_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    nr = max(2, a.rendered_frames)
+    frames = render_frames(nr)
+    r_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    r_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
+
+    class Sweep:                                   # frame i of the stream: 0,1,..,nr-1,nr-2,..,1,0,1,..
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, i):
+            j = i % (2 * nr - 2)
+            return self.arr[j if j < nr else 2 * nr - 2 - j]
+
+    d_rgb, d_depth, h_frames = Sweep(r_rgb), Sweep(r_depth), Sweep(frames)
 
     model, nvis = synthetic.seed_model_cam0(N_MODEL, W, H, stamp=30)
     if world > 1:
@@ -114,17 +131,34 @@ def main():
         model_local, nvis_local = model, nvis
     n_local = len(model_local["confidences"])
     cap = n_local + 65536
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    depth = a.pipeline_depth if world == 1 else 0
-    batch = a.extract_batch if world == 1 else 1
+    depth, batch = a.pipeline_depth, a.extract_batch
+    # N > 1: the map is sharded and the library exchanges natively over RCCL on its track stream
+    # (ssf_comm_attach; torch.distributed only ships the communicator id and provides the barrier).
+    # --py-driver runs the same protocol through the stage seams with torch.distributed collectives instead.
+    exchange = world > 1 or a.force_sharded
+    if exchange and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    tstream, stream = None, None                   # library-owned (high-priority) track stream
+    if exchange and a.py_driver:
+        tstream = torch.cuda.Stream(dev)           # the torch stream the collectives are ordered on
+        stream = tstream.cuda_stream
     f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch))
     f.set_model(model_local, nvis_local, 30)
-    drv = sharded.ShardedFusion(f, device=dev) if world > 1 else None
+    drv = None
+    if exchange and a.py_driver:
+        drv = sharded.ShardedFusion(f, device=dev, stream=tstream, always_reduce=a.force_sharded)
+    elif exchange:
+        f.comm_attach()
+    eng = drv if drv is not None else f
 
     def step(i):
         if drv is not None:
             return drv.process_frame(d_rgb[i].data_ptr(), d_depth[i].data_ptr(), on_device=True)
         return f.process_frame_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr()).as_dict()
+
+    def as_dict(r):
+        return r if isinstance(r, dict) else r.as_dict()
 
     def barrier():
         if world > 1:
@@ -142,10 +176,10 @@ def main():
             return res
         nsub = first
         for i in range(first, first + count):
-            while nsub < first + count and f.can_submit():
-                f.submit_frame(d_rgb[nsub].data_ptr(), d_depth[nsub].data_ptr(), on_device=True)
+            while nsub < first + count and eng.can_submit():
+                eng.submit_frame(d_rgb[nsub].data_ptr(), d_depth[nsub].data_ptr(), on_device=True)
                 nsub += 1
-            res.append(f.process_submitted().as_dict())
+            res.append(as_dict(eng.process_submitted()))
         return res
 
     run(0, Wm)
@@ -156,15 +190,27 @@ def main():
     dt = time.perf_counter() - t0
     iters = [r["icp_iters"] for r in results]
     last = results[-1]
-    # strictly sequential latency of the same frames on the same handle (one frame in flight)
+    # strictly sequential latency (one frame in flight, pipeline_depth 0 / extract_batch 1): a second handle at
+    # N = 1, the same handle through the one-frame entry point otherwise
     nseq = a.profile_frames
+    if not exchange:
+        fseq = binding.Fusion(lib, make_cfg(lib, cap, rank, world, None, a.force_icp, 0, 1))
+        fseq.set_model(model_local, nvis_local, 30)
+        seq_step = lambda i: fseq.process_frame_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr())  # noqa: E731
+    else:
+        fseq, seq_step = None, step
+    s0 = 0 if fseq is not None else Wm + K         # the fresh handle starts at frame 0, the shared one continues
+    for i in range(s0, s0 + 4):
+        seq_step(i)
     barrier()
     t1 = time.perf_counter()
-    for i in range(Wm + K, Wm + K + nseq):
-        step(i)
+    for i in range(s0 + 4, s0 + 4 + nseq):
+        seq_step(i)
     barrier()
     seq_ms = 1000.0 * (time.perf_counter() - t1) / max(nseq, 1)
-    base = Wm + K + nseq
+    if fseq is not None:
+        fseq.close()
+    base = Wm + K + (0 if fseq is not None else 4 + nseq)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -216,19 +262,19 @@ def main():
             olib = binding.Library(olib_path)
             fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp))
             fo.set_model(model, nvis, 30)
-            fo.process_frame(*frames[0])                      # warm-up frame
+            fo.process_frame(*h_frames[0])                    # warm-up frame
             t1 = time.perf_counter()
             for i in range(1, 1 + a.cpu_frames):
-                fo.process_frame(*frames[i])
+                fo.process_frame(*h_frames[i])
             cdt = time.perf_counter() - t1
             cpu = dict(value=a.cpu_frames / cdt, unit="frames/s", cores=1, kind="port",
                        sample="%d frames of the same 640x480 / ~1M-supersurfel workload, oracle/libssf_oracle.so "
                               "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, cdt))
             fo.close()
 
+    gcounts = f.global_counts() if drv is None else dict(n_model=last["global_n_model"], n_visible=last["global_n_visible"])
     if rank == 0:
-        gn = last.get("global_n_model", last["n_model"])
-        gv = last.get("global_n_visible", last["n_visible"])
+        gn, gv = gcounts["n_model"], gcounts["n_visible"]
         out = {
             "metric": "frames_per_sec", "value": K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -244,9 +290,13 @@ def main():
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
             "roofline": roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }
-        print(json.dumps(out))
-    if world > 1:
+    f.close()
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)             # C-level stdout of the runtime libraries first: the JSON line is the last line
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

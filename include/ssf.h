@@ -43,6 +43,10 @@ extern "C" {
 #endif
 
 #define SSF_ABI_VERSION 2
+/* "no candidate" key of the association tables: the largest value that orders the same as a signed
+ * and as an unsigned 64-bit integer (valid keys are < 2^63: the distance is a positive float), so a
+ * MIN all-reduce works on backends without unsigned types */
+#define SSF_NO_MATCH 0x7FFFFFFFFFFFFFFFull
 #define SSF_MAX_PIPELINE_DEPTH 3
 #define SSF_MAX_EXTRACT_BATCH 8
 
@@ -219,11 +223,44 @@ int ssf_stage_icp_accumulate(ssf_handle* h, int64_t* sums);
 int ssf_stage_icp_update(ssf_handle* h, const int64_t* sums, int* again);
 int ssf_stage_icp_end(ssf_handle* h, int* valid);
 /* Projective association of this shard's visible supersurfels.  best[S]: packed
- * (dist_bits << 32 | global_id), UINT64_MAX = none; matched[S] as findBestMatches sets it. */
+ * (dist_bits << 32 | global_id), SSF_NO_MATCH = none; matched[S] as findBestMatches sets it. */
 int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched);
 /* update winners owned by this shard, insert owned unmatched frame surfels, classify, reorder. */
 int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched,
                    ssf_frame_result* out);
+
+/* Device-resident variants for the multi-GPU driver: the exchanged records stay in HBM, where the
+ * RCCL collectives run on them (the buffers are the caller's, e.g. torch tensors; for the CPU
+ * checker "device" pointers are host pointers).  All work is enqueued on the handle's stream
+ * (cfg.stream), which must be the stream the caller's collectives are ordered on.
+ *   ssf_stage_begin_submitted    the oldest frame submitted with ssf_submit_frame becomes the
+ *                                current frame of the stage calls (extract ran ahead)
+ *   ssf_stage_icp_accumulate_device  as ssf_stage_icp_accumulate, record -> d_sums[29], no wait
+ *   ssf_stage_icp_fetch          bring a (reduced) device record to the host: sums[29]
+ *   ssf_stage_match_device       association, tables -> d_best[S] / d_matched[S], no wait
+ *   ssf_stage_fuse_device        as ssf_stage_fuse with the (reduced) tables taken from HBM */
+int ssf_stage_begin_submitted(ssf_handle* h);
+int ssf_stage_icp_accumulate_device(ssf_handle* h, int64_t* d_sums);
+int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums);
+int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched);
+int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched,
+                          ssf_frame_result* out);
+
+/* ---- multi-GPU, native: RCCL on the handle's stream --------------------------------------------
+ * One process per GPU, cfg.rank / cfg.nranks / cfg.shard_tile describe this handle's shard of the
+ * map.  Rank 0 calls ssf_comm_unique_id and ships the 128 bytes to the other ranks out of band
+ * (e.g. a torch.distributed broadcast); every rank then calls ssf_comm_attach.  From then on
+ * ssf_process_frame* / ssf_process_submitted run the exchange steps themselves, all in HBM on the
+ * track stream: SUM all-reduce of the 29 x int64 ICP record per iteration, MIN / MAX all-reduce of
+ * the association tables, one all-gather of the shard sizes per frame (read lazily at the start of
+ * the next frame).  All ranks must process the same frames in the same order.
+ * ssf_get_global_counts: (n_model, n_visible, n_removed, n_inserted, n_updated) of the last frame
+ * summed over the ranks.  The CPU checker exports these symbols and returns SSF_ERR_DEVICE (it has
+ * no RCCL; the Python driver supersurfel_fusion_amd/sharded.py runs the same protocol over any
+ * torch.distributed backend through the stage seams). */
+int ssf_comm_unique_id(uint8_t* id128);
+int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
+int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
 
 /* ---- read back -------------------------------------------------------------------------------- */
 int ssf_get_pose(const ssf_handle* h, float* pose12);

@@ -116,6 +116,32 @@ int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, 
     fuse(h->s, best, matched, out); return SSF_OK;
 }
 
+// the checker has no RCCL: the native multi-GPU entry points report that (sharded.py covers N > 1 on CPU)
+int ssf_comm_unique_id(uint8_t* id128) { (void)id128; g_create_err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
+int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) { (void)id128; if (h) h->s.err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
+int ssf_get_global_counts(ssf_handle* h, int64_t* out5) {
+    if (!h || !out5) return SSF_ERR_INVALID_ARG;
+    out5[0] = h->s.n_model; out5[1] = h->s.n_visible; out5[2] = out5[3] = out5[4] = 0;
+    return SSF_OK;
+}
+// "device" variants: for the checker a device pointer is a host pointer
+int ssf_stage_begin_submitted(ssf_handle* h) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (h->pending.empty()) return SSF_ERR_STATE;
+    PendingFrame f = std::move(h->pending.front());
+    h->pending.pop_front();
+    return ssf_stage_extract(h, f.rgb.data(), f.depth.data(), 0, f.has_mask ? f.mask.data() : nullptr);
+}
+int ssf_stage_icp_accumulate_device(ssf_handle* h, int64_t* d_sums) { return ssf_stage_icp_accumulate(h, d_sums); }
+int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums) {
+    if (!h || !d_sums || !sums) return SSF_ERR_INVALID_ARG;
+    std::memcpy(sums, d_sums, SSF_ICP_RECORD * sizeof(int64_t)); return SSF_OK;
+}
+int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched) { return ssf_stage_match(h, d_best, d_matched); }
+int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, ssf_frame_result* out) {
+    return ssf_stage_fuse(h, d_best, d_matched, out);
+}
+
 int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, const float* prior,
                       const uint8_t* mask, ssf_frame_result* out) {
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;

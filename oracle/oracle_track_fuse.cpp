@@ -178,7 +178,7 @@ void icp_end(State& s, int* valid) {
 // findBestMatches, supersurfel_fusion_kernels.cu:522-599 (decision A13)
 void match(State& s, uint64_t* best, uint8_t* matched) {
     const ssf_config& c = s.cfg;
-    for (int f = 0; f < s.S; f++) { best[f] = UINT64_MAX; matched[f] = 0; }
+    for (int f = 0; f < s.S; f++) { best[f] = SSF_NO_MATCH; matched[f] = 0; }
     const int64_t nmodel = (c.nranks > 1 && s.global_n_model >= 0) ? s.global_n_model : s.n_model;
     const int64_t nvis = (c.nranks > 1 && s.global_n_visible >= 0) ? s.global_n_visible : s.n_visible;
     if (!(nmodel > 0 && nvis > 0)) return;                  // supersurfel_fusion.cu:351,356
@@ -271,7 +271,7 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
         const Mat33 R = s.pose.R; const f3 t = s.pose.t;
         if (nvis_g > 0)                                                         // :356, update (:386)
             for (int f = 0; f < s.S; f++) {
-                if (!matched[f] || best[f] == UINT64_MAX) continue;             // model_id >= 0 (:626)
+                if (!matched[f] || best[f] == SSF_NO_MATCH) continue;             // model_id >= 0 (:626)
                 int64_t local = (int64_t)(uint32_t)(best[f] & 0xFFFFFFFFull) - s.id_offset;
                 if (local < 0 || local >= s.n_visible) continue;                // owned by another shard
                 update_one(s, f, (int)local); n_updated++;

@@ -63,7 +63,9 @@ ABI_SYMBOLS = [
     "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
-    "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit",
+    "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
+    "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -124,6 +126,14 @@ class Library:
         L.ssf_pending_frames.argtypes = [vp]
         L.ssf_pipeline_capacity.argtypes = [vp]
         L.ssf_can_submit.argtypes = [vp]
+        L.ssf_comm_unique_id.argtypes = [vp]
+        L.ssf_comm_attach.argtypes = [vp, vp]
+        L.ssf_get_global_counts.argtypes = [vp, vp]
+        L.ssf_stage_begin_submitted.argtypes = [vp]
+        L.ssf_stage_icp_accumulate_device.argtypes = [vp, vp]
+        L.ssf_stage_icp_fetch.argtypes = [vp, vp, vp]
+        L.ssf_stage_match_device.argtypes = [vp, vp, vp]
+        L.ssf_stage_fuse_device.argtypes = [vp, vp, vp, C.POINTER(SsfFrameResult)]
 
     @property
     def backend(self):
@@ -283,6 +293,49 @@ class Fusion:
         matched = np.ascontiguousarray(matched, np.uint8)
         res = SsfFrameResult()
         self._ck(self.L.lib.ssf_stage_fuse(self.h, _ptr(best), _ptr(matched), C.byref(res)), "ssf_stage_fuse")
+        return res.as_dict()
+
+    # ---- multi-GPU, native RCCL ------------------------------------------------------------------
+    def comm_attach(self, group=None):
+        """Attach an RCCL communicator over the ranks of a torch.distributed group (which is only used
+        to ship rank 0's unique id); afterwards process_frame / process_submitted exchange natively."""
+        import torch
+        import torch.distributed as dist
+        ident = np.zeros(128, np.uint8)
+        if dist.get_rank(group) == 0:
+            rc = self.L.lib.ssf_comm_unique_id(_ptr(ident))
+            if rc != 0:
+                raise SsfError("ssf_comm_unique_id failed (%d): %s" % (rc, self.L.lib.ssf_last_error(None).decode()))
+        obj = [ident.tobytes()]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        ident = np.frombuffer(obj[0], np.uint8).copy()
+        self._ck(self.L.lib.ssf_comm_attach(self.h, _ptr(ident)), "ssf_comm_attach")
+
+    def global_counts(self):
+        out = np.zeros(5, np.int64)
+        self._ck(self.L.lib.ssf_get_global_counts(self.h, _ptr(out)), "ssf_get_global_counts")
+        return dict(zip(("n_model", "n_visible", "n_removed", "n_inserted", "n_updated"), (int(v) for v in out)))
+
+    # device-resident variants: the arguments are raw addresses (torch tensor .data_ptr())
+    def begin_submitted(self):
+        self._ck(self.L.lib.ssf_stage_begin_submitted(self.h), "ssf_stage_begin_submitted")
+
+    def icp_accumulate_device(self, d_sums_ptr):
+        self._ck(self.L.lib.ssf_stage_icp_accumulate_device(self.h, C.c_void_p(d_sums_ptr)), "ssf_stage_icp_accumulate_device")
+
+    def icp_fetch(self, d_sums_ptr):
+        sums = np.zeros(ICP_RECORD, np.int64)
+        self._ck(self.L.lib.ssf_stage_icp_fetch(self.h, C.c_void_p(d_sums_ptr), _ptr(sums)), "ssf_stage_icp_fetch")
+        return sums
+
+    def match_device(self, d_best_ptr, d_matched_ptr):
+        self._ck(self.L.lib.ssf_stage_match_device(self.h, C.c_void_p(d_best_ptr), C.c_void_p(d_matched_ptr)),
+                 "ssf_stage_match_device")
+
+    def fuse_device(self, d_best_ptr, d_matched_ptr):
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_stage_fuse_device(self.h, C.c_void_p(d_best_ptr), C.c_void_p(d_matched_ptr), C.byref(res)),
+                 "ssf_stage_fuse_device")
         return res.as_dict()
 
     # ---- read back ---------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ssf_math.hpp"
+#include "../../include/ssf.h"
 
 namespace ssf {
 
@@ -39,7 +40,11 @@ struct Counters {
     int n_removed;
     int n_state0, n_state1, n_state2;
     int part_n, part_s0, part_s1;   // frozen inputs of the scatter (rows to move, sizes of the first two classes)
+    // the published counters of the last frame (n_model, n_visible, n_removed, n_inserted, n_updated): never reset,
+    // the source of the per-frame RCCL all-gather of the shard sizes
+    int last[5];
 };
+#define SSF_MAX_RANKS 64
 
 struct Cam { float fx, fy, cx, cy; int W, H; };
 struct Rt { M3 R; V3 t; };
@@ -133,6 +138,9 @@ struct Mailbox {
     Counters cnt;
     unsigned long long cnt_check;
     unsigned long long cnt_seq;
+    int all_cnt[5 * SSF_MAX_RANKS];       // Counters::last of every rank (multi-GPU)
+    unsigned long long all_check;
+    unsigned long long all_seq;
 };
 #define SSF_ICP_REPLICAS 32
 
@@ -174,6 +182,8 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, Surf
                              const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
                              float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
                              unsigned long long seq);
+void launch_publish_icp(hipStream_t st, const long long* rec29, Mailbox* mb, unsigned long long seq);
+void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mailbox* mb, unsigned long long seq);
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);

@@ -118,7 +118,7 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
 // ---- relabelling pass --------------------------------------------------------------------------
 #define TILE 32
 #define TW (TILE + 2)
-#define WIN_MAX 144
+#define WIN_MAX 64
 static inline dim3 tile_grid(const SegParams& p) { return dim3((p.W + TILE - 1) / TILE, (p.H + TILE - 1) / TILE); }
 
 __device__ __forceinline__ void load_label_tile(int* tile, const int32_t* __restrict__ src, int X0, int Y0, int W, int H) {
@@ -258,6 +258,12 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const int x = X0 + lx0, y = Y0 + ly0;
     const bool in_image = x >= 0 && x < p.W && y < p.H;
     const size_t q = in_image ? (size_t)y * p.W + x : 0;
+    // this tile's log of the previous pass is replayed at the very end; its entry count is requested first so
+    // that only the valid entries are fetched (an unconditional 256-entry fetch costs 5 B per pixel of HBM)
+    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lp = (pass + 2) % 3, lc = pass % 3;
+    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
+    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
     // operands that do not depend on the label tile: in flight while the tile is staged
     const uint32_t px = m.rgba[q];
     float disp = 0.f; unsigned char prev_inlier = 0;
@@ -276,15 +282,13 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
             const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
             if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) w_row[i] = row_from_sums(sr, cy * p.gx + cx, RGBD, zero_row);
         }
-    // this tile's log entry of the previous pass: requested now, replayed at the very end
-    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int lp = (pass + 2) % 3, lc = pass % 3;
     const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
     const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
-    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
-    const int4 prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
-    const float prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
+    int4 prev_ent = make_int4(0, 0, 0, 0); float prev_disp = 0.f;
+    if (threadIdx.x < n_prev) {
+        prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
+        if (RGBD) prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
+    }
     if (threadIdx.x == 0) s_nlog = 0;
     if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
     if (!(dbg & 32)) load_label_tile(tile, lab, X0, Y0, p.W, p.H);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
         float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
         const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < 256 by construction
         cent[(size_t)tile_id * 256 + slot] = make_int4(index, new_index, x | (y << 16), (int)rgbf);
-        cdis[(size_t)tile_id * 256 + slot] = disp;
+        if (RGBD) cdis[(size_t)tile_id * 256 + slot] = disp;
     }
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
     if (threadIdx.x < n_prev && !(dbg & 8))
@@ -745,7 +749,7 @@ __global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float 
     best = slab_shift(best, off); matched = slab_shift(matched, off);
     dyn_mask = ((mask_bits >> fb) & 1u) ? slab_shift(dyn_mask, off) : nullptr;
     const int stamp = stamp0 + fb;
-    best[k] = 0xFFFFFFFFFFFFFFFFull; matched[k] = 0;         // association tables of this frame (findBestMatches init)
+    best[k] = SSF_NO_MATCH; matched[k] = 0;         // association tables of this frame (findBestMatches init)
     const long long* a = &m.moments[(size_t)k * 13];
     const double inv = 1.0 / SSF_MOM_SCALE;
     float sum[12];

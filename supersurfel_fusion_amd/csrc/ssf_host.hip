@@ -18,6 +18,8 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is resolved at run time (dlopen), never linked
 #include "../../include/ssf.h"
 #include "ssf_device.hpp"
 
@@ -199,6 +201,41 @@ void mat4_lmul(const double* a, double* b) {      // b <- a * b
 
 }  // namespace
 
+// ---- RCCL, resolved at run time -------------------------------------------------------------------------
+// The multi-GPU exchanges (ssf_comm_attach) call RCCL directly on the track stream.  The symbols come from
+// the librccl the process already holds (torch ships one, SONAME librccl.so.1) or from /opt/rocm; a box
+// without RCCL still loads libssf_hip.so and runs single-GPU.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.lib) break; }   // already in the process?
+    if (!api.lib) for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+    if (!api.lib) { api.err = "librccl.so.1 not found"; return nullptr; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) {
+        api.err = "librccl lacks a required symbol"; api.lib = nullptr; return nullptr;
+    }
+    return &api;
+}
+
 // ---- handle -----------------------------------------------------------------------------------------
 struct IcpLoop {
     bool active = false, valid = true, done = true;
@@ -243,6 +280,11 @@ struct ssf_handle {
     std::deque<std::pair<int, int>> pending;      // (context, slot) submitted, not yet processed (oldest first)
     ActiveFrame active; ActiveFrame* cc = &active; // the frame the track/fuse chain is working on (or last worked on)
     uint32_t extract_ordinal = 0;                 // frames submitted so far = RNG epoch of the next frame
+    // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
+    // are all-gathered at the end of every frame and read lazily at the start of the next one
+    ncclComm_t comm = nullptr; int* d_all5 = nullptr;
+    unsigned long long all_seq = 0; bool all_pending = false, all_valid = false;
+    long long all_cnt[5 * SSF_MAX_RANKS];
     SurfelSoA model[2]; int mcur = 0;
     std::vector<void*> allocs;
     float* d_bf_in = nullptr; float* d_bf_out = nullptr;
@@ -274,6 +316,16 @@ static std::string g_create_err;
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess) {                                                                      \
             h->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return SSF_ERR_DEVICE;                                                                   \
+        }                                                                                            \
+    } while (0)
+
+#define NCK(call)                                                                                    \
+    do {                                                                                             \
+        ncclResult_t r_ = (call);                                                                    \
+        if (r_ != ncclSuccess) {                                                                     \
+            RcclApi* a_ = rccl_api();                                                                \
+            h->err = std::string(#call) + ": " + ((a_ && a_->GetErrorString) ? a_->GetErrorString(r_) : "RCCL error"); \
             return SSF_ERR_DEVICE;                                                                   \
         }                                                                                            \
     } while (0)
@@ -483,7 +535,8 @@ static void inc_to_float(const double* tf, M3& R, V3& t) {
     t = v3((float)tf[3], (float)tf[7], (float)tf[11]);
 }
 // device accumulate; the record lands in d_icp and in the mailbox (h_icp points at the mailbox copy)
-static int icp_accumulate(ssf_handle* h, bool to_host) {
+static int icp_fetch(ssf_handle* h, unsigned long long seq);
+static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullptr) {
     IcpLoop& I = h->icp;
     M3 R_inc; V3 t_inc;
     inc_to_float(I.tf_inc, R_inc, t_inc);
@@ -491,22 +544,24 @@ static int icp_accumulate(ssf_handle* h, bool to_host) {
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     const unsigned long long seq = ++h->icp_seq;
     launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T,
-               h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, seq);
+               h->d_icp_replicas, h->d_tickets + 1, d_out ? d_out : h->d_icp, h->mb_dev, seq);
     HCK(hipGetLastError());
-    if (to_host) {
-        int rc = wait_seq(h, &h->mb_host->icp_seq, seq);
-        if (rc) return rc;
-        for (int attempt = 0;; attempt++) {          // checksum guards against a torn record
-            unsigned long long check = seq;
-            for (int i = 0; i < SSF_ICP_RECORD; i++) {
-                h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
-                check += (unsigned long long)h->h_icp_local[i];
-            }
-            if (check == __atomic_load_n(&h->mb_host->icp_check, __ATOMIC_ACQUIRE)) break;
-            if (attempt > 100000) { h->err = "ICP mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
+    return to_host ? icp_fetch(h, seq) : SSF_OK;
+}
+// wait for mailbox record `seq` and copy it to h->h_icp_local
+static int icp_fetch(ssf_handle* h, unsigned long long seq) {
+    int rc = wait_seq(h, &h->mb_host->icp_seq, seq);
+    if (rc) return rc;
+    for (int attempt = 0;; attempt++) {          // checksum guards against a torn record
+        unsigned long long check = seq;
+        for (int i = 0; i < SSF_ICP_RECORD; i++) {
+            h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
+            check += (unsigned long long)h->h_icp_local[i];
         }
-        h->h_icp = h->h_icp_local;
+        if (check == __atomic_load_n(&h->mb_host->icp_check, __ATOMIC_ACQUIRE)) break;
+        if (attempt > 100000) { h->err = "ICP mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
     }
+    h->h_icp = h->h_icp_local;
     return SSF_OK;
 }
 static void icp_update(ssf_handle* h, const int64_t* sums, int* again) {
@@ -618,10 +673,52 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         out->icp_valid = h->last_icp_valid; out->icp_iters = h->last_icp_iters;
         out->n_model = h->n_model; out->n_visible = h->n_visible; out->n_removed = c.n_removed;
         out->n_inserted = c.n_inserted; out->n_updated = c.n_updated; out->stamp = h->stamp;
+        ExtractCtx* ec = h->active.ctx;            // extract time of the batch this frame came in, per frame
+        float ms;
+        if (h->cfg.profile != 0 && ec && ec->timed && hipEventElapsedTime(&ms, ec->ev_t0, ec->ev_t1) == hipSuccess)
+            out->stage_ms[0] = ms / (float)ec->nb_launched;
     }
     h->stamp++;
     h->global_n_model = -1; h->global_n_visible = -1;
     if (h->cfg.profile == 1) { HCK(hipStreamSynchronize(h->stream)); timer_collect(&h->timer); }
+    return SSF_OK;
+}
+
+// ---- multi-GPU exchanges (native RCCL on the track stream) -------------------------------------------------
+// enqueue the all-gather of every rank's Counters::last and its publication to the mailbox
+static int comm_gather_counts(ssf_handle* h) {
+    RcclApi* api = rccl_api();
+    NCK(api->AllGather(h->d_cnt->last, h->d_all5, 5, ncclInt32, h->comm, h->stream));
+    const unsigned long long seq = ++h->all_seq;
+    launch_publish_all_counts(h->stream, h->d_all5, h->cfg.nranks, h->mb_dev, seq);
+    HCK(hipGetLastError());
+    h->all_pending = true;
+    return SSF_OK;
+}
+// the shard sizes of all ranks after the previous frame -> global counts and this shard's id offset
+static int comm_counts(ssf_handle* h) {
+    if (!h->all_valid && !h->all_pending) { int rc = comm_gather_counts(h); if (rc) return rc; }
+    if (h->all_pending) {
+        int rc = wait_seq(h, &h->mb_host->all_seq, h->all_seq);
+        if (rc) return rc;
+        const int n = 5 * h->cfg.nranks;
+        for (int attempt = 0;; attempt++) {
+            unsigned long long check = h->all_seq;
+            for (int i = 0; i < n; i++) {
+                const int v = __atomic_load_n(&h->mb_host->all_cnt[i], __ATOMIC_RELAXED);
+                h->all_cnt[i] = v; check += (unsigned long long)(unsigned int)v;
+            }
+            if (check == __atomic_load_n(&h->mb_host->all_check, __ATOMIC_ACQUIRE)) break;
+            if (attempt > 100000) { h->err = "shard-size mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
+        }
+        h->all_pending = false; h->all_valid = true;
+    }
+    long long gm = 0, gv = 0, off = 0;
+    for (int r = 0; r < h->cfg.nranks; r++) {
+        gm += h->all_cnt[5 * r]; gv += h->all_cnt[5 * r + 1];
+        if (r < h->cfg.rank) off += h->all_cnt[5 * r + 1];
+    }
+    h->global_n_model = gm; h->global_n_visible = gv; h->id_offset = off;
     return SSF_OK;
 }
 
@@ -636,10 +733,22 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     bool first_it = true;
     const bool timing = h->cfg.profile != 0 && h->cc->ctx->timed;     // stage split costs an event synchronise: opt-in
     if (timing) HCK(hipEventRecord(h->ev[1], h->stream));
+    RcclApi* api = h->comm ? rccl_api() : nullptr;
+    if (h->comm) { rc = comm_counts(h); if (rc) return rc; }
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
     while (again) {
-        rc = icp_accumulate(h, true);
+        if (h->comm) {
+            // shard record -> SUM over the ranks in HBM (exact: int64) -> mailbox -> host solve
+            rc = icp_accumulate(h, false);
+            if (rc) return rc;
+            NCK(api->AllReduce(h->d_icp, h->d_icp, SSF_ICP_RECORD, ncclInt64, ncclSum, h->comm, h->stream));
+            const unsigned long long seq = ++h->icp_seq;
+            launch_publish_icp(h->stream, h->d_icp, h->mb_dev, seq);
+            HCK(hipGetLastError());
+            rc = icp_fetch(h, seq);
+        } else
+            rc = icp_accumulate(h, true);
         if (rc) return rc;
         if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
         icp_update(h, (const int64_t*)h->h_icp, &again);
@@ -649,9 +758,15 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
     rc = do_match(h);
     if (rc) return rc;
+    if (h->comm) {
+        // best key over the ranks (keys < 2^63: signed MIN == unsigned MIN), matched = OR over the ranks
+        NCK(api->AllReduce(h->cc->d_best, h->cc->d_best, h->S, ncclInt64, ncclMin, h->comm, h->stream));
+        NCK(api->AllReduce(h->cc->d_matched, h->cc->d_matched, h->S, ncclUint8, ncclMax, h->comm, h->stream));
+    }
     ssf_frame_result r;
     rc = do_fuse(h, &r);
     if (rc) return rc;
+    if (h->comm) { rc = comm_gather_counts(h); if (rc) return rc; }     // read at the start of the next frame
     h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
     if (timing) {
         HCK(hipEventRecord(h->ev[3], h->stream));
@@ -697,6 +812,7 @@ void ssf_destroy(ssf_handle* h) {
     if (!h) return;
     for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     for (auto& c : h->ctx) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
@@ -731,7 +847,15 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
-    else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; } h->own_stream = true; }
+    else {
+        // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
+        // should not queue behind the wide extract launches of the low-priority context streams)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio = getenv("SSF_TRACK_PRIORITY") ? atoi(getenv("SSF_TRACK_PRIORITY")) : greatest;
+        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio) != hipSuccess) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; }
+        h->own_stream = true;
+    }
     SegParams& p = h->seg;
     p.W = W; p.H = H; p.cell = c; p.gx = h->gx; p.gy = h->gy; p.S = h->S; p.nb_samples = cfg->nb_samples;
     p.min_size = (int)((float)(c * c) / 4.f);                                   // TPS_RGBD.cu:198 (float -> int parameter)
@@ -853,6 +977,46 @@ int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() 
 int ssf_pipeline_capacity(const ssf_handle* h) { return h ? (int)h->ctx.size() * h->batch : 0; }
 int ssf_can_submit(const ssf_handle* h) { return (h && !h->ctx[h->open_ctx].launched) ? 1 : 0; }
 
+// ---- multi-GPU (native RCCL) ------------------------------------------------------------------------------
+int ssf_comm_unique_id(uint8_t* id128) {
+    if (!id128) return SSF_ERR_INVALID_ARG;
+    RcclApi* api = rccl_api();
+    if (!api) { g_create_err = "RCCL is not available in this process"; return SSF_ERR_DEVICE; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (api->GetUniqueId(&id) != ncclSuccess) { g_create_err = "ncclGetUniqueId failed"; return SSF_ERR_DEVICE; }
+    std::memcpy(id128, &id, 128);
+    return SSF_OK;
+}
+int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) {
+    if (!h || !id128) return SSF_ERR_INVALID_ARG;
+    if (h->comm) { h->err = "a communicator is already attached"; return SSF_ERR_STATE; }
+    if (h->cfg.nranks > SSF_MAX_RANKS) { h->err = "too many ranks"; return SSF_ERR_INVALID_ARG; }
+    RcclApi* api = rccl_api();
+    if (!api) { h->err = "RCCL is not available in this process"; return SSF_ERR_DEVICE; }
+    HCK(hipSetDevice(h->cfg.device_id));
+    if (!h->d_all5 && !dalloc(h, &h->d_all5, 5 * SSF_MAX_RANKS)) { h->err = "allocation failed"; return SSF_ERR_DEVICE; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    NCK(api->CommInitRank(&h->comm, h->cfg.nranks, id, h->cfg.rank));
+    h->all_valid = false; h->all_pending = false;
+    return SSF_OK;
+}
+int ssf_get_global_counts(ssf_handle* h, int64_t* out5) {
+    if (!h || !out5) return SSF_ERR_INVALID_ARG;
+    if (!h->comm) {
+        int rc = hipStreamSynchronize(h->stream) == hipSuccess ? SSF_OK : SSF_ERR_DEVICE;
+        Counters c;
+        if (rc || hipMemcpy(&c, h->d_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { h->err = "device error"; return SSF_ERR_DEVICE; }
+        for (int i = 0; i < 5; i++) out5[i] = c.last[i];
+        return SSF_OK;
+    }
+    int rc = comm_counts(h);
+    if (rc) return rc;
+    for (int i = 0; i < 5; i++) { out5[i] = 0; for (int r = 0; r < h->cfg.nranks; r++) out5[i] += h->all_cnt[5 * r + i]; }
+    return SSF_OK;
+}
+
 int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
     TimerScope ts(h);
@@ -893,6 +1057,44 @@ int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched) {
     HCK(hipMemcpyAsync(matched, h->cc->d_matched, (size_t)h->S, hipMemcpyDeviceToHost, h->stream));
     HCK(hipStreamSynchronize(h->stream));
     return SSF_OK;
+}
+int ssf_stage_begin_submitted(ssf_handle* h) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    return activate_oldest(h);
+}
+int ssf_stage_icp_accumulate_device(ssf_handle* h, int64_t* d_sums) {
+    if (!h || !d_sums) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    return icp_accumulate(h, false, (long long*)d_sums);
+}
+int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums) {
+    if (!h || !d_sums || !sums) return SSF_ERR_INVALID_ARG;
+    const unsigned long long seq = ++h->icp_seq;
+    launch_publish_icp(h->stream, (const long long*)d_sums, h->mb_dev, seq);
+    HCK(hipGetLastError());
+    int rc = icp_fetch(h, seq);
+    if (rc) return rc;
+    std::memcpy(sums, h->h_icp, SSF_ICP_RECORD * sizeof(int64_t));
+    return SSF_OK;
+}
+int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched) {
+    if (!h || !d_best || !d_matched) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    int rc = do_match(h);
+    if (rc) return rc;
+    HCK(hipMemcpyAsync(d_best, h->cc->d_best, (size_t)h->S * 8, hipMemcpyDeviceToDevice, h->stream));
+    HCK(hipMemcpyAsync(d_matched, h->cc->d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
+    return SSF_OK;
+}
+int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, ssf_frame_result* out) {
+    if (!h || !d_best || !d_matched) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    HCK(hipMemcpyAsync(h->cc->d_best, d_best, (size_t)h->S * 8, hipMemcpyDeviceToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->cc->d_matched, d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
+    return do_fuse(h, out);
 }
 int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
     if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
@@ -969,6 +1171,7 @@ int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, in
     }
     h->n_model = n; h->n_visible = n_visible; h->stamp = stamp;
     Counters c; std::memset(&c, 0, sizeof(c)); c.n_model = n; c.n_visible = n_visible;
+    c.last[0] = n; c.last[1] = n_visible; h->all_valid = false;
     HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
     return SSF_OK;
 }
@@ -1103,13 +1306,15 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
 }
 
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
-double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg) {
-    if (!h) return -1.0;
+double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg, int nb) {
+    if (!h || !h->active.ctx) return -1.0;
+    ExtractCtx& c = *h->active.ctx;                   // all slots of the batch context (nb <= extract_batch)
+    nb = std::max(1, std::min(nb, h->batch));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};
-    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 1, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, c.maps, nb, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, h->cc->maps, 1, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
+    for (int i = 0; i < reps; i++) launch_update_pass(h->stream, h->seg, c.maps, nb, 24 + i, ox[i & 3], oy[i & 3], rgbd != 0, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -169,7 +169,7 @@ __device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, in
                                            int n_visible, const unsigned long long* __restrict__ best,
                                            const uint8_t* __restrict__ matched, int S, Counters* cnt, int f) {
     if (f >= S) return;
-    if (!matched[f] || best[f] == 0xFFFFFFFFFFFFFFFFull) return;
+    if (!matched[f] || best[f] == SSF_NO_MATCH) return;
     const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
     if (local < 0 || local >= n_visible) return;
     const size_t m = (size_t)local;
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const
 __device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
     Counters c = *cnt;
     if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
+    c.last[0] = c.n_model; c.last[1] = c.n_visible; c.last[2] = c.n_removed; c.last[3] = c.n_inserted; c.last[4] = c.n_updated;
     Counters next = c;
     next.n_inserted = 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
     *cnt = next;
@@ -441,6 +442,30 @@ __device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_re
     __hip_atomic_store(&mb->cnt_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // payload write-through stores acknowledged
     __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// a 29-value device record (e.g. the rank-reduced ICP system) -> mailbox, as the ICP kernel's tail does
+__global__ void k_publish_icp(const long long* __restrict__ rec, Mailbox* mb, unsigned long long seq) {
+    long long v = 0;
+    if (threadIdx.x < 29) {
+        v = rec[threadIdx.x];
+        __hip_atomic_store(&mb->icp[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long check = (unsigned long long)wsum64(v) + seq;
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_publish_all_counts(const int* __restrict__ all5, int n, Mailbox* mb, unsigned long long seq) {
+    unsigned long long part = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const int v = all5[i];
+        __hip_atomic_store(&mb->all_cnt[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        part += (unsigned long long)(unsigned int)v;
+    }
+    const unsigned long long check = (unsigned long long)wsum64((long long)part) + seq;
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->all_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->all_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
     publish_counters(cnt, shrink_by_removed, mb, seq);
@@ -563,6 +588,12 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, Surf
         { ScopedKernel sk("reorder_scatter", st);
           hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
     }
+}
+void launch_publish_icp(hipStream_t st, const long long* rec, Mailbox* mb, unsigned long long seq) {
+    hipLaunchKernelGGL(k_publish_icp, dim3(1), dim3(64), 0, st, rec, mb, seq);
+}
+void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mailbox* mb, unsigned long long seq) {
+    hipLaunchKernelGGL(k_publish_all_counts, dim3(1), dim3(64), 0, st, all5, 5 * nranks, mb, seq);
 }
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
     hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, st, cnt, shrink_by_removed, mb, seq);

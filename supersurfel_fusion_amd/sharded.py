@@ -8,22 +8,36 @@ work is a model supersurfel run on the local shard with three real exchange step
               (exact: integer addition is associative, so 1/2/4/8 ranks give identical bits)
   association MIN all-reduce of S packed (dist_bits<<32 | global id) keys + MAX of the S matched
               bytes; the shard that owns the winner applies the update
-  counts      all-gather of (n_model, n_visible) to form global id offsets
+  counts      one all-gather of the per-rank frame counters at the end of the frame: their sums
+              are the global counts, their prefix gives the next frame's global id offsets
 
 Insertion is decided locally: the owner of a new supersurfel is a pure function of its world tile
 (ssf_stage_fuse, shard_owner), evaluated identically on every rank.
 
+The exchanged records never leave HBM: the library writes them into torch tensors
+(ssf_stage_*_device), the collectives run on those tensors, and only the 29 reduced ICP values
+come to the host (the Gauss-Newton solve is host double arithmetic).  All library work is
+enqueued on the stream given in ssf_config.stream, which must be the torch stream the collectives
+are issued under (`stream=` below); extract runs ahead on the library's own streams
+(submit_frame / process_submitted).
+
 The collectives go through torch.distributed: backend "nccl" (= RCCL over xGMI) with device
-tensors on the GPU box, "gloo" with CPU tensors in the CPU tests.  The engine is any Fusion
-(binding.py); the product path constructs it from load_product() and never touches the oracle.
+tensors on the GPU box, "gloo" with CPU tensors in the CPU tests (for the CPU checker a "device"
+pointer is a host pointer).  The engine is any Fusion (binding.py); the product path constructs
+it from load_product() and never touches the oracle.
 """
+import contextlib
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
+COUNT_KEYS = ("n_model", "n_visible", "n_removed", "n_inserted", "n_updated")
+
 
 class ShardedFusion:
-    def __init__(self, fusion, device=None, group=None):
+    def __init__(self, fusion, device=None, group=None, stream=None, always_reduce=False):
         self.f = fusion
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -31,62 +45,84 @@ class ShardedFusion:
         assert fusion.cfg.nranks == self.world and fusion.cfg.rank == self.rank, \
             "ssf_config.rank/nranks must match the process group"
         self.device = device if device is not None else torch.device("cpu")
-        self._counts = torch.zeros(2, dtype=torch.int64, device=self.device)
-        self._all = [torch.zeros(2, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-        self._icp = torch.zeros(29, dtype=torch.int64, device=self.device)
+        self.reduce = self.world > 1 or always_reduce   # always_reduce: exercise the collectives on one rank (tests)
+        self.stream = stream                      # torch.cuda.Stream whose handle is ssf_config.stream (None on CPU)
         S = fusion.S
-        # uint64 MIN is not available on every backend: the key is < 2^63 or the all-ones sentinel,
-        # so it is exchanged as int64 with the sentinel mapped to INT64_MAX (order preserved).
-        self._best = torch.zeros(S, dtype=torch.int64, device=self.device)
-        self._matched = torch.zeros(S, dtype=torch.uint8, device=self.device)
+        with self._on_stream():
+            self._icp = torch.zeros(29, dtype=torch.int64, device=self.device)
+            # keys are < 2^63 (SSF_NO_MATCH = INT64_MAX): exchanged as int64, MIN order is preserved
+            self._best = torch.zeros(S, dtype=torch.int64, device=self.device)
+            self._matched = torch.zeros(S, dtype=torch.uint8, device=self.device)
+            self._mine = torch.zeros(len(COUNT_KEYS), dtype=torch.int64, device=self.device)
+            self._all = torch.zeros(self.world * len(COUNT_KEYS), dtype=torch.int64, device=self.device)
+        self._counts = None                       # per-rank (n_model, n_visible) after the previous frame
 
-    def _sum(self, t):
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
-    def process_frame(self, rgb, depth, prior_pose=None, dynamic_mask=None, on_device=False):
+    def _gather_counts(self, values):
+        """all-gather of this rank's COUNT_KEYS -> (world, 5) numpy array."""
+        with self._on_stream():
+            self._mine.copy_(torch.tensor(values, dtype=torch.int64), non_blocking=False)
+            if self.reduce:
+                dist.all_gather_into_tensor(self._all, self._mine, group=self.group)
+                allc = self._all.cpu().numpy()
+            else:
+                allc = self._mine.cpu().numpy()
+        return allc.reshape(self.world, len(COUNT_KEYS))
+
+    # ---- pipelined form: extract of submitted frames runs ahead of the exchange-bound stages ----
+    def submit_frame(self, rgb, depth, dynamic_mask=None, on_device=False):
+        self.f.submit_frame(rgb, depth, dynamic_mask, on_device=on_device)
+
+    def can_submit(self):
+        return self.f.can_submit()
+
+    def pending_frames(self):
+        return self.f.pending_frames()
+
+    def process_submitted(self, prior_pose=None):
         f = self.f
-        f.stage_extract(rgb, depth, dynamic_mask, on_device=on_device)
-        c = f.counts()
-        self._counts[0], self._counts[1] = c["n_model"], c["n_visible"]
-        if self.world > 1:
-            dist.all_gather(self._all, self._counts, group=self.group)
-            allc = torch.stack(self._all).cpu().numpy()
-        else:
-            allc = self._counts.cpu().numpy()[None]
-        g_model, g_vis = int(allc[:, 0].sum()), int(allc[:, 1].sum())
-        id_offset = int(allc[:self.rank, 1].sum())
-        f.set_shard(id_offset, g_model, g_vis)
-        # ---- ICP ----
+        t0 = time.perf_counter()
+        f.begin_submitted()
+        if self._counts is None:                  # first frame (or after set_model): exchange the shard sizes
+            c = f.counts()
+            self._counts = self._gather_counts([c["n_model"], c["n_visible"], 0, 0, 0])[:, :2]
+        g_model, g_vis = int(self._counts[:, 0].sum()), int(self._counts[:, 1].sum())
+        f.set_shard(int(self._counts[:self.rank, 1].sum()), g_model, g_vis)
+        # ---- ICP: kernel -> device record -> all-reduce in HBM -> 29 values to the host solve ----
         f.icp_begin(prior_pose)
         again = g_vis > 0 and f.cfg.icp_iter > 0
         iters = 0
-        while again:
-            sums = f.icp_accumulate()
-            self._icp.copy_(torch.from_numpy(sums))
-            self._sum(self._icp)
-            again = f.icp_update(self._icp.cpu().numpy())
-            iters += 1
-        valid = f.icp_end()
-        # ---- association ----
-        best, matched = f.match()
-        if self.world > 1:
-            key = best.view(np.int64).copy()
-            key[best == np.uint64(0xFFFFFFFFFFFFFFFF)] = np.iinfo(np.int64).max
-            self._best.copy_(torch.from_numpy(key))
-            self._matched.copy_(torch.from_numpy(matched))
-            dist.all_reduce(self._best, op=dist.ReduceOp.MIN, group=self.group)
-            dist.all_reduce(self._matched, op=dist.ReduceOp.MAX, group=self.group)
-            key = self._best.cpu().numpy()
-            best = key.view(np.uint64).copy()
-            best[key == np.iinfo(np.int64).max] = np.uint64(0xFFFFFFFFFFFFFFFF)
-            matched = self._matched.cpu().numpy()
-        res = f.fuse(best, matched)
+        with self._on_stream():
+            while again:
+                f.icp_accumulate_device(self._icp.data_ptr())
+                if self.reduce:
+                    dist.all_reduce(self._icp, op=dist.ReduceOp.SUM, group=self.group)
+                again = f.icp_update(f.icp_fetch(self._icp.data_ptr()))
+                iters += 1
+            valid = f.icp_end()
+            t1 = time.perf_counter()
+            # ---- association: tables stay in HBM ----
+            f.match_device(self._best.data_ptr(), self._matched.data_ptr())
+            if self.reduce:
+                dist.all_reduce(self._best, op=dist.ReduceOp.MIN, group=self.group)
+                dist.all_reduce(self._matched, op=dist.ReduceOp.MAX, group=self.group)
+            res = f.fuse_device(self._best.data_ptr(), self._matched.data_ptr())
         res["icp_valid"], res["icp_iters"] = int(valid), iters
-        tot = torch.tensor([res["n_model"], res["n_visible"], res["n_removed"], res["n_inserted"], res["n_updated"]],
-                           dtype=torch.int64, device=self.device)
-        self._sum(tot)
-        tot = tot.cpu().numpy()
-        res.update(global_n_model=int(tot[0]), global_n_visible=int(tot[1]), global_n_removed=int(tot[2]),
-                   global_n_inserted=int(tot[3]), global_n_updated=int(tot[4]))
+        allc = self._gather_counts([res[k] for k in COUNT_KEYS])
+        # host-side split of the exchange-bound stages (extract: the library's own per-batch events)
+        res["stage_ms"] = [res["stage_ms"][0], 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)]
+        self._counts = allc[:, :2]
+        tot = allc.sum(axis=0)
+        res.update({"global_" + k: int(tot[i]) for i, k in enumerate(COUNT_KEYS)})
         return res
+
+    def process_frame(self, rgb, depth, prior_pose=None, dynamic_mask=None, on_device=False):
+        assert self.f.pending_frames() == 0, "frames are pending: use process_submitted"
+        self.f.submit_frame(rgb, depth, dynamic_mask, on_device=on_device)
+        return self.process_submitted(prior_pose)
+
+    def invalidate_counts(self):
+        """Call after Fusion.set_model / apply_deformation changed the shard outside process_frame."""
+        self._counts = None

@@ -1,0 +1,50 @@
+"""Native RCCL exchange path (ssf_comm_attach) on one GPU: a one-rank communicator runs every
+collective of the N > 1 protocol (self-reduction), and the results must equal the plain
+single-shard run bit for bit.  The multi-rank protocol itself is pinned on CPU (test_sharded.py,
+gloo, world 2 and 3) through the stage seams that both drivers share."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from supersurfel_fusion_amd import binding
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = False
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    yield dist
+    if created:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth_ahead,batch", [(0, 1), (2, 4)])
+def test_one_rank_communicator_equals_plain_run(depth_ahead, batch, one_rank_group, product_lib):
+    W, H, nf = 320, 240, 7
+    plain = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H))
+    comm = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+    comm.comm_attach()
+    frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
+    want = [plain.process_frame(*fr) for fr in frames]
+    got, nsub = [], 0
+    for k in range(nf):
+        while nsub < nf and comm.can_submit():
+            comm.submit_frame(*frames[nsub]); nsub += 1
+        got.append(comm.process_submitted().as_dict())
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(plain, comm)
+    g = comm.global_counts()
+    assert g["n_model"] == want[-1]["n_model"] and g["n_visible"] == want[-1]["n_visible"]
+    assert g["n_inserted"] == want[-1]["n_inserted"] and g["n_updated"] == want[-1]["n_updated"]
