@@ -54,6 +54,9 @@ ALGO_BYTES = {
 }
 
 
+EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
+
+
 def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1):
     K = synthetic.intrinsics(W, H)
     kw = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=cap,
@@ -249,7 +252,9 @@ def main():
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_r01.json")
         if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            if pmc.get("extract_batch", 1) == batch or dom not in EXTRACT_KERNELS:     # per-launch traffic depends on the batch
+                traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
