@@ -163,7 +163,7 @@ void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H,
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
 
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
-// replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: zeroed u32
+// replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: 65 zeroed u32 (global + 64 group arrival counters)
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                 const int32_t* label, const float* plane_depth, Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1);

@@ -544,7 +544,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     const unsigned long long seq = ++h->icp_seq;
     launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T,
-               h->d_icp_replicas, h->d_tickets + 1, d_out ? d_out : h->d_icp, h->mb_dev, seq);
+               h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq);
     HCK(hipGetLastError());
     return to_host ? icp_fetch(h, seq) : SSF_OK;
 }
@@ -869,7 +869,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
     h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
-    bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 4);
+    bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 128);
     // working set of one frame, carved out of a slab (256 B aligned pieces); a context owns `batch` slabs
     auto carve = [&](ExtractCtx& c, char* base) -> size_t {
         size_t off = 0;
@@ -936,7 +936,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         (void)hipMemcpy(h->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     }
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
-    (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->stream);
     zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = "initialisation failed"; ssf_destroy(h); return SSF_ERR_DEVICE; }
@@ -1292,14 +1292,14 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     if (!h || !h->have_frame) return -1.0;
     Rt T; T.R = m3_transpose(h->pose.R); T.t = negate(m3_mulv(T.R, h->pose.t));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 1, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
-    (void)hipMemsetAsync(h->d_tickets, 0, 4 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
     (void)hipStreamSynchronize(h->stream);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 1000.0 * ms / reps;

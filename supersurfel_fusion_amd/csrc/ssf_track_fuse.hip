@@ -42,19 +42,22 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 // workgroup that arrives last sums the replicas (agent-scope loads), leaves them zeroed for the next
 // launch and publishes the record to device memory and to the host-mapped mailbox.  All adds are
 // integer, so the record is independent of every one of these decompositions.
+#ifndef ICP_SLOTS
+#define ICP_SLOTS 16      // lane & 15 spreads the same-address traffic (64 columns measured no faster)
+#endif
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                                              const int32_t* __restrict__ label, const float* __restrict__ plane_depth,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
     __shared__ int s_last;
-    __shared__ unsigned long long red[32 * 16];
-    for (int i = threadIdx.x; i < 32 * 16; i += blockDim.x) red[i] = 0ull;
+    __shared__ unsigned long long red[29 * ICP_SLOTS];
+    for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
     __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
-    const int slot = lane() & 15;
+    const int slot = lane() & (ICP_SLOTS - 1);
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
         const V3 ps = add(m3_mulv(R, ld3(model.pos, id)), t);
-        if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * 16 + slot], 1ull); continue; }
+        if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull); continue; }
         const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
         const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
         if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) continue;
@@ -77,18 +80,18 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         for (int i = 0; i < 6; i++)
 #pragma unroll
             for (int j = i; j < 6; j++, k++)
-                atomicAdd(&red[k * 16 + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
+                atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
 #pragma unroll
         for (int i = 0; i < 6; i++)
-            atomicAdd(&red[(21 + i) * 16 + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
-        atomicAdd(&red[27 * 16 + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
-        atomicAdd(&red[28 * 16 + slot], 1ull);
+            atomicAdd(&red[(21 + i) * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
+        atomicAdd(&red[27 * ICP_SLOTS + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+        atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull);
     }
     __syncthreads();
     if (threadIdx.x < 29) {
         unsigned long long tot = 0;
 #pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++) tot += red[threadIdx.x * 16 + sidx];
+        for (int sidx = 0; sidx < ICP_SLOTS; sidx++) tot += red[threadIdx.x * ICP_SLOTS + sidx];
         long long* rep = replicas + (size_t)(blockIdx.x % SSF_ICP_REPLICAS) * 32;
         if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&rep[threadIdx.x]), tot);
     }
@@ -100,27 +103,38 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     // atomic loads.  Everything exchanged between workgroups is an atomic at the coherence point, so
     // no cache write-back / invalidate fence is needed.
     if (threadIdx.x == 0) {
-        const unsigned int tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1) ? 1 : 0;
-        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // two-level arrival count (a single counter serialises thousands of same-address atomics at L2):
+        // 64 group counters, the last workgroup of a group reports to the global counter
+        const unsigned int g = blockIdx.x & 63u;
+        const unsigned int in_group = (gridDim.x - g + 63u) / 64u, groups = min(gridDim.x, 64u);
+        int last = 0;
+        const unsigned int tk = __hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == in_group - 1) {
+            __hip_atomic_store(&ticket[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int tg = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tg == groups - 1) { last = 1; __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (s_last) {
-        // 32 x 32 replica words: every thread fetches 4 independent words (one round trip), LDS column sums
-        __shared__ long long part[SSF_ICP_REPLICAS * 32];
-        long long v[4];
+        // SSF_ICP_REPLICAS x 32 replica words: thread t sums field t & 31 over every 8th replica (independent
+        // loads, one round trip), then 8 partial rows are folded through LDS
+        __shared__ long long part[8 * 32];
+        const int field = threadIdx.x & 31, group = threadIdx.x >> 5;
+        long long v = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = __hip_atomic_load(&replicas[threadIdx.x + 256 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            part[threadIdx.x + 256 * j] = v[j];
-            __hip_atomic_store(&replicas[threadIdx.x + 256 * j], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < SSF_ICP_REPLICAS / 8; j++) {
+            const int r = group + 8 * j;
+            v += __hip_atomic_load(&replicas[r * 32 + field], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&replicas[r * 32 + field], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        part[group * 32 + field] = v;
         __syncthreads();
         if (threadIdx.x < 64) {
             long long tot = 0;
             if (threadIdx.x < 29) {
-                for (int r = 0; r < SSF_ICP_REPLICAS; r++) tot += part[r * 32 + threadIdx.x];
+                for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
                 sums[threadIdx.x] = tot;
                 __hip_atomic_store(&mb->icp[threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -548,7 +562,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     const int per_block = 256 * per_lane;
     int grid = (n_visible + per_block - 1) / per_block;
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
-    if (grid > 2048) grid = 2048;
+    if (grid > 4096) grid = 4096;
     const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
     hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, frame, label, plane_depth, T, replicas,
                        ticket, sums29, mb, seq, dbg);

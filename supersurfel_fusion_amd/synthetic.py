@@ -206,6 +206,19 @@ def seed_model_cam0(n, width=640, height=480, stamp=30, seed=1234):
     return visible_first(model, np.eye(3), np.zeros(3), width, height)
 
 
+def seed_model_cam0_visible(n, width=640, height=480, stamp=30, seed=1234, chunk=1000000):
+    """n seeded supersurfels that are ALL inside the view frustum of camera 0 (BASELINE config 3: "~1M
+    surfels, all visible"): seed_model_cam0 chunks (seeds seed, seed+1, ..) filtered to their visible rows."""
+    parts, have, k = [], 0, 0
+    while have < n:
+        m, nv = seed_model_cam0(chunk, width, height, stamp=stamp, seed=seed + k)
+        parts.append({key: v[:nv] for key, v in m.items()})
+        have += nv
+        k += 1
+    model = {key: np.concatenate([p_[key] for p_ in parts])[:n] for key in parts[0]}
+    return model, n
+
+
 def tile_owner(positions, nranks, tile=0.5):
     """numpy twin of the library's spatial-tile owner hash (ssf_stage_fuse / shard_owner)."""
     if nranks <= 1:

@@ -7,10 +7,11 @@ from supersurfel_fusion_amd import binding, synthetic
 lib = binding.load_product()
 lib.lib.ssf_dbg_time_icp.restype = C.c_double
 lib.lib.ssf_dbg_time_icp.argtypes = [C.c_void_p, C.c_int, C.c_int]
-f = binding.Fusion(lib, util.make_cfg(lib, 640, 480, nb_supersurfels_max=1100000))
-model, nvis = synthetic.seed_model_cam0(1000000, 640, 480)
+W, H = (1280, 960) if "--config3" in sys.argv else (640, 480)
+f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=1100000))
+model, nvis = (synthetic.seed_model_cam0_visible if "--config3" in sys.argv else synthetic.seed_model_cam0)(1000000, W, H)
 f.set_model(model, nvis, 30)
-rgb, depth = util.frame(0, 640, 480)
+rgb, depth = util.frame(0, W, H)
 f.stage_extract(rgb, depth); f.icp_begin()
 names = {0: "full", 4: "no tail", 6: "no accumulation, no tail", 7: "loads only"}
 print("per_lane", os.environ.get("SSF_ICP_PER_LANE"), "nvis", nvis, {names[d]: "%.1f us" % lib.lib.ssf_dbg_time_icp(f.h, 200, d) for d in (0, 4, 6, 7)})
