@@ -71,6 +71,10 @@ typedef enum ssf_status {
 #define SSF_ICP_SCALE_JTJ 1048576.0          /* 2^20 */
 #define SSF_ICP_SCALE_JTR 16777216.0         /* 2^24 */
 #define SSF_ICP_SCALE_R   17592186044416.0   /* 2^44 */
+/* ssf_align: fixed-point scales of the centroid sums (metres) and of the squared-distance sum */
+#define SSF_ALIGN_SCALE_POS 16777216.0         /* 2^24 */
+#define SSF_ALIGN_SCALE_D2  1073741824.0       /* 2^30 */
+#define SSF_ALIGN_LIM       4503599627370496.0 /* 2^52 */
 
 /* POD mirror of the path-relevant arguments of SupersurfelFusion::initialize
  * (supersurfel_fusion.hpp:46-74) + CamParam (cam_param.hpp:27-31).  Defaults (ssf_default_config)
@@ -245,6 +249,30 @@ int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums);
 int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched);
 int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched,
                           ssf_frame_result* out);
+
+/* ---- loop-closure registration -----------------------------------
+ * DenseRegistration::align (dense_registration.cu:52-243; makeCorrespondences,
+ * dense_registration_kernels.cu:27-100; buildSymmetricPoint2PlaneSystem,
+ * dense_registration_kernels.cuh:87-173): register `n` source supersurfels (a fern keyframe's
+ * positions / colours / orientations in the keyframe's camera frame, host arrays in the layout of
+ * ssf_surfels; confidences NULL = all 1, as closeGlobalLoop passes, supersurfel_fusion.cu:777-797)
+ * against the CURRENT frame of the handle (the last processed / extracted one: its supersurfels,
+ * index map and plane depth), starting from init_pose (R_init, t_init: source -> current camera,
+ * the PnP result; NULL = identity).  cfg.icp_iter iterations, centroid- and scale-normalised
+ * symmetric point-to-plane system, host LDLT step; no early stop.
+ * rel_pose[12] = (R, t) as the reference returns them (transpose(R_inc), -R t_inc); *valid as the
+ * reference's return value (>= 100 pairs every iteration, covariance diagonal <= icp_cov_thresh,
+ * |t_inc| <= 0.3); *iters = executed iterations; pairs_last = pairs of the last iteration. */
+int ssf_align(ssf_handle* h, const ssf_surfels* source, int n, const float* init_pose,
+              float* rel_pose, int* valid, int* iters, int* pairs_last);
+
+/* Fern encoding (computeCodes_kernel, ferns_kernels.cu:48-70): 4-bit code per fern from an RGB
+ * image (H x W x 3 u8) and a depth image (H x W f32) given by the caller (the reference feeds a
+ * pyramid level built with cv::cuda::resize, third party).  fern_pos: 2*n u32 (x, y),
+ * fern_rgb: 3*n u8, fern_depth: n f32; codes: n bytes (bit0 r>, bit1 g>, bit2 b>, bit3 depth>). */
+int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int width, int height,
+                   const uint32_t* fern_pos, const uint8_t* fern_rgb, const float* fern_depth,
+                   int n, uint8_t* codes);
 
 /* ---- multi-GPU, native: RCCL on the handle's stream --------------------------------------------
  * One process per GPU, cfg.rank / cfg.nranks / cfg.shard_tile describe this handle's shard of the

@@ -20,6 +20,9 @@ int ssf_dbg_renormalise_d(double* R9);
 int ssf_dbg_renormalise_f(float* R9);
 /* tf_iter (4x4 row-major) from the solved 6-vector X = (omega, tau), dense_registration.cu:369-384 */
 int ssf_dbg_gn_increment(const double* X6, double* tf16);
+/* host step of one loop-closure (align) iteration: LDLT solve of (JtJ, Jtr), translation divided by the
+ * normalisation scale, T(ct) * Rot * T(tran) * Rot * T(-cs), dense_registration.cu:186-205 */
+int ssf_dbg_align_increment(const double* JtJ36, const double* Jtr6, float scale, const float* cs3, const float* ct3, double* tf16);
 /* per-element arithmetic of the kernels, evaluated on the host (same inline code as on the device):
  * rgbToLab / labToRgb (vector_math.cuh:543-585), inverse(Cov3) (matrix_math.cuh:41-63),
  * eigenDecomposition (supersurfel_fusion_kernels.cu:48-111), solvePlaneEquations

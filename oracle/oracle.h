@@ -109,6 +109,11 @@ void bilateral_filter(const float* in, float* out, int W, int H, float sigma_col
 // oracle_track_fuse.cpp
 void icp_begin(State& s, const float* prior);
 void icp_accumulate(State& s, int64_t* sums);
+// loop-closure registration against the current frame (DenseRegistration::align); src_conf may be null (= 1)
+bool align(State& s, const f3* src_pos, const f3* src_col, const Mat33* src_orient, const float* src_conf, int n,
+           const float* init12, float* rel12, int* iters, int* pairs_last);
+// host step of one align iteration (dense_registration.cu:168-210): sums = 29-value record, cs/ct = centroids
+void align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf_iter16);
 void icp_update(State& s, const int64_t* sums, int* again);
 void icp_end(State& s, int* valid);
 void match(State& s, uint64_t* best, uint8_t* matched);

@@ -3,6 +3,7 @@
 // Exports the C ABI of include/ssf.h on top of the CPU restatement so that the same host code
 // (tests, bench cpu_baseline leg) can drive the checker exactly like the HIP product.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -116,6 +117,33 @@ int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, 
     fuse(h->s, best, matched, out); return SSF_OK;
 }
 
+int ssf_align(ssf_handle* h, const ssf_surfels* src, int n, const float* init_pose, float* rel_pose, int* valid, int* iters, int* pairs_last) {
+    if (!h || !src || n < 0 || !rel_pose || !valid || !src->positions || !src->colors || !src->orientations) return SSF_ERR_INVALID_ARG;
+    std::vector<f3> pos(n), col(n); std::vector<Mat33> ori(n);
+    for (int i = 0; i < n; i++) {
+        pos[i] = mk3(src->positions[3 * i], src->positions[3 * i + 1], src->positions[3 * i + 2]);
+        col[i] = mk3(src->colors[3 * i], src->colors[3 * i + 1], src->colors[3 * i + 2]);
+        for (int r = 0; r < 3; r++) ori[i].r[r] = mk3(src->orientations[9 * i + 3 * r], src->orientations[9 * i + 3 * r + 1], src->orientations[9 * i + 3 * r + 2]);
+    }
+    *valid = align(h->s, pos.data(), col.data(), ori.data(), src->confidences, n, init_pose, rel_pose, iters, pairs_last) ? 1 : 0;
+    return SSF_OK;
+}
+// computeCodes_kernel, ferns_kernels.cu:48-70
+int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int width, int height, const uint32_t* fern_pos,
+                   const uint8_t* fern_rgb, const float* fern_depth, int n, uint8_t* codes) {
+    if (!h || !rgb || !depth || !fern_pos || !fern_rgb || !fern_depth || !codes || width <= 0 || height <= 0 || n < 0) return SSF_ERR_INVALID_ARG;
+    for (int k = 0; k < n; k++) {
+        const int x = (int)std::min<uint32_t>(fern_pos[2 * k], (uint32_t)width - 1), y = (int)std::min<uint32_t>(fern_pos[2 * k + 1], (uint32_t)height - 1);
+        const size_t q = (size_t)y * width + x;                     // point sampling, clamp (texture_impl.hpp:43-46)
+        uint8_t r = 0;
+        r |= rgb[3 * q] > fern_rgb[3 * k] ? 1 : 0;
+        r |= rgb[3 * q + 1] > fern_rgb[3 * k + 1] ? 2 : 0;
+        r |= rgb[3 * q + 2] > fern_rgb[3 * k + 2] ? 4 : 0;
+        r |= depth[q] > fern_depth[k] ? 8 : 0;
+        codes[k] = r;
+    }
+    return SSF_OK;
+}
 // the checker has no RCCL: the native multi-GPU entry points report that (sharded.py covers N > 1 on CPU)
 int ssf_comm_unique_id(uint8_t* id128) { (void)id128; g_create_err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
 int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) { (void)id128; if (h) h->s.err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
@@ -312,6 +340,9 @@ int ssf_set_profile(ssf_handle* h, int enable) { (void)h; (void)enable; return S
 // test hooks of include/ssf_testing.h
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); return 0; }
 int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { lu_inverse6(A, Ainv); return 0; }
+int ssf_dbg_align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf16) {
+    align_increment(JtJ, Jtr, scale, cs, ct, tf16); return 0;
+}
 int ssf_dbg_renormalise_d(double* R9) { quat_normalize_rot_d(R9); return 0; }
 int ssf_dbg_renormalise_f(float* R9) { quat_normalize_rot_f(R9); return 0; }
 int ssf_dbg_gn_increment(const double* X, double* tf) {

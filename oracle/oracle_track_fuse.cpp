@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include "oracle.h"
 
 namespace orc {
@@ -173,6 +174,155 @@ void icp_end(State& s, int* valid) {
     *valid = ok ? 1 : 0;
     s.last_icp_valid = *valid;
     I.active = false;
+}
+
+// ---- loop-closure registration: DenseRegistration::align, dense_registration.cu:52-243 ------------------
+// host step of one iteration (:168-210): LDLT solve, half-angle rotation, translation un-scaled,
+// iso_iter = T(target_centroid) * Rot * T(tran) * Rot * T(-source_centroid) (Eigen Isometry products, left to
+// right: linear = a.linear * b.linear, translation = a.linear * b.translation + a.translation), rotation block
+// re-normalised through a quaternion
+void align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf_iter) {
+    double X[6];
+    ldlt_solve6(JtJ, Jtr, X);                                                   // :186
+    double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
+    const double nrm = std::sqrt((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+    const double angle = 0.5 * std::atan(nrm);                                  // :192
+    double Rr[9];
+    if (nrm == 0.0) { for (int i = 0; i < 9; i++) Rr[i] = (i % 4 == 0) ? 1.0 : 0.0; }   // deviation: reference -> NaN
+    else { for (int i = 0; i < 3; i++) axis[i] /= nrm; angle_axis_to_rot_d(angle, axis, Rr); }
+    const double ca = std::cos(angle);
+    for (int i = 0; i < 3; i++) { tran[i] /= (double)scale; tran[i] *= ca; }    // :194-195
+    double RR[9], t2[3], t4[3];
+    for (int i = 0; i < 3; i++) {
+        t2[i] = ((Rr[i * 3 + 0] * tran[0] + Rr[i * 3 + 1] * tran[1]) + Rr[i * 3 + 2] * tran[2]) + (double)ct[i];
+        for (int j = 0; j < 3; j++)
+            RR[i * 3 + j] = (Rr[i * 3 + 0] * Rr[0 * 3 + j] + Rr[i * 3 + 1] * Rr[1 * 3 + j]) + Rr[i * 3 + 2] * Rr[2 * 3 + j];
+    }
+    const double ncs[3] = {-1.0 * (double)cs[0], -1.0 * (double)cs[1], -1.0 * (double)cs[2]};
+    for (int i = 0; i < 3; i++) t4[i] = ((RR[i * 3 + 0] * ncs[0] + RR[i * 3 + 1] * ncs[1]) + RR[i * 3 + 2] * ncs[2]) + t2[i];
+    quat_normalize_rot_d(RR);                                                   // :205
+    for (int i = 0; i < 16; i++) tf_iter[i] = 0.0;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) tf_iter[i * 4 + j] = RR[i * 3 + j]; tf_iter[i * 4 + 3] = t4[i]; }
+    tf_iter[15] = 1.0;
+}
+
+// One pass of makeCorrespondences (dense_registration_kernels.cu:27-100) over the sources; `visit` is called for
+// every valid pair.  The reference compacts the pairs (thrust::remove_if) only to feed reductions; with exact
+// integer sums the order is irrelevant, so the pairs are consumed in place (decision A4).
+template <typename F>
+static void for_each_pair(State& s, const f3* src_pos, const f3* src_lab, const Mat33* src_orient, const float* src_conf, int n,
+                          const Mat33& R, const f3& t, F visit) {
+    const ssf_config& c = s.cfg;
+    for (int id = 0; id < n; id++) {
+        if (src_conf && !(src_conf[id] > 0.0f)) continue;
+        const f3 pv = R * src_pos[id] + t;
+        const int u = project_round(pv.x * c.fx / pv.z + c.cx), v = project_round(pv.y * c.fy / pv.z + c.cy);
+        if (!(u >= 0 && u < s.W && v >= 0 && v < s.H)) continue;
+        const size_t p = (size_t)v * s.W + u;
+        const int tid = s.label[p];
+        if (!(s.frame.conf[tid] > 0.0f)) continue;
+        const float dist_color = length(src_lab[id] - s.frame_lab[tid]);
+        const float td = s.plane_depth[p];
+        if (!std::isfinite(td)) continue;
+        f3 sn = normalize(src_orient[id].r[2]);
+        sn = normalize(R * sn);
+        const f3 tn = normalize(s.frame.orient[tid].r[2]);
+        const f3 tp = mk3(td * ((float)u - c.cx) / c.fx, td * ((float)v - c.cy) / c.fy, td);
+        if (!(dist_color < 20.0f && length(pv - tp) < 0.1f && fabsf(dot(sn, tn)) > 0.8f)) continue;
+        visit(pv, sn, tp, tn);
+    }
+}
+
+bool align(State& s, const f3* src_pos, const f3* src_col, const Mat33* src_orient, const float* src_conf, int n,
+           const float* init12, float* rel12, int* iters, int* pairs_last) {
+    Mat33 R_init = identity33(); f3 t_init = mk3(0, 0, 0);
+    if (init12) {
+        for (int i = 0; i < 3; i++) R_init.r[i] = mk3(init12[3 * i], init12[3 * i + 1], init12[3 * i + 2]);
+        t_init = mk3(init12[9], init12[10], init12[11]);
+    }
+    std::vector<f3> src_lab(n);
+    for (int i = 0; i < n; i++) src_lab[i] = rgbToLab(src_col[i]);
+    double tf_inc[16], JtJ[36];
+    for (int i = 0; i < 16; i++) tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 36; i++) JtJ[i] = 0.0;
+    Mat33 R_inc = identity33(); f3 t_inc = mk3(0, 0, 0);
+    bool valid = true;
+    int it = 0, pairs = 0;
+    static const int tri[6][6] = {{0, 1, 2, 3, 4, 5}, {1, 6, 7, 8, 9, 10}, {2, 7, 11, 12, 13, 14},
+                                  {3, 8, 12, 15, 16, 17}, {4, 9, 13, 16, 18, 19}, {5, 10, 14, 17, 19, 20}};
+    while (it < s.cfg.icp_iter) {                                               // while(iter++ < nbIter), :86
+        it++;
+        for (int i = 0; i < 3; i++) R_inc.r[i] = mk3((float)tf_inc[i * 4], (float)tf_inc[i * 4 + 1], (float)tf_inc[i * 4 + 2]);
+        t_inc = mk3((float)tf_inc[3], (float)tf_inc[7], (float)tf_inc[11]);
+        const Mat33 R = R_inc * R_init;                                         // :96-97
+        const f3 t = R_inc * t_init + t_inc;
+        // pass 1: pair count and centroids (:131-150), exact fixed-point sums (2^24)
+        int64_t cs_sum[3] = {0, 0, 0}, ct_sum[3] = {0, 0, 0}; pairs = 0;
+        for_each_pair(s, src_pos, src_lab.data(), src_orient, src_conf, n, R, t, [&](const f3& ps, const f3&, const f3& pt, const f3&) {
+            cs_sum[0] += fx_quant(ps.x, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM); cs_sum[1] += fx_quant(ps.y, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM);
+            cs_sum[2] += fx_quant(ps.z, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM);
+            ct_sum[0] += fx_quant(pt.x, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM); ct_sum[1] += fx_quant(pt.y, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM);
+            ct_sum[2] += fx_quant(pt.z, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM);
+            pairs++;
+        });
+        if (pairs < 100) { valid = false; break; }                              // :133-138
+        float cs[3], ct[3];
+        for (int i = 0; i < 3; i++) {
+            cs[i] = (float)((double)cs_sum[i] / SSF_ALIGN_SCALE_POS) / (float)pairs;
+            ct[i] = (float)((double)ct_sum[i] / SSF_ALIGN_SCALE_POS) / (float)pairs;
+        }
+        // pass 2: scale (:152-158)
+        int64_t d2 = 0;
+        for_each_pair(s, src_pos, src_lab.data(), src_orient, src_conf, n, R, t, [&](const f3& ps, const f3&, const f3& pt, const f3&) {
+            const f3 a = mk3(pt.x - ct[0], pt.y - ct[1], pt.z - ct[2]), b = mk3(ps.x - cs[0], ps.y - cs[1], ps.z - cs[2]);
+            d2 += fx_quant((double)((a.x * a.x + a.y * a.y) + a.z * a.z), SSF_ALIGN_SCALE_D2, SSF_ALIGN_LIM);
+            d2 += fx_quant((double)((b.x * b.x + b.y * b.y) + b.z * b.z), SSF_ALIGN_SCALE_D2, SSF_ALIGN_LIM);
+        });
+        float scale = (float)((double)d2 / SSF_ALIGN_SCALE_D2);
+        scale = std::sqrt(scale / (2.0f * (float)pairs));
+        scale = 1.0f / scale;
+        // pass 3: buildSymmetricPoint2PlaneSystem (dense_registration_kernels.cuh:87-173), record as in ssf.h
+        int64_t sums[SSF_ICP_RECORD];
+        for (int i = 0; i < SSF_ICP_RECORD; i++) sums[i] = 0;
+        const f3 csv = mk3(cs[0], cs[1], cs[2]), ctv = mk3(ct[0], ct[1], ct[2]);
+        for_each_pair(s, src_pos, src_lab.data(), src_orient, src_conf, n, R, t, [&](const f3& psrc, const f3& nsrc, const f3& ptgt, const f3& ntgt) {
+            const f3 ps = scale * (psrc - csv), pt = scale * (ptgt - ctv);
+            const f3 ns = normalize(nsrc), nt = normalize(ntgt);
+            const f3 d = pt - ps, c1 = cross(pt, ns), c2 = cross(ps, nt);
+            const float dn1 = dot(d, ns), dn2 = dot(d, nt);
+            const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
+            const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+            int k = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i; j < 6; j++, k++)
+                    sums[k] += (int64_t)fx_quant32(x1[i] * x1[j] + x2[i] * x2[j], (float)SSF_ICP_SCALE_JTJ);
+            for (int i = 0; i < 6; i++)
+                sums[21 + i] += (int64_t)fx_quant32(dn1 * x1[i] + dn2 * x2[i], (float)SSF_ICP_SCALE_JTR);
+            sums[27] += fx_quant((double)(dn2 * dn2), SSF_ICP_SCALE_R, 4611686018427387904.0);
+            sums[28] += 1;
+        });
+        double Jtr[6];
+        for (int i = 0; i < 6; i++) {
+            for (int j = 0; j < 6; j++) JtJ[i * 6 + j] = (double)sums[tri[i][j]] / SSF_ICP_SCALE_JTJ;
+            Jtr[i] = (double)sums[21 + i] / SSF_ICP_SCALE_JTR;
+        }
+        double tf_iter[16];
+        align_increment(JtJ, Jtr, scale, cs, ct, tf_iter);
+        mat4_mul(tf_iter, tf_inc, tf_inc);                                      // :210
+    }
+    double cov[36];
+    lu_inverse6(JtJ, cov);                                                      // :213
+    for (int i = 0; i < 6; i++) if (cov[i * 6 + i] > s.cfg.icp_cov_thresh) { valid = false; break; }
+    Mat33 Rr = identity33(); f3 tr = mk3(0, 0, 0);
+    if (valid) {
+        if (length(t_inc) > 0.3f) valid = false;                                // stale t_inc, :226
+        else { Rr = transpose(R_inc); tr = neg(Rr * t_inc); }                   // :230-231 (R_inc of the last iteration's start)
+    }
+    for (int i = 0; i < 3; i++) { rel12[3 * i] = Rr.r[i].x; rel12[3 * i + 1] = Rr.r[i].y; rel12[3 * i + 2] = Rr.r[i].z; }
+    rel12[9] = tr.x; rel12[10] = tr.y; rel12[11] = tr.z;
+    if (iters) *iters = it;
+    if (pairs_last) *pairs_last = pairs;
+    return valid;
 }
 
 // findBestMatches, supersurfel_fusion_kernels.cu:522-599 (decision A13)

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -126,6 +126,8 @@ class Library:
         L.ssf_pending_frames.argtypes = [vp]
         L.ssf_pipeline_capacity.argtypes = [vp]
         L.ssf_can_submit.argtypes = [vp]
+        L.ssf_align.argtypes = [vp, C.POINTER(SsfSurfels), C.c_int, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ssf_fern_codes.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
         L.ssf_comm_unique_id.argtypes = [vp]
         L.ssf_comm_attach.argtypes = [vp, vp]
         L.ssf_get_global_counts.argtypes = [vp, vp]
@@ -294,6 +296,34 @@ class Fusion:
         res = SsfFrameResult()
         self._ck(self.L.lib.ssf_stage_fuse(self.h, _ptr(best), _ptr(matched), C.byref(res)), "ssf_stage_fuse")
         return res.as_dict()
+
+    # ---- loop closure: registration of a keyframe's supersurfels against the current frame ---------
+    def align(self, source, init_pose=None):
+        """source: dict with positions (n,3), colors (n,3), orientations (n,9) [, confidences (n,)].
+        Returns dict(rel_pose (12,), valid, iters, pairs)."""
+        pos = np.ascontiguousarray(source["positions"], np.float32)
+        col = np.ascontiguousarray(source["colors"], np.float32)
+        ori = np.ascontiguousarray(source["orientations"], np.float32)
+        conf = source.get("confidences")
+        conf = None if conf is None else np.ascontiguousarray(conf, np.float32)
+        n = len(pos)
+        st = SsfSurfels(_ptr(pos), _ptr(col), None, _ptr(ori), None, None, _ptr(conf))
+        init = None if init_pose is None else np.ascontiguousarray(init_pose, np.float32)
+        rel = np.zeros(12, np.float32)
+        valid, iters, pairs = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(self.L.lib.ssf_align(self.h, C.byref(st), n, _ptr(init), _ptr(rel), C.byref(valid), C.byref(iters),
+                                      C.byref(pairs)), "ssf_align")
+        return dict(rel_pose=rel, valid=bool(valid.value), iters=iters.value, pairs=pairs.value)
+
+    def fern_codes(self, rgb, depth, fern_pos, fern_rgb, fern_depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8); depth = np.ascontiguousarray(depth, np.float32)
+        fp = np.ascontiguousarray(fern_pos, np.uint32); fr = np.ascontiguousarray(fern_rgb, np.uint8)
+        fd = np.ascontiguousarray(fern_depth, np.float32)
+        n = len(fd)
+        codes = np.zeros(n, np.uint8)
+        self._ck(self.L.lib.ssf_fern_codes(self.h, _ptr(rgb), _ptr(depth), depth.shape[1], depth.shape[0], _ptr(fp), _ptr(fr),
+                                           _ptr(fd), n, _ptr(codes)), "ssf_fern_codes")
+        return codes
 
     # ---- multi-GPU, native RCCL ------------------------------------------------------------------
     def comm_attach(self, group=None):

@@ -182,6 +182,11 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, Surf
                              const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
                              float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
                              unsigned long long seq);
+// one iteration of the loop-closure registration against a frame; out40: see k_align
+void launch_align(hipStream_t st, const Cam& cam, const float* spos, const float* slab, const float* snrm, const float* sconf,
+                  int n, SurfelSoA frame, const int32_t* label, const float* plane_depth, Rt T, long long* out40);
+void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, int W, int H, const uint32_t* fpos,
+                       const uint8_t* frgb, const float* fdepth, int n, uint8_t* codes);
 void launch_publish_icp(hipStream_t st, const long long* rec29, Mailbox* mb, unsigned long long seq);
 void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mailbox* mb, unsigned long long seq);
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones

@@ -191,6 +191,33 @@ void gn_increment(const double* X, double* tf_iter) {
     tf_iter[15] = 1.0;
 }
 
+// host step of one align iteration (DenseRegistration::align, dense_registration.cu:168-210): as gn_increment, with
+// the translation un-scaled and the increment conjugated by the centroid translations:
+// T(ct) * Rot * T(tran) * Rot * T(-cs), Eigen Isometry products left to right
+void align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf_iter) {
+    double X[6];
+    sym6_ldlt_solve(JtJ, Jtr, X);
+    double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
+    const double nrm = std::sqrt((axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2]);
+    const double angle = 0.5 * std::atan(nrm);
+    double Rr[9];
+    if (nrm == 0.0) { for (int i = 0; i < 9; i++) Rr[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    else { for (int i = 0; i < 3; i++) axis[i] /= nrm; rodrigues(angle, axis, Rr); }
+    const double ca = std::cos(angle);
+    for (int i = 0; i < 3; i++) { tran[i] /= (double)scale; tran[i] *= ca; }
+    double RR[9], t2[3], t4[3];
+    for (int i = 0; i < 3; i++) {
+        t2[i] = ((Rr[i * 3] * tran[0] + Rr[i * 3 + 1] * tran[1]) + Rr[i * 3 + 2] * tran[2]) + (double)ct[i];
+        for (int j = 0; j < 3; j++) RR[i * 3 + j] = (Rr[i * 3] * Rr[j] + Rr[i * 3 + 1] * Rr[3 + j]) + Rr[i * 3 + 2] * Rr[6 + j];
+    }
+    const double ncs[3] = {-1.0 * (double)cs[0], -1.0 * (double)cs[1], -1.0 * (double)cs[2]};
+    for (int i = 0; i < 3; i++) t4[i] = ((RR[i * 3] * ncs[0] + RR[i * 3 + 1] * ncs[1]) + RR[i * 3 + 2] * ncs[2]) + t2[i];
+    renormalise_rotation<double>(RR);
+    for (int i = 0; i < 16; i++) tf_iter[i] = 0.0;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) tf_iter[i * 4 + j] = RR[i * 3 + j]; tf_iter[i * 4 + 3] = t4[i]; }
+    tf_iter[15] = 1.0;
+}
+
 void mat4_lmul(const double* a, double* b) {      // b <- a * b
     double r[16];
     for (int i = 0; i < 4; i++)
@@ -977,6 +1004,110 @@ int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() 
 int ssf_pipeline_capacity(const ssf_handle* h) { return h ? (int)h->ctx.size() * h->batch : 0; }
 int ssf_can_submit(const ssf_handle* h) { return (h && !h->ctx[h->open_ctx].launched) ? 1 : 0; }
 
+// ---- loop-closure registration + fern codes -------------------------------------
+int ssf_align(ssf_handle* h, const ssf_surfels* src, int n, const float* init_pose, float* rel_pose, int* valid, int* iters,
+              int* pairs_last) {
+    if (!h || !src || n < 0 || !rel_pose || !valid || !src->positions || !src->colors || !src->orientations) return SSF_ERR_INVALID_ARG;
+    TimerScope ts(h);
+    // sources: positions, Lab of the colours (same inline function as the kernels), normals = rows[2]
+    const size_t N = (size_t)std::max(n, 1);
+    std::vector<float> lab(3 * N), nrm(3 * N);
+    for (int i = 0; i < n; i++) {
+        const V3 l = rgb_to_lab(v3(src->colors[3 * i], src->colors[3 * i + 1], src->colors[3 * i + 2]));
+        lab[3 * i] = l.x; lab[3 * i + 1] = l.y; lab[3 * i + 2] = l.z;
+        for (int c = 0; c < 3; c++) nrm[3 * i + c] = src->orientations[9 * i + 6 + c];
+    }
+    float *d_pos = nullptr, *d_lab = nullptr, *d_nrm = nullptr, *d_conf = nullptr; long long* d_out = nullptr;
+    HCK(hipMalloc((void**)&d_pos, 12 * N)); HCK(hipMalloc((void**)&d_lab, 12 * N)); HCK(hipMalloc((void**)&d_nrm, 12 * N));
+    HCK(hipMalloc((void**)&d_out, 40 * sizeof(long long)));
+    if (src->confidences) HCK(hipMalloc((void**)&d_conf, 4 * N));
+    hipStream_t st = h->stream;
+    int rc = SSF_OK;
+    auto cleanup = [&]() { (void)hipFree(d_pos); (void)hipFree(d_lab); (void)hipFree(d_nrm); (void)hipFree(d_out); if (d_conf) (void)hipFree(d_conf); };
+    if (n > 0) {
+        if (hipMemcpyAsync(d_pos, src->positions, 12 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_lab, lab.data(), 12 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_nrm, nrm.data(), 12 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            (d_conf && hipMemcpyAsync(d_conf, src->confidences, 4 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess)) {
+            cleanup(); h->err = "upload of the source supersurfels failed"; return SSF_ERR_DEVICE;
+        }
+    }
+    M3 R_init = m3_identity(); V3 t_init = v3(0, 0, 0);
+    if (init_pose) { const Rt p0 = pose_from12(init_pose); R_init = p0.R; t_init = p0.t; }
+    double tf_inc[16], JtJ[36];
+    for (int i = 0; i < 16; i++) tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 36; i++) JtJ[i] = 0.0;
+    M3 R_inc = m3_identity(); V3 t_inc = v3(0, 0, 0);
+    bool ok = true;
+    int it = 0, pairs = 0;
+    static const int tri[6][6] = {{0, 1, 2, 3, 4, 5}, {1, 6, 7, 8, 9, 10}, {2, 7, 11, 12, 13, 14},
+                                  {3, 8, 12, 15, 16, 17}, {4, 9, 13, 16, 18, 19}, {5, 10, 14, 17, 19, 20}};
+    while (it < h->cfg.icp_iter) {
+        it++;
+        inc_to_float(tf_inc, R_inc, t_inc);
+        Rt T; T.R = m3_mul(R_inc, R_init); T.t = add(m3_mulv(R_inc, t_init), t_inc);
+        launch_align(st, h->cam, d_pos, d_lab, d_nrm, d_conf, n, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, d_out);
+        long long rec[40];
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(rec, d_out, 37 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { rc = SSF_ERR_DEVICE; h->err = "align iteration failed on the device"; break; }
+        pairs = (int)rec[29];
+        if (pairs < 100) { ok = false; break; }
+        float cs[3], ct[3], scale;
+        for (int i = 0; i < 3; i++) {
+            const uint32_t a = (uint32_t)rec[30 + i], b = (uint32_t)rec[33 + i];
+            std::memcpy(&cs[i], &a, 4); std::memcpy(&ct[i], &b, 4);
+        }
+        { const uint32_t a = (uint32_t)rec[36]; std::memcpy(&scale, &a, 4); }
+        double Jtr[6];
+        for (int i = 0; i < 6; i++) {
+            for (int j = 0; j < 6; j++) JtJ[i * 6 + j] = (double)rec[tri[i][j]] / SSF_ICP_SCALE_JTJ;
+            Jtr[i] = (double)rec[21 + i] / SSF_ICP_SCALE_JTR;
+        }
+        double tf_iter[16];
+        align_increment(JtJ, Jtr, scale, cs, ct, tf_iter);
+        mat4_lmul(tf_iter, tf_inc);
+    }
+    cleanup();
+    if (rc) return rc;
+    double cov[36];
+    mat6_inverse_lu(JtJ, cov);
+    for (int i = 0; i < 6; i++) if (cov[i * 6 + i] > h->cfg.icp_cov_thresh) { ok = false; break; }
+    Rt rel; rel.R = m3_identity(); rel.t = v3(0, 0, 0);
+    if (ok) {
+        if (len3(t_inc) > 0.3f) ok = false;                      // stale t_inc (start of the last iteration), :226
+        else { rel.R = m3_transpose(R_inc); rel.t = negate(m3_mulv(rel.R, t_inc)); }
+    }
+    pose_to12(rel, rel_pose);
+    *valid = ok ? 1 : 0;
+    if (iters) *iters = it;
+    if (pairs_last) *pairs_last = pairs;
+    if (h->cfg.profile == 1) timer_collect(&h->timer);
+    return SSF_OK;
+}
+int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int width, int height, const uint32_t* fern_pos,
+                   const uint8_t* fern_rgb, const float* fern_depth, int n, uint8_t* codes) {
+    if (!h || !rgb || !depth || !fern_pos || !fern_rgb || !fern_depth || !codes || width <= 0 || height <= 0 || n < 0) return SSF_ERR_INVALID_ARG;
+    if (n == 0) return SSF_OK;
+    const size_t P = (size_t)width * height;
+    uint8_t *d_rgb = nullptr, *d_frgb = nullptr, *d_codes = nullptr; float *d_depth = nullptr, *d_fd = nullptr; uint32_t* d_fp = nullptr;
+    HCK(hipMalloc((void**)&d_rgb, 3 * P)); HCK(hipMalloc((void**)&d_depth, 4 * P)); HCK(hipMalloc((void**)&d_fp, 8 * (size_t)n));
+    HCK(hipMalloc((void**)&d_frgb, 3 * (size_t)n)); HCK(hipMalloc((void**)&d_fd, 4 * (size_t)n)); HCK(hipMalloc((void**)&d_codes, (size_t)n));
+    hipStream_t st = h->stream;
+    bool ok = hipMemcpyAsync(d_rgb, rgb, 3 * P, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(d_depth, depth, 4 * P, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(d_fp, fern_pos, 8 * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(d_frgb, fern_rgb, 3 * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(d_fd, fern_depth, 4 * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) {
+        launch_fern_codes(st, d_rgb, d_depth, width, height, d_fp, d_frgb, d_fd, n, d_codes);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(codes, d_codes, (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    (void)hipFree(d_rgb); (void)hipFree(d_depth); (void)hipFree(d_fp); (void)hipFree(d_frgb); (void)hipFree(d_fd); (void)hipFree(d_codes);
+    if (!ok) { h->err = "fern encoding failed on the device"; return SSF_ERR_DEVICE; }
+    return SSF_OK;
+}
+
 // ---- multi-GPU (native RCCL) ------------------------------------------------------------------------------
 int ssf_comm_unique_id(uint8_t* id128) {
     if (!id128) return SSF_ERR_INVALID_ARG;
@@ -1328,6 +1459,9 @@ int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { mat6_inverse_lu(A, Ainv
 int ssf_dbg_renormalise_d(double* R9) { renormalise_rotation<double>(R9); return 0; }
 int ssf_dbg_renormalise_f(float* R9) { renormalise_rotation<float>(R9); return 0; }
 int ssf_dbg_gn_increment(const double* X6, double* tf16) { gn_increment(X6, tf16); return 0; }
+int ssf_dbg_align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf16) {
+    align_increment(JtJ, Jtr, scale, cs, ct, tf16); return 0;
+}
 
 int ssf_dbg_rgb_to_lab(const float* c, float* o) { V3 r = rgb_to_lab(v3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
 int ssf_dbg_lab_to_rgb(const float* c, float* o) { V3 r = lab_to_rgb(v3(c[0], c[1], c[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }

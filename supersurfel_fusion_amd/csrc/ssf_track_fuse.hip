@@ -146,6 +146,132 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     }
 }
 
+// ---- loop-closure registration (DenseRegistration::align) -----------------------------------------------------
+// makeCorrespondences, dense_registration_kernels.cu:27-100, for one source supersurfel
+__device__ __forceinline__ bool align_pair(const Cam& cam, const float* __restrict__ spos, const float* __restrict__ slab,
+                                           const float* __restrict__ snrm, const float* __restrict__ sconf, int id,
+                                           const SurfelSoA& frame, const int32_t* __restrict__ label,
+                                           const float* __restrict__ plane_depth, const M3& R, const V3& t,
+                                           V3& pv, V3& sn, V3& tp, V3& tn) {
+    if (sconf && !(sconf[id] > 0.0f)) return false;
+    pv = add(m3_mulv(R, ld3(spos, id)), t);
+    const int u = pixel_round(pv.x * cam.fx / pv.z + cam.cx), v = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
+    if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return false;
+    const size_t q = (size_t)v * cam.W + u;
+    const int tid = label[q];
+    if (!(frame.conf[tid] > 0.0f)) return false;
+    const float dist_color = len3(sub(ld3(slab, id), ld3(frame.lab, tid)));
+    const float td = plane_depth[q];
+    if (!isfinite(td)) return false;
+    sn = unit3(ld3(snrm, id));
+    sn = unit3(m3_mulv(R, sn));
+    tn = unit3(ld3(frame.r2, tid));
+    tp = v3(td * ((float)u - cam.cx) / cam.fx, td * ((float)v - cam.cy) / cam.fy, td);
+    return dist_color < 20.0f && len3(sub(pv, tp)) < 0.1f && fabsf(dot3(sn, tn)) > 0.8f;
+}
+// One iteration of align in ONE single-workgroup launch: pair count + centroids, scale, normalised symmetric
+// point-to-plane system (buildSymmetricPoint2PlaneSystem, dense_registration_kernels.cuh:87-173).  The reference
+// compacts the valid pairs (thrust::remove_if) to feed three reductions; all sums here are exact integers, so the
+// pairs are simply re-derived in each phase (a keyframe has ~S sources: the whole problem is LDS-sized).
+// out: [0..28] record as k_icp, [29] pairs, [30..32] source centroid bits, [33..35] target centroid bits, [36] scale bits
+__global__ __launch_bounds__(1024) void k_align(Cam cam, const float* __restrict__ spos, const float* __restrict__ slab,
+                                                const float* __restrict__ snrm, const float* __restrict__ sconf, int n,
+                                                SurfelSoA frame, const int32_t* __restrict__ label,
+                                                const float* __restrict__ plane_depth, Rt T, long long* __restrict__ out) {
+    __shared__ unsigned long long acc[8];
+    __shared__ unsigned long long red[29 * 16];
+    __shared__ float s_c[7];
+    __shared__ int s_pairs;
+    for (int i = threadIdx.x; i < 29 * 16; i += blockDim.x) red[i] = 0ull;
+    if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    const M3 R = T.R; const V3 t = T.t;
+    V3 pv, sn, tp, tn;
+    for (int id = threadIdx.x; id < n; id += blockDim.x) {
+        if (!align_pair(cam, spos, slab, snrm, sconf, id, frame, label, plane_depth, R, t, pv, sn, tp, tn)) continue;
+        atomicAdd(&acc[0], (unsigned long long)fx64((double)pv.x, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[1], (unsigned long long)fx64((double)pv.y, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[2], (unsigned long long)fx64((double)pv.z, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[3], (unsigned long long)fx64((double)tp.x, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[4], (unsigned long long)fx64((double)tp.y, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[5], (unsigned long long)fx64((double)tp.z, SSF_ALIGN_SCALE_POS, SSF_ALIGN_LIM));
+        atomicAdd(&acc[6], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int pairs = (int)acc[6];
+        s_pairs = pairs;
+        for (int i = 0; i < 6; i++) s_c[i] = (float)((double)(long long)acc[i] / SSF_ALIGN_SCALE_POS) / (float)pairs;
+        out[29] = pairs;
+    }
+    __syncthreads();
+    const int pairs = s_pairs;
+    if (pairs < 100) {                                       // the host stops here (dense_registration.cu:133-138)
+        if (threadIdx.x < 29) out[threadIdx.x] = 0;
+        if (threadIdx.x >= 30 && threadIdx.x < 37) out[threadIdx.x] = 0;
+        return;
+    }
+    const V3 cs = v3(s_c[0], s_c[1], s_c[2]), ct = v3(s_c[3], s_c[4], s_c[5]);
+    for (int id = threadIdx.x; id < n; id += blockDim.x) {
+        if (!align_pair(cam, spos, slab, snrm, sconf, id, frame, label, plane_depth, R, t, pv, sn, tp, tn)) continue;
+        const V3 a = v3(tp.x - ct.x, tp.y - ct.y, tp.z - ct.z), b = v3(pv.x - cs.x, pv.y - cs.y, pv.z - cs.z);
+        atomicAdd(&acc[7], (unsigned long long)fx64((double)((a.x * a.x + a.y * a.y) + a.z * a.z), SSF_ALIGN_SCALE_D2, SSF_ALIGN_LIM));
+        atomicAdd(&acc[7], (unsigned long long)fx64((double)((b.x * b.x + b.y * b.y) + b.z * b.z), SSF_ALIGN_SCALE_D2, SSF_ALIGN_LIM));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sv = (float)((double)(long long)acc[7] / SSF_ALIGN_SCALE_D2);
+        sv = sqrtf(sv / (2.0f * (float)pairs));
+        s_c[6] = 1.0f / sv;
+    }
+    __syncthreads();
+    const float sc = s_c[6];
+    const int slot = lane() & 15;
+    for (int id = threadIdx.x; id < n; id += blockDim.x) {
+        if (!align_pair(cam, spos, slab, snrm, sconf, id, frame, label, plane_depth, R, t, pv, sn, tp, tn)) continue;
+        const V3 ps = scale(sc, sub(pv, cs)), pt = scale(sc, sub(tp, ct));
+        const V3 ns = unit3(sn), nt = unit3(tn);
+        const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
+        const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
+        const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
+        const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++, k++)
+                atomicAdd(&red[k * 16 + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            atomicAdd(&red[(21 + i) * 16 + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
+        atomicAdd(&red[27 * 16 + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+        atomicAdd(&red[28 * 16 + slot], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        unsigned long long tot = 0;
+        for (int sidx = 0; sidx < 16; sidx++) tot += red[threadIdx.x * 16 + sidx];
+        out[threadIdx.x] = (long long)tot;
+    }
+    if (threadIdx.x < 7) out[30 + threadIdx.x] = (long long)__float_as_uint(s_c[threadIdx.x]);
+}
+
+// computeCodes_kernel, ferns_kernels.cu:48-70 (point sampling, clamp: texture_impl.hpp:43-46)
+__global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __restrict__ depth, int W, int H,
+                             const uint32_t* __restrict__ fpos, const uint8_t* __restrict__ frgb,
+                             const float* __restrict__ fdepth, int n, uint8_t* __restrict__ codes) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int x = (int)min(fpos[2 * k], (uint32_t)W - 1u), y = (int)min(fpos[2 * k + 1], (uint32_t)H - 1u);
+    const size_t q = (size_t)y * W + x;
+    uint8_t r = 0;
+    r |= rgb[3 * q] > frgb[3 * k] ? 1 : 0;
+    r |= rgb[3 * q + 1] > frgb[3 * k + 1] ? 2 : 0;
+    r |= rgb[3 * q + 2] > frgb[3 * k + 2] ? 4 : 0;
+    r |= depth[q] > fdepth[k] ? 8 : 0;
+    codes[k] = r;
+}
+
 // ---- association ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
                                                const int32_t* __restrict__ label, Rt pose, float zmin, float zmax,
@@ -602,6 +728,16 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, Surf
         { ScopedKernel sk("reorder_scatter", st);
           hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
     }
+}
+void launch_align(hipStream_t st, const Cam& cam, const float* spos, const float* slab, const float* snrm, const float* sconf,
+                  int n, SurfelSoA frame, const int32_t* label, const float* plane_depth, Rt T, long long* out40) {
+    ScopedKernel sk("align_iteration", st);
+    hipLaunchKernelGGL(k_align, dim3(1), dim3(1024), 0, st, cam, spos, slab, snrm, sconf, n, frame, label, plane_depth, T, out40);
+}
+void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, int W, int H, const uint32_t* fpos,
+                       const uint8_t* frgb, const float* fdepth, int n, uint8_t* codes) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fern_codes, dim3((n + 63) / 64), dim3(64), 0, st, rgb, depth, W, H, fpos, frgb, fdepth, n, codes);
 }
 void launch_publish_icp(hipStream_t st, const long long* rec, Mailbox* mb, unsigned long long seq) {
     hipLaunchKernelGGL(k_publish_icp, dim3(1), dim3(64), 0, st, rec, mb, seq);

@@ -65,6 +65,21 @@ def test_gauss_newton_increment_matches_eigen(lib):
         assert np.allclose(tf.reshape(4, 4), ref, rtol=0, atol=1e-13)
 
 
+def test_align_increment_matches_eigen(lib):
+    """Loop-closure host step (DenseRegistration::align, dense_registration.cu:186-205) against the reference's Eigen."""
+    lib.ssf_dbg_align_increment.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = 0
+    for c in cases():
+        A = np.array(c["JtJ"], np.float64); b = np.array(c["Jtr"], np.float64)
+        if np.linalg.cond(A.reshape(6, 6)) > 1e12:
+            continue
+        cs = np.array(c["align_cs"], np.float32); ct = np.array(c["align_ct"], np.float32); tf = np.zeros(16)
+        lib.ssf_dbg_align_increment(dptr(A), dptr(b), C.c_float(c["align_scale"][0]), dptr(cs), dptr(ct), dptr(tf))
+        assert np.allclose(tf.reshape(4, 4), np.array(c["align_tf_iter"]).reshape(4, 4), rtol=0, atol=1e-11)
+        n += 1
+    assert n >= 50
+
+
 def test_quaternion_renormalisation_matches_eigen(lib):
     for c in cases():
         Rf = np.array(c["Rf_in"], np.float32).copy()
