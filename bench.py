@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 # algorithmic bytes per unit of each kernel (DESIGN.md "Kernels")
 P = W * H
 ALGO_BYTES = {
-    "reorder_scatter": lambda c: 209.0 * c["n_model"],           # state 1 + row 104 read + row 104 written
+    # stable partition: only the rows that change place move (visible rows are compacted, view changes cross over)
+    "reorder_move": lambda c: 2.0 * c["n_model"] + 208.0 * c["n_visible"],     # state + live byte per slot, visible rows read + written
     "classify": lambda c: 28.0 * c["n_model"],                   # pos 12 + stamps 8 + conf 4 read, state 4 written
     "icp_accumulate": lambda c: 36.0 * c["n_visible"] + 8.0 * P + 28.0 * c["S"],
     "match": lambda c: 40.0 * c["n_visible"],

@@ -216,6 +216,9 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth_m, int o
                       const uint8_t* dynamic_mask);
 /* Stop the segmentation after max_passes relabelling passes (0 = all); test/bisect aid. */
 int ssf_debug_set_max_passes(ssf_handle* h, int max_passes);
+/* Product-internal upkeep made callable for tests: compact the out-of-view row store now (DESIGN.md
+ * section 3; a no-op for the results).  The CPU checker has no such store and returns SSF_OK. */
+int ssf_debug_recentre(ssf_handle* h);
 /* Global (all-shard) model counts and this shard's global id offset; must precede icp_begin when
  * nranks > 1.  Unsharded handles ignore it. */
 int ssf_stage_set_shard(ssf_handle* h, int64_t id_offset, int64_t global_n_model,

@@ -39,7 +39,11 @@ struct Counters {
     int n_updated;
     int n_removed;
     int n_state0, n_state1, n_state2;
-    int part_n, part_s0, part_s1;   // frozen inputs of the scatter (rows to move, sizes of the first two classes)
+    // out-of-view store: live rows occupy (with holes) the span [oov_head, oov_tail) of the current OOV array
+    int oov_head, oov_tail, oov_live;
+    // frozen inputs of the move kernel: old visible count, class totals A0 (visible staying), B0 (out-of-view
+    // becoming visible), new head / old tail of the out-of-view span
+    int mv_nv, mv_a0, mv_b0, mv_head_new, mv_tail_old, mv_head_old;
     // the published counters of the last frame (n_model, n_visible, n_removed, n_inserted, n_updated): never reset,
     // the source of the per-frame RCCL all-gather of the shard sizes
     int last[5];
@@ -172,16 +176,29 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
                   unsigned long long* best, uint8_t* matched, int S);
 // update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
 // (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)
-void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+void launch_update_insert(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
                           int capacity, int rank, int nranks, float tile, Counters* cnt);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
-// classify + stable 3-way partition src -> dst; n_upper = host upper bound of cnt->n_model
-void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
-                             const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
-                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
-                             unsigned long long seq);
+// Model store: the visible rows are a dense array (two of them, ping-pong); the out-of-view
+// rows live in a deque-like store with a live flag per row.  The per-frame stable partition
+//   [visible | out-of-view] = [A0 B0 C0 | A1 B1 C1]   (A = old visible rows, B = old out-of-view rows, C = rows
+//   inserted this frame; 0 = classified visible, 1 = out of view, 2 = removed)
+// then only moves A0/B0/C0 into the other visible array, pushes A1 in front of the out-of-view span, appends C1
+// behind it and clears the live flag of B0/B2: the (large) B1 block is never touched.
+struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };
+// classify (filterModel) every visible row incl. this frame's insertions and every live out-of-view row, scan the
+// per-block class histograms (publishes the frame's counters) and move the rows; nv_upper / span_upper = host
+// upper bounds of the visible rows (incl. insertions) and of the out-of-view span
+void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
+                             int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
+                             float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
+                             uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq);
+// stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
+// new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
+void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
+                        int set_span);
 // one iteration of the loop-closure registration against a frame; out40: see k_align
 void launch_align(hipStream_t st, const Cam& cam, const float* spos, const float* slab, const float* snrm, const float* sconf,
                   int n, SurfelSoA frame, const int32_t* label, const float* plane_depth, Rt T, long long* out40);

@@ -317,6 +317,12 @@ struct ssf_handle {
     float* d_bf_in = nullptr; float* d_bf_out = nullptr;
     long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; uint32_t* d_block_counts = nullptr; Counters* d_cnt = nullptr;
+    // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
+    // with live flags, host mirror of the span below), dense = materialised [visible | out-of-view] view for the
+    // consumers of the whole model (get/set model, export, deformation)
+    OovStore oov[2]; int ocur = 0; int oov_head = 0, oov_tail = 0, oov_live = 0;
+    uint8_t* d_state_oov = nullptr; uint32_t* d_bc_oov = nullptr;
+    SurfelSoA dense; uint8_t* d_live_scratch = nullptr;
     int32_t* d_scratch_map = nullptr;
     long long* d_icp_replicas = nullptr; unsigned int* d_tickets = nullptr; float* d_srgb_lut = nullptr;
     // host-mapped mailbox (fine-grained): results the host waits for are polled, not synchronised on
@@ -644,6 +650,65 @@ static void icp_end(ssf_handle* h, int* valid) {
     I.active = false;
 }
 
+// ---- model store upkeep -----------------------------------------------------------------------------------
+static SurfelSoA soa_rows(const SurfelSoA& s, size_t r) {       // view starting at row r
+    SurfelSoA v = s;
+    v.pos += 3 * r; v.col += 3 * r; v.lab += 3 * r; v.stamps += 2 * r; v.r0 += 3 * r; v.r1 += 3 * r; v.r2 += 3 * r;
+    v.shape += 6 * r; v.dims += 2 * r; v.conf += r;
+    return v;
+}
+static int copy_soa(ssf_handle* h, const SurfelSoA& d, const SurfelSoA& s, size_t n) {      // device -> device, n rows
+    if (n == 0) return SSF_OK;
+    hipStream_t st = h->stream;
+    HCK(hipMemcpyAsync(d.pos, s.pos, 12 * n, hipMemcpyDeviceToDevice, st)); HCK(hipMemcpyAsync(d.col, s.col, 12 * n, hipMemcpyDeviceToDevice, st));
+    HCK(hipMemcpyAsync(d.lab, s.lab, 12 * n, hipMemcpyDeviceToDevice, st)); HCK(hipMemcpyAsync(d.stamps, s.stamps, 8 * n, hipMemcpyDeviceToDevice, st));
+    HCK(hipMemcpyAsync(d.r0, s.r0, 12 * n, hipMemcpyDeviceToDevice, st)); HCK(hipMemcpyAsync(d.r1, s.r1, 12 * n, hipMemcpyDeviceToDevice, st));
+    HCK(hipMemcpyAsync(d.r2, s.r2, 12 * n, hipMemcpyDeviceToDevice, st)); HCK(hipMemcpyAsync(d.shape, s.shape, 24 * n, hipMemcpyDeviceToDevice, st));
+    HCK(hipMemcpyAsync(d.dims, s.dims, 8 * n, hipMemcpyDeviceToDevice, st)); HCK(hipMemcpyAsync(d.conf, s.conf, 4 * n, hipMemcpyDeviceToDevice, st));
+    return SSF_OK;
+}
+static int oov_home(const ssf_handle* h) { return h->cfg.nb_supersurfels_max + h->S + 256; }   // head after a recentre
+// compact the live out-of-view rows into the other store, span starting at oov_home (no dead slots afterwards)
+static int oov_recentre(ssf_handle* h) {
+    OovStore& src = h->oov[h->ocur]; OovStore& dst = h->oov[h->ocur ^ 1];
+    HCK(hipMemsetAsync(dst.live, 0, (size_t)dst.cap, h->stream));
+    launch_oov_compact(h->stream, src, dst, h->oov_tail - h->oov_head, oov_home(h), h->d_bc_oov, h->d_cnt, 1);
+    HCK(hipGetLastError());
+    h->ocur ^= 1;
+    h->oov_head = oov_home(h); h->oov_tail = h->oov_head + h->oov_live;
+    return SSF_OK;
+}
+// dense [visible | out-of-view] copy of the model in h->dense (stream ordered)
+static int materialise(ssf_handle* h) {
+    int rc = copy_soa(h, h->dense, h->model[h->mcur], (size_t)h->n_visible);
+    if (rc) return rc;
+    if (h->oov_live > 0) {
+        OovStore dst; dst.rows = h->dense; dst.live = h->d_live_scratch; dst.cap = h->cfg.nb_supersurfels_max;
+        launch_oov_compact(h->stream, h->oov[h->ocur], dst, h->oov_tail - h->oov_head, h->n_visible, h->d_bc_oov, h->d_cnt, 0);
+        HCK(hipGetLastError());
+    }
+    return SSF_OK;
+}
+// the stores <- h->dense (n rows, the first n_visible of them visible); also resets the device counters
+static int store_from_dense(ssf_handle* h, int n, int n_visible) {
+    int rc = copy_soa(h, h->model[h->mcur], h->dense, (size_t)n_visible);
+    if (rc) return rc;
+    OovStore& o = h->oov[h->ocur];
+    const int head = oov_home(h), n_oov = n - n_visible;
+    rc = copy_soa(h, soa_rows(o.rows, (size_t)head), soa_rows(h->dense, (size_t)n_visible), (size_t)n_oov);
+    if (rc) return rc;
+    HCK(hipMemsetAsync(o.live, 0, (size_t)o.cap, h->stream));
+    if (n_oov > 0) HCK(hipMemsetAsync(o.live + head, 1, (size_t)n_oov, h->stream));
+    Counters c; std::memset(&c, 0, sizeof(c));
+    c.n_model = n; c.n_visible = n_visible; c.oov_head = head; c.oov_tail = head + n_oov; c.oov_live = n_oov;
+    c.last[0] = n; c.last[1] = n_visible;
+    HCK(hipStreamSynchronize(h->stream));
+    HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
+    h->n_model = n; h->n_visible = n_visible; h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = n_oov;
+    h->all_valid = false;
+    return SSF_OK;
+}
+
 static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
@@ -664,16 +729,23 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     if (nmodel_g > 0) {
         launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
                              nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
-        const int n_upper = std::max(1, std::min(h->n_model + h->S, h->cfg.nb_supersurfels_max));
-        // classify | scan (publishes the counters) | scatter: the host continues once the counters arrive,
-        // the scatter of this frame overlaps the host-side launch work of the next one (stream order keeps
-        // every later reader of the model behind it)
-        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], n_upper, h->pose, h->cc->maps.plane_depth, h->stamp,
-                                h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state,
-                                h->d_block_counts, h->d_cnt, h->mb_dev, seq);
+        // out-of-view store upkeep before the frame's moves: room in front for the rows that leave the view (at most
+        // all visible rows), room behind for out-of-view insertions, and not too many dead slots in the span
+        {
+            const int span = h->oov_tail - h->oov_head;
+            if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < h->S + 256 ||
+                span > h->oov_live + h->oov_live / 4 + 65536) { int rc2 = oov_recentre(h); if (rc2) return rc2; }
+        }
+        // classify | scan (publishes the counters) | move: the host continues once the counters arrive,
+        // the row moves of this frame overlap the host-side launch work of the next one (stream order keeps
+        // every later reader of the model behind them)
+        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S,
+                                h->oov_tail - h->oov_head, h->pose, h->cc->maps.plane_depth, h->stamp, h->cfg.delta_t,
+                                h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov,
+                                h->d_block_counts, h->d_bc_oov, h->d_cnt, h->mb_dev, seq);
         h->mcur ^= 1;
     } else {
-            launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
+        launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
         launch_publish_counts(h->stream, h->d_cnt, 0, h->mb_dev, seq);
     }
@@ -694,6 +766,7 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         if (attempt > 100000) { h->err = "counter mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
     }
     h->n_model = c.n_model; h->n_visible = c.n_visible;
+    h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = c.oov_live;
     if (out) {
         std::memset(out, 0, sizeof(*out));
         pose_to12(h->pose, out->pose);
@@ -947,8 +1020,12 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
              hipEventCreate(&c.ev_t0) == hipSuccess && hipEventCreate(&c.ev_t1) == hipSuccess;
     }
-    ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
-         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 3 * ((N + 255) / 256 + 1)) &&
+    const size_t OC = 3 * N + 2 * S + 1024;        // out-of-view store: home of the span = N + S + 256, room for N rows either side
+    ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && alloc_surfels(h, h->dense, N) &&
+         alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
+         dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, 3 * ((OC + 255) / 256 + 1)) &&
+         dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
+         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 6 * ((N + 255) / 256 + 2)) &&
          dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
@@ -964,8 +1041,14 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     }
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
-    (void)hipMemsetAsync(h->d_cnt, 0, sizeof(Counters), h->stream);
-    zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N);
+    h->oov[0].cap = h->oov[1].cap = (int)OC;
+    h->oov_head = h->oov_tail = oov_home(h); h->oov_live = 0;
+    {
+        Counters c0; std::memset(&c0, 0, sizeof(c0)); c0.oov_head = c0.oov_tail = h->oov_head;
+        (void)hipMemcpy(h->d_cnt, &c0, sizeof(c0), hipMemcpyHostToDevice);
+    }
+    (void)hipMemsetAsync(h->oov[0].live, 0, OC, h->stream); (void)hipMemsetAsync(h->oov[1].live, 0, OC, h->stream);
+    zero_surfels(h, h->model[0], N); zero_surfels(h, h->model[1], N); zero_surfels(h, h->dense, N);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { g_create_err = "initialisation failed"; ssf_destroy(h); return SSF_ERR_DEVICE; }
     {   // getters before the first frame see slot 0 of context 0 (zeroed)
         ExtractCtx& c0 = h->ctx[0];
@@ -1153,6 +1236,12 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
     TimerScope ts(h);
     return do_extract(h, rgb, depth, on_device, mask);
 }
+// test hook: compact / recentre the out-of-view store now (normally done when its span runs out of room or holes pile up)
+int ssf_debug_recentre(ssf_handle* h) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) return SSF_ERR_STATE;
+    return oov_recentre(h);
+}
 int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->max_passes = n; return SSF_OK; }
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;
@@ -1273,14 +1362,15 @@ static int copy_out(ssf_handle* h, const SurfelSoA& s, int first, int count, ssf
 }
 int ssf_get_model(ssf_handle* h, int first, int count, ssf_surfels* o) {
     if (!h || !o || first < 0 || count < 0 || first + count > h->cfg.nb_supersurfels_max) return SSF_ERR_INVALID_ARG;
-    return copy_out(h, h->model[h->mcur], first, count, o);
+    int rc = materialise(h);
+    return rc ? rc : copy_out(h, h->dense, first, count, o);
 }
 int ssf_get_frame(ssf_handle* h, ssf_surfels* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_out(h, h->cc->frame, 0, h->S, o); }
 int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, int stamp) {
     if (!h || !in || n < 0 || n > h->cfg.nb_supersurfels_max || n_visible < 0 || n_visible > n) return SSF_ERR_INVALID_ARG;
     if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
-    SurfelSoA& s = h->model[h->mcur];
+    SurfelSoA& s = h->dense;                       // upload the logical order, then split it into the two stores
     hipStream_t st = h->stream;
     const size_t N = n;
     if (n > 0) {
@@ -1300,10 +1390,8 @@ int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, in
         launch_lab_refresh(st, s, n);
         HCK(hipStreamSynchronize(st));
     }
-    h->n_model = n; h->n_visible = n_visible; h->stamp = stamp;
-    Counters c; std::memset(&c, 0, sizeof(c)); c.n_model = n; c.n_visible = n_visible;
-    c.last[0] = n; c.last[1] = n_visible; h->all_valid = false;
-    HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
+    h->stamp = stamp;
+    { int rc = store_from_dense(h, n, n_visible); if (rc) return rc; }
     return SSF_OK;
 }
 static int copy_map(ssf_handle* h, void* dst, const void* src, size_t bytes) {
@@ -1333,7 +1421,8 @@ int ssf_get_superpixels(ssf_handle* h, float* o) {
 }
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    const SurfelSoA& s = h->model[h->mcur];
+    { int rc = materialise(h); if (rc) return rc; HCK(hipStreamSynchronize(h->stream)); }
+    const SurfelSoA& s = h->dense;                 // a dense copy: [visible | out-of-view], valid until the next call
     o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = s.r0; o->shapes = s.shape;
     o->dims = s.dims; o->confidences = s.conf;     // orientations: r0 stream (r1, r2 follow the SoA layout of DESIGN.md)
     if (n) *n = h->n_model;
@@ -1347,7 +1436,8 @@ int ssf_export_model_txt(ssf_handle* h, const char* path) {
     std::vector<float> pos(3 * (size_t)n), col(3 * (size_t)n), ori(9 * (size_t)n), shp(6 * (size_t)n), dims(2 * (size_t)n), conf(n);
     std::vector<int32_t> stamps(2 * (size_t)n);
     ssf_surfels o = {pos.data(), col.data(), stamps.data(), ori.data(), shp.data(), dims.data(), conf.data()};
-    int rc = copy_out(h, h->model[h->mcur], 0, n, &o);
+    int rc = materialise(h);
+    if (!rc) rc = copy_out(h, h->dense, 0, n, &o);
     if (rc) return rc;
     FILE* f = std::fopen(path, "w");
     if (!f) { h->err = "cannot open file"; return SSF_ERR_IO; }
@@ -1379,7 +1469,10 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     HCK(hipMemcpyAsync(d_nt, nt, 12 * (size_t)m, hipMemcpyHostToDevice, st));
     HCK(hipMemcpyAsync(d_w, w4, 16 * n, hipMemcpyHostToDevice, st));
     HCK(hipMemcpyAsync(d_i, idx4, 16 * n, hipMemcpyHostToDevice, st));
-    { TimerScope ts(h); launch_deformation(st, h->model[h->mcur], (int)n, d_np, d_nr, d_nt, d_w, d_i); }
+    // applied to the dense logical view (weights are per logical row), then split back into the two stores
+    { int rc = materialise(h); if (rc) return rc; }
+    { TimerScope ts(h); launch_deformation(st, h->dense, (int)n, d_np, d_nr, d_nt, d_w, d_i); }
+    { int rc = store_from_dense(h, h->n_model, h->n_visible); if (rc) return rc; }
     HCK(hipStreamSynchronize(st));
     if (h->cfg.profile == 1) timer_collect(&h->timer);
     (void)hipFree(d_np); (void)hipFree(d_nr); (void)hipFree(d_nt); (void)hipFree(d_w); (void)hipFree(d_i);

@@ -16,6 +16,7 @@
 //     per-block histograms, a single-workgroup scan turns them into offsets, one pass scatters all
 //     ten SoA streams (116 B read + 116 B written per supersurfel) into the other model buffer.
 #include <stdlib.h>
+#include <algorithm>
 #include "ssf_device.hpp"
 
 namespace ssf {
@@ -379,7 +380,9 @@ __device__ __forceinline__ int block_rank_1024(bool flag, int* wave_tot, int& bl
 __device__ __forceinline__ void insert_all(SurfelSoA M, SurfelSoA F, Rt pose, int stamp,
                                            const uint8_t* __restrict__ matched, int S, int capacity, int rank,
                                            int nranks, float tile, Counters* cnt, int* wave_tot) {
-    const int base = cnt->n_model;
+    // new rows go behind the visible rows of the visible array (they are classified right after); the capacity
+    // bounds the whole model (visible + out-of-view)
+    const int base = cnt->n_visible, base_total = cnt->n_model;
     __syncthreads();
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
@@ -391,7 +394,7 @@ __device__ __forceinline__ void insert_all(SurfelSoA M, SurfelSoA F, Rt pose, in
         int total;
         const int r = block_rank_1024(flag, wave_tot, total);
         const int k = base + running + r;
-        if (flag && k < capacity) {
+        if (flag && base_total + running + r < capacity) {
             st3(M.pos, k, add(m3_mulv(R, ld3(F.pos, f)), t));
             M.conf[k] = F.conf[f];
             st3(M.col, k, ld3(F.col, f));
@@ -406,8 +409,8 @@ __device__ __forceinline__ void insert_all(SurfelSoA M, SurfelSoA F, Rt pose, in
         running += total;
     }
     if (threadIdx.x == 0) {
-        const int n_new = min(base + running, capacity);
-        cnt->n_inserted = n_new - base;
+        const int n_new = min(base_total + running, capacity);
+        cnt->n_inserted = n_new - base_total;
         cnt->n_model = n_new;
     }
 }
@@ -448,63 +451,79 @@ __global__ __launch_bounds__(1024) void k_first_frame(SurfelSoA M, SurfelSoA F, 
     }
 }
 
-// ---- classify + stable partition -----------------------------------------------------------------
-// filterModel, supersurfel_fusion_kernels.cu:397-467 -> state byte + per-block 3-bin histogram
-__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA M, Rt pose, const float* __restrict__ plane_depth,
-                                                  int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
-                                                  uint8_t* __restrict__ state, uint32_t* __restrict__ block_counts,
-                                                  const Counters* __restrict__ cnt) {
-    __shared__ int hist[4][3];
-    const int n = cnt->n_model;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int st = 3;   // 3 = beyond the end
-    if (idx < n) {
-        st = 0;
-        const float conf = M.conf[idx];
-        const int time_diff = stamp - M.stamps[2 * idx + 1];
-        if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) {
-            M.conf[idx] = -1.0f; st = 2;
-        } else {
-            const M3 Rv = m3_transpose(pose.R);
-            const V3 tv = negate(m3_mulv(Rv, pose.t));
-            const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
-            if (p.z > zmin && p.z < zmax) {
-                const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
-                if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
-                    const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
-                    if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; st = 2; }
-                } else st = 1;
-            } else st = 1;
+// ---- classify + stable partition over the model store (see OovStore in ssf_device.hpp) ---------------------------
+// filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
+__device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
+                                            const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
+                                            float zmin, float zmax) {
+    const float conf = M.conf[idx];
+    const int time_diff = stamp - M.stamps[2 * idx + 1];
+    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) { M.conf[idx] = -1.0f; return 2; }
+    const M3 Rv = m3_transpose(pose.R);
+    const V3 tv = negate(m3_mulv(Rv, pose.t));
+    const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
+    if (p.z > zmin && p.z < zmax) {
+        const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
+        if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
+            const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
+            if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; return 2; }
+            return 0;
         }
-        state[idx] = (uint8_t)st;
     }
+    return 1;
+}
+// blocks [0, nb_vis): 256 rows of the visible array each (old visible rows = class A, this frame's insertions =
+// class C; 6-bin histogram A0 A1 A2 C0 C1 C2); blocks [nb_vis, ..): 256 slots of the out-of-view span (class B,
+// 3-bin histogram; dead slots are skipped)
+__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, OovStore O, Rt pose, const float* __restrict__ plane_depth,
+                                                  int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
+                                                  uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
+                                                  uint32_t* __restrict__ bc_vis, uint32_t* __restrict__ bc_oov,
+                                                  const Counters* __restrict__ cnt, int nb_vis) {
+    __shared__ int hist[4][6];
     const int wv = threadIdx.x >> 6;
+    int cls = 7;                                   // 7 = no row
+    if ((int)blockIdx.x < nb_vis) {
+        const int nv = cnt->n_visible, n_rows = nv + cnt->n_inserted;
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx < n_rows) {
+            const int st = classify_row(cam, V, idx, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+            state_vis[idx] = (uint8_t)st;
+            cls = (idx < nv ? 0 : 3) + st;
+        }
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const int c = __popcll(__ballot(st == s));
-        if (lane() == 0) hist[wv][s] = c;
+        for (int c = 0; c < 6; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+        __syncthreads();
+        if (threadIdx.x < 6) bc_vis[6 * blockIdx.x + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+    } else {
+        const int ob = blockIdx.x - nb_vis;
+        const long long phys = (long long)cnt->oov_head + (long long)ob * blockDim.x + threadIdx.x;
+        if (phys < cnt->oov_tail && O.live[phys]) {
+            const int st = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+            state_oov[phys] = (uint8_t)st;
+            cls = st;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+        __syncthreads();
+        if (threadIdx.x < 3) bc_oov[3 * ob + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
     }
-    __syncthreads();
-    if (threadIdx.x < 3) block_counts[3 * blockIdx.x + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
 }
 
-// exclusive scan of the per-block histograms (single workgroup); totals -> counters
-__device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ block_counts, int nblocks_upper, Counters* cnt,
-                                                      Mailbox* mb, unsigned long long seq) {
-    __shared__ uint32_t wtot[16][3];
-    __shared__ uint32_t run[3];
-    const int n = cnt->n_model;
-    const int nblocks = min(nblocks_upper, (n + 255) / 256);
-    if (threadIdx.x < 3) run[threadIdx.x] = 0;
+// exclusive scan of NC counters per block over nblocks blocks by one 1024-thread workgroup (one block per thread
+// and round: coalesced loads); totals -> tot[NC]
+template <int NC>
+__device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int nblocks, uint32_t* tot /* LDS, NC */,
+                                                  uint32_t (*wtot)[6] /* LDS, 16 x 6 */) {
+    if (threadIdx.x < NC) tot[threadIdx.x] = 0;
     __syncthreads();
     for (int b0 = 0; b0 < nblocks; b0 += 1024) {
         const int b = b0 + threadIdx.x;
-        uint32_t c[3] = {0, 0, 0};
-        if (b < nblocks) { c[0] = block_counts[3 * b]; c[1] = block_counts[3 * b + 1]; c[2] = block_counts[3 * b + 2]; }
-        uint32_t incl[3];
+        uint32_t c[NC], incl[NC];
 #pragma unroll
-        for (int s = 0; s < 3; s++) {
+        for (int s = 0; s < NC; s++) c[s] = (b < nblocks) ? bc[NC * b + s] : 0u;
+#pragma unroll
+        for (int s = 0; s < NC; s++) {
             uint32_t v = c[s];
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
@@ -512,61 +531,142 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ blo
             if (lane() == 63) wtot[threadIdx.x >> 6][s] = v;
         }
         __syncthreads();
-        uint32_t before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+        uint32_t before[NC], total[NC];
+#pragma unroll
+        for (int s = 0; s < NC; s++) { before[s] = 0; total[s] = 0; }
         for (int w = 0; w < 16; w++)
 #pragma unroll
-            for (int s = 0; s < 3; s++) { const uint32_t t = wtot[w][s]; if (w < (int)(threadIdx.x >> 6)) before[s] += t; total[s] += t; }
+            for (int s = 0; s < NC; s++) { const uint32_t t = wtot[w][s]; if (w < (int)(threadIdx.x >> 6)) before[s] += t; total[s] += t; }
         if (b < nblocks)
 #pragma unroll
-            for (int s = 0; s < 3; s++) block_counts[3 * b + s] = run[s] + before[s] + incl[s] - c[s];
+            for (int s = 0; s < NC; s++) bc[NC * b + s] = tot[s] + before[s] + incl[s] - c[s];
         __syncthreads();
-        if (threadIdx.x < 3) run[threadIdx.x] += total[threadIdx.x];
+        if (threadIdx.x < NC) tot[threadIdx.x] += total[threadIdx.x];
         __syncthreads();
     }
+}
+// scans of the visible-array and out-of-view histograms (single workgroup); totals -> counters, published
+__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ bc_vis, int nb_vis_upper, uint32_t* __restrict__ bc_oov,
+                                                      int nb_oov_upper, Counters* cnt, Mailbox* mb, unsigned long long seq) {
+    __shared__ uint32_t wtot[16][6];
+    __shared__ uint32_t tot[9];
+    const Counters c_in = *cnt;                       // one wide load (uniform)
+    const int nv = c_in.n_visible, n_rows = nv + c_in.n_inserted;
+    const int nb_vis = min(nb_vis_upper, (n_rows + 255) / 256);
+    const int nb_oov = min(nb_oov_upper, (c_in.oov_tail - c_in.oov_head + 255) / 256);
+    block_scan_counts<6>(bc_vis, nb_vis, tot, wtot);
+    block_scan_counts<3>(bc_oov, nb_oov, tot + 6, wtot);
     if (threadIdx.x == 0) {
-        cnt->n_state0 = (int)run[0]; cnt->n_state1 = (int)run[1]; cnt->n_state2 = (int)run[2];
-        cnt->n_visible = (int)run[0]; cnt->n_removed = (int)run[2];
-        cnt->part_n = n; cnt->part_s0 = (int)run[0]; cnt->part_s1 = (int)run[1];     // what the scatter needs
+        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
+        const int b0 = (int)tot[6], b1 = (int)tot[7], b2 = (int)tot[8];
+        Counters c = c_in;                            // loaded at kernel start: no dependent reloads here
+        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
+        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
+        c.mv_nv = nv; c.mv_a0 = a0; c.mv_b0 = b0;
+        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
+        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
+        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
         // the frame's counters are final here: publish them now, the host overlaps its next launches
-        // with the scatter that follows in the stream
-        publish_counters(cnt, 1, mb, seq);
+        // with the row moves that follow in the stream
+        publish_counters_value(cnt, c, 1, mb, seq);
     }
 }
 
-// scatter every SoA stream of row i to its partitioned slot (stable within each state).  Removed rows
-// (state 2) are not moved: they would land beyond the new row count, where nothing reads them.
-__global__ __launch_bounds__(256) void k_scatter(SurfelSoA A, SurfelSoA B, const uint8_t* __restrict__ state,
-                                                 const uint32_t* __restrict__ block_off, const Counters* __restrict__ cnt) {
-    __shared__ int hist[4][3];
-    const int n = cnt->part_n;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int st = (i < n) ? (int)state[i] : 3;
+__device__ __forceinline__ void copy_row(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j) {
+    st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
+    B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
+    st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, ld3(A.r2, i));
+    st6(B.shape, j, ld6(A.shape, i));
+    B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
+    B.conf[j] = A.conf[i];
+}
+// move the rows whose place changes (stable within each class): A0, C0 -> new visible array, A1 -> in front of the
+// out-of-view span, C1 -> behind it, B0 -> new visible array (slot freed), B2 -> slot freed.  B1 stays where it is.
+__global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
+                                                   const uint8_t* __restrict__ state_oov, const uint32_t* __restrict__ bc_vis,
+                                                   const uint32_t* __restrict__ bc_oov, const Counters* __restrict__ cnt, int nb_vis) {
+    __shared__ int hist[4][6];
     const int wv = threadIdx.x >> 6;
-    int in_wave = 0;
+    int cls = 7, in_wave = 0;
+    if ((int)blockIdx.x < nb_vis) {
+        const int nv = cnt->mv_nv, n_rows = nv + cnt->last[3];            // last[3] = insertions of this frame (published)
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const unsigned long long mask = __ballot(st == s);
-        if (st == s) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
-        if (lane() == 0) hist[wv][s] = __popcll(mask);
-    }
-    __syncthreads();
-    if (i < n && st < 2) {
-        int before = 0;
-        for (int w = 0; w < wv; w++) before += hist[w][st];
-        const int base = (st == 0) ? 0 : cnt->part_s0;
-        const size_t j = (size_t)base + block_off[3 * blockIdx.x + st] + before + in_wave;
-        st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
-        B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
-        st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, ld3(A.r2, i));
-        st6(B.shape, j, ld6(A.shape, i));
-        B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
-        B.conf[j] = A.conf[i];
+        for (int c = 0; c < 6; c++) {
+            const unsigned long long mask = __ballot(cls == c);
+            if (cls == c) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
+            if (lane() == 0) hist[wv][c] = __popcll(mask);
+        }
+        __syncthreads();
+        if (cls == 0 || cls == 1 || cls == 3 || cls == 4) {
+            int before = 0;
+            for (int w = 0; w < wv; w++) before += hist[w][cls];
+            const size_t r = (size_t)bc_vis[6 * blockIdx.x + cls] + before + in_wave;
+            if (cls == 0) copy_row(V, i, Vn, r);
+            else if (cls == 3) copy_row(V, i, Vn, (size_t)cnt->mv_a0 + cnt->mv_b0 + r);
+            else {
+                const size_t j = (cls == 1 ? (size_t)cnt->mv_head_new : (size_t)cnt->mv_tail_old) + r;
+                copy_row(V, i, O.rows, j);
+                O.live[j] = 1;
+            }
+        }
+    } else {
+        const int ob = blockIdx.x - nb_vis;
+        const long long phys = (long long)cnt->mv_head_old + (long long)ob * blockDim.x + threadIdx.x;
+        if (phys < cnt->mv_tail_old && O.live[phys]) cls = (int)state_oov[phys];
+        const unsigned long long mask = __ballot(cls == 0);
+        if (cls == 0) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
+        if (lane() == 0) hist[wv][0] = __popcll(mask);
+        __syncthreads();
+        if (cls == 0) {
+            int before = 0;
+            for (int w = 0; w < wv; w++) before += hist[w][0];
+            copy_row(O.rows, (size_t)phys, Vn, (size_t)cnt->mv_a0 + bc_oov[3 * ob] + before + in_wave);
+        }
+        if (cls == 0 || cls == 2) O.live[phys] = 0;
     }
 }
+
+// ---- out-of-view store maintenance: stable compaction of the live rows into the other store -------------------
+__global__ __launch_bounds__(256) void k_oov_count(OovStore O, uint32_t* __restrict__ bc, const Counters* __restrict__ cnt) {
+    __shared__ int part[4];
+    const long long phys = (long long)cnt->oov_head + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lv = phys < cnt->oov_tail && O.live[phys];
+    const int k = __popcll(__ballot(lv));
+    if (lane() == 0) part[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) bc[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void k_oov_scan(uint32_t* __restrict__ bc, int nb_upper, const Counters* __restrict__ cnt) {
+    __shared__ uint32_t wtot[16][6];
+    __shared__ uint32_t tot[1];
+    const int nb = min(nb_upper, (cnt->oov_tail - cnt->oov_head + 255) / 256);
+    block_scan_counts<1>(bc, nb, tot, wtot);
+}
+__global__ __launch_bounds__(256) void k_oov_compact(OovStore A, OovStore B, const uint32_t* __restrict__ bc, int new_head,
+                                                     const Counters* __restrict__ cnt) {
+    __shared__ int part[4];
+    const long long phys = (long long)cnt->oov_head + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lv = phys < cnt->oov_tail && A.live[phys];
+    const unsigned long long mask = __ballot(lv);
+    const int wv = threadIdx.x >> 6;
+    if (lane() == 0) part[wv] = __popcll(mask);
+    __syncthreads();
+    if (lv) {
+        int before = 0;
+        for (int w = 0; w < wv; w++) before += part[w];
+        const size_t j = (size_t)new_head + bc[blockIdx.x] + before + __popcll(mask & ((1ull << lane()) - 1ull));
+        copy_row(A.rows, (size_t)phys, B.rows, j);
+        B.live[j] = 1;
+    }
+}
+__global__ void k_oov_set_span(Counters* cnt, int new_head) { cnt->oov_head = new_head; cnt->oov_tail = new_head + cnt->oov_live; }
+
 // end of the fuse stage: nbSupersurfels -= nbRemoved (supersurfel_fusion.cu:474), publish the
 // counters to the host-mapped mailbox, reset the per-frame ones for the next frame
-__device__ __forceinline__ void publish_counters(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
-    Counters c = *cnt;
+__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
     if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
     c.last[0] = c.n_model; c.last[1] = c.n_visible; c.last[2] = c.n_removed; c.last[3] = c.n_inserted; c.last[4] = c.n_updated;
     Counters next = c;
@@ -608,7 +708,7 @@ __global__ void k_publish_all_counts(const int* __restrict__ all5, int n, Mailbo
     if (threadIdx.x == 0) __hip_atomic_store(&mb->all_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
-    publish_counters(cnt, shrink_by_removed, mb, seq);
+    publish_counters_value(cnt, *cnt, shrink_by_removed, mb, seq);
 }
 
 __global__ void k_lab_refresh(SurfelSoA s, int n) {
@@ -714,20 +814,30 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
     ScopedKernel sk("first_frame", st);
     hipLaunchKernelGGL(k_first_frame, dim3(1), dim3(1024), 0, st, model, frame, pose, S, capacity, rank, nranks, tile, cnt);
 }
-void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA src, SurfelSoA dst, int n_upper, Rt pose,
-                             const float* plane_depth, int stamp, int delta_t, float conf_thresh, float zmin,
-                             float zmax, uint8_t* state, uint32_t* block_counts, Counters* cnt, Mailbox* mb,
-                             unsigned long long seq) {
-    const int nblocks = (n_upper + 255) / 256;
-    {
-        { ScopedKernel sk("classify", st);
-          hipLaunchKernelGGL(k_classify, dim3(nblocks), dim3(256), 0, st, cam, src, pose, plane_depth, stamp, delta_t,
-                             conf_thresh, zmin, zmax, state, block_counts, cnt); }
-        { ScopedKernel sk("scan_blocks", st);
-          hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_counts, nblocks, cnt, mb, seq); }
-        { ScopedKernel sk("reorder_scatter", st);
-          hipLaunchKernelGGL(k_scatter, dim3(nblocks), dim3(256), 0, st, src, dst, state, block_counts, cnt); }
+void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
+                             int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
+                             float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
+                             uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq) {
+    const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
+    { ScopedKernel sk("classify", st);
+      hipLaunchKernelGGL(k_classify, dim3(nb_vis + nb_oov), dim3(256), 0, st, cam, vis_src, oov, pose, plane_depth, stamp, delta_t,
+                         conf_thresh, zmin, zmax, state_vis, state_oov, bc_vis, bc_oov, cnt, nb_vis); }
+    { ScopedKernel sk("scan_blocks", st);
+      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bc_vis, nb_vis, bc_oov, nb_oov, cnt, mb, seq); }
+    { ScopedKernel sk("reorder_move", st);
+      hipLaunchKernelGGL(k_move_rows, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov, bc_vis,
+                         bc_oov, cnt, nb_vis); }
+}
+void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
+                        int set_span) {
+    const int nb = (span_upper + 255) / 256;
+    ScopedKernel sk("oov_compact", st);
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_oov_count, dim3(nb), dim3(256), 0, st, src, bc_oov, cnt);
+        hipLaunchKernelGGL(k_oov_scan, dim3(1), dim3(1024), 0, st, bc_oov, nb, cnt);
+        hipLaunchKernelGGL(k_oov_compact, dim3(nb), dim3(256), 0, st, src, dst, bc_oov, new_head, cnt);
     }
+    if (set_span) hipLaunchKernelGGL(k_oov_set_span, dim3(1), dim3(1), 0, st, cnt, new_head);
 }
 void launch_align(hipStream_t st, const Cam& cam, const float* spos, const float* slab, const float* snrm, const float* sconf,
                   int n, SurfelSoA frame, const int32_t* label, const float* plane_depth, Rt T, long long* out40) {

@@ -224,3 +224,25 @@ def test_pipeline_full_and_empty_are_errors(product_lib):
         fh.process_frame(rgb, depth)
     fh.process_submitted(); fh.process_submitted()
     fh.process_frame(rgb, depth)
+
+
+def test_long_sweep_with_view_changes_and_store_upkeep(oracle_lib, product_lib):
+    """A back-and-forth sweep with 4-degree steps: rows leave and re-enter the view every frame, rows are culled
+    and inserted.  The product keeps the out-of-view rows in a deque-like store with holes:
+    the logical model must stay equal to the oracle's stable partition, with forced compactions in between and
+    with a capacity so small that the store has to recentre by itself."""
+    W, H = 160, 128
+    kw = dict(nb_supersurfels_max=600, delta_t=3, conf_thresh=1e9)       # aggressive culling, tiny capacity
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, **kw))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, **kw))
+    ks = list(range(0, 40, 4)) + list(range(40, -1, -4)) + list(range(0, 24, 4))
+    for n, k in enumerate(ks):
+        rgb, depth = util.frame(k, W, H, noise=True, holes=0.02)
+        prior = synthetic.pose12(*synthetic.relative_pose(k))             # large steps: give ICP the pose prior
+        util.same_result(fo.process_frame(rgb, depth, prior_pose=prior), fh.process_frame(rgb, depth, prior_pose=prior))
+        if n % 5 == 2:
+            fh.debug_recentre()
+        if n % 3 == 0 or n == len(ks) - 1:
+            util.compare_state(fo, fh, maps=False, frame_surfels=False)
+    c = fh.counts()
+    assert c["n_model"] > 0 and c["n_visible"] > 0
