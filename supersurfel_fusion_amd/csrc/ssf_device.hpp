@@ -197,6 +197,8 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, 
                              uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq);
 // stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
 // new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
+void launch_scan_probe(hipStream_t st, uint32_t* bc_vis, int nb_vis, uint32_t* bc_oov, int oov_stride, int nb_oov, Counters* cnt,
+                       Mailbox* mb, unsigned long long seq, int mode);
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
                         int set_span);
 // one iteration of the loop-closure registration against a frame; out40: see k_align

@@ -1023,7 +1023,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const size_t OC = 3 * N + 2 * S + 1024;        // out-of-view store: home of the span = N + S + 256, room for N rows either side
     ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && alloc_surfels(h, h->dense, N) &&
          alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
-         dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, 3 * ((OC + 255) / 256 + 1)) &&
+         dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, 3 * ((OC + 255) / 256 + 8)) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 6 * ((N + 255) / 256 + 2)) &&
          dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
@@ -1508,6 +1508,22 @@ int ssf_dbg_host_times(ssf_handle* h, double* out8) {
     if (!h || !out8) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; i++) { out8[i] = h->host_us[i]; h->host_us[i] = 0; }
     return SSF_OK;
+}
+
+// timing probe for the scan / publication kernel (tools/scan_probe.py); leaves the counters garbage
+double ssf_dbg_time_scan(ssf_handle* h, int reps, int mode) {
+    if (!h) return -1.0;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int nb_vis = (h->n_visible + h->S + 255) / 256, nb_oov = (h->oov_tail - h->oov_head + 255) / 256;
+    const int stride = ((h->oov[h->ocur].cap + 255) / 256 + 4) & ~3;
+    for (int i = 0; i < 3; i++) launch_scan_probe(h->stream, h->d_block_counts, nb_vis, h->d_bc_oov, stride, nb_oov, h->d_cnt, h->mb_dev, ++h->cnt_seq, mode);
+    (void)hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps; i++) launch_scan_probe(h->stream, h->d_block_counts, nb_vis, h->d_bc_oov, stride, nb_oov, h->d_cnt, h->mb_dev, ++h->cnt_seq, mode);
+    (void)hipEventRecord(e1, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 1000.0 * ms / reps;
 }
 
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`

@@ -478,7 +478,7 @@ __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, 
 __global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, OovStore O, Rt pose, const float* __restrict__ plane_depth,
                                                   int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
                                                   uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
-                                                  uint32_t* __restrict__ bc_vis, uint32_t* __restrict__ bc_oov,
+                                                  uint32_t* __restrict__ bc_vis, uint32_t* __restrict__ bc_oov, int oov_stride,
                                                   const Counters* __restrict__ cnt, int nb_vis) {
     __shared__ int hist[4][6];
     const int wv = threadIdx.x >> 6;
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, OovStore
 #pragma unroll
         for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
         __syncthreads();
-        if (threadIdx.x < 3) bc_oov[3 * ob + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+        // three planes (B0 | B1 | B2) of oov_stride counters each: the scan reads four blocks per lane as one uint4
+        if (threadIdx.x < 3) bc_oov[(size_t)threadIdx.x * oov_stride + ob] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
     }
 }
 
@@ -545,18 +546,83 @@ __device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int
         __syncthreads();
     }
 }
-// scans of the visible-array and out-of-view histograms (single workgroup); totals -> counters, published
+// scans of the visible-array and out-of-view histograms by one SMALL workgroup; totals -> counters, published.
+// 256 threads on purpose: next to the wide extract launches of the other streams a 16-wave workgroup waits for
+// a compute unit with 16 free wave slots (rocprofv3: 17.6 us in the frame vs 4 us alone); 4 waves fit anywhere.
+// A thread owns SCAN_VIS consecutive visible blocks (6 counters each) and SCAN_OOV consecutive out-of-view blocks;
+// of the latter only B0 needs a prefix (B1 rows stay in place, B2 rows are dropped), the three planes are read
+// as uint4.  One round = 1024 visible blocks (262 k rows) + 4096 out-of-view blocks (1 M slots).
+#define SCAN_VIS 4
+#define SCAN_OOV 16
 __device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
-__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t* __restrict__ bc_vis, int nb_vis_upper, uint32_t* __restrict__ bc_oov,
-                                                      int nb_oov_upper, Counters* cnt, Mailbox* mb, unsigned long long seq) {
-    __shared__ uint32_t wtot[16][6];
+__global__ __launch_bounds__(256) void k_scan_blocks(uint32_t* __restrict__ bc_vis, int nb_vis_upper, uint32_t* __restrict__ bc_oov,
+                                                     int oov_stride, int nb_oov_upper, Counters* cnt, Mailbox* mb, unsigned long long seq) {
+    __shared__ uint32_t wtot[4][9];
     __shared__ uint32_t tot[9];
     const Counters c_in = *cnt;                       // one wide load (uniform)
     const int nv = c_in.n_visible, n_rows = nv + c_in.n_inserted;
     const int nb_vis = min(nb_vis_upper, (n_rows + 255) / 256);
     const int nb_oov = min(nb_oov_upper, (c_in.oov_tail - c_in.oov_head + 255) / 256);
-    block_scan_counts<6>(bc_vis, nb_vis, tot, wtot);
-    block_scan_counts<3>(bc_oov, nb_oov, tot + 6, wtot);
+    if (threadIdx.x < 9) tot[threadIdx.x] = 0;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    const int rounds = max((nb_vis + 256 * SCAN_VIS - 1) / (256 * SCAN_VIS), (nb_oov + 256 * SCAN_OOV - 1) / (256 * SCAN_OOV));
+    for (int r = 0; r < rounds; r++) {
+        const int bv = (r * 256 + threadIdx.x) * SCAN_VIS, bo = (r * 256 + threadIdx.x) * SCAN_OOV;
+        uint32_t cv[SCAN_VIS][6], c[9], incl[9];
+        uint4 q0[SCAN_OOV / 4];
+#pragma unroll
+        for (int s = 0; s < 9; s++) c[s] = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_VIS; k++)
+#pragma unroll
+            for (int s = 0; s < 6; s++) { cv[k][s] = (bv + k < nb_vis) ? bc_vis[6 * (bv + k) + s] : 0u; c[s] += cv[k][s]; }
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+            for (int k = 0; k < SCAN_OOV / 4; k++) {
+                uint4 q = make_uint4(0u, 0u, 0u, 0u);
+                const int b4 = bo + 4 * k;
+                if (b4 < nb_oov) q = *reinterpret_cast<const uint4*>(&bc_oov[(size_t)s * oov_stride + b4]);
+                if (b4 + 1 >= nb_oov) q.y = 0u;            // slots past the span hold stale counts
+                if (b4 + 2 >= nb_oov) q.z = 0u;
+                if (b4 + 3 >= nb_oov) q.w = 0u;
+                c[6 + s] += (q.x + q.y) + (q.z + q.w);
+                if (s == 0) q0[k] = q;
+            }
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            uint32_t v = c[s];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
+            incl[s] = v;
+            if (lane() == 63) wtot[wv][s] = v;
+        }
+        __syncthreads();
+        uint32_t total[9];
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            uint32_t before = 0, tt = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t t = wtot[w][s]; if (w < wv) before += t; tt += t; }
+            total[s] = tt;
+            uint32_t run = tot[s] + before + incl[s] - c[s];       // exclusive prefix of this thread's first block
+            if (s < 6) {
+#pragma unroll
+                for (int k = 0; k < SCAN_VIS; k++) { if (bv + k < nb_vis) bc_vis[6 * (bv + k) + s] = run; run += cv[k][s]; }
+            } else if (s == 6) {
+#pragma unroll
+                for (int k = 0; k < SCAN_OOV / 4; k++) {
+                    const int b4 = bo + 4 * k;
+                    if (b4 < nb_oov)
+                        *reinterpret_cast<uint4*>(&bc_oov[b4]) = make_uint4(run, run + q0[k].x, run + q0[k].x + q0[k].y, run + q0[k].x + q0[k].y + q0[k].z);
+                    run += (q0[k].x + q0[k].y) + (q0[k].z + q0[k].w);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) tot[threadIdx.x] += total[threadIdx.x];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
         const int b0 = (int)tot[6], b1 = (int)tot[7], b2 = (int)tot[8];
@@ -623,7 +689,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         if (cls == 0) {
             int before = 0;
             for (int w = 0; w < wv; w++) before += hist[w][0];
-            copy_row(O.rows, (size_t)phys, Vn, (size_t)cnt->mv_a0 + bc_oov[3 * ob] + before + in_wave);
+            copy_row(O.rows, (size_t)phys, Vn, (size_t)cnt->mv_a0 + bc_oov[ob] + before + in_wave);
         }
         if (cls == 0 || cls == 2) O.live[phys] = 0;
     }
@@ -819,14 +885,29 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, 
                              float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
                              uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
+    const int oov_stride = ((oov.cap + 255) / 256 + 4) & ~3;          // counters per plane, multiple of 4 (uint4 access)
     { ScopedKernel sk("classify", st);
       hipLaunchKernelGGL(k_classify, dim3(nb_vis + nb_oov), dim3(256), 0, st, cam, vis_src, oov, pose, plane_depth, stamp, delta_t,
-                         conf_thresh, zmin, zmax, state_vis, state_oov, bc_vis, bc_oov, cnt, nb_vis); }
+                         conf_thresh, zmin, zmax, state_vis, state_oov, bc_vis, bc_oov, oov_stride, cnt, nb_vis); }
     { ScopedKernel sk("scan_blocks", st);
-      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, bc_vis, nb_vis, bc_oov, nb_oov, cnt, mb, seq); }
+      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq); }
     { ScopedKernel sk("reorder_move", st);
       hipLaunchKernelGGL(k_move_rows, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov, bc_vis,
                          bc_oov, cnt, nb_vis); }
+}
+// timing probe (tools/scan_probe.py): the scan kernel alone, `mode` 0 = full, 1 = no publication
+__global__ __launch_bounds__(256) void k_scan_probe(Counters* cnt, Mailbox* mb, unsigned long long seq, int mode) {
+    if (threadIdx.x == 0) {
+        Counters c = *cnt;
+        c.n_updated += 1;
+        if (mode == 0) publish_counters_value(cnt, c, 0, mb, seq);
+        else *cnt = c;
+    }
+}
+void launch_scan_probe(hipStream_t st, uint32_t* bc_vis, int nb_vis, uint32_t* bc_oov, int oov_stride, int nb_oov, Counters* cnt,
+                       Mailbox* mb, unsigned long long seq, int mode) {
+    if (mode < 2) hipLaunchKernelGGL(k_scan_probe, dim3(1), dim3(256), 0, st, cnt, mb, seq, mode);
+    else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
                         int set_span) {

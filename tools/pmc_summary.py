@@ -10,7 +10,7 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = [("k_update_pass<true>", "update_pass_rgbd"), ("k_update_pass<false>", "update_pass_rgb"), ("k_scatter", "reorder_scatter"),
+NAMES = [("k_update_pass<true>", "update_pass_rgbd"), ("k_update_pass<false>", "update_pass_rgb"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
          ("k_classify", "classify"), ("k_icp", "icp_accumulate"), ("k_match", "match"), ("k_render_moments", "render_moments"),
          ("k_ingest", "ingest"), ("k_eval_samples", "eval_samples"), ("k_init_disp", "init_disp"), ("k_init_samples", "init_samples"),
          ("k_plane_filter", "plane_filter"), ("k_finalize_surfels", "finalize_surfels"), ("k_update_insert", "update_insert"),
