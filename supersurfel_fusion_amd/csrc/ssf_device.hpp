@@ -2,16 +2,20 @@
 //
 // Layout (all device-resident, allocated once in ssf_create; P = W*H pixels, S superpixels,
 // N = nb_supersurfels_max):
-//   per-pixel maps   rgba u32[P] | disp f32[P] | label i32[P] x2 (ping-pong per relabelling pass)
-//                    inlier u8[P] | plane_depth f32[P]
-//   superpixel sums  9 x i32[S] (x,y,r,g,b,n,dx,dy,dn) + 6 x i64[S] (dxx,dyy,dxy | dxd,dyd,dd fixed
-//                    point 2^30): exact integers, updated with integer atomics only
-//   superpixel table SpRow[S] (48 B rows, 16 B aligned)
+//   per-frame working set ("slab", one per frame of an extract batch, see batch_slot):
+//     per-pixel maps   rgba u32[P] | disp f32[P] | label i32[P] (ONE map, relabelled in place)
+//                      inlier u8[P] | plane_depth f32[P]
+//     superpixel sums  two sets (double buffer) of 9 x i32[S] (x,y,r,g,b,n,dx,dy,dn) + 6 x i64[S]
+//                      (dxx,dyy,dxy | dxd,dyd,dd fixed point 2^30): exact integers, integer atomics only
+//     pass logs        3 x (int4 + f32) x 256 entries per relabelling tile + per-tile counts
+//     superpixel table SpRow[S] (48 B rows, 16 B aligned), RANSAC samples, moments, filter scratch
+//     frame supersurfels + association tables (best u64[S], matched u8[S]) + input staging
 //   supersurfels     structure of arrays, 3-float rows kept as separate streams so that a kernel
 //                    reads only what it needs (ICP: pos 12 + lab 12 + normal 12 B per surfel):
 //                    pos[3n] col[3n] lab[3n] stamps[2n] r0[3n] r1[3n] r2[3n] shape[6n] dims[2n] conf[n]
-//                    (r0,r1,r2 = rows of the reference's Mat33; r2 is the normal).  The model has
-//                    two such sets (ping-pong for the per-frame stable partition).
+//                    (r0,r1,r2 = rows of the reference's Mat33; r2 is the normal)
+//   model store      visible rows: dense SoA x 2 (rebuilt every frame); out-of-view rows: OovStore x 2
+//                    (deque-like span with live flags); dense SoA for whole-model consumers
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -72,14 +76,13 @@ struct PassLog {
 };
 
 struct FrameMaps {
-    uint32_t* rgba; float* disp; int32_t* label[2]; uint8_t* inlier; float* plane_depth;
+    uint32_t* rgba; float* disp; int32_t* label; uint8_t* inlier; float* plane_depth;   // label: ONE map, relabelled in place
     // Exact sums, double buffered: relabelling pass k reads sums[k & 1] (quiescent: nothing writes it
     // during the pass) and applies its own deltas plus the log of pass k-1 to sums[(k + 1) & 1].
     SpSums sums[2]; PassLog log; SpRow* sp; float4* samples; int32_t* sample_score;
     uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
-    unsigned int* ticket; // arrival counter of the relabelling pass (last workgroup runs the merge)
     const float* srgb_lut; // srgb_expand(c/255) for c = 0..255, built on the host with the same function
     size_t slab;          // bytes between the working sets of consecutive frames of a batch (see batch_slot)
 };
@@ -87,7 +90,7 @@ struct FrameMaps {
 // Frame batching: an extract context holds up to SSF_MAX_BATCH frames whose working sets are carved
 // identically out of consecutive slabs, so frame b of a batch lives at (every pointer) + b * slab.
 // The extract kernels take the batch index from the grid (blockIdx.z, or .y for 1-D kernels): one
-// launch relabels the tiles of all frames of the batch.  srgb_lut / ticket are shared.
+// launch relabels the tiles of all frames of the batch.  srgb_lut is shared.
 #define SSF_MAX_BATCH 8
 template <typename T> SSF_HD T* slab_shift(T* p, size_t off) {
     return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
@@ -101,8 +104,8 @@ SSF_HD SpSums batch_slot(SpSums s, size_t o) {
 }
 SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     const size_t o = (size_t)b * m.slab;
-    m.rgba = slab_shift(m.rgba, o); m.disp = slab_shift(m.disp, o); m.label[0] = slab_shift(m.label[0], o);
-    m.label[1] = slab_shift(m.label[1], o); m.inlier = slab_shift(m.inlier, o); m.plane_depth = slab_shift(m.plane_depth, o);
+    m.rgba = slab_shift(m.rgba, o); m.disp = slab_shift(m.disp, o); m.label = slab_shift(m.label, o);
+    m.inlier = slab_shift(m.inlier, o); m.plane_depth = slab_shift(m.plane_depth, o);
     m.sums[0] = batch_slot(m.sums[0], o); m.sums[1] = batch_slot(m.sums[1], o);
     for (int i = 0; i < 3; i++) {
         m.log.ent[i] = slab_shift(m.log.ent[i], o); m.log.disp[i] = slab_shift(m.log.disp[i], o);

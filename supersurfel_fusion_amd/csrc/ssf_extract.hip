@@ -5,12 +5,15 @@
 // core/src/TPS_RGBD.cu:101-525; generateSupersurfels, core/src/supersurfel_fusion.cu:551-593);
 // how is this build's own:
 //   * 64-wide wavefronts; every per-superpixel sum is an exact integer (int32 / int64 / fixed-point
-//     int64), built by wave-level aggregation by label (ballot + shuffle) and ONE integer atomic per
-//     (wave, label, term) -- no float atomics, bit-reproducible for any launch geometry.
-//   * a relabelling pass reads the previous label map through a 34x34 LDS tile (1-pixel halo) and
-//     writes the next map (ping-pong), so the cross-tile race of the reference cannot occur; the
-//     boundary count is derived from the tile, never stored.
-//   * the plane filter runs all its Jacobi sweeps in one single-workgroup launch.
+//     int64), accumulated per 32x32 tile in LDS (integer ds_add into the tile's window of grid cells)
+//     and flushed with ONE global integer atomic per non-zero (tile, superpixel, term) -- no float
+//     atomics, bit-reproducible for any launch geometry.
+//   * a relabelling pass snapshots its tile + 1-pixel halo of the label map in LDS and updates the map
+//     in place (the tile grid is shifted so that a workgroup is the only writer of what it read); the
+//     boundary count is derived from the tile, never stored; no merge launch between passes (double
+//     buffered sums + replayed per-tile log, see k_update_pass).
+//   * the plane filter runs the final merge and all its Jacobi sweeps in one workgroup per frame.
+//   * every kernel covers all frames of an extract batch (batch index = blockIdx.z / .y, batch_slot).
 #include <stdio.h>
 #include <stdlib.h>
 #include "ssf_device.hpp"
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
         const uint32_t r = rgb[3 * q], g = rgb[3 * q + 1], b = rgb[3 * q + 2];
         m.rgba[q] = r | (g << 8) | (b << 16) | (255u << 24);
         m.disp[q] = 1.f / depth[q];
-        m.label[0][q] = cell;
+        m.label[q] = cell;
         m.inlier[q] = 0;
         sx += x; sy += y; sr += (int)r; sg += (int)g; sb += (int)b; n += 1;
     }
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
     const int X0 = blockIdx.x * TILE - (OX ? 0 : 30), Y0 = blockIdx.y * TILE;  // OX = 0: tiles start at 2 (mod 4)
-    int32_t* __restrict__ lab = m.label[0];
+    int32_t* __restrict__ lab = m.label;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;          // pass pixels: local columns 4j+1, 4j+2
     const int x = X0 + lx0, y = Y0 + ly0;
@@ -438,7 +441,7 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
     uint32_t ctr = m.epoch[0] * 64u;
     const float radius = (float)p.cell / 2.f;
     {
-        const int32_t* __restrict__ label = m.label[0];
+        const int32_t* __restrict__ label = m.label;
         // centroid = mergeTPSRGBCoeffs of this superpixel, straight from the exact sums
         const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
         const float nn = (float)sm.n[index];
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const int ns = p.nb_samples;
     CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? EVAL_WIN : 0);
-    const int32_t* __restrict__ label = m.label[0];
+    const int32_t* __restrict__ label = m.label;
     for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
         const int l = win.label_of(i / ns, p.gy);
         w_plane[i] = l >= 0 ? m.samples[(size_t)l * ns + i % ns] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
-    const int32_t* __restrict__ label = m.label[0];
+    const int32_t* __restrict__ label = m.label;
     for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) w_acc[i] = 0ull;
     if (ransac)
         for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         if (l >= 0) w_row[i] = m.sp[l];
     }
     for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) w_acc[i] = 0ull;
-    load_label_tile(tile, m.label[0], X0, Y0, p.W, p.H);
+    load_label_tile(tile, m.label, X0, Y0, p.W, p.H);
     __syncthreads();
     for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
         const int lx = i % TILE, ly = i / TILE;

@@ -1,7 +1,9 @@
 // ssf_host.hip -- host side of the product library: handle, HBM allocation, the per-frame driver
 // (the C++ counterpart of SupersurfelFusion::processFrame, core/src/supersurfel_fusion.cu:166-530,
-// hot-path parts only), the host Gauss-Newton step of the ICP loop
-// (core/src/dense_registration.cu:324-421) and the C ABI of include/ssf.h.
+// hot-path parts only): extract contexts (pipelined / batched extract on their own streams and graphs),
+// the track chain (ICP loop with the host Gauss-Newton step of core/src/dense_registration.cu:324-421,
+// association, fusion, model-store upkeep), the RCCL exchanges of the multi-GPU mode, the loop-closure
+// registration, and the C ABI of include/ssf.h.
 //
 // There is NO CPU fallback here: without a gfx950 device ssf_create fails with SSF_ERR_NO_DEVICE.
 #include <algorithm>
@@ -576,7 +578,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     I.t_inc_stale = t_inc;
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     const unsigned long long seq = ++h->icp_seq;
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T,
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T,
                h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq);
     HCK(hipGetLastError());
     return to_host ? icp_fetch(h, seq) : SSF_OK;
@@ -713,7 +715,7 @@ static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->frame, h->cc->maps.label[0], h->pose, h->cfg.range_min,
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->frame, h->cc->maps.label, h->pose, h->cfg.range_min,
                  h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->S);
     HCK(hipGetLastError());
     return SSF_OK;
@@ -980,9 +982,8 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             off += std::max<size_t>(count, 1) * sizeof(T);
         };
         FrameMaps& m = c.maps;
-        take(m.rgba, P); take(m.disp, P); take(m.label[0], P); take(m.inlier, P); take(m.plane_depth, P);
+        take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
         take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1);
-        m.label[1] = m.label[0];                                        // labels are relabelled in place (single map)
         for (int b = 0; b < 2; b++) {
             SpSums& q = m.sums[b];
             take(q.sx, S); take(q.sy, S); take(q.sr, S); take(q.sg, S); take(q.sb, S); take(q.n, S); take(q.dx, S); take(q.dy, S);
@@ -1005,7 +1006,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         (void)carve(c, base);
         FrameMaps& m = c.maps;
         m.slab = slab_bytes;
-        m.srgb_lut = h->d_srgb_lut; m.ticket = h->d_tickets;
+        m.srgb_lut = h->d_srgb_lut;
         (void)hipMemsetAsync(base, 0, slab_bytes * h->batch, h->stream);
         if (nctx == 1) c.stream = h->stream;                            // sequential: extract shares the track stream
         else {
@@ -1129,7 +1130,7 @@ int ssf_align(ssf_handle* h, const ssf_surfels* src, int n, const float* init_po
         it++;
         inc_to_float(tf_inc, R_inc, t_inc);
         Rt T; T.R = m3_mul(R_inc, R_init); T.t = add(m3_mulv(R_inc, t_init), t_inc);
-        launch_align(st, h->cam, d_pos, d_lab, d_nrm, d_conf, n, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, d_out);
+        launch_align(st, h->cam, d_pos, d_lab, d_nrm, d_conf, n, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T, d_out);
         long long rec[40];
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(rec, d_out, 37 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { rc = SSF_ERR_DEVICE; h->err = "align iteration failed on the device"; break; }
@@ -1399,10 +1400,10 @@ static int copy_map(ssf_handle* h, void* dst, const void* src, size_t bytes) {
     HCK(hipStreamSynchronize(h->stream));
     return SSF_OK;
 }
-int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.label[0], (size_t)h->cfg.width * h->cfg.height * 4); }
+int ssf_get_index_map(ssf_handle* h, int32_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.label, (size_t)h->cfg.width * h->cfg.height * 4); }
 int ssf_get_boundary_map(ssf_handle* h, int32_t* o) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    launch_boundary_map(h->stream, h->seg, h->cc->maps.label[0], h->d_scratch_map);
+    launch_boundary_map(h->stream, h->seg, h->cc->maps.label, h->d_scratch_map);
     return copy_map(h, o, h->d_scratch_map, (size_t)h->cfg.width * h->cfg.height * 4);
 }
 int ssf_get_inlier_map(ssf_handle* h, uint8_t* o) { if (!h || !o) return SSF_ERR_INVALID_ARG; return copy_map(h, o, h->cc->maps.inlier, (size_t)h->cfg.width * h->cfg.height); }
@@ -1527,14 +1528,14 @@ double ssf_dbg_time_scan(ssf_handle* h, int reps, int mode) {
 }
 
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
-// (bit0: skip the per-surfel math, bit1: skip the wave reduction, bit2: skip ticket + tail)
+// (bit0: skip the per-surfel math, bit1: skip the LDS accumulation, bit2: skip arrival counting + tail)
 double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     if (!h || !h->have_frame) return -1.0;
     Rt T; T.R = m3_transpose(h->pose.R); T.t = negate(m3_mulv(T.R, h->pose.t));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label[0], h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

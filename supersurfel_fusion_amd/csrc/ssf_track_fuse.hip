@@ -6,15 +6,19 @@
 // 348-467,522-682), thrust::sort_by_key over the model (core/src/supersurfel_fusion.cu:469-472) and
 // applyDeformation (core/src/deformation_graph_kernels.cu:27-73).  How:
 //   * ICP streams 36 B per visible supersurfel (pos, cached Lab, normal row) from separate SoA
-//     streams, accumulates the 29-value record per lane as exact int64 fixed point, reduces across
-//     the 64-lane wave with shuffles and issues 29 integer atomics per wave: bit-identical for any
-//     grid, block or rank decomposition (no float atomics, no 14.8 KB LDS tree).
+//     streams; an inlier adds its 29 fixed-point terms with LDS integer atomics, every workgroup
+//     issues 29 global integer atomics, the last workgroup (two-level arrival counter) publishes
+//     the record: bit-identical for any grid, block or rank decomposition (no float atomics, no
+//     14.8 KB LDS tree).
 //   * association is one packed (dist_bits<<32 | id) 64-bit atomicMin per candidate: exact arg-min,
 //     ties to the lowest id.
 //   * insertion is an ordered block scan (ascending frame id), not atomic arrival order.
-//   * classify + stable 3-way partition replaces the radix sort: one pass computes the state and
-//     per-block histograms, a single-workgroup scan turns them into offsets, one pass scatters all
-//     ten SoA streams (116 B read + 116 B written per supersurfel) into the other model buffer.
+//   * classify + stable partition replaces the radix sort: one pass computes the state and
+//     per-block class histograms, a one-workgroup scan turns them into offsets (and publishes the
+//     frame's counters), one pass moves only the rows whose place changes (visible rows are a dense
+//     array, out-of-view rows a deque-like store with live flags: OovStore, ssf_device.hpp).
+//   * the loop-closure registration (DenseRegistration::align) is one single-workgroup launch per
+//     iteration with exact sums; fern codes are a gather.
 #include <stdlib.h>
 #include <algorithm>
 #include "ssf_device.hpp"
