@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const int x = X0 + lx0, y = Y0 + ly0;
     const bool in_image = x >= 0 && x < p.W && y < p.H;
     const size_t q = in_image ? (size_t)y * p.W + x : 0;
-    // this tile's log of the previous pass is replayed at the very end; its entry count is requested first so
-    // that only the valid entries are fetched (an unconditional 256-entry fetch costs 5 B per pixel of HBM)
+    // this tile's log of the previous pass is replayed at the very end; its entry count (uniform, a scalar load)
+    // is requested first so that only the valid entries are fetched (an unconditional 256-entry fetch costs 5 B
+    // per pixel of HBM)
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int lp = (pass + 2) % 3, lc = pass % 3;
     const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
@@ -271,6 +272,26 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const uint32_t px = m.rgba[q];
     float disp = 0.f; unsigned char prev_inlier = 0;
     if (RGBD) { disp = m.disp[q]; prev_inlier = m.inlier[q]; }
+    // the label tile + halo: requested into registers NOW (5 independent loads per thread), stored to LDS after the
+    // superpixel rows have been computed -- one memory round trip for tile, pixel operands, sums and log instead of two
+    constexpr int TILE_LOADS = (TW * TW + 255) / 256;
+    int tile_reg[TILE_LOADS];
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int lx = i % TW, ly = i / TW;
+        const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
+        tile_reg[k] = -1;
+        if (!(dbg & 32) && i < TW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
+    }
+    // the valid entries of the previous pass' log (replayed at the very end)
+    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
+    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
+    int4 prev_ent = make_int4(0, 0, 0, 0); float prev_disp = 0.f;
+    if (threadIdx.x < n_prev) {
+        prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
+        if (RGBD) prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
+    }
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
     const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
@@ -285,16 +306,10 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
             const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
             if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) w_row[i] = row_from_sums(sr, cy * p.gx + cx, RGBD, zero_row);
         }
-    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
-    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    int4 prev_ent = make_int4(0, 0, 0, 0); float prev_disp = 0.f;
-    if (threadIdx.x < n_prev) {
-        prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
-        if (RGBD) prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
-    }
     if (threadIdx.x == 0) s_nlog = 0;
     if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
-    if (!(dbg & 32)) load_label_tile(tile, lab, X0, Y0, p.W, p.H);
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; k++) { const int i = threadIdx.x + 256 * k; if (i < TW * TW) tile[i] = tile_reg[k]; }
     __syncthreads();
     const float inv_gx = 1.0f / (float)p.gx;
     auto slot_of = [&](int l) -> int {
@@ -485,43 +500,61 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
 // planes of the window's superpixels are staged in LDS, every pixel tests its label's planes and
 // counts with LDS integer atomics; the tile flushes non-zero counts with one global atomic each.
 #define EVAL_WIN 64
+#define ACC_REP 4
 #define EVAL_NS 16
+#define EVAL_REP 8
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
     __shared__ float4 w_plane[EVAL_WIN * EVAL_NS];
-    __shared__ int w_cnt[EVAL_WIN * EVAL_NS];
+    // EVAL_REP replicas of every counter (lane & 7): the 64 pixels of a wave sit in a handful of superpixels, and
+    // same-address LDS atomics serialise (SQ_LDS_BANK_CONFLICT was 80 % of the LDS cycles with one replica)
+    __shared__ int w_cnt[EVAL_WIN * EVAL_NS * EVAL_REP];
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const int ns = p.nb_samples;
     CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? EVAL_WIN : 0);
     const int32_t* __restrict__ label = m.label;
+    // this thread's pixels: requested up front, in flight while the window's planes are staged
+    constexpr int PX = TILE * TILE / 256;
+    int pl[PX]; float pd[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        pl[k] = -1; pd[k] = 0.f;
+        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pl[k] = label[q]; pd[k] = m.disp[q]; }
+    }
     for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
         const int l = win.label_of(i / ns, p.gy);
         w_plane[i] = l >= 0 ? m.samples[(size_t)l * ns + i % ns] : make_float4(0.f, 0.f, 0.f, 0.f);
-        w_cnt[i] = 0;
     }
+    for (int i = threadIdx.x; i < win.size() * ns * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
         const int x = X0 + i % TILE, y = Y0 + i / TILE;
         if (x >= p.W || y >= p.H) continue;
-        const size_t q = (size_t)y * p.W + x;
-        const int l = label[q];
-        const float d = m.disp[q];
+        const int l = pl[k];
+        const float d = pd[k];
         const int ws = win.slot(l);
-        for (int k = 0; k < ns; k++) {
-            const float4 th = ws >= 0 ? w_plane[ws * ns + k] : m.samples[(size_t)l * ns + k];
+        // (a ballot/popcount aggregation per (label, sample) instead of replicas was measured slower: 41 us)
+        for (int sk = 0; sk < ns; sk++) {
+            const float4 th = ws >= 0 ? w_plane[ws * ns + sk] : m.samples[(size_t)l * ns + sk];
             if (isfinite(th.z)) {
                 const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
                 const float dd = (d - dp) * (d - dp);
                 if (dd < p.thresh_disp) {
-                    if (ws >= 0) atomicAdd(&w_cnt[ws * ns + k], 1);
-                    else atomicAdd(&m.sample_score[(size_t)l * ns + k], 1);
+                    if (ws >= 0) atomicAdd(&w_cnt[(ws * ns + sk) * EVAL_REP + (lane_id() & (EVAL_REP - 1))], 1);
+                    else atomicAdd(&m.sample_score[(size_t)l * ns + sk], 1);
                 }
             }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
-        const int c = w_cnt[i];
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < EVAL_REP; r++) c += w_cnt[i * EVAL_REP + r];
         if (c) atomicAdd(&m.sample_score[(size_t)win.label_of(i / ns, p.gy) * ns + i % ns], c);
     }
 }
@@ -544,25 +577,37 @@ __device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int n
 // the 9 exact integer sums of every inlier go into LDS accumulators of the window's superpixels and
 // are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
 __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int ransac) {
-    __shared__ unsigned long long w_acc[WIN_MAX * 9];
+    __shared__ unsigned long long w_acc[WIN_MAX * 9 * ACC_REP];     // ACC_REP replicas (lane & 3) against same-address serialisation
     __shared__ float4 w_theta[WIN_MAX];
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
     const int32_t* __restrict__ label = m.label;
-    for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) w_acc[i] = 0ull;
+    // this thread's pixels: requested up front, in flight while the window's planes are selected
+    constexpr int PX = TILE * TILE / 256;
+    int pl[PX]; float pd[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        pl[k] = -1; pd[k] = 0.f;
+        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pl[k] = label[q]; pd[k] = m.disp[q]; }
+    }
+    for (int i = threadIdx.x; i < win.size() * 9 * ACC_REP; i += blockDim.x) w_acc[i] = 0ull;
     if (ransac)
         for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
             const int l = win.label_of(i, p.gy);
             if (l >= 0) w_theta[i] = select_sample(m, l, p.nb_samples);
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
         const int x = X0 + i % TILE, y = Y0 + i / TILE;
         if (x >= p.W || y >= p.H) continue;
         const size_t q = (size_t)y * p.W + x;
-        const int l = label[q];
-        const float d = m.disp[q];
+        const int l = pl[k];
+        const float d = pd[k];
         bool inl = false;
         if (isfinite(d)) {
             if (ransac) {
@@ -580,7 +625,7 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
         const long long t8 = fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM);
         const int ws = win.slot(l);
         if (ws >= 0) {
-            unsigned long long* a = &w_acc[ws * 9];
+            unsigned long long* a = &w_acc[(ws * ACC_REP + (lane_id() & (ACC_REP - 1))) * 9];
             lds_add_i64(&a[0], x); lds_add_i64(&a[1], y); lds_add_i64(&a[2], 1);
             lds_add_i64(&a[3], (long long)x * x); lds_add_i64(&a[4], (long long)y * y); lds_add_i64(&a[5], (long long)x * y);
             lds_add_i64(&a[6], t6); lds_add_i64(&a[7], t7); lds_add_i64(&a[8], t8);
@@ -591,7 +636,9 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
     }
     __syncthreads();
     for (int i = threadIdx.x; i < win.size() * 9; i += blockDim.x) {
-        const long long v = (long long)w_acc[i];
+        long long v = 0;
+#pragma unroll
+        for (int r = 0; r < ACC_REP; r++) v += (long long)w_acc[((i / 9) * ACC_REP + r) * 9 + i % 9];
         if (v == 0) continue;
         const int l = win.label_of(i / 9, p.gy), j = i % 9;
         for (int b = 0; b < 2; b++) {
@@ -694,7 +741,7 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m,
 __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m) {
     __shared__ int tile[TW * TW];
     __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * 13];
+    __shared__ unsigned long long w_acc[WIN_MAX * 13 * ACC_REP];    // ACC_REP replicas (lane & 3) against same-address serialisation
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
@@ -702,10 +749,22 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const int l = win.label_of(i, p.gy);
         if (l >= 0) w_row[i] = m.sp[l];
     }
-    for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) w_acc[i] = 0ull;
+    for (int i = threadIdx.x; i < win.size() * 13 * ACC_REP; i += blockDim.x) w_acc[i] = 0ull;
+    // this thread's pixels: inlier flag and colour requested up front (in flight while the tile is staged)
+    constexpr int PX = TILE * TILE / 256;
+    unsigned char pin[PX]; uint32_t prgba[PX];
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int x = X0 + i % TILE, y = Y0 + i / TILE;
+        pin[k] = 0; prgba[k] = 0;
+        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pin[k] = m.inlier[q]; prgba[k] = m.rgba[q]; }
+    }
     load_label_tile(tile, m.label, X0, Y0, p.W, p.H);
     __syncthreads();
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        const int i = threadIdx.x + 256 * k;
         const int lx = i % TILE, ly = i / TILE;
         const int x = X0 + lx, y = Y0 + ly;
         if (x >= p.W || y >= p.H) continue;
@@ -717,16 +776,17 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const float depth = 1.f / disp;
         m.plane_depth[q] = depth;
         const int bound = tile_boundary(tile, lx + 1, ly + 1);
-        if (!(m.inlier[q] && isfinite(depth) && depth > 0.0f && bound == 0)) continue;
+        if (!(pin[k] && isfinite(depth) && depth > 0.0f && bound == 0)) continue;
         const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
-        const uint32_t px = m.rgba[q];
+        const uint32_t px = prgba[k];
         const V3 lab = rgb8_to_lab(m.srgb_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
         const Sym3 c = sym_outer(pos);
         const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
         if (ws >= 0) {
+            unsigned long long* a = &w_acc[(ws * ACC_REP + (lane_id() & (ACC_REP - 1))) * 13];
 #pragma unroll
-            for (int j = 0; j < 12; j++) lds_add_i64(&w_acc[ws * 13 + j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
-            lds_add_i64(&w_acc[ws * 13 + 12], 1);
+            for (int j = 0; j < 12; j++) lds_add_i64(&a[j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
+            lds_add_i64(&a[12], 1);
         } else {
 #pragma unroll
             for (int j = 0; j < 12; j++) atomic_add_i64(&m.moments[(size_t)label * 13 + j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
@@ -735,7 +795,9 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
     }
     __syncthreads();
     for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) {
-        const long long v = (long long)w_acc[i];
+        long long v = 0;
+#pragma unroll
+        for (int r = 0; r < ACC_REP; r++) v += (long long)w_acc[((i / 13) * ACC_REP + r) * 13 + i % 13];
         if (v != 0) atomic_add_i64(&m.moments[(size_t)win.label_of(i / 13, p.gy) * 13 + i % 13], v);
     }
 }
