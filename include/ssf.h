@@ -309,7 +309,13 @@ int ssf_get_plane_depth(ssf_handle* h, float* out /* H*W */);
 /* SuperpixelRGBD table (TPS_RGBD.hpp:32-37) as 9 floats per superpixel:
  * cx, cy, r, g, b, theta_a, theta_b, theta_c, size. */
 int ssf_get_superpixels(ssf_handle* h, float* out /* 9*S */);
-/* Device-resident views (product only; valid until the next call on the handle). */
+/* Device-resident view of the whole model in the reference's order [visible | out-of-view]
+ * (getModel() returns device vectors, supersurfel_fusion.hpp:87).  The product keeps the two classes
+ * in separate stores and materialises this dense copy on demand: n_model rows,
+ * device pointers in ssf_surfels; `orientations` points at the stream of FIRST rows (3 floats per
+ * supersurfel: the major axis) -- the product stores the three rows of the reference's Mat33 as
+ * three separate streams and this view exposes only the first; use ssf_get_model for full 3x3
+ * orientations.  Valid until the next call on the handle.  Product only. */
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_model);
 int ssf_export_model_txt(ssf_handle* h, const char* path);
 
