@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--py-driver", action="store_true",
                     help="N > 1 through supersurfel_fusion_amd/sharded.py (torch.distributed collectives) instead of native RCCL")
     a = ap.parse_args()
+    # stdout carries exactly one JSON line: everything the runtime libraries print there (RCCL's banner) is sent to
+    # stderr until the result is ready
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     global W, H, P
     if a.config == 3:
         W, H, a.force_icp = 1280, 960, True
@@ -154,17 +158,37 @@ def main():
     if exchange and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    tstream, stream = None, None                   # library-owned (high-priority) track stream
-    if exchange and a.py_driver:
-        tstream = torch.cuda.Stream(dev)           # the torch stream the collectives are ordered on
-        stream = tstream.cuda_stream
-    f = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch))
-    f.set_model(model_local, nvis_local, 30)
-    drv = None
-    if exchange and a.py_driver:
-        drv = sharded.ShardedFusion(f, device=dev, stream=tstream, always_reduce=a.force_sharded)
-    elif exchange:
-        f.comm_attach()
+
+    def make_engine(py_driver):
+        tstream, stream = None, None               # library-owned (high-priority) track stream
+        if py_driver:
+            tstream = torch.cuda.Stream(dev)       # the torch stream the collectives are ordered on
+            stream = tstream.cuda_stream
+        fus = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch))
+        fus.set_model(model_local, nvis_local, 30)
+        if py_driver:
+            return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
+        if exchange:
+            fus.comm_attach()
+        return fus, None
+
+    native_ok = 1
+    if exchange and not a.py_driver:
+        # every rank must take the same path: agree on whether the native RCCL attach worked everywhere
+        try:
+            f, drv = make_engine(False)
+        except binding.SsfError as e:
+            sys.stderr.write("native RCCL attach failed on rank %d (%s): falling back to the torch.distributed driver\n" % (rank, e))
+            native_ok, f, drv = 0, None, None
+        flag = torch.tensor([native_ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_ok = int(flag.item())
+        if not native_ok:
+            if f is not None:
+                f.close()
+            f, drv = make_engine(True)
+    else:
+        f, drv = make_engine(exchange and a.py_driver)
     eng = drv if drv is not None else f
 
     def step(i):
@@ -302,6 +326,7 @@ def main():
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
+                       "exchange": ("native RCCL on the track stream" if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams" % (world, depth + 1 if depth else 0)},
             "pipeline_depth": depth, "extract_batch": batch, "sequential_ms_per_frame": seq_ms,
@@ -313,7 +338,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         import ctypes
-        ctypes.CDLL(None).fflush(None)             # C-level stdout of the runtime libraries first: the JSON line is the last line
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)             # C-level buffers of the runtime libraries (to stderr)
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
 
 

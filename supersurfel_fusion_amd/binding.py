@@ -335,13 +335,15 @@ class Fusion:
         to ship rank 0's unique id); afterwards process_frame / process_submitted exchange natively."""
         import torch
         import torch.distributed as dist
-        ident = np.zeros(128, np.uint8)
+        ident, err = np.zeros(128, np.uint8), None
         if dist.get_rank(group) == 0:
             rc = self.L.lib.ssf_comm_unique_id(_ptr(ident))
             if rc != 0:
-                raise SsfError("ssf_comm_unique_id failed (%d): %s" % (rc, self.L.lib.ssf_last_error(None).decode()))
-        obj = [ident.tobytes()]
-        dist.broadcast_object_list(obj, src=0, group=group)
+                err = "ssf_comm_unique_id failed (%d): %s" % (rc, self.L.lib.ssf_last_error(None).decode())
+        obj = [None if err else ident.tobytes(), err]
+        dist.broadcast_object_list(obj, src=0, group=group)      # every rank learns about a failure on rank 0
+        if obj[0] is None:
+            raise SsfError(obj[1])
         ident = np.frombuffer(obj[0], np.uint8).copy()
         self._ck(self.L.lib.ssf_comm_attach(self.h, _ptr(ident)), "ssf_comm_attach")
 
