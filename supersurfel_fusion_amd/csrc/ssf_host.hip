@@ -35,6 +35,9 @@ struct KernelTimer {
     std::vector<Rec> pending;
     std::map<std::string, std::pair<double, long long>> acc;
     const char* cur_name = nullptr; hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;
+    // what an EMPTY (e0, e1) bracket measures on this device: the two event packets themselves.  Subtracted from
+    // every bracket so that the live per-kernel times agree with rocprofv3's kernel durations.
+    double bracket_bias_ms = -1.0;
 };
 static thread_local KernelTimer* g_timer = nullptr;
 KernelTimer* current_timer() { return g_timer; }
@@ -52,10 +55,22 @@ void timer_end(KernelTimer* t, hipStream_t st) {
     (void)hipEventRecord(r.e1, st);
     t->pending.push_back(r);
 }
+static void timer_calibrate(KernelTimer* t, hipStream_t st) {
+    if (t->bracket_bias_ms >= 0.0) return;
+    hipEvent_t e[2 * 16];
+    for (auto& x : e) (void)hipEventCreate(&x);
+    for (int i = 0; i < 16; i++) { (void)hipEventRecord(e[2 * i], st); (void)hipEventRecord(e[2 * i + 1], st); }
+    (void)hipStreamSynchronize(st);
+    double sum = 0; int n = 0;
+    for (int i = 4; i < 16; i++) { float ms; if (hipEventElapsedTime(&ms, e[2 * i], e[2 * i + 1]) == hipSuccess) { sum += ms; n++; } }
+    for (auto& x : e) (void)hipEventDestroy(x);
+    t->bracket_bias_ms = n ? sum / n : 0.0;
+}
 static void timer_collect(KernelTimer* t) {     // call after a stream sync
+    const double bias = t->bracket_bias_ms > 0.0 ? t->bracket_bias_ms : 0.0;
     for (auto& r : t->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = t->acc[r.name]; a.first += ms; a.second += 1; }
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = t->acc[r.name]; a.first += std::max(0.0, (double)ms - bias); a.second += 1; }
         t->pool_free.push_back(r);
     }
     t->pending.clear();
@@ -415,7 +430,10 @@ static void pose_to12(const Rt& r, float* p) {
 }
 struct TimerScope {
     ssf_handle* h;
-    explicit TimerScope(ssf_handle* hh) : h(hh) { set_current_timer(hh->cfg.profile == 1 ? &hh->timer : nullptr); }
+    explicit TimerScope(ssf_handle* hh) : h(hh) {
+        if (hh->cfg.profile == 1) timer_calibrate(&hh->timer, hh->stream);       // first use only
+        set_current_timer(hh->cfg.profile == 1 ? &hh->timer : nullptr);
+    }
     ~TimerScope() { set_current_timer(nullptr); }
 };
 
@@ -1502,7 +1520,12 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
     return k;
 }
 int ssf_reset_kernel_times(ssf_handle* h) { if (!h) return SSF_ERR_INVALID_ARG; h->timer.acc.clear(); return SSF_OK; }
-int ssf_set_profile(ssf_handle* h, int enable) { if (!h) return SSF_ERR_INVALID_ARG; h->cfg.profile = enable; return SSF_OK; }
+int ssf_set_profile(ssf_handle* h, int enable) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    h->cfg.profile = enable;
+    if (enable == 1) timer_calibrate(&h->timer, h->stream);
+    return SSF_OK;
+}
 
 // host-side time split of the pipelined loop (tools/pipeline_probe.py); reset on read
 int ssf_dbg_host_times(ssf_handle* h, double* out8) {
