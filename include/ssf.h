@@ -219,6 +219,8 @@ int ssf_debug_set_max_passes(ssf_handle* h, int max_passes);
 /* Product-internal upkeep made callable for tests: compact the out-of-view row store now (DESIGN.md
  * section 3; a no-op for the results).  The CPU checker has no such store and returns SSF_OK. */
 int ssf_debug_recentre(ssf_handle* h);
+/* Number of compactions of the out-of-view store so far, forced or automatic (0 for the CPU checker). */
+long long ssf_debug_recentre_count(const ssf_handle* h);
 /* Global (all-shard) model counts and this shard's global id offset; must precede icp_begin when
  * nranks > 1.  Unsharded handles ignore it. */
 int ssf_stage_set_shard(ssf_handle* h, int64_t id_offset, int64_t global_n_model,

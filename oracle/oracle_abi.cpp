@@ -86,6 +86,7 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
     return SSF_OK;
 }
 int ssf_debug_recentre(ssf_handle* h) { return h ? SSF_OK : SSF_ERR_INVALID_ARG; }
+long long ssf_debug_recentre_count(const ssf_handle* h) { return h ? 0 : -1; }
 int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->s.max_passes = n; return SSF_OK; }
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;

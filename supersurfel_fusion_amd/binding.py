@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_debug_recentre",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_debug_recentre", "ssf_debug_recentre_count",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -99,6 +99,8 @@ class Library:
         L.ssf_stage_extract.argtypes = [vp, vp, vp, C.c_int, vp]
         L.ssf_debug_set_max_passes.argtypes = [vp, C.c_int]
         L.ssf_debug_recentre.argtypes = [vp]
+        L.ssf_debug_recentre_count.argtypes = [vp]
+        L.ssf_debug_recentre_count.restype = C.c_longlong
         L.ssf_stage_set_shard.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64]
         L.ssf_stage_icp_begin.argtypes = [vp, vp]
         L.ssf_stage_icp_accumulate.argtypes = [vp, vp]
@@ -261,6 +263,9 @@ class Fusion:
 
     def debug_recentre(self):
         self._ck(self.L.lib.ssf_debug_recentre(self.h), "ssf_debug_recentre")
+
+    def debug_recentre_count(self):
+        return int(self.L.lib.ssf_debug_recentre_count(self.h))
 
     def set_max_passes(self, n):
         self._ck(self.L.lib.ssf_debug_set_max_passes(self.h, n), "ssf_debug_set_max_passes")

@@ -337,7 +337,7 @@ struct ssf_handle {
     // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
     // with live flags, host mirror of the span below), dense = materialised [visible | out-of-view] view for the
     // consumers of the whole model (get/set model, export, deformation)
-    OovStore oov[2]; int ocur = 0; int oov_head = 0, oov_tail = 0, oov_live = 0;
+    OovStore oov[2]; int ocur = 0; int oov_head = 0, oov_tail = 0, oov_live = 0; long long n_recentres = 0;
     uint8_t* d_state_oov = nullptr; uint32_t* d_bc_oov = nullptr;
     SurfelSoA dense; uint8_t* d_live_scratch = nullptr;
     int32_t* d_scratch_map = nullptr;
@@ -696,6 +696,7 @@ static int oov_recentre(ssf_handle* h) {
     HCK(hipGetLastError());
     h->ocur ^= 1;
     h->oov_head = oov_home(h); h->oov_tail = h->oov_head + h->oov_live;
+    h->n_recentres++;
     return SSF_OK;
 }
 // dense [visible | out-of-view] copy of the model in h->dense (stream ordered)
@@ -1261,6 +1262,7 @@ int ssf_debug_recentre(ssf_handle* h) {
     if (!h->pending.empty()) return SSF_ERR_STATE;
     return oov_recentre(h);
 }
+long long ssf_debug_recentre_count(const ssf_handle* h) { return h ? h->n_recentres : -1; }
 int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->max_passes = n; return SSF_OK; }
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;

@@ -246,3 +246,19 @@ def test_long_sweep_with_view_changes_and_store_upkeep(oracle_lib, product_lib):
             util.compare_state(fo, fh, maps=False, frame_surfels=False)
     c = fh.counts()
     assert c["n_model"] > 0 and c["n_visible"] > 0
+
+
+def test_out_of_view_store_recentres_by_itself(oracle_lib, product_lib):
+    """Same sweep without forced compactions: with a capacity this small the span of the out-of-view store runs out
+    of room in front and has to be compacted automatically, several times; results stay equal to the oracle."""
+    W, H = 160, 128
+    kw = dict(nb_supersurfels_max=400, delta_t=1000, conf_thresh=0.0)     # nothing is culled by age: rows pile up
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, **kw))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, **kw))
+    ks = (list(range(0, 48, 6)) + list(range(48, -1, -6))) * 3
+    for n, k in enumerate(ks):
+        rgb, depth = util.frame(k, W, H, noise=True)
+        prior = synthetic.pose12(*synthetic.relative_pose(k))
+        util.same_result(fo.process_frame(rgb, depth, prior_pose=prior), fh.process_frame(rgb, depth, prior_pose=prior))
+    util.compare_state(fo, fh, maps=False, frame_surfels=False)
+    assert fh.debug_recentre_count() >= 2, fh.debug_recentre_count()
