@@ -85,13 +85,33 @@ def tum_line(stamp, pose12):
     return " ".join([stamp] + ["%g" % v for v in list(t) + list(q)])
 
 
-def replay(fusion, frames, out_path=None, export_model=None):
-    """frames: iterable of (stamp, rgb u8 HxWx3, depth f32 HxW).  Returns (lines, results)."""
+def replay(fusion, frames, out_path=None, export_model=None, pipelined=False):
+    """frames: iterable of (stamp, rgb u8 HxWx3, depth f32 HxW).  Returns (lines, results).
+    pipelined: decode / submit ahead while earlier frames are tracked and fused (ssf_submit_frame /
+    ssf_process_submitted, for handles created with pipeline_depth / extract_batch > 0 / 1); the trajectory is the
+    same, bit for bit, as with one process_frame per line."""
     lines, results = [], []
-    for stamp, rgb, depth in frames:
-        r = fusion.process_frame(rgb, depth)
-        results.append(r)
-        lines.append(tum_line(stamp, r["pose"]))
+    if not pipelined:
+        for stamp, rgb, depth in frames:
+            r = fusion.process_frame(rgb, depth)
+            results.append(r)
+            lines.append(tum_line(stamp, r["pose"]))
+    else:
+        it, stamps, done = iter(frames), [], False
+        while True:
+            while not done and fusion.can_submit():
+                try:
+                    stamp, rgb, depth = next(it)
+                except StopIteration:
+                    done = True
+                    break
+                fusion.submit_frame(rgb, depth)           # host buffers are copied at submit
+                stamps.append(stamp)
+            if fusion.pending_frames() == 0:
+                break
+            r = fusion.process_submitted().as_dict()
+            results.append(r)
+            lines.append(tum_line(stamps[len(lines)], r["pose"]))
     if out_path:
         with open(out_path, "w") as f:
             f.write("\n".join(lines) + "\n")
@@ -137,16 +157,18 @@ def main():
     ap.add_argument("--depth-scale", type=float, default=0.0002)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--export-model", default=None)
+    ap.add_argument("--pipelined", action="store_true", help="extract of later frames runs ahead (pipeline_depth 2, extract_batch 4)")
     a = ap.parse_args()
     from . import binding
     lib = binding.load_product()
     # rgbd_benchmark launch column of SURVEY.md Appendix B, TUM fr1 intrinsics (rgbd_benchmark/fr1_cam.yaml)
     cfg = lib.default_config(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, lambda_pos=10.0,
                              lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, filter_iter=3, delta_t=20,
-                             conf_thresh=2560.0, nb_supersurfels_max=100000, icp_cov_thresh=0.05)
+                             conf_thresh=2560.0, nb_supersurfels_max=100000, icp_cov_thresh=0.05,
+                             pipeline_depth=2 if a.pipelined else 0, extract_batch=4 if a.pipelined else 1)
     f = binding.Fusion(lib, cfg)
     frames = frames_from_npz(a.npz, a.depth_scale) if a.npz else frames_from_dataset(a.dataset, a.depth_scale, a.max_frames)
-    lines, res = replay(f, frames, a.out, a.export_model)
+    lines, res = replay(f, frames, a.out, a.export_model, pipelined=a.pipelined)
     print("%d frames -> %s ; %d supersurfels" % (len(lines), a.out, res[-1]["n_model"] if res else 0))
 
 

@@ -15,8 +15,8 @@ TUM = os.path.join(ROOT, "tests", "golden", "tum_fr1_xyz_3frames.npz")
 TUM_CFG = dict(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, nb_supersurfels_max=20000)
 
 
-def tum_fusion(lib):
-    cfg = dict(TUM_CFG); cfg.update(util.BENCH_PARAMS)
+def tum_fusion(lib, **kw):
+    cfg = dict(TUM_CFG); cfg.update(util.BENCH_PARAMS); cfg.update(kw)
     return binding.Fusion(lib, lib.default_config(**cfg))
 
 
@@ -80,6 +80,24 @@ def test_real_tum_frames_bit_exact_on_gpu(oracle_lib, product_lib):
     fo, fh = tum_fusion(oracle_lib), tum_fusion(product_lib)
     lo, ro = replay.replay(fo, replay.frames_from_npz(TUM))
     lh, rh = replay.replay(fh, replay.frames_from_npz(TUM))
+    assert lo == lh
+    for a, b in zip(ro, rh):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
+
+
+def test_pipelined_replay_gives_the_same_trajectory(oracle_lib):
+    f1, f2 = tum_fusion(oracle_lib), tum_fusion(oracle_lib, pipeline_depth=1, extract_batch=2)
+    l1, _ = replay.replay(f1, replay.frames_from_npz(TUM))
+    l2, _ = replay.replay(f2, replay.frames_from_npz(TUM), pipelined=True)
+    assert l1 == l2 and len(l2) == 3
+
+
+@pytest.mark.gpu
+def test_pipelined_replay_on_gpu_equals_the_oracle(oracle_lib, product_lib):
+    fo, fh = tum_fusion(oracle_lib), tum_fusion(product_lib, pipeline_depth=2, extract_batch=4)
+    lo, ro = replay.replay(fo, replay.frames_from_npz(TUM))
+    lh, rh = replay.replay(fh, replay.frames_from_npz(TUM), pipelined=True)
     assert lo == lh
     for a, b in zip(ro, rh):
         util.same_result(a, b)
