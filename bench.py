@@ -313,6 +313,15 @@ def main():
                               "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, cdt))
             fo.close()
 
+    # whole-frame view: algorithmic bytes of one frame over the measured frame time
+    it_mean = float(np.mean(iters))
+    fb = dict(extract=180.0 * P, icp=(36.0 * counts["n_visible"] + 8.0 * P + 28.0 * counts["S"]) * it_mean,
+              fuse=40.0 * counts["n_visible"] + 28.0 * counts["n_model"] + 2.0 * counts["n_model"] + 208.0 * counts["n_visible"])
+    fbytes = sum(fb.values())
+    frame_roofline = dict(bound="hbm", algo_bytes_per_frame=fbytes, bytes_by_stage=fb, achieved=fbytes / (dt / K) / 1e9,
+                          peak=HBM_PEAK_GBS, unit="GB/s", frac=fbytes / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                          note="extract 180 B/pixel, ICP 36 B/visible supersurfel/iteration + frame tables, fuse: association 40 B/visible, "
+                               "classify 28 B/row, row moves 2 B/slot + 208 B/visible row (the reference's full reorder would be 212 B/row)")
     gcounts = f.global_counts() if drv is None else dict(n_model=last["global_n_model"], n_visible=last["global_n_visible"])
     if rank == 0:
         gn, gv = gcounts["n_model"], gcounts["n_visible"]
@@ -331,7 +340,7 @@ def main():
                                       "ahead of ICP/fusion on its own HIP streams" % (world, depth + 1 if depth else 0)},
             "pipeline_depth": depth, "extract_batch": batch, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
-            "roofline": roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
+            "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }
     f.close()
     if dist.is_initialized():
