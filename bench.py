@@ -213,6 +213,9 @@ def main():
             for i in range(first, first + count):
                 res.append(step(i))
             return res
+        if drv is None:                             # the submit-ahead / process-in-order loop, natively
+            return f.process_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)],
+                                      [d_depth[i].data_ptr() for i in range(first, first + count)], on_device=True)
         nsub = first
         for i in range(first, first + count):
             while nsub < first + count and eng.can_submit():

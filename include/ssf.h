@@ -210,6 +210,12 @@ int ssf_pipeline_capacity(const ssf_handle* h);
  * a batch whose frames are still being consumed keeps its context until the last one is fused. */
 int ssf_can_submit(const ssf_handle* h);
 
+/* A whole recorded sequence in one call: the submit-ahead / process-in-order loop above in native code (what
+ * SupersurfelFusionRGBDBenchmarkNode::run does frame by frame).  rgb[i] / depth_m[i]: the n frames (host or
+ * device pointers, see ssf_submit_frame); out[i]: result of frame i.  No pose priors, no dynamic masks. */
+int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth_m, int n, int on_device,
+                         ssf_frame_result* out);
+
 /* ---- stage seams (used by the sharded multi-GPU driver and by the parity tests) ------------- */
 /* extract: ingest + TPS segmentation + plane filter + plane depth + frame supersurfels. */
 int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth_m, int on_device,

@@ -225,6 +225,15 @@ int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* o
     h->pending.pop_front();
     return ssf_process_frame(h, f.rgb.data(), f.depth.data(), prior, f.has_mask ? f.mask.data() : nullptr, out);
 }
+int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth, int n, int /*on_device*/, ssf_frame_result* out) {
+    if (!h || !rgb || !depth || n < 0) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) return SSF_ERR_STATE;
+    for (int k = 0; k < n; k++) {
+        int rc = ssf_process_frame(h, (const uint8_t*)rgb[k], (const float*)depth[k], nullptr, nullptr, out ? &out[k] : nullptr);
+        if (rc) return rc;
+    }
+    return SSF_OK;
+}
 int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
 
 int ssf_process_frame_device(ssf_handle* h, const void* rgb, const void* depth, const float* prior,

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_debug_recentre", "ssf_debug_recentre_count",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -125,6 +125,7 @@ class Library:
         L.ssf_set_profile.argtypes = [vp, C.c_int]
         L.ssf_bilateral_filter.argtypes = [vp, vp, vp, C.c_int]
         L.ssf_submit_frame.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.ssf_process_sequence.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
         L.ssf_process_submitted.argtypes = [vp, vp, C.POINTER(SsfFrameResult)]
         L.ssf_pending_frames.argtypes = [vp]
         L.ssf_pipeline_capacity.argtypes = [vp]
@@ -233,6 +234,15 @@ class Fusion:
             rp, dp = _ptr(rgb), _ptr(depth)
         mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
         self._ck(self.L.lib.ssf_submit_frame(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_submit_frame")
+
+    def process_sequence(self, rgb_ptrs, depth_ptrs, on_device=True):
+        """The whole submit-ahead / process-in-order loop in native code.  rgb_ptrs / depth_ptrs: raw addresses
+        (device pointers when on_device, else addresses of contiguous host arrays).  Returns a list of result dicts."""
+        n = len(rgb_ptrs)
+        pr = (C.c_void_p * n)(*rgb_ptrs); pd = (C.c_void_p * n)(*depth_ptrs)
+        res = (SsfFrameResult * n)()
+        self._ck(self.L.lib.ssf_process_sequence(self.h, pr, pd, n, 1 if on_device else 0, res), "ssf_process_sequence")
+        return [r.as_dict() for r in res]
 
     def process_submitted(self, prior_pose=None):
         """ICP + association + fusion of the oldest submitted frame; returns its SsfFrameResult."""

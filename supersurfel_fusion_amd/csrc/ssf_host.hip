@@ -1103,6 +1103,23 @@ int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (!h) return SSF_ERR_INVALID_ARG;
     return process_oldest(h, prior, out);
 }
+int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth, int n, int on_device, ssf_frame_result* out) {
+    if (!h || !rgb || !depth || n < 0) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    int next = 0;
+    for (int k = 0; k < n; k++) {
+        while (next < n && !h->ctx[h->open_ctx].launched) {
+            if (!rgb[next] || !depth[next]) return SSF_ERR_INVALID_ARG;
+            int rc;
+            { TimerScope ts(h); rc = submit_extract(h, rgb[next], depth[next], on_device, nullptr); }
+            if (rc) return rc;
+            next++;
+        }
+        int rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
+        if (rc) return rc;
+    }
+    return SSF_OK;
+}
 int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
 int ssf_pipeline_capacity(const ssf_handle* h) { return h ? (int)h->ctx.size() * h->batch : 0; }
 int ssf_can_submit(const ssf_handle* h) { return (h && !h->ctx[h->open_ctx].launched) ? 1 : 0; }

@@ -262,3 +262,16 @@ def test_out_of_view_store_recentres_by_itself(oracle_lib, product_lib):
         util.same_result(fo.process_frame(rgb, depth, prior_pose=prior), fh.process_frame(rgb, depth, prior_pose=prior))
     util.compare_state(fo, fh, maps=False, frame_surfels=False)
     assert fh.debug_recentre_count() >= 2, fh.debug_recentre_count()
+
+
+def test_process_sequence_equals_frame_by_frame(oracle_lib, product_lib):
+    W, H, nf = 320, 240, 9
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=2, extract_batch=4))
+    frames = [util.frame(k, W, H, noise=True) for k in range(nf)]
+    want = [fo.process_frame(*fr) for fr in frames]
+    keep = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in keep], [d.ctypes.data for _, d in keep], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
