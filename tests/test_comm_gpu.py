@@ -22,7 +22,10 @@ def one_rank_group():
     created = False
     if not dist.is_initialized():
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        except Exception as e:                      # no usable RCCL / rendezvous on this box: nothing to exercise
+            pytest.skip("torch.distributed nccl group unavailable: %s" % e)
         created = True
     yield dist
     if created:
