@@ -80,6 +80,10 @@ struct FrameMaps {
     // Exact sums, double buffered: relabelling pass k reads sums[k & 1] (quiescent: nothing writes it
     // during the pass) and applies its own deltas plus the log of pass k-1 to sums[(k + 1) & 1].
     SpSums sums[2]; PassLog log; SpRow* sp; float4* samples; int32_t* sample_score;
+    // gather-friendly copies for the ICP / association kernels (one cache line per lookup instead of two / five):
+    // per pixel (label, plane-depth bits); per frame supersurfel one 64-byte line (conf, lab.xyz) (normal.xyz, 0)
+    // (pos.xyz, 0) (unused)
+    uint2* pix2; float4* fpack;
     uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
@@ -113,6 +117,7 @@ SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     }
     m.sp = slab_shift(m.sp, o); m.samples = slab_shift(m.samples, o); m.sample_score = slab_shift(m.sample_score, o);
     m.moments = slab_shift(m.moments, o); m.filt = slab_shift(m.filt, o); m.epoch = slab_shift(m.epoch, o);
+    m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
     return m;
 }
 SSF_HD SurfelSoA batch_slot(SurfelSoA s, size_t o) {
@@ -171,11 +176,12 @@ void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* labe
 
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
 // replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: 65 zeroed u32 (global + 64 group arrival counters)
-void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                const int32_t* label, const float* plane_depth, Rt T, long long* replicas, unsigned int* ticket,
+// pix2 / fpack: FrameMaps::pix2 / fpack of the frame
+void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+                Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1);
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                  const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+                  Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S);
 // update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
 // (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)

@@ -775,6 +775,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
         const float depth = 1.f / disp;
         m.plane_depth[q] = depth;
+        m.pix2[q] = make_uint2((uint32_t)label, __float_as_uint(depth));
         const int bound = tile_boundary(tile, lx + 1, ly + 1);
         if (!(pin[k] && isfinite(depth) && depth > 0.0f && bound == 0)) continue;
         const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
@@ -849,6 +850,9 @@ __global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float 
     f.shape[6 * k + 3] = shape.yy; f.shape[6 * k + 4] = shape.yz; f.shape[6 * k + 5] = shape.zz;
     f.dims[2 * k] = d0; f.dims[2 * k + 1] = d1;
     f.conf[k] = conf;
+    m.fpack[4 * k] = make_float4(conf, lab.x, lab.y, lab.z);          // one 64-byte line per frame supersurfel
+    m.fpack[4 * k + 1] = make_float4(vecs.r2.x, vecs.r2.y, vecs.r2.z, 0.f);
+    m.fpack[4 * k + 2] = make_float4(pos.x, pos.y, pos.z, 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t* __restrict__ label, int32_t* __restrict__ out) {

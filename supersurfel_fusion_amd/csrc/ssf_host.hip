@@ -596,7 +596,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     I.t_inc_stale = t_inc;
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     const unsigned long long seq = ++h->icp_seq;
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T,
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
                h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq);
     HCK(hipGetLastError());
     return to_host ? icp_fetch(h, seq) : SSF_OK;
@@ -734,7 +734,7 @@ static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->frame, h->cc->maps.label, h->pose, h->cfg.range_min,
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
                  h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->S);
     HCK(hipGetLastError());
     return SSF_OK;
@@ -1002,7 +1002,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         };
         FrameMaps& m = c.maps;
         take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
-        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1);
+        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1); take(m.pix2, P); take(m.fpack, 4 * S);
         for (int b = 0; b < 2; b++) {
             SpSums& q = m.sums[b];
             take(q.sx, S); take(q.sy, S); take(q.sr, S); take(q.sg, S); take(q.sb, S); take(q.n, S); take(q.dx, S); take(q.dy, S);
@@ -1575,9 +1575,9 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     if (!h || !h->have_frame) return -1.0;
     Rt T; T.R = m3_transpose(h->pose.R); T.t = negate(m3_mulv(T.R, h->pose.t));
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < 3; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->frame, h->cc->maps.label, h->cc->maps.plane_depth, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
+    for (int i = 0; i < reps; i++) launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T, h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, ++h->icp_seq, dbg);
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -50,8 +50,8 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 #ifndef ICP_SLOTS
 #define ICP_SLOTS 16      // lane & 15 spreads the same-address traffic (64 columns measured no faster)
 #endif
-__global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                                             const int32_t* __restrict__ label, const float* __restrict__ plane_depth,
+__global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
+                                             const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
     __shared__ int s_last;
@@ -67,12 +67,14 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
         if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) continue;
         const size_t q = (size_t)v * cam.W + u;
-        const int tid = label[q];
-        const float zt = plane_depth[q];
-        if (!(frame.conf[tid] > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;
-        const float dist_color = len3(sub(ld3(model.lab, id), ld3(frame.lab, tid)));
+        const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
+        const int tid = (int)pl.x;
+        const float zt = __uint_as_float(pl.y);
+        const float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];   // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
+        if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;
+        const float dist_color = len3(sub(ld3(model.lab, id), v3(f0.y, f0.z, f0.w)));
         const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
-        const V3 nt = ld3(frame.r2, tid);
+        const V3 nt = v3(f1.x, f1.y, f1.z);
         const V3 ns = unit3(m3_mulv(R, ld3(model.r2, id)));
         if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) continue;
         const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
@@ -278,8 +280,8 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 }
 
 // ---- association ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                                               const int32_t* __restrict__ label, Rt pose, float zmin, float zmax,
+__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
+                                               const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
                                                uint8_t* __restrict__ matched) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,19 +295,20 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
     if (!(pv.z > zmin && pv.z < zmax)) return;
     const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
     if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return;
-    const int f = label[(size_t)py * cam.W + px];
+    const int f = (int)pix2[(size_t)py * cam.W + px].x;
     matched[f] = 1;
-    if (!(frame.conf[f] > 0.0f)) return;
-    const V3 fp = add(m3_mulv(R, ld3(frame.pos, f)), t);
-    const V3 fn = unit3(row_mul(ld3(frame.r2, f), Rt_));        // third row of frame_orientation * R^T
+    const float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];     // (conf, lab) (normal) (pos): one line
+    if (!(f0.x > 0.0f)) return;
+    const V3 fp = add(m3_mulv(R, v3(f2.x, f2.y, f2.z)), t);
+    const V3 fn = unit3(row_mul(v3(f1.x, f1.y, f1.z), Rt_));    // third row of frame_orientation * R^T
     const V3 mn = unit3(ld3(model.r2, id));
     const float dist = len3(sub(mp, fp));
-    const float lab_dist = len3(sub(ld3(model.lab, id), ld3(frame.lab, f)));
+    const float lab_dist = len3(sub(ld3(model.lab, id), v3(f0.y, f0.z, f0.w)));
     const float delta_norm = fabsf(dot3(mn, fn));
     if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
                                        (unsigned long long)(uint32_t)(id_offset + id);
-        atomicMin(&best[f], key);
+        atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
     }
 }
 
@@ -380,51 +383,57 @@ __device__ __forceinline__ int block_rank_1024(bool flag, int* wave_tot, int& bl
     return before + in_wave;
 }
 
-// insertSupersurfels (supersurfel_fusion_kernels.cu:348-395) in ascending frame id
-__device__ __forceinline__ void insert_all(SurfelSoA M, SurfelSoA F, Rt pose, int stamp,
-                                           const uint8_t* __restrict__ matched, int S, int capacity, int rank,
-                                           int nranks, float tile, Counters* cnt, int* wave_tot) {
-    // new rows go behind the visible rows of the visible array (they are classified right after); the capacity
-    // bounds the whole model (visible + out-of-view)
+// insertSupersurfels (supersurfel_fusion_kernels.cu:348-395) in ascending frame id.  One workgroup per chunk of 256
+// frame supersurfels: a chunk needs the number of insertions of the chunks before it, and simply re-evaluates their
+// flags (a few cheap tests per thread) instead of waiting for a serial pass -- S = 4800 at 1280x960 was 19 serial
+// chunks (57 us) in one workgroup.  cnt->n_visible / n_model are not written by this kernel (the scan adds
+// n_inserted to n_model), so every chunk reads the same bases.
+__device__ __forceinline__ bool insert_flag(const SurfelSoA& F, int f, int S, const uint8_t* __restrict__ matched, const Rt& pose,
+                                            int rank, int nranks, float tile) {
+    return f < S && (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
+}
+__device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, const uint8_t* __restrict__ matched,
+                                             int S, int capacity, int rank, int nranks, float tile, Counters* cnt, int* wave_tot,
+                                             int chunk, int nchunks) {
+    __shared__ int s_before[4];
     const int base = cnt->n_visible, base_total = cnt->n_model;
+    int mine = 0;
+    for (int c = 0; c < chunk; c++) mine += insert_flag(F, c * 256 + (int)threadIdx.x, S, matched, pose, rank, nranks, tile) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane() == 0) s_before[threadIdx.x >> 6] = mine;
     __syncthreads();
+    const int before = s_before[0] + s_before[1] + s_before[2] + s_before[3];
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
-    int running = 0;
-    for (int c0 = 0; c0 < S; c0 += blockDim.x) {
-        const int f = c0 + threadIdx.x;
-        bool flag = false;
-        if (f < S) flag = (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
-        int total;
-        const int r = block_rank_1024(flag, wave_tot, total);
-        const int k = base + running + r;
-        if (flag && base_total + running + r < capacity) {
-            st3(M.pos, k, add(m3_mulv(R, ld3(F.pos, f)), t));
-            M.conf[k] = F.conf[f];
-            st3(M.col, k, ld3(F.col, f));
-            st3(M.lab, k, ld3(F.lab, f));
-            M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
-            M.dims[2 * k] = F.dims[2 * f]; M.dims[2 * k + 1] = F.dims[2 * f + 1];
-            st3(M.r0, k, row_mul(ld3(F.r0, f), Rt_));
-            st3(M.r1, k, row_mul(ld3(F.r1, f), Rt_));
-            st3(M.r2, k, row_mul(ld3(F.r2, f), Rt_));
-            st6(M.shape, k, rot_sym(R, ld6(F.shape, f)));
-        }
-        running += total;
+    const int f = chunk * 256 + threadIdx.x;
+    const bool flag = insert_flag(F, f, S, matched, pose, rank, nranks, tile);
+    int total;
+    const int r = block_rank_1024(flag, wave_tot, total);
+    const int k = base + before + r;
+    if (flag && base_total + before + r < capacity) {
+        st3(M.pos, k, add(m3_mulv(R, ld3(F.pos, f)), t));
+        M.conf[k] = F.conf[f];
+        st3(M.col, k, ld3(F.col, f));
+        st3(M.lab, k, ld3(F.lab, f));
+        M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
+        M.dims[2 * k] = F.dims[2 * f]; M.dims[2 * k + 1] = F.dims[2 * f + 1];
+        st3(M.r0, k, row_mul(ld3(F.r0, f), Rt_));
+        st3(M.r1, k, row_mul(ld3(F.r1, f), Rt_));
+        st3(M.r2, k, row_mul(ld3(F.r2, f), Rt_));
+        st6(M.shape, k, rot_sym(R, ld6(F.shape, f)));
     }
-    if (threadIdx.x == 0) {
-        const int n_new = min(base_total + running, capacity);
-        cnt->n_inserted = n_new - base_total;
-        cnt->n_model = n_new;
-    }
+    if (chunk == nchunks - 1 && threadIdx.x == 0) cnt->n_inserted = min(base_total + before + total, capacity) - base_total;
 }
-// update (blocks 0 .. gridDim-2, one frame supersurfel per thread) | insert (last block)
+// update (blocks 0 .. nchunks-1, one frame supersurfel per thread) | insert (blocks nchunks .. 2 nchunks-1, one chunk each)
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, int S, int do_update, int capacity,
                                                        int rank, int nranks, float tile, Counters* cnt) {
     __shared__ int wave_tot[16];
-    if (blockIdx.x == gridDim.x - 1) insert_all(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot);
+    const int nchunks = gridDim.x / 2;
+    if ((int)blockIdx.x >= nchunks)
+        insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, blockIdx.x - nchunks, nchunks);
     else if (do_update) update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -555,10 +564,11 @@ __device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int
 // a compute unit with 16 free wave slots (rocprofv3: 17.6 us in the frame vs 4 us alone); 4 waves fit anywhere.
 // A thread owns SCAN_VIS consecutive visible blocks (6 counters each) and SCAN_OOV consecutive out-of-view blocks;
 // of the latter only B0 needs a prefix (B1 rows stay in place, B2 rows are dropped), the three planes are read
-// as uint4.  One round = 1024 visible blocks (262 k rows) + 4096 out-of-view blocks (1 M slots).
-#define SCAN_VIS 4
+// as uint4.  One round = 256 x SCAN_VIS visible blocks (4: 262 k rows, 16: 1 M rows; the launcher picks the smaller
+// one when it suffices, its loads coalesce better) + 4096 out-of-view blocks (1 M slots).
 #define SCAN_OOV 16
 __device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
+template <int SCAN_VIS>
 __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t* __restrict__ bc_vis, int nb_vis_upper, uint32_t* __restrict__ bc_oov,
                                                      int oov_stride, int nb_oov_upper, Counters* cnt, Mailbox* mb, unsigned long long seq) {
     __shared__ uint32_t wtot[4][9];
@@ -631,6 +641,7 @@ __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t* __restrict__ bc_v
         const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
         const int b0 = (int)tot[6], b1 = (int)tot[7], b2 = (int)tot[8];
         Counters c = c_in;                            // loaded at kernel start: no dependent reloads here
+        c.n_model = c_in.n_model + c_in.n_inserted;   // k_update_insert reports its insertions in n_inserted only
         c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
         c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
         c.mv_nv = nv; c.mv_a0 = a0; c.mv_b0 = b0;
@@ -849,8 +860,8 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
-void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                const int32_t* label, const float* plane_depth, Rt T, long long* replicas, unsigned int* ticket,
+void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+                Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg) {
     ScopedKernel sk("icp_accumulate", st);
     static int per_lane = 0;             // supersurfels per lane before the wave reduction
@@ -860,23 +871,23 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
     if (grid > 4096) grid = 4096;
     const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
-    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, frame, label, plane_depth, T, replicas,
+    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
                        ticket, sums29, mb, seq, dbg);
 }
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, SurfelSoA frame,
-                  const int32_t* label, Rt pose, float zmin, float zmax, long long id_offset,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+                  Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S) {
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
-    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, frame, label,
+    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
                        pose, zmin, zmax, id_offset, best, matched);
 }
 void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
                           int capacity, int rank, int nranks, float tile, Counters* cnt) {
     ScopedKernel sk("update_insert", st);
-    hipLaunchKernelGGL(k_update_insert, dim3((S + 255) / 256 + 1), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
+    hipLaunchKernelGGL(k_update_insert, dim3(2 * ((S + 255) / 256)), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
                        n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
@@ -894,7 +905,8 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, 
       hipLaunchKernelGGL(k_classify, dim3(nb_vis + nb_oov), dim3(256), 0, st, cam, vis_src, oov, pose, plane_depth, stamp, delta_t,
                          conf_thresh, zmin, zmax, state_vis, state_oov, bc_vis, bc_oov, oov_stride, cnt, nb_vis); }
     { ScopedKernel sk("scan_blocks", st);
-      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq); }
+      if (nb_vis <= 1024) hipLaunchKernelGGL(k_scan_blocks<4>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
+      else hipLaunchKernelGGL(k_scan_blocks<16>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq); }
     { ScopedKernel sk("reorder_move", st);
       hipLaunchKernelGGL(k_move_rows, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov, bc_vis,
                          bc_oov, cnt, nb_vis); }
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(256) void k_scan_probe(Counters* cnt, Mailbox* mb, 
 void launch_scan_probe(hipStream_t st, uint32_t* bc_vis, int nb_vis, uint32_t* bc_oov, int oov_stride, int nb_oov, Counters* cnt,
                        Mailbox* mb, unsigned long long seq, int mode) {
     if (mode < 2) hipLaunchKernelGGL(k_scan_probe, dim3(1), dim3(256), 0, st, cnt, mb, seq, mode);
-    else hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
+    else hipLaunchKernelGGL(k_scan_blocks<4>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
                         int set_span) {
