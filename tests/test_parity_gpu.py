@@ -275,3 +275,71 @@ def test_process_sequence_equals_frame_by_frame(oracle_lib, product_lib):
     for a, b in zip(want, got):
         util.same_result(a, b)
     util.compare_state(fo, fh)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(cell_size=8), dict(cell_size=32), dict(cell_size=12), dict(cell_size=20),
+    dict(nb_samples=8), dict(nb_samples=32), dict(nb_samples=5),
+    dict(seg_iter=3), dict(seg_iter=1), dict(seg_iter=2, filter_iter=0), dict(filter_iter=7),
+    dict(cell_size=8, nb_samples=4, seg_iter=5),
+], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()))
+def test_segmentation_parameter_space(kw, oracle_lib, product_lib):
+    """Cell sizes that change the LDS cell window (8: many cells per tile, 32: one, 12 / 20: not powers of two, image
+    not a multiple of the cell), sample counts beyond the LDS table (32) and odd ones, odd / minimal iteration
+    counts: the fallbacks (global slow paths, plane filter in global memory) must equal the oracle too."""
+    W, H = 320, 240
+    cfg = dict(nb_supersurfels_max=40000); cfg.update(kw)
+    fo, fh = pair(oracle_lib, product_lib, W, H, **cfg)
+    for k in range(3):
+        rgb, depth = util.frame(k, W, H, noise=True, holes=0.03)
+        util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+        util.compare_state(fo, fh)
+
+
+def test_segmentation_parameter_space_batched(oracle_lib, product_lib):
+    """The same fallbacks through the batched / pipelined extract (cell 8 at 150x100: partial cells and tiles)."""
+    W, H, nf = 150, 100, 7
+    kw = dict(cell_size=8, nb_samples=32, seg_iter=3, nb_supersurfels_max=20000)
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, **kw))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=1, extract_batch=3, **kw))
+    frames = [util.frame(k, W, H, noise=True, holes=0.05) for k in range(nf)]
+    want = [fo.process_frame(*fr) for fr in frames]
+    keep = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in keep], [d.ctypes.data for _, d in keep], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(lambda_pos=0.01, lambda_size=0.0, lambda_bound=0.0),          # superpixels free to drift far from their cells
+    dict(lambda_pos=0.01, lambda_size=0.0, lambda_bound=0.0, cell_size=8),
+    dict(lambda_disp=0.0), dict(thresh_disp=1e-7), dict(thresh_disp=1.0),
+    dict(filter_alpha=10.0, filter_beta=0.01, filter_threshold=1.0),
+    dict(range_min=1.5, range_max=2.5),
+], ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()))
+def test_energy_parameter_space(kw, oracle_lib, product_lib):
+    """Energy weights that let superpixels wander out of the LDS cell window of their tile (exact global slow
+    paths), disparity thresholds at both extremes, a strong plane filter and a narrow depth range."""
+    W, H = 320, 240
+    cfg = dict(nb_supersurfels_max=40000); cfg.update(kw)
+    fo, fh = pair(oracle_lib, product_lib, W, H, **cfg)
+    for k in range(3):
+        rgb, depth = util.frame(k, W, H, noise=True, holes=0.03)
+        util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+        util.compare_state(fo, fh)
+
+
+@pytest.mark.parametrize("kw", [dict(icp_iter=1), dict(icp_iter=3), dict(icp_iter=0), dict(icp_cov_thresh=1e-9),
+                                dict(icp_force_iters=1, icp_iter=6), dict(delta_t=1, conf_thresh=1e9)],
+                         ids=lambda kw: ",".join("%s=%s" % kv for kv in kw.items()))
+def test_tracking_parameter_space(kw, oracle_lib, product_lib):
+    """Iteration caps (0 = no ICP at all), an unreachable covariance threshold (ICP always rejected), forced
+    iterations, immediate culling: 640x480 so that ICP has enough pairs to be valid where it can be."""
+    W, H = 640, 480
+    cfg = dict(nb_supersurfels_max=60000); cfg.update(kw)
+    fo, fh = pair(oracle_lib, product_lib, W, H, **cfg)
+    for k in range(4):
+        rgb, depth = util.frame(k, W, H, noise=True)
+        util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+    util.compare_state(fo, fh)
