@@ -343,3 +343,30 @@ def test_tracking_parameter_space(kw, oracle_lib, product_lib):
         rgb, depth = util.frame(k, W, H, noise=True)
         util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
     util.compare_state(fo, fh)
+
+
+@pytest.mark.parametrize("size", [(48, 32), (33, 17), (16, 16), (641, 479), (96, 250)])
+def test_odd_image_sizes(size, oracle_lib, product_lib):
+    """Images smaller than a relabelling tile, not multiples of the cell or of the tile, taller than wide."""
+    W, H = size
+    fo, fh = pair(oracle_lib, product_lib, W, H, nb_supersurfels_max=30000)
+    for k in range(3):
+        rgb, depth = util.frame(k, W, H, noise=True, holes=0.05)
+        util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+        util.compare_state(fo, fh)
+
+
+def test_hostile_depth_values(oracle_lib, product_lib):
+    """NaN, +-inf, negative, denormal and huge depths, saturated and zero colours: nothing may diverge from the oracle."""
+    W, H = 160, 128
+    fo, fh = pair(oracle_lib, product_lib, W, H, nb_supersurfels_max=8192)
+    rng = np.random.default_rng(7)
+    for k in range(3):
+        rgb, depth = util.frame(k, W, H, noise=True)
+        depth = depth.copy(); rgb = rgb.copy()
+        m = rng.random(depth.shape)
+        depth[m < 0.03] = np.nan; depth[(m >= 0.03) & (m < 0.06)] = np.inf; depth[(m >= 0.06) & (m < 0.08)] = -np.inf
+        depth[(m >= 0.08) & (m < 0.11)] = -1.5; depth[(m >= 0.11) & (m < 0.13)] = 1e-42; depth[(m >= 0.13) & (m < 0.15)] = 3e38
+        rgb[(m > 0.9)] = 255; rgb[(m > 0.8) & (m <= 0.9)] = 0
+        util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+        util.compare_state(fo, fh)
