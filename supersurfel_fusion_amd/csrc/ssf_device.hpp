@@ -183,11 +183,14 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S);
+struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
 // update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
 // (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)
 void launch_update_insert(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
-                          int capacity, int rank, int nranks, float tile, Counters* cnt);
+                          int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
+                          int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
+                          uint8_t* state_oov, uint32_t* bc_oov);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // Model store: the visible rows are a dense array (two of them, ping-pong); the out-of-view
@@ -196,7 +199,6 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 //   inserted this frame; 0 = classified visible, 1 = out of view, 2 = removed)
 // then only moves A0/B0/C0 into the other visible array, pushes A1 in front of the out-of-view span, appends C1
 // behind it and clears the live flag of B0/B2: the (large) B1 block is never touched.
-struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };
 // classify (filterModel) every visible row incl. this frame's insertions and every live out-of-view row, scan the
 // per-block class histograms (publishes the frame's counters) and move the rows; nv_upper / span_upper = host
 // upper bounds of the visible rows (incl. insertions) and of the out-of-view span

@@ -748,15 +748,18 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     SurfelSoA& M = h->model[h->mcur];
     const unsigned long long seq = ++h->cnt_seq;
     if (nmodel_g > 0) {
-        launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
-                             nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt);
-        // out-of-view store upkeep before the frame's moves: room in front for the rows that leave the view (at most
-        // all visible rows), room behind for out-of-view insertions, and not too many dead slots in the span
+        // out-of-view store upkeep before the frame's launches: room in front for the rows that leave the view (at
+        // most all visible rows), room behind for out-of-view insertions, and not too many dead slots in the span
         {
             const int span = h->oov_tail - h->oov_head;
             if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < h->S + 256 ||
                 span > h->oov_live + h->oov_live / 4 + 65536) { int rc2 = oov_recentre(h); if (rc2) return rc2; }
         }
+        // update | insert | classification of the out-of-view rows (independent of the other two), one launch
+        launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
+                             nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
+                             h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
+                             h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state_oov, h->d_bc_oov);
         // classify | scan (publishes the counters) | move: the host continues once the counters arrive,
         // the row moves of this frame overlap the host-side launch work of the next one (stream order keeps
         // every later reader of the model behind them)

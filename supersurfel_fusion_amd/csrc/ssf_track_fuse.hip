@@ -312,6 +312,47 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
     }
 }
 
+// ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
+// filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
+__device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
+                                            const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
+                                            float zmin, float zmax) {
+    const float conf = M.conf[idx];
+    const int time_diff = stamp - M.stamps[2 * idx + 1];
+    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) { M.conf[idx] = -1.0f; return 2; }
+    const M3 Rv = m3_transpose(pose.R);
+    const V3 tv = negate(m3_mulv(Rv, pose.t));
+    const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
+    if (p.z > zmin && p.z < zmax) {
+        const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
+        if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
+            const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
+            if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; return 2; }
+            return 0;
+        }
+    }
+    return 1;
+}
+// 256 slots of the out-of-view span (class B, 3-bin histogram; dead slots are skipped).  These rows are touched by
+// neither the update nor the insertion of the frame, so their blocks ride along in the update/insert launch (whose
+// duration is set by the long serial chain of the updated rows) instead of lengthening the classify launch.
+__device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStore& O, const Rt& pose, const float* __restrict__ plane_depth,
+                                                   int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
+                                                   uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, int oov_stride,
+                                                   const Counters* __restrict__ cnt, int ob, int (*hist)[6]) {
+    const int wv = threadIdx.x >> 6;
+    int cls = 7;
+    const long long phys = (long long)cnt->oov_head + (long long)ob * blockDim.x + threadIdx.x;
+    if (phys < cnt->oov_tail && O.live[phys]) {
+        cls = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+        state_oov[phys] = (uint8_t)cls;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+    __syncthreads();
+    // three planes (B0 | B1 | B2) of oov_stride counters each: the scan reads four blocks per lane as one uint4
+    if (threadIdx.x < 3) bc_oov[(size_t)threadIdx.x * oov_stride + ob] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+}
 // ---- update ----------------------------------------------------------------------------------------
 __device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                            int n_visible, const unsigned long long* __restrict__ best,
@@ -425,14 +466,21 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
     }
     if (chunk == nchunks - 1 && threadIdx.x == 0) cnt->n_inserted = min(base_total + before + total, capacity) - base_total;
 }
-// update (blocks 0 .. nchunks-1, one frame supersurfel per thread) | insert (blocks nchunks .. 2 nchunks-1, one chunk each)
+struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
+// update (blocks 0 .. nchunks-1, one frame supersurfel per thread) | insert (blocks nchunks .. 2 nchunks-1, one chunk
+// each) | classification of the out-of-view rows (the remaining blocks)
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, int S, int do_update, int capacity,
-                                                       int rank, int nranks, float tile, Counters* cnt) {
+                                                       int rank, int nranks, float tile, Counters* cnt, int nchunks, OovStore O,
+                                                       ClassifyArgs ca, uint8_t* __restrict__ state_oov,
+                                                       uint32_t* __restrict__ bc_oov, int oov_stride) {
     __shared__ int wave_tot[16];
-    const int nchunks = gridDim.x / 2;
-    if ((int)blockIdx.x >= nchunks)
+    __shared__ int hist[4][6];
+    if ((int)blockIdx.x >= 2 * nchunks)
+        classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
+                           oov_stride, cnt, blockIdx.x - 2 * nchunks, hist);
+    else if ((int)blockIdx.x >= nchunks)
         insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, blockIdx.x - nchunks, nchunks);
     else if (do_update) update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, blockIdx.x * blockDim.x + threadIdx.x);
 }
@@ -465,38 +513,16 @@ __global__ __launch_bounds__(1024) void k_first_frame(SurfelSoA M, SurfelSoA F, 
 }
 
 // ---- classify + stable partition over the model store (see OovStore in ssf_device.hpp) ---------------------------
-// filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
-__device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
-                                            const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
-                                            float zmin, float zmax) {
-    const float conf = M.conf[idx];
-    const int time_diff = stamp - M.stamps[2 * idx + 1];
-    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) { M.conf[idx] = -1.0f; return 2; }
-    const M3 Rv = m3_transpose(pose.R);
-    const V3 tv = negate(m3_mulv(Rv, pose.t));
-    const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
-    if (p.z > zmin && p.z < zmax) {
-        const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
-        if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
-            const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
-            if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; return 2; }
-            return 0;
-        }
-    }
-    return 1;
-}
-// blocks [0, nb_vis): 256 rows of the visible array each (old visible rows = class A, this frame's insertions =
-// class C; 6-bin histogram A0 A1 A2 C0 C1 C2); blocks [nb_vis, ..): 256 slots of the out-of-view span (class B,
-// 3-bin histogram; dead slots are skipped)
-__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, OovStore O, Rt pose, const float* __restrict__ plane_depth,
+// 256 rows of the visible array per block (old visible rows = class A, this frame's insertions = class C; 6-bin
+// histogram A0 A1 A2 C0 C1 C2)
+__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, Rt pose, const float* __restrict__ plane_depth,
                                                   int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
-                                                  uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
-                                                  uint32_t* __restrict__ bc_vis, uint32_t* __restrict__ bc_oov, int oov_stride,
-                                                  const Counters* __restrict__ cnt, int nb_vis) {
+                                                  uint8_t* __restrict__ state_vis, uint32_t* __restrict__ bc_vis,
+                                                  const Counters* __restrict__ cnt) {
     __shared__ int hist[4][6];
     const int wv = threadIdx.x >> 6;
     int cls = 7;                                   // 7 = no row
-    if ((int)blockIdx.x < nb_vis) {
+    {
         const int nv = cnt->n_visible, n_rows = nv + cnt->n_inserted;
         const int idx = blockIdx.x * blockDim.x + threadIdx.x;
         if (idx < n_rows) {
@@ -508,19 +534,6 @@ __global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, OovStore
         for (int c = 0; c < 6; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
         __syncthreads();
         if (threadIdx.x < 6) bc_vis[6 * blockIdx.x + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
-    } else {
-        const int ob = blockIdx.x - nb_vis;
-        const long long phys = (long long)cnt->oov_head + (long long)ob * blockDim.x + threadIdx.x;
-        if (phys < cnt->oov_tail && O.live[phys]) {
-            const int st = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
-            state_oov[phys] = (uint8_t)st;
-            cls = st;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
-        __syncthreads();
-        // three planes (B0 | B1 | B2) of oov_stride counters each: the scan reads four blocks per lane as one uint4
-        if (threadIdx.x < 3) bc_oov[(size_t)threadIdx.x * oov_stride + ob] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
     }
 }
 
@@ -883,12 +896,18 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
                        pose, zmin, zmax, id_offset, best, matched);
 }
+static inline int oov_plane_stride(const OovStore& oov) { return ((oov.cap + 255) / 256 + 4) & ~3; }   // counters per plane, multiple of 4 (uint4 access)
 void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
-                          int capacity, int rank, int nranks, float tile, Counters* cnt) {
+                          int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
+                          int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
+                          uint8_t* state_oov, uint32_t* bc_oov) {
     ScopedKernel sk("update_insert", st);
-    hipLaunchKernelGGL(k_update_insert, dim3(2 * ((S + 255) / 256)), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
-                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt);
+    const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256;
+    ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
+    hipLaunchKernelGGL(k_update_insert, dim3(2 * nchunks + nb_oov), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
+                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, oov, ca, state_oov, bc_oov,
+                       oov_plane_stride(oov));
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {
@@ -900,10 +919,11 @@ void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, 
                              float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
                              uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
-    const int oov_stride = ((oov.cap + 255) / 256 + 4) & ~3;          // counters per plane, multiple of 4 (uint4 access)
+    const int oov_stride = oov_plane_stride(oov);
+    // (the out-of-view rows were classified inside the update/insert launch)
     { ScopedKernel sk("classify", st);
-      hipLaunchKernelGGL(k_classify, dim3(nb_vis + nb_oov), dim3(256), 0, st, cam, vis_src, oov, pose, plane_depth, stamp, delta_t,
-                         conf_thresh, zmin, zmax, state_vis, state_oov, bc_vis, bc_oov, oov_stride, cnt, nb_vis); }
+      hipLaunchKernelGGL(k_classify, dim3(nb_vis), dim3(256), 0, st, cam, vis_src, pose, plane_depth, stamp, delta_t,
+                         conf_thresh, zmin, zmax, state_vis, bc_vis, cnt); }
     { ScopedKernel sk("scan_blocks", st);
       if (nb_vis <= 1024) hipLaunchKernelGGL(k_scan_blocks<4>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
       else hipLaunchKernelGGL(k_scan_blocks<16>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq); }
