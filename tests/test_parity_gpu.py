@@ -370,3 +370,25 @@ def test_hostile_depth_values(oracle_lib, product_lib):
         rgb[(m > 0.9)] = 255; rgb[(m > 0.8) & (m <= 0.9)] = 0
         util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
         util.compare_state(fo, fh)
+
+
+def test_soak_600_frames_pipelined(oracle_lib, product_lib):
+    """600 frames of a back-and-forth sweep through the pipelined / batched path (3 extract contexts, 4 frames per
+    launch chain, partial batches at the end): every per-frame result and the final map equal the oracle.  Races
+    between the extract streams and the track chain, or in the model-store upkeep, would show up here."""
+    W, H, nf = 160, 128, 600
+    kw = dict(nb_supersurfels_max=3000, delta_t=15)
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, **kw))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=2, extract_batch=4, **kw))
+    base = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(0, 41, 2)]
+    seq = (base + base[-2:0:-1]) * 15
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in seq[:nf]]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False)
+    assert len(got) == nf
+    for i, (a, b) in enumerate(zip(want, got)):
+        for key in util.RESULT_KEYS:
+            assert a[key] == b[key], (i, key, a[key], b[key])
+        util.assert_same_bits(a["pose"], b["pose"], "pose of frame %d" % i)
+    util.compare_state(fo, fh)
+    assert want[-1]["n_model"] > 100
