@@ -5,8 +5,8 @@
 //   per-frame working set ("slab", one per frame of an extract batch, see batch_slot):
 //     per-pixel maps   rgba u32[P] | disp f32[P] | label i32[P] (ONE map, relabelled in place)
 //                      inlier u8[P] | plane_depth f32[P]
-//     superpixel sums  two sets (double buffer) of 9 x i32[S] (x,y,r,g,b,n,dx,dy,dn) + 6 x i64[S]
-//                      (dxx,dyy,dxy | dxd,dyd,dd fixed point 2^30): exact integers, integer atomics only
+//     superpixel sums  two sets (double buffer) of SumRec[S]: 9 x i32 (x,y,r,g,b,n,dx,dy,dn) + 6 x i64
+//                      (dxx,dyy,dxy | dxd,dyd,dd fixed point 2^30) per 128-byte record: exact integers, integer atomics only
 //     pass logs        3 x (int4 + f32) x 256 entries per relabelling tile + per-tile counts
 //     superpixel table SpRow[S] (48 B rows, 16 B aligned), RANSAC samples, moments, filter scratch
 //     frame supersurfels + association tables (best u64[S], matched u8[S]) + input staging
@@ -30,10 +30,13 @@ struct SurfelSoA {
     float *r0, *r1, *r2, *shape, *dims, *conf;
 };
 
-struct SpSums {
-    int32_t *sx, *sy, *sr, *sg, *sb, *n, *dx, *dy, *dn;
-    long long *dxx, *dyy, *dxy, *dxd, *dyd, *dd;
+// exact sums of one superpixel: one 128-byte record (two cache lines: the nine int32 sums, the six int64 sums), so
+// that a workgroup building the rows of its cell window touches 2 lines per superpixel instead of 15
+struct alignas(64) SumRec {
+    int32_t sx, sy, sr, sg, sb, n, dx, dy, dn; int32_t pad0[7];
+    long long dxx, dyy, dxy, dxd, dyd, dd; long long pad1[2];
 };
+struct SpSums { SumRec* r; };
 
 // device-side counters shared by the fuse kernels (no host round trip between them)
 struct Counters {
@@ -99,13 +102,7 @@ struct FrameMaps {
 template <typename T> SSF_HD T* slab_shift(T* p, size_t off) {
     return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
 }
-SSF_HD SpSums batch_slot(SpSums s, size_t o) {
-    s.sx = slab_shift(s.sx, o); s.sy = slab_shift(s.sy, o); s.sr = slab_shift(s.sr, o); s.sg = slab_shift(s.sg, o);
-    s.sb = slab_shift(s.sb, o); s.n = slab_shift(s.n, o); s.dx = slab_shift(s.dx, o); s.dy = slab_shift(s.dy, o);
-    s.dn = slab_shift(s.dn, o); s.dxx = slab_shift(s.dxx, o); s.dyy = slab_shift(s.dyy, o); s.dxy = slab_shift(s.dxy, o);
-    s.dxd = slab_shift(s.dxd, o); s.dyd = slab_shift(s.dyd, o); s.dd = slab_shift(s.dd, o);
-    return s;
-}
+SSF_HD SpSums batch_slot(SpSums s, size_t o) { s.r = slab_shift(s.r, o); return s; }
 SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     const size_t o = (size_t)b * m.slab;
     m.rgba = slab_shift(m.rgba, o); m.disp = slab_shift(m.disp, o); m.label = slab_shift(m.label, o);

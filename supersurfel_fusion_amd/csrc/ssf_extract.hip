@@ -86,9 +86,9 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
         for (int j = 0; j < 6; j++) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
         for (int b = 0; b < 2; b++) {
             SpSums& s = m.sums[b];
-            s.sx[cell] = t[0]; s.sy[cell] = t[1]; s.sr[cell] = t[2]; s.sg[cell] = t[3]; s.sb[cell] = t[4]; s.n[cell] = t[5];
-            s.dx[cell] = 0; s.dy[cell] = 0; s.dn[cell] = 0;
-            s.dxx[cell] = 0; s.dyy[cell] = 0; s.dxy[cell] = 0; s.dxd[cell] = 0; s.dyd[cell] = 0; s.dd[cell] = 0;
+            s.r[cell].sx = t[0]; s.r[cell].sy = t[1]; s.r[cell].sr = t[2]; s.r[cell].sg = t[3]; s.r[cell].sb = t[4]; s.r[cell].n = t[5];
+            s.r[cell].dx = 0; s.r[cell].dy = 0; s.r[cell].dn = 0;
+            s.r[cell].dxx = 0; s.r[cell].dyy = 0; s.r[cell].dxy = 0; s.r[cell].dxd = 0; s.r[cell].dyd = 0; s.r[cell].dd = 0;
         }
         SpRow z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         m.sp[cell] = z;
@@ -100,16 +100,22 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
 // merge leaves untouched.
 __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with_planes, SpRow prev) {
     SpRow row = prev;
-    const float n = (float)s.n[k];
-    row.cx = (float)s.sx[k] / n; row.cy = (float)s.sy[k] / n;
-    row.r = (float)s.sr[k] / n; row.g = (float)s.sg[k] / n; row.b = (float)s.sb[k] / n;
+    // the record is read as whole 16-byte pieces (two cache lines per superpixel)
+    const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
+    const int4 i0 = rec[0], i1 = rec[1];             // sx sy sr sg | sb n dx dy
+    const float n = (float)i1.y;
+    row.cx = (float)i0.x / n; row.cy = (float)i0.y / n;
+    row.r = (float)i0.z / n; row.g = (float)i0.w / n; row.b = (float)i1.x / n;
     row.size = n;
     if (with_planes) {
+        const int dn_i = s.r[k].dn;
+        const longlong2* __restrict__ q = reinterpret_cast<const longlong2*>(&s.r[k].dxx);
+        const longlong2 q0 = q[0], q1 = q[1], q2 = q[2];   // dxx dyy | dxy dxd | dyd dd
         const double inv = 1.0 / SSF_DISP_SCALE;
-        const float dx = (float)s.dx[k], dy = (float)s.dy[k], dn = (float)s.dn[k];
-        const float dxx = (float)s.dxx[k], dyy = (float)s.dyy[k], dxy = (float)s.dxy[k];
-        const float dxd = (float)((double)s.dxd[k] * inv), dyd = (float)((double)s.dyd[k] * inv);
-        const float dd = (float)((double)s.dd[k] * inv);
+        const float dx = (float)i1.z, dy = (float)i1.w, dn = (float)dn_i;
+        const float dxx = (float)q0.x, dyy = (float)q0.y, dxy = (float)q1.x;
+        const float dxd = (float)((double)q1.y * inv), dyd = (float)((double)q2.x * inv);
+        const float dd = (float)((double)q2.y * inv);
         float ta, tb, tc;
         if (!plane_solve(ta, tb, tc, dxx, dxy, dx, dxd, dxy, dyy, dy, dyd, dx, dy, dn, dd)) {
             ta = 0.f; tb = 0.f; tc = __uint_as_float(0xFFE00000u);
@@ -168,20 +174,20 @@ __device__ __forceinline__ void lds_add_i64(unsigned long long* p, long long v) 
 
 // the 9 inlier-only disparity sums of one pixel moved by `sign`
 __device__ __forceinline__ void disp_sums_add(const SpSums& s, int k, int x, int y, float d, int sign) {
-    atomicAdd(&s.dx[k], sign * x); atomicAdd(&s.dy[k], sign * y); atomicAdd(&s.dn[k], sign);
-    atomic_add_i64(&s.dxx[k], (long long)sign * x * x);
-    atomic_add_i64(&s.dyy[k], (long long)sign * y * y);
-    atomic_add_i64(&s.dxy[k], (long long)sign * x * y);
-    atomic_add_i64(&s.dxd[k], sign * fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM));
-    atomic_add_i64(&s.dyd[k], sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
-    atomic_add_i64(&s.dd[k], sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
+    atomicAdd(&s.r[k].dx, sign * x); atomicAdd(&s.r[k].dy, sign * y); atomicAdd(&s.r[k].dn, sign);
+    atomic_add_i64(&s.r[k].dxx, (long long)sign * x * x);
+    atomic_add_i64(&s.r[k].dyy, (long long)sign * y * y);
+    atomic_add_i64(&s.r[k].dxy, (long long)sign * x * y);
+    atomic_add_i64(&s.r[k].dxd, sign * fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    atomic_add_i64(&s.r[k].dyd, sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
+    atomic_add_i64(&s.r[k].dd, sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
 }
 // the six colour/position sums of one pixel moved from superpixel a to b
 __device__ __forceinline__ void rgb_sums_move(const SpSums& s, int a, int b, int x, int y, int ir, int ig, int ib) {
-    atomicAdd(&s.sx[a], -x); atomicAdd(&s.sy[a], -y); atomicAdd(&s.sr[a], -ir);
-    atomicAdd(&s.sg[a], -ig); atomicAdd(&s.sb[a], -ib); atomicAdd(&s.n[a], -1);
-    atomicAdd(&s.sx[b], x); atomicAdd(&s.sy[b], y); atomicAdd(&s.sr[b], ir);
-    atomicAdd(&s.sg[b], ig); atomicAdd(&s.sb[b], ib); atomicAdd(&s.n[b], 1);
+    atomicAdd(&s.r[a].sx, -x); atomicAdd(&s.r[a].sy, -y); atomicAdd(&s.r[a].sr, -ir);
+    atomicAdd(&s.r[a].sg, -ig); atomicAdd(&s.r[a].sb, -ib); atomicAdd(&s.r[a].n, -1);
+    atomicAdd(&s.r[b].sx, x); atomicAdd(&s.r[b].sy, y); atomicAdd(&s.r[b].sr, ir);
+    atomicAdd(&s.r[b].sg, ig); atomicAdd(&s.r[b].sb, ib); atomicAdd(&s.r[b].n, 1);
 }
 // all sum updates of one relabelled pixel (flags as in PassLog)
 __device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int to, int x, int y, uint32_t rgbf, float d) {
@@ -208,21 +214,21 @@ __device__ __forceinline__ void lds_disp(unsigned long long* a, int sign, int x,
 }
 __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, long long v) {
     switch (field) {
-        case F_SX: atomicAdd(&s.sx[l], (int)v); break;
-        case F_SY: atomicAdd(&s.sy[l], (int)v); break;
-        case F_SR: atomicAdd(&s.sr[l], (int)v); break;
-        case F_SG: atomicAdd(&s.sg[l], (int)v); break;
-        case F_SB: atomicAdd(&s.sb[l], (int)v); break;
-        case F_N: atomicAdd(&s.n[l], (int)v); break;
-        case F_DX: atomicAdd(&s.dx[l], (int)v); break;
-        case F_DY: atomicAdd(&s.dy[l], (int)v); break;
-        case F_DN: atomicAdd(&s.dn[l], (int)v); break;
-        case F_DXX: atomic_add_i64(&s.dxx[l], v); break;
-        case F_DYY: atomic_add_i64(&s.dyy[l], v); break;
-        case F_DXY: atomic_add_i64(&s.dxy[l], v); break;
-        case F_DXD: atomic_add_i64(&s.dxd[l], v); break;
-        case F_DYD: atomic_add_i64(&s.dyd[l], v); break;
-        default: atomic_add_i64(&s.dd[l], v); break;
+        case F_SX: atomicAdd(&s.r[l].sx, (int)v); break;
+        case F_SY: atomicAdd(&s.r[l].sy, (int)v); break;
+        case F_SR: atomicAdd(&s.r[l].sr, (int)v); break;
+        case F_SG: atomicAdd(&s.r[l].sg, (int)v); break;
+        case F_SB: atomicAdd(&s.r[l].sb, (int)v); break;
+        case F_N: atomicAdd(&s.r[l].n, (int)v); break;
+        case F_DX: atomicAdd(&s.r[l].dx, (int)v); break;
+        case F_DY: atomicAdd(&s.r[l].dy, (int)v); break;
+        case F_DN: atomicAdd(&s.r[l].dn, (int)v); break;
+        case F_DXX: atomic_add_i64(&s.r[l].dxx, v); break;
+        case F_DYY: atomic_add_i64(&s.r[l].dyy, v); break;
+        case F_DXY: atomic_add_i64(&s.r[l].dxy, v); break;
+        case F_DXD: atomic_add_i64(&s.r[l].dxd, v); break;
+        case F_DYD: atomic_add_i64(&s.r[l].dyd, v); break;
+        default: atomic_add_i64(&s.r[l].dd, v); break;
     }
 }
 
@@ -331,10 +337,10 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
             if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
             if (wf < 0 || wt < 0) {
                 const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
-                if (wf < 0) { atomicAdd(&sw.sx[from], -px_x); atomicAdd(&sw.sy[from], -px_y); atomicAdd(&sw.sr[from], -ir);
-                              atomicAdd(&sw.sg[from], -ig); atomicAdd(&sw.sb[from], -ib); atomicAdd(&sw.n[from], -1); }
-                if (wt < 0) { atomicAdd(&sw.sx[to], px_x); atomicAdd(&sw.sy[to], px_y); atomicAdd(&sw.sr[to], ir);
-                              atomicAdd(&sw.sg[to], ig); atomicAdd(&sw.sb[to], ib); atomicAdd(&sw.n[to], 1); }
+                if (wf < 0) { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
+                              atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
+                if (wt < 0) { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
+                              atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
             }
         }
         if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
@@ -459,8 +465,8 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
         const int32_t* __restrict__ label = m.label;
         // centroid = mergeTPSRGBCoeffs of this superpixel, straight from the exact sums
         const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
-        const float nn = (float)sm.n[index];
-        const float cx = (float)sm.sx[index] / nn, cy = (float)sm.sy[index] / nn;
+        const float nn = (float)sm.r[index].n;
+        const float cx = (float)sm.r[index].sx / nn, cy = (float)sm.r[index].sy / nn;
         float x = cx, y = cy;
         int i = label[tex_index(x, y, p.W, p.H)];
         int k = 0;
@@ -644,15 +650,15 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
         for (int b = 0; b < 2; b++) {
             const SpSums s = b ? m.sums[1] : m.sums[0];
             switch (j) {
-                case 0: atomicAdd(&s.dx[l], (int)v); break;
-                case 1: atomicAdd(&s.dy[l], (int)v); break;
-                case 2: atomicAdd(&s.dn[l], (int)v); break;
-                case 3: atomic_add_i64(&s.dxx[l], v); break;
-                case 4: atomic_add_i64(&s.dyy[l], v); break;
-                case 5: atomic_add_i64(&s.dxy[l], v); break;
-                case 6: atomic_add_i64(&s.dxd[l], v); break;
-                case 7: atomic_add_i64(&s.dyd[l], v); break;
-                default: atomic_add_i64(&s.dd[l], v); break;
+                case 0: atomicAdd(&s.r[l].dx, (int)v); break;
+                case 1: atomicAdd(&s.r[l].dy, (int)v); break;
+                case 2: atomicAdd(&s.r[l].dn, (int)v); break;
+                case 3: atomic_add_i64(&s.r[l].dxx, v); break;
+                case 4: atomic_add_i64(&s.r[l].dyy, v); break;
+                case 5: atomic_add_i64(&s.r[l].dxy, v); break;
+                case 6: atomic_add_i64(&s.r[l].dxd, v); break;
+                case 7: atomic_add_i64(&s.r[l].dyd, v); break;
+                default: atomic_add_i64(&s.r[l].dd, v); break;
             }
         }
     }

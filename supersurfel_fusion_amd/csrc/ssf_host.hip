@@ -1007,11 +1007,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         FrameMaps& m = c.maps;
         take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
         take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1); take(m.pix2, P); take(m.fpack, 4 * S);
-        for (int b = 0; b < 2; b++) {
-            SpSums& q = m.sums[b];
-            take(q.sx, S); take(q.sy, S); take(q.sr, S); take(q.sg, S); take(q.sb, S); take(q.n, S); take(q.dx, S); take(q.dy, S);
-            take(q.dn, S); take(q.dxx, S); take(q.dyy, S); take(q.dxy, S); take(q.dxd, S); take(q.dyd, S); take(q.dd, S);
-        }
+        for (int b = 0; b < 2; b++) take(m.sums[b].r, S);
         for (int b = 0; b < 3; b++) { take(m.log.ent[b], NT * 256); take(m.log.disp[b], NT * 256); take(m.log.count[b], NT); }
         SurfelSoA& f = c.frame;
         take(f.pos, 3 * S); take(f.col, 3 * S); take(f.lab, 3 * S); take(f.stamps, 2 * S); take(f.r0, 3 * S); take(f.r1, 3 * S);
