@@ -75,21 +75,25 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
         m.inlier[q] = 0;
         sx += x; sy += y; sr += (int)r; sg += (int)g; sb += (int)b; n += 1;
     }
-    __shared__ int red[4][6];
-    sx = wave_sum_i32(sx); sy = wave_sum_i32(sy); sr = wave_sum_i32(sr);
-    sg = wave_sum_i32(sg); sb = wave_sum_i32(sb); n = wave_sum_i32(n);
-    const int wv = threadIdx.x >> 6;
-    if (lane_id() == 0) { red[wv][0] = sx; red[wv][1] = sy; red[wv][2] = sr; red[wv][3] = sg; red[wv][4] = sb; red[wv][5] = n; }
+    // block sums through replicated LDS counters (lane & 15): 6 integer ds_add per thread instead of 36 cross-lane
+    // shuffles (which also go through the LDS pipe)
+    __shared__ int acc[16][8];
+    if (threadIdx.x < 128) acc[threadIdx.x >> 3][threadIdx.x & 7] = 0;
+    __syncthreads();
+    {
+        int* a = acc[lane_id() & 15];
+        atomicAdd(&a[0], sx); atomicAdd(&a[1], sy); atomicAdd(&a[2], sr); atomicAdd(&a[3], sg); atomicAdd(&a[4], sb); atomicAdd(&a[5], n);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int t[6];
-        for (int j = 0; j < 6; j++) t[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-        for (int b = 0; b < 2; b++) {
-            SpSums& s = m.sums[b];
-            s.r[cell].sx = t[0]; s.r[cell].sy = t[1]; s.r[cell].sr = t[2]; s.r[cell].sg = t[3]; s.r[cell].sb = t[4]; s.r[cell].n = t[5];
-            s.r[cell].dx = 0; s.r[cell].dy = 0; s.r[cell].dn = 0;
-            s.r[cell].dxx = 0; s.r[cell].dyy = 0; s.r[cell].dxy = 0; s.r[cell].dxd = 0; s.r[cell].dyd = 0; s.r[cell].dd = 0;
-        }
+        for (int j = 0; j < 6; j++) { int v = 0; for (int r = 0; r < 16; r++) v += acc[r][j]; t[j] = v; }
+        SumRec rec;                                  // whole-record stores (16-byte pieces), both buffers
+        rec.sx = t[0]; rec.sy = t[1]; rec.sr = t[2]; rec.sg = t[3]; rec.sb = t[4]; rec.n = t[5];
+        rec.dx = 0; rec.dy = 0; rec.dn = 0;
+        for (int j = 0; j < 7; j++) rec.pad0[j] = 0;
+        rec.dxx = 0; rec.dyy = 0; rec.dxy = 0; rec.dxd = 0; rec.dyd = 0; rec.dd = 0; rec.pad1[0] = 0; rec.pad1[1] = 0;
+        m.sums[0].r[cell] = rec; m.sums[1].r[cell] = rec;
         SpRow z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         m.sp[cell] = z;
     }
