@@ -24,34 +24,9 @@ namespace ssf {
 
 // ---- wave64 helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ void atomic_add_i64(long long* p, long long v) {
     atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
 }
-// Iterate over the distinct labels held by the active lanes of a wave.  `body(l, in_group)` is
-// executed by ALL lanes (uniform control flow) once per distinct label.
-template <typename F>
-__device__ __forceinline__ void for_each_label(int label, bool active, F body) {
-    unsigned long long remaining = __ballot(active);
-    while (remaining) {
-        const int leader = __ffsll((long long)remaining) - 1;
-        const int l = __shfl(label, leader, 64);
-        const bool in_group = active && (label == l);
-        const unsigned long long grp = __ballot(in_group);
-        body(l, in_group);
-        remaining &= ~grp;
-    }
-}
-
 // ---- ingest ------------------------------------------------------------------------------------
 // One workgroup per grid cell: RGB->RGBA, disparity = 1/depth, label = cell id, and the cell's
 // initial sums by an in-block reduction (depth2disp32F_kernel TPS_RGBD_kernels.cu:278-296,
@@ -186,21 +161,6 @@ __device__ __forceinline__ void disp_sums_add(const SpSums& s, int k, int x, int
     atomic_add_i64(&s.r[k].dyd, sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM));
     atomic_add_i64(&s.r[k].dd, sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM));
 }
-// the six colour/position sums of one pixel moved from superpixel a to b
-__device__ __forceinline__ void rgb_sums_move(const SpSums& s, int a, int b, int x, int y, int ir, int ig, int ib) {
-    atomicAdd(&s.r[a].sx, -x); atomicAdd(&s.r[a].sy, -y); atomicAdd(&s.r[a].sr, -ir);
-    atomicAdd(&s.r[a].sg, -ig); atomicAdd(&s.r[a].sb, -ib); atomicAdd(&s.r[a].n, -1);
-    atomicAdd(&s.r[b].sx, x); atomicAdd(&s.r[b].sy, y); atomicAdd(&s.r[b].sr, ir);
-    atomicAdd(&s.r[b].sg, ig); atomicAdd(&s.r[b].sb, ib); atomicAdd(&s.r[b].n, 1);
-}
-// all sum updates of one relabelled pixel (flags as in PassLog)
-__device__ __forceinline__ void apply_pixel_delta(const SpSums& s, int from, int to, int x, int y, uint32_t rgbf, float d) {
-    const unsigned flags = rgbf >> 24;
-    if (flags & 1u) rgb_sums_move(s, from, to, x, y, (int)(rgbf & 255u), (int)((rgbf >> 8) & 255u), (int)((rgbf >> 16) & 255u));
-    if (flags & 2u) disp_sums_add(s, to, x, y, d, +1);
-    if (flags & 4u) disp_sums_add(s, from, x, y, d, -1);
-}
-
 // Field order of the per-window-superpixel LDS accumulators of a pass (15 exact integer sums).
 enum { F_SX, F_SY, F_SR, F_SG, F_SB, F_N, F_DX, F_DY, F_DN, F_DXX, F_DYY, F_DXY, F_DXD, F_DYD, F_DD, F_COUNT };
 __device__ __forceinline__ void lds_rgb(unsigned long long* a, int sign, int x, int y, uint32_t rgbf) {
