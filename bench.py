@@ -340,7 +340,7 @@ def main():
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
                        "exchange": ("native RCCL on the track stream" if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
-                                      "ahead of ICP/fusion on its own HIP streams" % (world, depth + 1 if depth else 0)},
+                                      "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
             "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
