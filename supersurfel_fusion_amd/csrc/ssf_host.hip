@@ -325,6 +325,9 @@ struct ssf_handle {
     std::deque<std::pair<int, int>> pending;      // (context, slot) submitted, not yet processed (oldest first)
     ActiveFrame active; ActiveFrame* cc = &active; // the frame the track/fuse chain is working on (or last worked on)
     uint32_t extract_ordinal = 0;                 // frames submitted so far = RNG epoch of the next frame
+    // ssf_process_sequence: frames still to be submitted; do_fuse submits them between its launches and its wait for
+    // the counters (the ~40 us of host work of a batch launch hide behind the ~55 us fuse chain on the GPU)
+    const void* const* seq_rgb = nullptr; const void* const* seq_depth = nullptr; int seq_next = 0, seq_n = 0, seq_on_device = 0, stamp_bias = 0;
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
     ncclComm_t comm = nullptr; int* d_all5 = nullptr;
@@ -516,7 +519,7 @@ static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int
     ExtractCtx& c = h->ctx[h->open_ctx];
     if (c.launched) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
     const int b = c.count;
-    if (b == 0) { c.stamp0 = h->stamp + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal; }
+    if (b == 0) { c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal; }
     h->extract_ordinal++;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, off = (size_t)b * c.maps.slab;
     c.in.rgb[b] = (const uint8_t*)rgb; c.in.depth[b] = (const float*)depth;
@@ -776,6 +779,13 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     }
     HCK(hipGetLastError());
     { int rr = retire_active(h); if (rr) return rr; }     // last reader of this frame's buffers is enqueued
+    h->stamp_bias = 1;                                     // the frame being fused still holds h->stamp
+    while (h->seq_next < h->seq_n && !h->ctx[h->open_ctx].launched) {      // see seq_rgb
+        int rs = submit_extract(h, h->seq_rgb[h->seq_next], h->seq_depth[h->seq_next], h->seq_on_device, nullptr);
+        if (rs) { h->stamp_bias = 0; return rs; }
+        h->seq_next++;
+    }
+    h->stamp_bias = 0;
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
     if (rc) return rc;
     Counters c;
@@ -1106,19 +1116,19 @@ int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* o
 int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth, int n, int on_device, ssf_frame_result* out) {
     if (!h || !rgb || !depth || n < 0) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
-    int next = 0;
-    for (int k = 0; k < n; k++) {
-        while (next < n && !h->ctx[h->open_ctx].launched) {
-            if (!rgb[next] || !depth[next]) return SSF_ERR_INVALID_ARG;
-            int rc;
-            { TimerScope ts(h); rc = submit_extract(h, rgb[next], depth[next], on_device, nullptr); }
-            if (rc) return rc;
-            next++;
+    for (int i = 0; i < n; i++) if (!rgb[i] || !depth[i]) return SSF_ERR_INVALID_ARG;
+    h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device;
+    int rc = SSF_OK;
+    for (int k = 0; k < n && !rc; k++) {
+        while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
+            TimerScope ts(h);
+            rc = submit_extract(h, rgb[h->seq_next], depth[h->seq_next], on_device, nullptr);
+            if (!rc) h->seq_next++;
         }
-        int rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
-        if (rc) return rc;
+        if (!rc) rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
     }
-    return SSF_OK;
+    h->seq_rgb = nullptr; h->seq_depth = nullptr; h->seq_n = 0; h->seq_next = 0;
+    return rc;
 }
 int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
 int ssf_pipeline_capacity(const ssf_handle* h) { return h ? (int)h->ctx.size() * h->batch : 0; }
