@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     const M3 R = T.R; const V3 t = T.t;
     const int slot = lane() & (ICP_SLOTS - 1);
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
-        const V3 ps = add(m3_mulv(R, ld3(model.pos, id)), t);
+        // the whole model row (36 B, three coalesced streams) is requested up front: its lab / normal part would
+        // otherwise be a further dependent round trip after the two frame-side gathers
+        const V3 mpos = ld3(model.pos, id), mlab = ld3(model.lab, id), mnrm = ld3(model.r2, id);
+        const V3 ps = add(m3_mulv(R, mpos), t);
         if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull); continue; }
         const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
         const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
@@ -72,10 +75,10 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         const float zt = __uint_as_float(pl.y);
         const float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];   // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
         if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;
-        const float dist_color = len3(sub(ld3(model.lab, id), v3(f0.y, f0.z, f0.w)));
+        const float dist_color = len3(sub(mlab, v3(f0.y, f0.z, f0.w)));
         const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
         const V3 nt = v3(f1.x, f1.y, f1.z);
-        const V3 ns = unit3(m3_mulv(R, ld3(model.r2, id)));
+        const V3 ns = unit3(m3_mulv(R, mnrm));
         if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) continue;
         const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
         const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
