@@ -141,9 +141,10 @@ template <typename T> SSF_HD T batch_pick(const T* arr, int b) {     // uniform 
 // Each record carries a checksum (sum of the payload words + sequence number) so that the host can
 // detect a torn read without the device paying a system-scope cache write-back per publication.
 struct Mailbox {
-    long long icp[29];
-    unsigned long long icp_check;
-    unsigned long long icp_seq;
+    // ICP record: five self-validating 64-byte lines (7 payload words + the sequence number each; payload = the 29
+    // sums, then the checksum).  One wave store writes all 40 words; the host accepts the record when every line
+    // carries the awaited sequence number and the checksum matches -- no wait for write acknowledgements in between.
+    alignas(64) unsigned long long icp_rec[40];
     Counters cnt;
     unsigned long long cnt_check;
     unsigned long long cnt_seq;
@@ -152,6 +153,8 @@ struct Mailbox {
     unsigned long long all_seq;
 };
 #define SSF_ICP_REPLICAS 32
+// word w of Mailbox::icp_rec for payload p[0..29] (29 sums + checksum) and sequence number seq
+#define SSF_ICP_REC_WORD(w, p, seq) ((((w) & 7) == 7) ? (unsigned long long)(seq) : ((7 * ((w) >> 3) + ((w) & 7)) < 30 ? (unsigned long long)(p)[7 * ((w) >> 3) + ((w) & 7)] : 0ull))
 
 // ---- extract stage (ssf_extract.hip) -----------------------------------------------------------
 // every extract launch processes the nb frames of a batch (m, frame, best, matched, dynamic_mask = slot 0)

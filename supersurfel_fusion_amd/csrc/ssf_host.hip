@@ -607,16 +607,32 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
 }
 // wait for mailbox record `seq` and copy it to h->h_icp_local
 static int icp_fetch(ssf_handle* h, unsigned long long seq) {
-    int rc = wait_seq(h, &h->mb_host->icp_seq, seq);
-    if (rc) return rc;
-    for (int attempt = 0;; attempt++) {          // checksum guards against a torn record
-        unsigned long long check = seq;
-        for (int i = 0; i < SSF_ICP_RECORD; i++) {
-            h->h_icp_local[i] = __atomic_load_n(&h->mb_host->icp[i], __ATOMIC_RELAXED);
-            check += (unsigned long long)h->h_icp_local[i];
+    // the record is five 64-byte lines that each end in the sequence number (Mailbox::icp_rec): accept it when all
+    // five carry `seq` and the checksum over the payload matches; anything else is a record still in flight
+    const volatile unsigned long long* rec = h->mb_host->icp_rec;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 0;; spins++) {
+        bool ok = true;
+        for (int j = 0; j < 5 && ok; j++) ok = __atomic_load_n(&rec[8 * j + 7], __ATOMIC_ACQUIRE) == seq;
+        if (ok) {
+            unsigned long long check = seq, w29 = 0;
+            for (int p = 0; p < 30; p++) {
+                const unsigned long long v = __atomic_load_n(&rec[8 * (p / 7) + p % 7], __ATOMIC_RELAXED);
+                if (p < 29) { h->h_icp_local[p] = (long long)v; check += v; } else w29 = v;
+            }
+            bool still = true;                          // the lines must not have been overwritten while we read them
+            for (int j = 0; j < 5 && still; j++) still = __atomic_load_n(&rec[8 * j + 7], __ATOMIC_ACQUIRE) == seq;
+            if (still && check == w29) break;
         }
-        if (check == __atomic_load_n(&h->mb_host->icp_check, __ATOMIC_ACQUIRE)) break;
-        if (attempt > 100000) { h->err = "ICP mailbox record failed its checksum"; return SSF_ERR_DEVICE; }
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+            hipError_t e = hipStreamSynchronize(h->stream);
+            h->err = e != hipSuccess ? std::string("device error while waiting for the ICP record: ") + hipGetErrorString(e)
+                                     : std::string("ICP mailbox record never arrived");
+            return SSF_ERR_DEVICE;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
     }
     h->h_icp = h->h_icp_local;
     return SSF_OK;

@@ -142,16 +142,20 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         part[group * 32 + field] = v;
         __syncthreads();
         if (threadIdx.x < 64) {
+            __shared__ unsigned long long pay[30];
             long long tot = 0;
             if (threadIdx.x < 29) {
                 for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
                 sums[threadIdx.x] = tot;
-                __hip_atomic_store(&mb->icp[threadIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pay[threadIdx.x] = (unsigned long long)tot;
             }
             const unsigned long long check = (unsigned long long)wsum64(tot) + seq;
-            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // payload write-through stores acknowledged
-            if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) pay[29] = check;
+            // one wave, no barrier needed between the LDS writes above and the reads below on CDNA (in-order LDS per
+            // wave); 40 lanes store the five self-validating lines in one instruction
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the LDS writes have landed
+            if (threadIdx.x < 40)
+                __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -782,15 +786,14 @@ __device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c
 }
 // a 29-value device record (e.g. the rank-reduced ICP system) -> mailbox, as the ICP kernel's tail does
 __global__ void k_publish_icp(const long long* __restrict__ rec, Mailbox* mb, unsigned long long seq) {
+    __shared__ unsigned long long pay[30];
     long long v = 0;
-    if (threadIdx.x < 29) {
-        v = rec[threadIdx.x];
-        __hip_atomic_store(&mb->icp[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x < 29) { v = rec[threadIdx.x]; pay[threadIdx.x] = (unsigned long long)v; }
     const unsigned long long check = (unsigned long long)wsum64(v) + seq;
-    if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) __hip_atomic_store(&mb->icp_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) pay[29] = check;
+    __syncthreads();
+    if (threadIdx.x < 40)
+        __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_publish_all_counts(const int* __restrict__ all5, int n, Mailbox* mb, unsigned long long seq) {
     unsigned long long part = 0;
