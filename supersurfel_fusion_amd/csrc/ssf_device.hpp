@@ -184,15 +184,28 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int S);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
+// Sums the per-frame stable partition works from (k_classify in ssf_track_fuse.hip): per group of PART_GROUP blocks
+// the class counts (sup_vis: 6 per group, sup_oov: rows that come back into view), and the frame totals
+// a0 a1 a2 c0 c1 c2 b0 b2 in PART_REPLICAS copies of 8 words.  Two sets alternate by frame: `other` (all `words`
+// of it) is cleared by the frame that uses this one.  ticket: arrival counters of k_classify (65 words, zero at rest).
+#define PART_GROUP 32
+#define PART_REPLICAS 8
+struct PartitionWs { uint32_t* sup_vis; uint32_t* sup_oov; uint32_t* tot; uint32_t* ticket; uint32_t* other; int words; };
 // update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
 // (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)
 void launch_update_insert(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
                           int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                           int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                          uint8_t* state_oov, uint32_t* bc_oov);
+                          uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
+// first ICP iteration of the next frame, accumulated by the row-move kernel of this one (launch_classify_reorder)
+struct NextFrameIcp {
+    const uint2* pix2; const float4* fpack;   // packed tables of the next frame
+    Rt T;                                     // model -> camera transform of that iteration
+    long long* replicas; unsigned int* ticket; long long* sums; unsigned long long seq;
+};
 // Model store: the visible rows are a dense array (two of them, ping-pong); the out-of-view
 // rows live in a deque-like store with a live flag per row.  The per-frame stable partition
 //   [visible | out-of-view] = [A0 B0 C0 | A1 B1 C1]   (A = old visible rows, B = old out-of-view rows, C = rows
@@ -205,11 +218,10 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
                              int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
                              float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
-                             uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq);
+                             uint32_t* bc_oov, const PartitionWs& ws, Counters* cnt, Mailbox* mb, unsigned long long seq,
+                             const NextFrameIcp* next);
 // stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
 // new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
-void launch_scan_probe(hipStream_t st, uint32_t* bc_vis, int nb_vis, uint32_t* bc_oov, int oov_stride, int nb_oov, Counters* cnt,
-                       Mailbox* mb, unsigned long long seq, int mode);
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
                         int set_span);
 // one iteration of the loop-closure registration against a frame; out40: see k_align

@@ -285,6 +285,7 @@ static RcclApi* rccl_api() {
 struct IcpLoop {
     bool active = false, valid = true, done = true;
     int iter = 0;
+    unsigned long long ahead_seq = 0;         // != 0: the first iteration's record was accumulated ahead (ssf_handle::ahead)
     double tf_inc[16], prev_error, JtJ[36];
     M3 R_init; V3 t_init, t_inc_stale;
 };
@@ -343,12 +344,18 @@ struct ssf_handle {
     // consumers of the whole model (get/set model, export, deformation)
     OovStore oov[2]; int ocur = 0; int oov_head = 0, oov_tail = 0, oov_live = 0; long long n_recentres = 0;
     uint8_t* d_state_oov = nullptr; uint32_t* d_bc_oov = nullptr;
+    // sums of the per-frame partition (PartitionWs): two sets of part_words, used alternately; 128 arrival counters
+    uint32_t* d_part = nullptr; uint32_t* d_part_ticket = nullptr; int part_words = 0, part_sup_vis = 0, part_sup_oov = 0, part_set = 0;
     SurfelSoA dense; uint8_t* d_live_scratch = nullptr;
     int32_t* d_scratch_map = nullptr;
     long long* d_icp_replicas = nullptr; unsigned int* d_tickets = nullptr; float* d_srgb_lut = nullptr;
     // host-mapped mailbox (fine-grained): results the host waits for are polled, not synchronised on
     Mailbox* mb_host = nullptr; Mailbox* mb_dev = nullptr;
     unsigned long long icp_seq = 0, cnt_seq = 0;
+    // first ICP iteration of the next submitted frame, accumulated ahead by the row-move kernel of the frame just
+    // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
+    struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
+    bool icp_ahead = true;
     bool graph_failed = false;
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
@@ -572,15 +579,23 @@ static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
     return rc ? rc : activate_oldest(h);
 }
 
+static void icp_start_from(IcpLoop& I, const Rt& pose) {
+    I.R_init = m3_transpose(pose.R);
+    I.t_init = negate(m3_mulv(I.R_init, pose.t));
+    for (int i = 0; i < 16; i++) I.tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
 static void icp_begin(ssf_handle* h, const float* prior) {
     if (prior) h->pose = pose_from12(prior);
     IcpLoop& I = h->icp;
+    // a record accumulated ahead is this frame's first iteration only if nothing it was computed from has changed
+    I.ahead_seq = 0;
+    if (h->ahead.valid && !prior && h->have_frame && h->active.ctx == h->ahead.ctx && h->active.slot == h->ahead.slot &&
+        h->stamp == h->ahead.stamp && std::memcmp(&h->pose, &h->ahead.pose, sizeof(Rt)) == 0) I.ahead_seq = h->ahead.seq;
+    h->ahead.valid = false;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     I.active = nvis > 0 && h->cfg.icp_iter > 0;
     I.valid = true; I.done = !I.active; I.iter = 0;
-    I.R_init = m3_transpose(h->pose.R);
-    I.t_init = negate(m3_mulv(I.R_init, h->pose.t));
-    for (int i = 0; i < 16; i++) I.tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    icp_start_from(I, h->pose);
     for (int i = 0; i < 36; i++) I.JtJ[i] = 0.0;
     I.prev_error = DBL_MAX;
     I.t_inc_stale = v3(0, 0, 0);
@@ -593,12 +608,17 @@ static void inc_to_float(const double* tf, M3& R, V3& t) {
 }
 // device accumulate; the record lands in d_icp and in the mailbox (h_icp points at the mailbox copy)
 static int icp_fetch(ssf_handle* h, unsigned long long seq);
-static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullptr) {
-    IcpLoop& I = h->icp;
+// model -> camera transform of the coming iteration
+static Rt icp_transform(IcpLoop& I) {
     M3 R_inc; V3 t_inc;
     inc_to_float(I.tf_inc, R_inc, t_inc);
     I.t_inc_stale = t_inc;
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
+    return T;
+}
+static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullptr) {
+    IcpLoop& I = h->icp;
+    const Rt T = icp_transform(I);
     const unsigned long long seq = ++h->icp_seq;
     launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
                h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq);
@@ -732,6 +752,7 @@ static int materialise(ssf_handle* h) {
 }
 // the stores <- h->dense (n rows, the first n_visible of them visible); also resets the device counters
 static int store_from_dense(ssf_handle* h, int n, int n_visible) {
+    h->ahead.valid = false;                       // the model is replaced: a record accumulated ahead is stale
     int rc = copy_soa(h, h->model[h->mcur], h->dense, (size_t)n_visible);
     if (rc) return rc;
     OovStore& o = h->oov[h->ocur];
@@ -775,18 +796,49 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
             if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < h->S + 256 ||
                 span > h->oov_live + h->oov_live / 4 + 65536) { int rc2 = oov_recentre(h); if (rc2) return rc2; }
         }
+        PartitionWs ws;
+        {
+            uint32_t* set = h->d_part + (size_t)h->part_set * h->part_words;
+            ws.sup_vis = set; ws.sup_oov = set + h->part_sup_vis; ws.tot = ws.sup_oov + h->part_sup_oov;
+            ws.ticket = h->d_part_ticket; ws.other = h->d_part + (size_t)(h->part_set ^ 1) * h->part_words; ws.words = h->part_words;
+            h->part_set ^= 1;
+        }
         // update | insert | classification of the out-of-view rows (independent of the other two), one launch
         launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
                              nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
                              h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
-                             h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state_oov, h->d_bc_oov);
+                             h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state_oov, h->d_bc_oov, ws);
+        // The rows the move kernel writes to the new visible array are the rows the next frame's first ICP iteration
+        // reads, under a transform that is known now (the pose just estimated, when the caller supplies no prior):
+        // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).
+        NextFrameIcp next{};
+        bool have_next = false;
+        if (h->icp_ahead && !h->comm && h->cfg.nranks == 1 && h->cfg.icp_iter > 0 && !h->pending.empty()) {
+            ExtractCtx& nc = h->ctx[h->pending.front().first];
+            const int nslot = h->pending.front().second;
+            const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
+            // (not finished yet: the track stream waits here instead of at the start of the next frame; the host
+            // does not, it continues on the counters the scan kernel has published before the move)
+            if (nc.launched) {
+                if (multi && !nc.waited) { HCK(hipStreamWaitEvent(h->stream, nc.ev_done, 0)); nc.waited = true; }
+                const FrameMaps nm = batch_slot(nc.maps, nslot);
+                IcpLoop first;
+                icp_start_from(first, h->pose);
+                next.pix2 = nm.pix2; next.fpack = nm.fpack; next.T = icp_transform(first);
+                next.replicas = h->d_icp_replicas; next.ticket = h->d_tickets + 8; next.sums = h->d_icp;
+                next.seq = ++h->icp_seq;
+                h->ahead.valid = true; h->ahead.seq = next.seq; h->ahead.ctx = &nc; h->ahead.slot = nslot;
+                h->ahead.stamp = h->stamp + 1; h->ahead.pose = h->pose;
+                have_next = true;
+            }
+        }
         // classify | scan (publishes the counters) | move: the host continues once the counters arrive,
         // the row moves of this frame overlap the host-side launch work of the next one (stream order keeps
         // every later reader of the model behind them)
         launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S,
                                 h->oov_tail - h->oov_head, h->pose, h->cc->maps.plane_depth, h->stamp, h->cfg.delta_t,
                                 h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov,
-                                h->d_block_counts, h->d_bc_oov, h->d_cnt, h->mb_dev, seq);
+                                h->d_block_counts, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
         h->mcur ^= 1;
     } else {
         launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
@@ -898,6 +950,10 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             launch_publish_icp(h->stream, h->d_icp, h->mb_dev, seq);
             HCK(hipGetLastError());
             rc = icp_fetch(h, seq);
+        } else if (h->icp.ahead_seq) {
+            // first iteration: the record was accumulated by the previous frame's move kernel
+            rc = icp_fetch(h, h->icp.ahead_seq);
+            h->icp.ahead_seq = 0;
         } else
             rc = icp_accumulate(h, true);
         if (rc) return rc;
@@ -997,6 +1053,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int W = cfg->width, H = cfg->height, c = cfg->cell_size;
     h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
+    if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switch (tools/)
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
@@ -1067,9 +1124,13 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
              hipEventCreate(&c.ev_t0) == hipSuccess && hipEventCreate(&c.ev_t1) == hipSuccess;
     }
     const size_t OC = 3 * N + 2 * S + 1024;        // out-of-view store: home of the span = N + S + 256, room for N rows either side
+    h->part_sup_vis = 6 * (int)(((N + 255) / 256 + 2) / PART_GROUP + 1);
+    h->part_sup_oov = (int)(((OC + 255) / 256 + 8) / PART_GROUP + 1);
+    h->part_words = h->part_sup_vis + h->part_sup_oov + 8 * PART_REPLICAS;
+    ok = ok && dalloc(h, &h->d_part, 2 * (size_t)h->part_words) && dalloc(h, &h->d_part_ticket, 128);
     ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && alloc_surfels(h, h->dense, N) &&
          alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
-         dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, 3 * ((OC + 255) / 256 + 8)) &&
+         dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 6 * ((N + 255) / 256 + 2)) &&
          dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
@@ -1087,6 +1148,8 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     }
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
+    (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
     h->oov[0].cap = h->oov[1].cap = (int)OC;
     h->oov_head = h->oov_tail = oov_home(h); h->oov_live = 0;
     {
@@ -1579,21 +1642,27 @@ int ssf_dbg_host_times(ssf_handle* h, double* out8) {
     return SSF_OK;
 }
 
-// timing probe for the scan / publication kernel (tools/scan_probe.py); leaves the counters garbage
-double ssf_dbg_time_scan(ssf_handle* h, int reps, int mode) {
-    if (!h) return -1.0;
-    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const int nb_vis = (h->n_visible + h->S + 255) / 256, nb_oov = (h->oov_tail - h->oov_head + 255) / 256;
-    const int stride = ((h->oov[h->ocur].cap + 255) / 256 + 4) & ~3;
-    for (int i = 0; i < 3; i++) launch_scan_probe(h->stream, h->d_block_counts, nb_vis, h->d_bc_oov, stride, nb_oov, h->d_cnt, h->mb_dev, ++h->cnt_seq, mode);
-    (void)hipEventRecord(e0, h->stream);
-    for (int i = 0; i < reps; i++) launch_scan_probe(h->stream, h->d_block_counts, nb_vis, h->d_bc_oov, stride, nb_oov, h->d_cnt, h->mb_dev, ++h->cnt_seq, mode);
-    (void)hipEventRecord(e1, h->stream);
+// throughput of the extract stage alone (tools/extract_only_probe.py): frames (device pointers, `nlist` of them,
+// cycled) go through the batch contexts and are retired unread; returns microseconds per frame.  The handle's
+// frame stamp advances as if the frames had been fused.
+double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* const* depth, int nlist, int n) {
+    if (!h || !rgb || !depth || nlist <= 0 || !h->pending.empty()) return -1.0;
+    int nsub = 0;
+    double t0 = 0;
+    for (int i = 0; i < n; i++) {
+        if (i == n / 4) { for (auto& c : h->ctx) (void)hipStreamSynchronize(c.stream); (void)hipStreamSynchronize(h->stream); t0 = now_us(); }
+        while (nsub < n && !h->ctx[h->open_ctx].launched) {
+            if (submit_extract(h, rgb[nsub % nlist], depth[nsub % nlist], 1, nullptr)) return -1.0;
+            nsub++;
+        }
+        if (activate_oldest(h) || retire_active(h)) return -1.0;
+        h->stamp++;
+    }
+    for (auto& c : h->ctx) (void)hipStreamSynchronize(c.stream);
     (void)hipStreamSynchronize(h->stream);
-    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return 1000.0 * ms / reps;
+    return (now_us() - t0) / (double)(n - n / 4);
 }
+
 
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
 // (bit0: skip the per-surfel math, bit1: skip the LDS accumulation, bit2: skip arrival counting + tail)
@@ -1609,6 +1678,8 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
+    (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
     (void)hipStreamSynchronize(h->stream);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 1000.0 * ms / reps;

@@ -50,54 +50,46 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 #ifndef ICP_SLOTS
 #define ICP_SLOTS 16      // lane & 15 spreads the same-address traffic (64 columns measured no faster)
 #endif
-__global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
-                                             const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
-                                             Rt T, long long* __restrict__ replicas, unsigned int* ticket,
-                                             long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
-    __shared__ int s_last;
-    __shared__ unsigned long long red[29 * ICP_SLOTS];
-    for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
-    __syncthreads();
-    const M3 R = T.R; const V3 t = T.t;
-    const int slot = lane() & (ICP_SLOTS - 1);
-    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
-        // the whole model row (36 B, three coalesced streams) is requested up front: its lab / normal part would
-        // otherwise be a further dependent round trip after the two frame-side gathers
-        const V3 mpos = ld3(model.pos, id), mlab = ld3(model.lab, id), mnrm = ld3(model.r2, id);
-        const V3 ps = add(m3_mulv(R, mpos), t);
-        if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull); continue; }
-        const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
-        const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
-        if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) continue;
-        const size_t q = (size_t)v * cam.W + u;
-        const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
-        const int tid = (int)pl.x;
-        const float zt = __uint_as_float(pl.y);
-        const float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];   // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
-        if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;
-        const float dist_color = len3(sub(mlab, v3(f0.y, f0.z, f0.w)));
-        const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
-        const V3 nt = v3(f1.x, f1.y, f1.z);
-        const V3 ns = unit3(m3_mulv(R, mnrm));
-        if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) continue;
-        const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
-        const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
-        const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
-        const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
-        if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) atomicAdd(&red[slot], 1ull); continue; }
-        int k = 0;
+// the 29 terms of one visible supersurfel (position, cached Lab, normal row) under transform (R, t)
+__device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                        const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm,
+                                        unsigned long long* red, int slot, int dbg) {
+    const V3 ps = add(m3_mulv(R, mpos), t);
+    if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull); return; }
+    const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
+    const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
+    if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return;
+    const size_t q = (size_t)v * cam.W + u;
+    const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
+    const int tid = (int)pl.x;
+    const float zt = __uint_as_float(pl.y);
+    const float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];   // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
+    if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) return;
+    const float dist_color = len3(sub(mlab, v3(f0.y, f0.z, f0.w)));
+    const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
+    const V3 nt = v3(f1.x, f1.y, f1.z);
+    const V3 ns = unit3(m3_mulv(R, mnrm));
+    if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) return;
+    const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
+    const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
+    const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
+    const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+    if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) atomicAdd(&red[slot], 1ull); return; }
+    int k = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = i; j < 6; j++, k++)
-                atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
+        for (int j = i; j < 6; j++, k++)
+            atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
 #pragma unroll
-        for (int i = 0; i < 6; i++)
-            atomicAdd(&red[(21 + i) * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
-        atomicAdd(&red[27 * ICP_SLOTS + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
-        atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull);
-    }
-    __syncthreads();
+    for (int i = 0; i < 6; i++)
+        atomicAdd(&red[(21 + i) * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
+    atomicAdd(&red[27 * ICP_SLOTS + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+    atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull);
+}
+// end of an accumulating kernel, in three steps called by every thread of a workgroup after a barrier:
+// fold the workgroup's table into a replica record ...
+__device__ __forceinline__ void icp_fold(unsigned long long* red, long long* __restrict__ replicas) {
     if (threadIdx.x < 29) {
         unsigned long long tot = 0;
 #pragma unroll
@@ -105,59 +97,82 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         long long* rep = replicas + (size_t)(blockIdx.x % SSF_ICP_REPLICAS) * 32;
         if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&rep[threadIdx.x]), tot);
     }
-    if (dbg & 4) return;
+    // The replica updates above are device-scope atomic RMWs; they have completed (vmcnt(0) + barrier) before this
+    // workgroup counts its arrival, and the last workgroup reads them back with device-scope atomic loads.
+    // Everything exchanged between workgroups is an atomic at the coherence point, so no cache write-back /
+    // invalidate fence is needed.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // The replica updates above are device-scope atomic RMWs and have completed (vmcnt(0) + barrier)
-    // before this workgroup takes its ticket; the last workgroup reads them back with device-scope
-    // atomic loads.  Everything exchanged between workgroups is an atomic at the coherence point, so
-    // no cache write-back / invalidate fence is needed.
-    if (threadIdx.x == 0) {
-        // two-level arrival count (a single counter serialises thousands of same-address atomics at L2):
-        // 64 group counters, the last workgroup of a group reports to the global counter
-        const unsigned int g = blockIdx.x & 63u;
-        const unsigned int in_group = (gridDim.x - g + 63u) / 64u, groups = min(gridDim.x, 64u);
-        int last = 0;
-        const unsigned int tk = __hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == in_group - 1) {
-            __hip_atomic_store(&ticket[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int tg = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tg == groups - 1) { last = 1; __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        }
-        s_last = last;
+}
+// ... count the arrival (is this the last workgroup?) ...
+// two-level arrival count over all workgroups of the grid (a single counter serialises thousands of same-address
+// atomics at L2): 64 group counters, the last workgroup of a group reports to the global counter.  Thread 0 only.
+__device__ __forceinline__ int grid_arrive(unsigned int* ticket) {
+    const unsigned int g = blockIdx.x & 63u;
+    const unsigned int in_group = (gridDim.x - g + 63u) / 64u, groups = min(gridDim.x, 64u);
+    int last = 0;
+    const unsigned int tk = __hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == in_group - 1) {
+        __hip_atomic_store(&ticket[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int tg = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tg == groups - 1) { last = 1; __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
-    __syncthreads();
-    if (s_last) {
-        // SSF_ICP_REPLICAS x 32 replica words: thread t sums field t & 31 over every 8th replica (independent
-        // loads, one round trip), then 8 partial rows are folded through LDS
-        __shared__ long long part[8 * 32];
-        const int field = threadIdx.x & 31, group = threadIdx.x >> 5;
-        long long v = 0;
+    return last;
+}
+// ... and, in the last workgroup, sum the replicas and publish the record
+__device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, long long* __restrict__ sums, Mailbox* mb,
+                                            unsigned long long seq) {
+    // SSF_ICP_REPLICAS x 32 replica words: thread t sums field t & 31 over every 8th replica (independent
+    // loads, one round trip), then 8 partial rows are folded through LDS
+    __shared__ long long part[8 * 32];
+    const int field = threadIdx.x & 31, group = threadIdx.x >> 5;
+    long long v = 0;
 #pragma unroll
-        for (int j = 0; j < SSF_ICP_REPLICAS / 8; j++) {
-            const int r = group + 8 * j;
-            v += __hip_atomic_load(&replicas[r * 32 + field], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&replicas[r * 32 + field], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        part[group * 32 + field] = v;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            __shared__ unsigned long long pay[30];
-            long long tot = 0;
-            if (threadIdx.x < 29) {
-                for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
-                sums[threadIdx.x] = tot;
-                pay[threadIdx.x] = (unsigned long long)tot;
-            }
-            const unsigned long long check = (unsigned long long)wsum64(tot) + seq;
-            if (threadIdx.x == 0) pay[29] = check;
-            // one wave, no barrier needed between the LDS writes above and the reads below on CDNA (in-order LDS per
-            // wave); 40 lanes store the five self-validating lines in one instruction
-            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the LDS writes have landed
-            if (threadIdx.x < 40)
-                __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    for (int j = 0; j < SSF_ICP_REPLICAS / 8; j++) {
+        const int r = group + 8 * j;
+        v += __hip_atomic_load(&replicas[r * 32 + field], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&replicas[r * 32 + field], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    part[group * 32 + field] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        __shared__ unsigned long long pay[30];
+        long long tot = 0;
+        if (threadIdx.x < 29) {
+            for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
+            sums[threadIdx.x] = tot;
+            pay[threadIdx.x] = (unsigned long long)tot;
+        }
+        const unsigned long long check = (unsigned long long)wsum64(tot) + seq;
+        if (threadIdx.x == 0) pay[29] = check;
+        // one wave: LDS operations of a wave execute in order, so the reads below see the writes above; 40 lanes
+        // store the five self-validating lines in one instruction
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the LDS writes have landed
+        if (threadIdx.x < 40)
+            __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
+                                             const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                             Rt T, long long* __restrict__ replicas, unsigned int* ticket,
+                                             long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
+    __shared__ unsigned long long red[29 * ICP_SLOTS];
+    for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
+    __syncthreads();
+    const M3 R = T.R; const V3 t = T.t;
+    const int slot = lane() & (ICP_SLOTS - 1);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
+        icp_row(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), red, slot, dbg);
+    __syncthreads();
+    __shared__ int s_last;
+    if (dbg & 4) {                              // probe: fold only
+        icp_fold(red, replicas);
+        return;
+    }
+    icp_fold(red, replicas);
+    if (threadIdx.x == 0) s_last = grid_arrive(ticket);
+    __syncthreads();
+    if (s_last) icp_publish(replicas, sums, mb, seq);
 }
 
 // ---- loop-closure registration (DenseRegistration::align) -----------------------------------------------------
@@ -340,12 +355,15 @@ __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, 
     }
     return 1;
 }
-// 256 slots of the out-of-view span (class B, 3-bin histogram; dead slots are skipped).  These rows are touched by
-// neither the update nor the insertion of the frame, so their blocks ride along in the update/insert launch (whose
-// duration is set by the long serial chain of the updated rows) instead of lengthening the classify launch.
+// 256 slots of the out-of-view span (class B; dead slots are skipped).  These rows are touched by neither the
+// update nor the insertion of the frame, so their blocks ride along in the update/insert launch (whose duration is
+// set by the long serial chain of the updated rows) instead of lengthening the classify launch.  Of the three
+// classes only B0 (rows that come back into view) needs positions: its per-block count goes to bc_oov, and to the
+// sum of its group of PART_GROUP blocks; the frame totals of B0 and B2 go to the replicated totals (B1 rows stay
+// where they are, their number follows from the live count).  Most blocks have neither and issue no atomic.
 __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStore& O, const Rt& pose, const float* __restrict__ plane_depth,
                                                    int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
-                                                   uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, int oov_stride,
+                                                   uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, PartitionWs ws,
                                                    const Counters* __restrict__ cnt, int ob, int (*hist)[6]) {
     const int wv = threadIdx.x >> 6;
     int cls = 7;
@@ -355,10 +373,16 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
         state_oov[phys] = (uint8_t)cls;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+    for (int c = 0; c < 3; c += 2) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
     __syncthreads();
-    // three planes (B0 | B1 | B2) of oov_stride counters each: the scan reads four blocks per lane as one uint4
-    if (threadIdx.x < 3) bc_oov[(size_t)threadIdx.x * oov_stride + ob] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+    if (threadIdx.x == 0 || threadIdx.x == 2) {
+        const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+        if (threadIdx.x == 0) bc_oov[ob] = k;
+        if (k) {
+            atomicAdd(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + (threadIdx.x == 0 ? 6 : 7)], k);
+            if (threadIdx.x == 0) atomicAdd(&ws.sup_oov[ob / PART_GROUP], k);
+        }
+    }
 }
 // ---- update ----------------------------------------------------------------------------------------
 __device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
@@ -481,12 +505,12 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                                                        const uint8_t* __restrict__ matched, int S, int do_update, int capacity,
                                                        int rank, int nranks, float tile, Counters* cnt, int nchunks, OovStore O,
                                                        ClassifyArgs ca, uint8_t* __restrict__ state_oov,
-                                                       uint32_t* __restrict__ bc_oov, int oov_stride) {
+                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws) {
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
     if ((int)blockIdx.x >= 2 * nchunks)
         classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
-                           oov_stride, cnt, blockIdx.x - 2 * nchunks, hist);
+                           ws, cnt, blockIdx.x - 2 * nchunks, hist);
     else if ((int)blockIdx.x >= nchunks)
         insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, blockIdx.x - nchunks, nchunks);
     else if (do_update) update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, blockIdx.x * blockDim.x + threadIdx.x);
@@ -520,32 +544,79 @@ __global__ __launch_bounds__(1024) void k_first_frame(SurfelSoA M, SurfelSoA F, 
 }
 
 // ---- classify + stable partition over the model store (see OovStore in ssf_device.hpp) ---------------------------
+// The partition needs, per row that moves, the number of rows of its class before it, and per class the frame total.
+// There is no scan kernel: every block leaves its class histogram (bc_vis / bc_oov), adds it to the sum of its group
+// of PART_GROUP blocks and to the (replicated) frame totals with atomics; the LAST block of k_classify to arrive
+// turns the totals into the frame's counters and publishes them; a block of k_move_rows then gets its prefix from the
+// sums of the groups before its own and the histograms of the blocks before it inside its group (a few hundred
+// words from L2).  The sums live in one of two sets (PartitionWs, frame parity); the publishing block clears the
+// other set for the next frame.
+__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 // 256 rows of the visible array per block (old visible rows = class A, this frame's insertions = class C; 6-bin
 // histogram A0 A1 A2 C0 C1 C2)
 __global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, Rt pose, const float* __restrict__ plane_depth,
                                                   int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
                                                   uint8_t* __restrict__ state_vis, uint32_t* __restrict__ bc_vis,
-                                                  const Counters* __restrict__ cnt) {
+                                                  Counters* cnt, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
     __shared__ int hist[4][6];
+    __shared__ int s_last;
+    __shared__ uint32_t tot[8];
     const int wv = threadIdx.x >> 6;
     int cls = 7;                                   // 7 = no row
-    {
-        const int nv = cnt->n_visible, n_rows = nv + cnt->n_inserted;
-        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-        if (idx < n_rows) {
-            const int st = classify_row(cam, V, idx, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
-            state_vis[idx] = (uint8_t)st;
-            cls = (idx < nv ? 0 : 3) + st;
-        }
+    const int nv = cnt->n_visible, n_rows = nv + cnt->n_inserted;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_rows) {
+        const int st = classify_row(cam, V, idx, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+        state_vis[idx] = (uint8_t)st;
+        cls = (idx < nv ? 0 : 3) + st;
+    }
 #pragma unroll
-        for (int c = 0; c < 6; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
-        __syncthreads();
-        if (threadIdx.x < 6) bc_vis[6 * blockIdx.x + threadIdx.x] = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+    for (int c = 0; c < 6; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+        bc_vis[6 * blockIdx.x + threadIdx.x] = k;
+        if (k) {
+            atomicAdd(&ws.sup_vis[(blockIdx.x / PART_GROUP) * 6 + threadIdx.x], k);
+            atomicAdd(&ws.tot[(blockIdx.x & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
+        }
+    }
+    // the atomics above are device-scope RMWs, complete (vmcnt(0) + barrier) before this block counts its arrival;
+    // the last block reads the totals back with device-scope atomic loads (same protocol as the ICP record)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = grid_arrive(ws.ticket);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 8) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < PART_REPLICAS; r++) v += __hip_atomic_load(&ws.tot[r * 8 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) {                      // (off the publishing wave's path)
+        for (int i = threadIdx.x - 64; i < ws.words; i += blockDim.x - 64) ws.other[i] = 0u;      // the other set: next frame's sums
+    } else if (threadIdx.x == 0) {
+        const Counters c_in = *cnt;
+        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
+        const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
+        Counters c = c_in;
+        c.n_model = c_in.n_model + c_in.n_inserted;   // k_update_insert reports its insertions in n_inserted only
+        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
+        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
+        c.mv_nv = nv; c.mv_a0 = a0; c.mv_b0 = b0;
+        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
+        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
+        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
+        // the frame's counters are final here: publish them now, the host overlaps its next launches
+        // with the row moves that follow in the stream
+        publish_counters_value(cnt, c, 1, mb, seq);
     }
 }
 
 // exclusive scan of NC counters per block over nblocks blocks by one 1024-thread workgroup (one block per thread
-// and round: coalesced loads); totals -> tot[NC]
+// and round: coalesced loads); totals -> tot[NC].  (Out-of-view store compaction only.)
 template <int NC>
 __device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int nblocks, uint32_t* tot /* LDS, NC */,
                                                   uint32_t (*wtot)[6] /* LDS, 16 x 6 */) {
@@ -579,100 +650,6 @@ __device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int
         __syncthreads();
     }
 }
-// scans of the visible-array and out-of-view histograms by one SMALL workgroup; totals -> counters, published.
-// 256 threads on purpose: next to the wide extract launches of the other streams a 16-wave workgroup waits for
-// a compute unit with 16 free wave slots (rocprofv3: 17.6 us in the frame vs 4 us alone); 4 waves fit anywhere.
-// A thread owns SCAN_VIS consecutive visible blocks (6 counters each) and SCAN_OOV consecutive out-of-view blocks;
-// of the latter only B0 needs a prefix (B1 rows stay in place, B2 rows are dropped), the three planes are read
-// as uint4.  One round = 256 x SCAN_VIS visible blocks (4: 262 k rows, 16: 1 M rows; the launcher picks the smaller
-// one when it suffices, its loads coalesce better) + 4096 out-of-view blocks (1 M slots).
-#define SCAN_OOV 16
-__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
-template <int SCAN_VIS>
-__global__ __launch_bounds__(256) void k_scan_blocks(uint32_t* __restrict__ bc_vis, int nb_vis_upper, uint32_t* __restrict__ bc_oov,
-                                                     int oov_stride, int nb_oov_upper, Counters* cnt, Mailbox* mb, unsigned long long seq) {
-    __shared__ uint32_t wtot[4][9];
-    __shared__ uint32_t tot[9];
-    const Counters c_in = *cnt;                       // one wide load (uniform)
-    const int nv = c_in.n_visible, n_rows = nv + c_in.n_inserted;
-    const int nb_vis = min(nb_vis_upper, (n_rows + 255) / 256);
-    const int nb_oov = min(nb_oov_upper, (c_in.oov_tail - c_in.oov_head + 255) / 256);
-    if (threadIdx.x < 9) tot[threadIdx.x] = 0;
-    __syncthreads();
-    const int wv = threadIdx.x >> 6;
-    const int rounds = max((nb_vis + 256 * SCAN_VIS - 1) / (256 * SCAN_VIS), (nb_oov + 256 * SCAN_OOV - 1) / (256 * SCAN_OOV));
-    for (int r = 0; r < rounds; r++) {
-        const int bv = (r * 256 + threadIdx.x) * SCAN_VIS, bo = (r * 256 + threadIdx.x) * SCAN_OOV;
-        uint32_t cv[SCAN_VIS][6], c[9], incl[9];
-        uint4 q0[SCAN_OOV / 4];
-#pragma unroll
-        for (int s = 0; s < 9; s++) c[s] = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_VIS; k++)
-#pragma unroll
-            for (int s = 0; s < 6; s++) { cv[k][s] = (bv + k < nb_vis) ? bc_vis[6 * (bv + k) + s] : 0u; c[s] += cv[k][s]; }
-#pragma unroll
-        for (int s = 0; s < 3; s++)
-#pragma unroll
-            for (int k = 0; k < SCAN_OOV / 4; k++) {
-                uint4 q = make_uint4(0u, 0u, 0u, 0u);
-                const int b4 = bo + 4 * k;
-                if (b4 < nb_oov) q = *reinterpret_cast<const uint4*>(&bc_oov[(size_t)s * oov_stride + b4]);
-                if (b4 + 1 >= nb_oov) q.y = 0u;            // slots past the span hold stale counts
-                if (b4 + 2 >= nb_oov) q.z = 0u;
-                if (b4 + 3 >= nb_oov) q.w = 0u;
-                c[6 + s] += (q.x + q.y) + (q.z + q.w);
-                if (s == 0) q0[k] = q;
-            }
-#pragma unroll
-        for (int s = 0; s < 9; s++) {
-            uint32_t v = c[s];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
-            incl[s] = v;
-            if (lane() == 63) wtot[wv][s] = v;
-        }
-        __syncthreads();
-        uint32_t total[9];
-#pragma unroll
-        for (int s = 0; s < 9; s++) {
-            uint32_t before = 0, tt = 0;
-            for (int w = 0; w < 4; w++) { const uint32_t t = wtot[w][s]; if (w < wv) before += t; tt += t; }
-            total[s] = tt;
-            uint32_t run = tot[s] + before + incl[s] - c[s];       // exclusive prefix of this thread's first block
-            if (s < 6) {
-#pragma unroll
-                for (int k = 0; k < SCAN_VIS; k++) { if (bv + k < nb_vis) bc_vis[6 * (bv + k) + s] = run; run += cv[k][s]; }
-            } else if (s == 6) {
-#pragma unroll
-                for (int k = 0; k < SCAN_OOV / 4; k++) {
-                    const int b4 = bo + 4 * k;
-                    if (b4 < nb_oov)
-                        *reinterpret_cast<uint4*>(&bc_oov[b4]) = make_uint4(run, run + q0[k].x, run + q0[k].x + q0[k].y, run + q0[k].x + q0[k].y + q0[k].z);
-                    run += (q0[k].x + q0[k].y) + (q0[k].z + q0[k].w);
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 9) tot[threadIdx.x] += total[threadIdx.x];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
-        const int b0 = (int)tot[6], b1 = (int)tot[7], b2 = (int)tot[8];
-        Counters c = c_in;                            // loaded at kernel start: no dependent reloads here
-        c.n_model = c_in.n_model + c_in.n_inserted;   // k_update_insert reports its insertions in n_inserted only
-        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
-        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
-        c.mv_nv = nv; c.mv_a0 = a0; c.mv_b0 = b0;
-        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
-        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
-        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
-        // the frame's counters are final here: publish them now, the host overlaps its next launches
-        // with the row moves that follow in the stream
-        publish_counters_value(cnt, c, 1, mb, seq);
-    }
-}
 
 __device__ __forceinline__ void copy_row(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j) {
     st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
@@ -682,18 +659,53 @@ __device__ __forceinline__ void copy_row(const SurfelSoA& A, size_t i, const Sur
     B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
     B.conf[j] = A.conf[i];
 }
+// copy of a row that enters the new visible array; hands back the three fields the ICP terms read
+__device__ __forceinline__ void copy_row_keep(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j, V3& pos, V3& lab, V3& nrm) {
+    pos = ld3(A.pos, i); lab = ld3(A.lab, i); nrm = ld3(A.r2, i);
+    st3(B.pos, j, pos); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, lab);
+    B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
+    st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, nrm);
+    st6(B.shape, j, ld6(A.shape, i));
+    B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
+    B.conf[j] = A.conf[i];
+}
+// what the fused form of k_move_rows needs to accumulate the first ICP iteration of the NEXT frame
+struct NextIcp {
+    Cam cam; const uint2* pix2; const float4* fpack; Rt T;
+    long long* replicas; unsigned int* ticket; long long* sums; Mailbox* mb; unsigned long long seq;
+};
 // move the rows whose place changes (stable within each class): A0, C0 -> new visible array, A1 -> in front of the
 // out-of-view span, C1 -> behind it, B0 -> new visible array (slot freed), B2 -> slot freed.  B1 stays where it is.
+// ICP = true: the rows written to the new visible array (A0, B0, C0) are exactly the rows the next frame's first ICP
+// iteration reads, and its transform (inverse of the pose just estimated) is already known: accumulate that record
+// here, while the rows are in registers, against the next frame's packed tables (the sums are exact integers, so
+// the order of accumulation does not matter), and publish it like k_icp does.
+template <bool ICP>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
                                                    const uint8_t* __restrict__ state_oov, const uint32_t* __restrict__ bc_vis,
-                                                   const uint32_t* __restrict__ bc_oov, const Counters* __restrict__ cnt, int nb_vis) {
+                                                   const uint32_t* __restrict__ bc_oov, PartitionWs ws,
+                                                   const Counters* __restrict__ cnt, int nb_vis, NextIcp nx) {
     __shared__ int hist[4][6];
+    __shared__ uint32_t base[6];                  // rows of each class in the blocks before this one
+    __shared__ unsigned long long red[ICP ? 29 * ICP_SLOTS : 1];
+    if (ICP) for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
+    if (threadIdx.x < 6) base[threadIdx.x] = 0u;
     const int wv = threadIdx.x >> 6;
     int cls = 7, in_wave = 0;
+    bool keep = false;
+    V3 pos, lab, nrm;
     if ((int)blockIdx.x < nb_vis) {
         const int nv = cnt->mv_nv, n_rows = nv + cnt->last[3];            // last[3] = insertions of this frame (published)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
+        // prefix: group sums before this block's group, then the block histograms before it inside the group
+        // (both 6 counters wide, so word w belongs to class w % 6)
+        const int g0 = (int)(blockIdx.x / PART_GROUP), ng = 6 * g0, nw = ng + 6 * ((int)blockIdx.x - g0 * PART_GROUP);
+        __syncthreads();
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            const uint32_t v = w < ng ? ws.sup_vis[w] : bc_vis[6 * (size_t)(g0 * PART_GROUP) + (w - ng)];
+            if (v) atomicAdd(&base[w % 6], v);
+        }
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             const unsigned long long mask = __ballot(cls == c);
@@ -704,10 +716,12 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         if (cls == 0 || cls == 1 || cls == 3 || cls == 4) {
             int before = 0;
             for (int w = 0; w < wv; w++) before += hist[w][cls];
-            const size_t r = (size_t)bc_vis[6 * blockIdx.x + cls] + before + in_wave;
-            if (cls == 0) copy_row(V, i, Vn, r);
-            else if (cls == 3) copy_row(V, i, Vn, (size_t)cnt->mv_a0 + cnt->mv_b0 + r);
-            else {
+            const size_t r = (size_t)base[cls] + before + in_wave;
+            if (cls == 0 || cls == 3) {
+                const size_t j = cls == 0 ? r : (size_t)cnt->mv_a0 + cnt->mv_b0 + r;
+                if (ICP) { copy_row_keep(V, i, Vn, j, pos, lab, nrm); keep = true; }
+                else copy_row(V, i, Vn, j);
+            } else {
                 const size_t j = (cls == 1 ? (size_t)cnt->mv_head_new : (size_t)cnt->mv_tail_old) + r;
                 copy_row(V, i, O.rows, j);
                 O.live[j] = 1;
@@ -720,13 +734,42 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         const unsigned long long mask = __ballot(cls == 0);
         if (cls == 0) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
         if (lane() == 0) hist[wv][0] = __popcll(mask);
-        __syncthreads();
+        if (__syncthreads_count(cls == 0)) {      // (few blocks have rows that come back into view)
+            const int g0 = ob / PART_GROUP, nw = g0 + (ob - g0 * PART_GROUP);
+            for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+                const uint32_t v = w < g0 ? ws.sup_oov[w] : bc_oov[g0 * PART_GROUP + (w - g0)];
+                if (v) atomicAdd(&base[0], v);
+            }
+            __syncthreads();
+        }
         if (cls == 0) {
             int before = 0;
             for (int w = 0; w < wv; w++) before += hist[w][0];
-            copy_row(O.rows, (size_t)phys, Vn, (size_t)cnt->mv_a0 + bc_oov[ob] + before + in_wave);
+            const size_t j = (size_t)cnt->mv_a0 + base[0] + before + in_wave;
+            if (ICP) { copy_row_keep(O.rows, (size_t)phys, Vn, j, pos, lab, nrm); keep = true; }
+            else copy_row(O.rows, (size_t)phys, Vn, j);
         }
         if (cls == 0 || cls == 2) O.live[phys] = 0;
+    }
+    if (ICP) {
+        // (the barrier after the class histogram also ordered the zeroing of `red`)
+        if (keep) icp_row(nx.cam, nx.pix2, nx.fpack, nx.T.R, nx.T.t, pos, lab, nrm, red, lane() & (ICP_SLOTS - 1), 0);
+        // only workgroups that hold rows of the new visible array take part; arrivals are counted in ROWS, and the
+        // workgroup that completes cnt->n_visible (written by the scan kernel before this launch) is the last
+        // (row counter: ticket word 65, next to the grid arrival counters of k_icp).
+        // No such rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
+        const int nkeep = __syncthreads_count(keep);
+        if (nkeep == 0) return;
+        __shared__ int s_last;
+        icp_fold(red, nx.replicas);
+        if (threadIdx.x == 0) {
+            const unsigned int total = (unsigned int)cnt->n_visible;
+            const unsigned int before = __hip_atomic_fetch_add(&nx.ticket[65], (unsigned int)nkeep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = before + (unsigned int)nkeep == total;
+            if (s_last) __hip_atomic_store(&nx.ticket[65], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last) icp_publish(nx.replicas, nx.sums, nx.mb, nx.seq);
     }
 }
 
@@ -902,18 +945,16 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
                        pose, zmin, zmax, id_offset, best, matched);
 }
-static inline int oov_plane_stride(const OovStore& oov) { return ((oov.cap + 255) / 256 + 4) & ~3; }   // counters per plane, multiple of 4 (uint4 access)
 void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                           int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
                           int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                           int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                          uint8_t* state_oov, uint32_t* bc_oov) {
+                          uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws) {
     ScopedKernel sk("update_insert", st);
     const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
     hipLaunchKernelGGL(k_update_insert, dim3(2 * nchunks + nb_oov), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
-                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, oov, ca, state_oov, bc_oov,
-                       oov_plane_stride(oov));
+                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, oov, ca, state_oov, bc_oov, ws);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {
@@ -923,33 +964,25 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
                              int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
                              float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
-                             uint32_t* bc_oov, Counters* cnt, Mailbox* mb, unsigned long long seq) {
+                             uint32_t* bc_oov, const PartitionWs& ws, Counters* cnt, Mailbox* mb, unsigned long long seq,
+                             const NextFrameIcp* next) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
-    const int oov_stride = oov_plane_stride(oov);
     // (the out-of-view rows were classified inside the update/insert launch)
     { ScopedKernel sk("classify", st);
       hipLaunchKernelGGL(k_classify, dim3(nb_vis), dim3(256), 0, st, cam, vis_src, pose, plane_depth, stamp, delta_t,
-                         conf_thresh, zmin, zmax, state_vis, bc_vis, cnt); }
-    { ScopedKernel sk("scan_blocks", st);
-      if (nb_vis <= 1024) hipLaunchKernelGGL(k_scan_blocks<4>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
-      else hipLaunchKernelGGL(k_scan_blocks<16>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq); }
-    { ScopedKernel sk("reorder_move", st);
-      hipLaunchKernelGGL(k_move_rows, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov, bc_vis,
-                         bc_oov, cnt, nb_vis); }
-}
-// timing probe (tools/scan_probe.py): the scan kernel alone, `mode` 0 = full, 1 = no publication
-__global__ __launch_bounds__(256) void k_scan_probe(Counters* cnt, Mailbox* mb, unsigned long long seq, int mode) {
-    if (threadIdx.x == 0) {
-        Counters c = *cnt;
-        c.n_updated += 1;
-        if (mode == 0) publish_counters_value(cnt, c, 0, mb, seq);
-        else *cnt = c;
+                         conf_thresh, zmin, zmax, state_vis, bc_vis, cnt, ws, mb, seq); }
+    NextIcp nx{};
+    if (next) {
+        nx.cam = cam; nx.pix2 = next->pix2; nx.fpack = next->fpack; nx.T = next->T; nx.replicas = next->replicas;
+        nx.ticket = next->ticket; nx.sums = next->sums; nx.mb = mb; nx.seq = next->seq;
+        ScopedKernel sk("reorder_move_icp", st);
+        hipLaunchKernelGGL(k_move_rows<true>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+                           bc_vis, bc_oov, ws, cnt, nb_vis, nx);
+    } else {
+        ScopedKernel sk("reorder_move", st);
+        hipLaunchKernelGGL(k_move_rows<false>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+                           bc_vis, bc_oov, ws, cnt, nb_vis, nx);
     }
-}
-void launch_scan_probe(hipStream_t st, uint32_t* bc_vis, int nb_vis, uint32_t* bc_oov, int oov_stride, int nb_oov, Counters* cnt,
-                       Mailbox* mb, unsigned long long seq, int mode) {
-    if (mode < 2) hipLaunchKernelGGL(k_scan_probe, dim3(1), dim3(256), 0, st, cnt, mb, seq, mode);
-    else hipLaunchKernelGGL(k_scan_blocks<4>, dim3(1), dim3(256), 0, st, bc_vis, nb_vis, bc_oov, oov_stride, nb_oov, cnt, mb, seq);
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
                         int set_span) {
