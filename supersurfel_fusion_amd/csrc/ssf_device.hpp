@@ -182,7 +182,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
-                  unsigned long long* best, uint8_t* matched, int S);
+                  unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
 // Sums the per-frame stable partition works from (k_classify in ssf_track_fuse.hip): per group of PART_GROUP blocks
 // the class counts (sup_vis: 6 per group, sup_oov: rows that come back into view), and the frame totals
@@ -191,13 +191,15 @@ struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view
 #define PART_GROUP 32
 #define PART_REPLICAS 8
 struct PartitionWs { uint32_t* sup_vis; uint32_t* sup_oov; uint32_t* tot; uint32_t* ticket; uint32_t* other; int words; };
-// update of the matched rows and ordered insertion of the unmatched frame supersurfels in ONE launch
-// (they touch disjoint model rows); do_update = 0 skips the update half (no visible rows anywhere)
-void launch_update_insert(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
-                          int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
-                          int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
-                          int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                          uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws);
+// The fuse launch (k_update_insert in ssf_track_fuse.hip): update of the matched rows | ordered insertion of the
+// unmatched frame supersurfels | classification (filterModel) of every row of the model store, and publication of the
+// frame's counters by the last block to finish.  do_update = 0 skips the update (no visible rows anywhere);
+// span_upper = host upper bound of the out-of-view span; cand = launch_match's per-row candidate.
+void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                 int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
+                 int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
+                 int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, Mailbox* mb, unsigned long long seq);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // first ICP iteration of the next frame, accumulated by the row-move kernel of this one (launch_classify_reorder)
@@ -212,14 +214,12 @@ struct NextFrameIcp {
 //   inserted this frame; 0 = classified visible, 1 = out of view, 2 = removed)
 // then only moves A0/B0/C0 into the other visible array, pushes A1 in front of the out-of-view span, appends C1
 // behind it and clears the live flag of B0/B2: the (large) B1 block is never touched.
-// classify (filterModel) every visible row incl. this frame's insertions and every live out-of-view row, scan the
-// per-block class histograms (publishes the frame's counters) and move the rows; nv_upper / span_upper = host
-// upper bounds of the visible rows (incl. insertions) and of the out-of-view span
-void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
-                             int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
-                             float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
-                             uint32_t* bc_oov, const PartitionWs& ws, Counters* cnt, Mailbox* mb, unsigned long long seq,
-                             const NextFrameIcp* next);
+// launch_move_rows moves the rows accordingly (after launch_fuse); nv_upper / span_upper = host upper bounds of the
+// visible rows (incl. insertions) and of the out-of-view span; next != nullptr: also accumulate the next frame's
+// first ICP iteration
+void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
+                      const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
+                      const Counters* cnt, Mailbox* mb, const NextFrameIcp* next);
 // stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
 // new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,

@@ -338,7 +338,7 @@ struct ssf_handle {
     std::vector<void*> allocs;
     float* d_bf_in = nullptr; float* d_bf_out = nullptr;
     long long* d_icp = nullptr;
-    uint8_t* d_state = nullptr; uint32_t* d_block_counts = nullptr; Counters* d_cnt = nullptr;
+    uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
     // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
     // with live flags, host mirror of the span below), dense = materialised [visible | out-of-view] view for the
     // consumers of the whole model (get/set model, export, deformation)
@@ -776,7 +776,7 @@ static int do_match(ssf_handle* h) {
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
     launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
-                 h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->S);
+                 h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
     HCK(hipGetLastError());
     return SSF_OK;
 }
@@ -803,11 +803,11 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
             ws.ticket = h->d_part_ticket; ws.other = h->d_part + (size_t)(h->part_set ^ 1) * h->part_words; ws.words = h->part_words;
             h->part_set ^= 1;
         }
-        // update | insert | classification of the out-of-view rows (independent of the other two), one launch
-        launch_update_insert(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->S,
-                             nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
-                             h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
-                             h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state_oov, h->d_bc_oov, ws);
+        // update | insert | classification of every row | publication of the counters: one launch
+        launch_fuse(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->d_cand,
+                    h->S, nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
+                    h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
+                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->mb_dev, seq);
         // The rows the move kernel writes to the new visible array are the rows the next frame's first ICP iteration
         // reads, under a transform that is known now (the pose just estimated, when the caller supplies no prior):
         // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).
@@ -832,13 +832,11 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
                 have_next = true;
             }
         }
-        // classify | scan (publishes the counters) | move: the host continues once the counters arrive,
-        // the row moves of this frame overlap the host-side launch work of the next one (stream order keeps
-        // every later reader of the model behind them)
-        launch_classify_reorder(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S,
-                                h->oov_tail - h->oov_head, h->pose, h->cc->maps.plane_depth, h->stamp, h->cfg.delta_t,
-                                h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov,
-                                h->d_block_counts, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
+        // move: the host continues once the counters arrive (published by the fuse launch), the row moves of this
+        // frame overlap the host-side launch work of the next one (stream order keeps every later reader of the
+        // model behind them)
+        launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S, h->oov_tail - h->oov_head,
+                         h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, have_next ? &next : nullptr);
         h->mcur ^= 1;
     } else {
         launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
@@ -1132,7 +1130,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
-         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N) && dalloc(h, &h->d_block_counts, 6 * ((N + 255) / 256 + 2)) &&
+         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
          dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
@@ -1150,6 +1148,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
+    (void)hipMemsetAsync(h->d_cand, 0xFF, N * sizeof(int32_t), h->stream);
     h->oov[0].cap = h->oov[1].cap = (int)OC;
     h->oov_head = h->oov_tail = oov_home(h); h->oov_live = 0;
     {
@@ -1678,8 +1677,6 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
-    (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
-    (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
     (void)hipStreamSynchronize(h->stream);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 1000.0 * ms / reps;

@@ -302,59 +302,74 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 }
 
 // ---- association ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
-                                               const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
-                                               long long id_offset, unsigned long long* __restrict__ best,
-                                               uint8_t* __restrict__ matched) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_visible) return;
-    if (!(model.conf[id] > 0.0f)) return;
+// one frame supersurfel (or none) per visible model row; cand[id] = the frame supersurfel this row has bid for
+// (-1: none) -- the fuse launch uses it to tell which rows the update is about to rewrite
+__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const uint2* __restrict__ pix2,
+                                         const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
+                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+    if (!(model.conf[id] > 0.0f)) return -1;
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
     const V3 tview = negate(m3_mulv(Rt_, t));
     const V3 mp = ld3(model.pos, id);
     const V3 pv = add(m3_mulv(Rt_, mp), tview);
-    if (!(pv.z > zmin && pv.z < zmax)) return;
+    if (!(pv.z > zmin && pv.z < zmax)) return -1;
     const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
-    if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return;
+    if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return -1;
     const int f = (int)pix2[(size_t)py * cam.W + px].x;
     matched[f] = 1;
     const float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];     // (conf, lab) (normal) (pos): one line
-    if (!(f0.x > 0.0f)) return;
+    if (!(f0.x > 0.0f)) return -1;
     const V3 fp = add(m3_mulv(R, v3(f2.x, f2.y, f2.z)), t);
     const V3 fn = unit3(row_mul(v3(f1.x, f1.y, f1.z), Rt_));    // third row of frame_orientation * R^T
     const V3 mn = unit3(ld3(model.r2, id));
     const float dist = len3(sub(mp, fp));
     const float lab_dist = len3(sub(ld3(model.lab, id), v3(f0.y, f0.z, f0.w)));
     const float delta_norm = fabsf(dot3(mn, fn));
-    if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
-                                       (unsigned long long)(uint32_t)(id_offset + id);
-        atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
-    }
+    if (!(lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f)) return -1;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
+                                   (unsigned long long)(uint32_t)(id_offset + id);
+    atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
+    return f;
+}
+__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
+                                               const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
+                                               long long id_offset, unsigned long long* __restrict__ best,
+                                               uint8_t* __restrict__ matched, int32_t* __restrict__ cand) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_visible) return;
+    cand[id] = match_row(cam, model, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
 }
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
 // filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
-__device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
-                                            const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
-                                            float zmin, float zmax) {
-    const float conf = M.conf[idx];
-    const int time_diff = stamp - M.stamps[2 * idx + 1];
-    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) { M.conf[idx] = -1.0f; return 2; }
+__device__ __forceinline__ int classify_values(const Cam& cam, float conf, int last_seen, const V3& pos, const Rt& pose,
+                                               const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
+                                               float zmin, float zmax) {
+    const int time_diff = stamp - last_seen;
+    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) return 2;
     const M3 Rv = m3_transpose(pose.R);
     const V3 tv = negate(m3_mulv(Rv, pose.t));
-    const V3 p = add(m3_mulv(Rv, ld3(M.pos, idx)), tv);
+    const V3 p = add(m3_mulv(Rv, pos), tv);
     if (p.z > zmin && p.z < zmax) {
         const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
         if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
             const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
-            if (p.z < 0.8f * z) { M.conf[idx] = -1.0f; return 2; }
-            return 0;
+            return p.z < 0.8f * z ? 2 : 0;
         }
     }
     return 1;
 }
+// the same for a row in memory; a removed row gets conf := -1
+__device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
+                                            const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
+                                            float zmin, float zmax) {
+    const int st = classify_values(cam, M.conf[idx], M.stamps[2 * idx + 1], ld3(M.pos, idx), pose, plane_depth, stamp, delta_t,
+                                   conf_thresh, zmin, zmax);
+    if (st == 2) M.conf[idx] = -1.0f;
+    return st;
+}
+#define OOV_PER_WG 8
 // 256 slots of the out-of-view span (class B; dead slots are skipped).  These rows are touched by neither the
 // update nor the insertion of the frame, so their blocks ride along in the update/insert launch (whose duration is
 // set by the long serial chain of the updated rows) instead of lengthening the classify launch.  Of the three
@@ -364,34 +379,50 @@ __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, 
 __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStore& O, const Rt& pose, const float* __restrict__ plane_depth,
                                                    int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
                                                    uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, PartitionWs ws,
-                                                   const Counters* __restrict__ cnt, int ob, int (*hist)[6]) {
+                                                   const Counters* __restrict__ cnt, int wg, int nb_oov, int (*hist)[6]) {
+    // OOV_PER_WG blocks of 256 slots per workgroup (fewer arrivals at the end of the launch)
+    __shared__ int h2[OOV_PER_WG][4][2];
     const int wv = threadIdx.x >> 6;
-    int cls = 7;
-    const long long phys = (long long)cnt->oov_head + (long long)ob * blockDim.x + threadIdx.x;
-    if (phys < cnt->oov_tail && O.live[phys]) {
-        cls = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
-        state_oov[phys] = (uint8_t)cls;
+    const long long head = cnt->oov_head, tail = cnt->oov_tail;
+    int cls[OOV_PER_WG];
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) {
+        const long long phys = head + ((long long)wg * OOV_PER_WG + j) * blockDim.x + threadIdx.x;
+        cls[j] = 7;
+        if (phys < tail && O.live[phys]) {
+            cls[j] = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+            state_oov[phys] = (uint8_t)cls[j];
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 3; c += 2) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+    for (int j = 0; j < OOV_PER_WG; j++) {
+        const int k0 = __popcll(__ballot(cls[j] == 0)), k2 = __popcll(__ballot(cls[j] == 2));
+        if (lane() == 0) { h2[j][wv][0] = k0; h2[j][wv][1] = k2; }
+    }
+    (void)hist;
     __syncthreads();
-    if (threadIdx.x == 0 || threadIdx.x == 2) {
-        const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
-        if (threadIdx.x == 0) bc_oov[ob] = k;
-        if (k) {
-            atomicAdd(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + (threadIdx.x == 0 ? 6 : 7)], k);
-            if (threadIdx.x == 0) atomicAdd(&ws.sup_oov[ob / PART_GROUP], k);
+    if (threadIdx.x < 2 * OOV_PER_WG) {
+        const int j = threadIdx.x >> 1, which = threadIdx.x & 1, ob = wg * OOV_PER_WG + j;
+        const uint32_t k = h2[j][0][which] + h2[j][1][which] + h2[j][2][which] + h2[j][3][which];
+        if (ob < nb_oov) {
+            if (which == 0) bc_oov[ob] = k;
+            if (k) {
+                atomicAdd(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + 6 + which], k);
+                if (which == 0) atomicAdd(&ws.sup_oov[ob / PART_GROUP], k);
+            }
         }
     }
 }
 // ---- update ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
-                                           int n_visible, const unsigned long long* __restrict__ best,
-                                           const uint8_t* __restrict__ matched, int S, Counters* cnt, int f) {
-    if (f >= S) return;
-    if (!matched[f] || best[f] == SSF_NO_MATCH) return;
+// returns the model row it rewrote (-1 if none) and the row's new position and confidence
+__device__ __forceinline__ long long update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
+                                                int n_visible, const unsigned long long* __restrict__ best,
+                                                const uint8_t* __restrict__ matched, int S, Counters* cnt, int f,
+                                                V3& new_pos, float& new_conf) {
+    if (f >= S) return -1;
+    if (!matched[f] || best[f] == SSF_NO_MATCH) return -1;
     const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
-    if (local < 0 || local >= n_visible) return;
+    if (local < 0 || local >= n_visible) return -1;
     const size_t m = (size_t)local;
     const M3 R = pose.R; const V3 t = pose.t;
     const V3 model_position = ld3(M.pos, m);
@@ -429,6 +460,8 @@ __device__ __forceinline__ void update_one(SurfelSoA M, SurfelSoA F, Rt pose, in
     M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
     M.stamps[2 * m + 1] = stamp;
     atomicAdd(&cnt->n_updated, 1);
+    new_pos = fused_position; new_conf = m_conf + f_conf;
+    return local;
 }
 
 // spatial-tile owner of a frame supersurfel (multi-GPU sharding)
@@ -464,10 +497,14 @@ __device__ __forceinline__ bool insert_flag(const SurfelSoA& F, int f, int S, co
                                             int rank, int nranks, float tile) {
     return f < S && (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
 }
+struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
 __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, const uint8_t* __restrict__ matched,
                                              int S, int capacity, int rank, int nranks, float tile, Counters* cnt, int* wave_tot,
-                                             int chunk, int nchunks) {
+                                             int chunk, int nchunks, const ClassifyArgs& ca, uint8_t* __restrict__ state_vis,
+                                             PartitionWs ws) {
     __shared__ int s_before[4];
+    __shared__ uint32_t s_cls[2][3];               // states of the rows inserted here, by partition group (a chunk spans at most two)
+    if (threadIdx.x < 6) s_cls[threadIdx.x / 3][threadIdx.x % 3] = 0u;
     const int base = cnt->n_visible, base_total = cnt->n_model;
     int mine = 0;
     for (int c = 0; c < chunk; c++) mine += insert_flag(F, c * 256 + (int)threadIdx.x, S, matched, pose, rank, nranks, tile) ? 1 : 0;
@@ -483,9 +520,12 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
     int total;
     const int r = block_rank_1024(flag, wave_tot, total);
     const int k = base + before + r;
+    const int g_first = ((base + before) >> 8) / PART_GROUP;        // partition group of the chunk's first row
     if (flag && base_total + before + r < capacity) {
-        st3(M.pos, k, add(m3_mulv(R, ld3(F.pos, f)), t));
-        M.conf[k] = F.conf[f];
+        const V3 new_pos = add(m3_mulv(R, ld3(F.pos, f)), t);
+        const float new_conf = F.conf[f];
+        st3(M.pos, k, new_pos);
+        M.conf[k] = new_conf;
         st3(M.col, k, ld3(F.col, f));
         st3(M.lab, k, ld3(F.lab, f));
         M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
@@ -494,26 +534,125 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
         st3(M.r1, k, row_mul(ld3(F.r1, f), Rt_));
         st3(M.r2, k, row_mul(ld3(F.r2, f), Rt_));
         st6(M.shape, k, rot_sym(R, ld6(F.shape, f)));
+        // classification (class C) of the row just written, for the partition
+        const int st = classify_values(ca.cam, new_conf, stamp, new_pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh,
+                                       ca.zmin, ca.zmax);
+        if (st == 2) M.conf[k] = -1.0f;
+        state_vis[k] = (uint8_t)st;
+        atomicAdd(&s_cls[(k >> 8) / PART_GROUP - g_first][st], 1u);
     }
-    if (chunk == nchunks - 1 && threadIdx.x == 0) cnt->n_inserted = min(base_total + before + total, capacity) - base_total;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int seg = threadIdx.x / 3, st = threadIdx.x % 3;
+        const uint32_t n = s_cls[seg][st];
+        if (n) {
+            atomicAdd(&ws.sup_vis[(g_first + seg) * 6 + 3 + st], n);
+            atomicAdd(&ws.tot[(chunk & (PART_REPLICAS - 1)) * 8 + 3 + st], n);
+        }
+    }
+    if (chunk == nchunks - 1 && threadIdx.x == 0)
+        __hip_atomic_store(&cnt->n_inserted, min(base_total + before + total, capacity) - base_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
-// update (blocks 0 .. nchunks-1, one frame supersurfel per thread) | insert (blocks nchunks .. 2 nchunks-1, one chunk
-// each) | classification of the out-of-view rows (the remaining blocks)
+// The fuse launch.  Blocks, in this order:
+//   update     nchunks blocks, one frame supersurfel per thread (updateModel); the thread also classifies the row
+//              it rewrote
+//   insert     nchunks blocks, one chunk each (insertSupersurfels); classifies the rows it inserts
+//   classify   nb_vis blocks of 256 old visible rows (filterModel), minus the rows the update rewrites (a row knows
+//              from cand / best whether it won its frame supersurfel)
+//   classify   the remaining blocks: 256 slots of the out-of-view span each
+// Every classification goes to state_vis / state_oov and, as counts, to the sums of the partition (PartitionWs:
+// per group of PART_GROUP blocks, and replicated frame totals) with atomics.  The LAST block to finish turns the
+// totals into the frame's counters and publishes them; the move kernel that follows derives its prefixes from the
+// group sums and the states themselves.  No scan kernel, no separate classify kernel.
+__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
-                                                       const uint8_t* __restrict__ matched, int S, int do_update, int capacity,
-                                                       int rank, int nranks, float tile, Counters* cnt, int nchunks, OovStore O,
-                                                       ClassifyArgs ca, uint8_t* __restrict__ state_oov,
-                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws) {
+                                                       const uint8_t* __restrict__ matched, const int32_t* __restrict__ cand, int S,
+                                                       int do_update, int capacity, int rank, int nranks, float tile, Counters* cnt,
+                                                       int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
+                                                       uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
+                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
-    if ((int)blockIdx.x >= 2 * nchunks)
+    __shared__ int s_last;
+    __shared__ uint32_t tot[8];
+    const int b = blockIdx.x;
+    if (b >= 2 * nchunks + nb_vis)
         classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
-                           ws, cnt, blockIdx.x - 2 * nchunks, hist);
-    else if ((int)blockIdx.x >= nchunks)
-        insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, blockIdx.x - nchunks, nchunks);
-    else if (do_update) update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, blockIdx.x * blockDim.x + threadIdx.x);
+                           ws, cnt, b - 2 * nchunks - nb_vis, nb_oov, hist);
+    else if (b >= 2 * nchunks) {
+        const int vb = b - 2 * nchunks, i = vb * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
+        int cls = 7;
+        if (i < n_visible) {
+            const int f = cand[i];
+            const bool rewritten = do_update && f >= 0 && (uint32_t)(best[f] & 0xFFFFFFFFull) == (uint32_t)(id_offset + i);
+            if (!rewritten) {
+                cls = classify_row(ca.cam, M, (size_t)i, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax);
+                state_vis[i] = (uint8_t)cls;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+            if (k) {
+                atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + threadIdx.x], k);
+                atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
+            }
+        }
+    } else if (b >= nchunks)
+        insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, b - nchunks, nchunks, ca, state_vis, ws);
+    else if (do_update) {
+        V3 new_pos; float new_conf;
+        const long long m = update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * blockDim.x + threadIdx.x,
+                                       new_pos, new_conf);
+        if (m >= 0) {
+            // (classified from the values just stored: the row is not read back; it was seen in this frame)
+            const int st = classify_values(ca.cam, new_conf, stamp, new_pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh,
+                                           ca.zmin, ca.zmax);
+            if (st == 2) M.conf[m] = -1.0f;
+            state_vis[m] = (uint8_t)st;
+            const int vb = (int)(m >> 8);
+            atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + st], 1u);
+            atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
+        }
+    }
+    // the atomics above (and cnt->n_updated / n_inserted) are device-scope, complete (vmcnt(0) + barrier) before this
+    // block counts its arrival; the last block reads them back with device-scope atomic loads (same protocol as the
+    // ICP record)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = grid_arrive(ws.ticket);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 8) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < PART_REPLICAS; r++) v += __hip_atomic_load(&ws.tot[r * 8 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) {                      // (off the publishing wave's path)
+        for (int i = threadIdx.x - 64; i < ws.words; i += blockDim.x - 64) ws.other[i] = 0u;      // the other set: next frame's sums
+    } else if (threadIdx.x == 0) {
+        Counters c_in = *cnt;
+        c_in.n_inserted = __hip_atomic_load(&cnt->n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written in this launch
+        c_in.n_updated = __hip_atomic_load(&cnt->n_updated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
+        const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
+        Counters c = c_in;
+        c.n_model = c_in.n_model + c_in.n_inserted;   // the insertion reports its rows in n_inserted only
+        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
+        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
+        c.mv_nv = c_in.n_visible; c.mv_a0 = a0; c.mv_b0 = b0;
+        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
+        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
+        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
+        // the frame's counters are final here: publish them now, the host overlaps its next launches
+        // with the row moves that follow in the stream
+        publish_counters_value(cnt, c, 1, mb, seq);
+    }
 }
 
 // first frame: thrust::copy(frame -> model), supersurfel_fusion.cu:477-483 (owned rows only)
@@ -543,78 +682,7 @@ __global__ __launch_bounds__(1024) void k_first_frame(SurfelSoA M, SurfelSoA F, 
     }
 }
 
-// ---- classify + stable partition over the model store (see OovStore in ssf_device.hpp) ---------------------------
-// The partition needs, per row that moves, the number of rows of its class before it, and per class the frame total.
-// There is no scan kernel: every block leaves its class histogram (bc_vis / bc_oov), adds it to the sum of its group
-// of PART_GROUP blocks and to the (replicated) frame totals with atomics; the LAST block of k_classify to arrive
-// turns the totals into the frame's counters and publishes them; a block of k_move_rows then gets its prefix from the
-// sums of the groups before its own and the histograms of the blocks before it inside its group (a few hundred
-// words from L2).  The sums live in one of two sets (PartitionWs, frame parity); the publishing block clears the
-// other set for the next frame.
-__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
-// 256 rows of the visible array per block (old visible rows = class A, this frame's insertions = class C; 6-bin
-// histogram A0 A1 A2 C0 C1 C2)
-__global__ __launch_bounds__(256) void k_classify(Cam cam, SurfelSoA V, Rt pose, const float* __restrict__ plane_depth,
-                                                  int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
-                                                  uint8_t* __restrict__ state_vis, uint32_t* __restrict__ bc_vis,
-                                                  Counters* cnt, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
-    __shared__ int hist[4][6];
-    __shared__ int s_last;
-    __shared__ uint32_t tot[8];
-    const int wv = threadIdx.x >> 6;
-    int cls = 7;                                   // 7 = no row
-    const int nv = cnt->n_visible, n_rows = nv + cnt->n_inserted;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n_rows) {
-        const int st = classify_row(cam, V, idx, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
-        state_vis[idx] = (uint8_t)st;
-        cls = (idx < nv ? 0 : 3) + st;
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++) { const int k = __popcll(__ballot(cls == c)); if (lane() == 0) hist[wv][c] = k; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
-        bc_vis[6 * blockIdx.x + threadIdx.x] = k;
-        if (k) {
-            atomicAdd(&ws.sup_vis[(blockIdx.x / PART_GROUP) * 6 + threadIdx.x], k);
-            atomicAdd(&ws.tot[(blockIdx.x & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
-        }
-    }
-    // the atomics above are device-scope RMWs, complete (vmcnt(0) + barrier) before this block counts its arrival;
-    // the last block reads the totals back with device-scope atomic loads (same protocol as the ICP record)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = grid_arrive(ws.ticket);
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x < 8) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int r = 0; r < PART_REPLICAS; r++) v += __hip_atomic_load(&ws.tot[r * 8 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tot[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) {                      // (off the publishing wave's path)
-        for (int i = threadIdx.x - 64; i < ws.words; i += blockDim.x - 64) ws.other[i] = 0u;      // the other set: next frame's sums
-    } else if (threadIdx.x == 0) {
-        const Counters c_in = *cnt;
-        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
-        const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
-        Counters c = c_in;
-        c.n_model = c_in.n_model + c_in.n_inserted;   // k_update_insert reports its insertions in n_inserted only
-        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
-        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
-        c.mv_nv = nv; c.mv_a0 = a0; c.mv_b0 = b0;
-        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
-        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
-        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
-        // the frame's counters are final here: publish them now, the host overlaps its next launches
-        // with the row moves that follow in the stream
-        publish_counters_value(cnt, c, 1, mb, seq);
-    }
-}
-
+// ---- stable partition over the model store (see OovStore in ssf_device.hpp) ----------------------------------------
 // exclusive scan of NC counters per block over nblocks blocks by one 1024-thread workgroup (one block per thread
 // and round: coalesced loads); totals -> tot[NC].  (Out-of-view store compaction only.)
 template <int NC>
@@ -682,7 +750,7 @@ struct NextIcp {
 // the order of accumulation does not matter), and publish it like k_icp does.
 template <bool ICP>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
-                                                   const uint8_t* __restrict__ state_oov, const uint32_t* __restrict__ bc_vis,
+                                                   const uint8_t* __restrict__ state_oov,
                                                    const uint32_t* __restrict__ bc_oov, PartitionWs ws,
                                                    const Counters* __restrict__ cnt, int nb_vis, NextIcp nx) {
     __shared__ int hist[4][6];
@@ -698,13 +766,43 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         const int nv = cnt->mv_nv, n_rows = nv + cnt->last[3];            // last[3] = insertions of this frame (published)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
-        // prefix: group sums before this block's group, then the block histograms before it inside the group
-        // (both 6 counters wide, so word w belongs to class w % 6)
-        const int g0 = (int)(blockIdx.x / PART_GROUP), ng = 6 * g0, nw = ng + 6 * ((int)blockIdx.x - g0 * PART_GROUP);
+        // prefix: the sums of the groups before this block's group (6 counters wide: word w belongs to class w % 6),
+        // then the states of the rows of the earlier blocks of its own group, 16 per load
+        const int g0 = (int)(blockIdx.x / PART_GROUP), ng = 6 * g0;
+        const int row0 = g0 * PART_GROUP * 256, n16 = 16 * ((int)blockIdx.x - g0 * PART_GROUP);
         __syncthreads();
-        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
-            const uint32_t v = w < ng ? ws.sup_vis[w] : bc_vis[6 * (size_t)(g0 * PART_GROUP) + (w - ng)];
+        for (int w = threadIdx.x; w < ng; w += blockDim.x) {
+            const uint32_t v = ws.sup_vis[w];
             if (v) atomicAdd(&base[w % 6], v);
+        }
+        uint32_t pa0 = 0, pa1 = 0, pc0 = 0, pc1 = 0;
+        for (int q = threadIdx.x; q < n16; q += blockDim.x) {
+            const int r0 = row0 + 16 * q;
+            if (r0 < n_rows) {
+                const uint4 sv = *reinterpret_cast<const uint4*>(state_vis + r0);
+                const uint32_t wd[4] = {sv.x, sv.y, sv.z, sv.w};
+                uint32_t a0 = 0, a1 = 0, c0 = 0, c1 = 0;         // the classes that move
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int rr = r0 + j;
+                    const uint32_t stt = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    const bool in = rr < n_rows, old = rr < nv;
+                    a0 += (in && old && stt == 0u) ? 1u : 0u; a1 += (in && old && stt == 1u) ? 1u : 0u;
+                    c0 += (in && !old && stt == 0u) ? 1u : 0u; c1 += (in && !old && stt == 1u) ? 1u : 0u;
+                }
+                pa0 += a0; pa1 += a1; pc0 += c0; pc1 += c1;
+            }
+        }
+        // (one LDS atomic per wave and class: 256 lanes on four addresses would serialise)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pa0 += __shfl_xor(pa0, o, 64); pa1 += __shfl_xor(pa1, o, 64); pc0 += __shfl_xor(pc0, o, 64); pc1 += __shfl_xor(pc1, o, 64);
+        }
+        if (lane() == 0) {
+            if (pa0) atomicAdd(&base[0], pa0);
+            if (pa1) atomicAdd(&base[1], pa1);
+            if (pc0) atomicAdd(&base[3], pc0);
+            if (pc1) atomicAdd(&base[4], pc1);
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) {
@@ -938,50 +1036,46 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
-                  unsigned long long* best, uint8_t* matched, int S) {
+                  unsigned long long* best, uint8_t* matched, int32_t* cand, int S) {
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
-                       pose, zmin, zmax, id_offset, best, matched);
+                       pose, zmin, zmax, id_offset, best, matched, cand);
 }
-void launch_update_insert(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
-                          int n_visible, const unsigned long long* best, const uint8_t* matched, int S, int do_update,
-                          int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
-                          int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                          uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws) {
+void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
+                 int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
+                 int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
+                 int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, Mailbox* mb, unsigned long long seq) {
     ScopedKernel sk("update_insert", st);
-    const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256;
+    const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256, nb_vis = (n_visible + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
-    hipLaunchKernelGGL(k_update_insert, dim3(2 * nchunks + nb_oov), dim3(256), 0, st, model, frame, pose, stamp, id_offset,
-                       n_visible, best, matched, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, oov, ca, state_oov, bc_oov, ws);
+    hipLaunchKernelGGL(k_update_insert, dim3(2 * nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
+                       frame, pose, stamp, id_offset,
+                       n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, nb_vis, nb_oov, oov, ca,
+                       state_vis, state_oov, bc_oov, ws, mb, seq);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {
     ScopedKernel sk("first_frame", st);
     hipLaunchKernelGGL(k_first_frame, dim3(1), dim3(1024), 0, st, model, frame, pose, S, capacity, rank, nranks, tile, cnt);
 }
-void launch_classify_reorder(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper,
-                             int span_upper, Rt pose, const float* plane_depth, int stamp, int delta_t, float conf_thresh,
-                             float zmin, float zmax, uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_vis,
-                             uint32_t* bc_oov, const PartitionWs& ws, Counters* cnt, Mailbox* mb, unsigned long long seq,
-                             const NextFrameIcp* next) {
+void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
+                      const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
+                      const Counters* cnt, Mailbox* mb, const NextFrameIcp* next) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
-    // (the out-of-view rows were classified inside the update/insert launch)
-    { ScopedKernel sk("classify", st);
-      hipLaunchKernelGGL(k_classify, dim3(nb_vis), dim3(256), 0, st, cam, vis_src, pose, plane_depth, stamp, delta_t,
-                         conf_thresh, zmin, zmax, state_vis, bc_vis, cnt, ws, mb, seq); }
     NextIcp nx{};
     if (next) {
         nx.cam = cam; nx.pix2 = next->pix2; nx.fpack = next->fpack; nx.T = next->T; nx.replicas = next->replicas;
         nx.ticket = next->ticket; nx.sums = next->sums; nx.mb = mb; nx.seq = next->seq;
         ScopedKernel sk("reorder_move_icp", st);
         hipLaunchKernelGGL(k_move_rows<true>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_vis, bc_oov, ws, cnt, nb_vis, nx);
+                           bc_oov, ws, cnt, nb_vis, nx);
     } else {
         ScopedKernel sk("reorder_move", st);
         hipLaunchKernelGGL(k_move_rows<false>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_vis, bc_oov, ws, cnt, nb_vis, nx);
+                           bc_oov, ws, cnt, nb_vis, nx);
     }
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
