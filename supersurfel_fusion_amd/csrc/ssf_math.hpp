@@ -127,38 +127,39 @@ SSF_HD float exp_neg_spec(float x) {
 // sRGB(0..255) -> CIE Lab, vector_math.cuh:566-585
 SSF_HD float srgb_expand(float c) { return (c > 0.04045f) ? pow24_spec((c + 0.055f) / 1.055f) : c / 12.92f; }
 SSF_HD float lab_f(float t) { return (t > 0.008856f) ? cbrtf_spec(t) : 7.787f * t + 16.0f / 116.0f; }
+// (in pieces, so that a kernel can spread the three channels over lanes: update_group in ssf_track_fuse.hip)
+SSF_HD V3 xyz_from_linear(float r, float g, float b) {
+    return v3(((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f, ((r * 0.2126f + g * 0.7152f) + b * 0.0722f),
+              ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f);
+}
+SSF_HD V3 lab_from_f(float x, float y, float z) { return v3(116.0f * y - 16.0f, 500.0f * (x - y), 200.0f * (y - z)); }
 SSF_HD V3 rgb_to_lab(V3 c) {
-    float r = srgb_expand(c.x / 255.0f), g = srgb_expand(c.y / 255.0f), b = srgb_expand(c.z / 255.0f);
-    float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
-    float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
-    float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;
-    x = lab_f(x); y = lab_f(y); z = lab_f(z);
-    return v3(116.0f * y - 16.0f, 500.0f * (x - y), 200.0f * (y - z));
+    const V3 q = xyz_from_linear(srgb_expand(c.x / 255.0f), srgb_expand(c.y / 255.0f), srgb_expand(c.z / 255.0f));
+    return lab_from_f(lab_f(q.x), lab_f(q.y), lab_f(q.z));
 }
 // same conversion for 8-bit colours: the gamma expansion of the 256 possible channel values comes
 // from a table built on the host with srgb_expand itself (identical bits), the rest is unchanged
 SSF_HD V3 rgb8_to_lab(const float* __restrict__ expand_lut, unsigned r8, unsigned g8, unsigned b8) {
-    const float r = expand_lut[r8], g = expand_lut[g8], b = expand_lut[b8];
-    float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
-    float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
-    float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;
-    x = lab_f(x); y = lab_f(y); z = lab_f(z);
-    return v3(116.0f * y - 16.0f, 500.0f * (x - y), 200.0f * (y - z));
+    const V3 q = xyz_from_linear(expand_lut[r8], expand_lut[g8], expand_lut[b8]);
+    return lab_from_f(lab_f(q.x), lab_f(q.y), lab_f(q.z));
 }
 // CIE Lab -> sRGB(0..255), vector_math.cuh:543-564 (its two double literals promote g and b)
 SSF_HD float lab_finv(float t) { float t3 = (t * t) * t; return (t3 > 0.008856f) ? t3 : (t - 16.0f / 116.0f) / 7.787f; }
 SSF_HD float srgb_compress(float c) { return (c > 0.0031308f) ? (1.055f * pow_inv24_spec(c) - 0.055f) : 12.92f * c; }
-SSF_HD V3 lab_to_rgb(V3 c) {
+SSF_HD V3 lab_to_linear_rgb(V3 c) {
     float y = (c.x + 16.0f) / 116.0f;
     float x = c.y / 500.0f + y;
     float z = y - c.z / 200.0f;
     x = 0.95047f * lab_finv(x); y = 1.0f * lab_finv(y); z = 1.08883f * lab_finv(z);
-    float r = (x * 3.2406f - y * 1.5372f) - z * 0.4986f;
-    float g = (float)(((double)(-x * 0.9689f) + (double)y * 1.8758) + (double)(z * 0.0415f));
-    float b = (float)((double)(x * 0.0557f - y * 0.2040f) + (double)z * 1.0570);
-    r = srgb_compress(r); g = srgb_compress(g); b = srgb_compress(b);
-    return v3(fmaxf(0.0f, fminf(1.0f, r)) * 255.0f, fmaxf(0.0f, fminf(1.0f, g)) * 255.0f,
-              fmaxf(0.0f, fminf(1.0f, b)) * 255.0f);
+    const float r = (x * 3.2406f - y * 1.5372f) - z * 0.4986f;
+    const float g = (float)(((double)(-x * 0.9689f) + (double)y * 1.8758) + (double)(z * 0.0415f));
+    const float b = (float)((double)(x * 0.0557f - y * 0.2040f) + (double)z * 1.0570);
+    return v3(r, g, b);
+}
+SSF_HD float srgb_to_255(float lin) { return fmaxf(0.0f, fminf(1.0f, srgb_compress(lin))) * 255.0f; }
+SSF_HD V3 lab_to_rgb(V3 c) {
+    const V3 l = lab_to_linear_rgb(c);
+    return v3(srgb_to_255(l.x), srgb_to_255(l.y), srgb_to_255(l.z));
 }
 
 // principal frame by repeated squaring, supersurfel_fusion_kernels.cu:48-111
@@ -174,17 +175,22 @@ SSF_HD float axis_eigenvalue(Sym3 A, V3 v) {
     if (v.y == emax) return ((A.xy * v.x + A.yy * v.y) + A.yz * v.z) / v.y;
     return ((A.xz * v.x + A.yz * v.y) + A.zz * v.z) / v.z;
 }
-SSF_HD void principal_frame(Sym3 A, M3& vecs, V3& vals) {
-    Sym3 P = sym_div(A, sym_trace(A));
-    Sym3 Q = sym3(1.f - P.xx, -P.xy, -P.xz, 1.f - P.yy, -P.yz, 1.f - P.zz);
-    for (int i = 0; i < 10; ++i) {
-        P = sym_square(P); P = sym_div(P, sym_trace(P));
-        Q = sym_square(Q); Q = sym_div(Q, sym_trace(Q));
-    }
-    vecs.r0 = dominant_column(P);
-    vecs.r2 = dominant_column(Q);
+// dominant eigenvector of X (trace 1) by ten squarings
+SSF_HD V3 principal_power(Sym3 X) {
+    for (int i = 0; i < 10; ++i) { X = sym_square(X); X = sym_div(X, sym_trace(X)); }
+    return dominant_column(X);
+}
+SSF_HD Sym3 principal_start(Sym3 A, bool smallest) {       // the two start matrices: A / tr A, and I - A / tr A
+    const Sym3 P = sym_div(A, sym_trace(A));
+    return smallest ? sym3(1.f - P.xx, -P.xy, -P.xz, 1.f - P.yy, -P.yz, 1.f - P.zz) : P;
+}
+SSF_HD void principal_finish(Sym3 A, V3 r0, V3 r2, M3& vecs, V3& vals) {
+    vecs.r0 = r0; vecs.r2 = r2;
     vecs.r1 = cross3(vecs.r2, vecs.r0);
     vals = v3(axis_eigenvalue(A, vecs.r0), axis_eigenvalue(A, vecs.r1), axis_eigenvalue(A, vecs.r2));
+}
+SSF_HD void principal_frame(Sym3 A, M3& vecs, V3& vals) {
+    principal_finish(A, principal_power(principal_start(A, false)), principal_power(principal_start(A, true)), vecs, vals);
 }
 
 // 3x3 plane normal equations, TPS_RGBD_kernels.cu:27-59 (its guard only rejects -inf; kept)

@@ -414,54 +414,90 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
     }
 }
 // ---- update ----------------------------------------------------------------------------------------
-// returns the model row it rewrote (-1 if none) and the row's new position and confidence
-__device__ __forceinline__ long long update_one(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
-                                                int n_visible, const unsigned long long* __restrict__ best,
-                                                const uint8_t* __restrict__ matched, int S, Counters* cnt, int f,
-                                                V3& new_pos, float& new_conf) {
-    if (f >= S) return -1;
-    if (!matched[f] || best[f] == SSF_NO_MATCH) return -1;
+// updateModel (supersurfel_fusion_kernels.cu:240-346) for UPD_PER_WG frame supersurfels per workgroup.  One thread
+// per supersurfel spent 13 us in a serial chain of ~5000 instructions, most of them the double-precision roots of
+// the two colour conversions and the twenty normalised squarings of the principal frame.  Those pieces are
+// independent, so they are spread over lanes -- identical arithmetic, only who computes what differs:
+//   wave 0      two lanes per supersurfel: fused shape and position (both lanes), then lane 0 iterates towards the
+//               largest axis, lane 1 towards the smallest; lane 0 stores geometry and classifies the row
+//   waves 1, 2  four lanes per supersurfel: one colour channel each (Lab -> sRGB compress, sRGB expand -> Lab f),
+//               exchanged with shuffles inside the group; the first lane stores colour and Lab
+// (the two kinds of work sit in different waves, so neither waits for the other's instruction stream)
+#define UPD_PER_WG 32
+struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
+__device__ __forceinline__ float pick3(const V3& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+__device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset, int n_visible,
+                                             const unsigned long long* __restrict__ best, const uint8_t* __restrict__ matched,
+                                             int S, Counters* cnt, int f0, const ClassifyArgs& ca, uint8_t* __restrict__ state_vis,
+                                             PartitionWs ws) {
+    const int wv = threadIdx.x >> 6, l = lane();
+    if (wv == 3) return;
+    const int f = wv == 0 ? f0 + (l >> 1) : f0 + (wv - 1) * 16 + (l >> 2);
+    if (f >= S) return;                                   // (uniform over a supersurfel's lanes, like every test below)
+    if (!matched[f] || best[f] == SSF_NO_MATCH) return;
     const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
-    if (local < 0 || local >= n_visible) return -1;
+    if (local < 0 || local >= n_visible) return;
     const size_t m = (size_t)local;
-    const M3 R = pose.R; const V3 t = pose.t;
-    const V3 model_position = ld3(M.pos, m);
-    const V3 frame_position = add(m3_mulv(R, ld3(F.pos, f)), t);
-    const Sym3 frame_shape = rot_sym(R, ld6(F.shape, f));
-    const Sym3 model_shape = ld6(M.shape, m);
-    const V3 frame_lab = ld3(F.lab, f), model_lab = ld3(M.lab, m);
     const float m_conf = M.conf[m], f_conf = F.conf[f];
     const float ratio = 1.0f / (m_conf + f_conf);
-    const V3 fused_color = lab_to_rgb(scale(ratio, add(scale(f_conf, frame_lab), scale(m_conf, model_lab))));
-    Sym3 f1, m1, fused_shape, fused_1;
-    V3 fused_position;
-    const float w = ratio * f_conf;
-    bool info = false;
-    if (sym_inverse(frame_shape, f1) && sym_inverse(model_shape, m1)) {
-        fused_1 = sym_add(sym_scale(w, f1), sym_scale(1.0f - w, m1));
-        if (sym_inverse(fused_1, fused_shape)) {
-            fused_position = sym_mul(fused_shape, add(sym_mul(sym_scale(w, f1), frame_position),
-                                                      sym_mul(sym_scale(1.0f - w, m1), model_position)));
-            info = true;
+    if (wv == 0) {
+        const int which = l & 1;
+        const M3 R = pose.R; const V3 t = pose.t;
+        const V3 model_position = ld3(M.pos, m);
+        const V3 frame_position = add(m3_mulv(R, ld3(F.pos, f)), t);
+        const Sym3 frame_shape = rot_sym(R, ld6(F.shape, f));
+        const Sym3 model_shape = ld6(M.shape, m);
+        Sym3 f1, m1, fused_shape, fused_1;
+        V3 fused_position;
+        const float w = ratio * f_conf;
+        bool info = false;
+        if (sym_inverse(frame_shape, f1) && sym_inverse(model_shape, m1)) {
+            fused_1 = sym_add(sym_scale(w, f1), sym_scale(1.0f - w, m1));
+            if (sym_inverse(fused_1, fused_shape)) {
+                fused_position = sym_mul(fused_shape, add(sym_mul(sym_scale(w, f1), frame_position),
+                                                          sym_mul(sym_scale(1.0f - w, m1), model_position)));
+                info = true;
+            }
         }
+        if (!info) {
+            fused_shape = sym_scale(ratio, sym_add(sym_scale(f_conf, frame_shape), sym_scale(m_conf, model_shape)));
+            fused_position = scale(ratio, add(scale(f_conf, frame_position), scale(m_conf, model_position)));
+        }
+        const V3 axis = principal_power(principal_start(fused_shape, which == 1));
+        const int l0 = l & ~1;
+        const V3 r0 = v3(__shfl(axis.x, l0, 64), __shfl(axis.y, l0, 64), __shfl(axis.z, l0, 64));
+        const V3 r2 = v3(__shfl(axis.x, l0 + 1, 64), __shfl(axis.y, l0 + 1, 64), __shfl(axis.z, l0 + 1, 64));
+        if (which == 0) {
+            M3 vecs; V3 vals;
+            principal_finish(fused_shape, r0, r2, vecs, vals);
+            st3(M.pos, m, fused_position);
+            M.conf[m] = m_conf + f_conf;
+            st6(M.shape, m, fused_shape);
+            st3(M.r0, m, vecs.r0); st3(M.r1, m, vecs.r1); st3(M.r2, m, vecs.r2);
+            M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
+            M.stamps[2 * m + 1] = stamp;
+            atomicAdd(&cnt->n_updated, 1);
+            // classification (from the values just stored: the row is not read back; it was seen in this frame)
+            const int st = classify_values(ca.cam, m_conf + f_conf, stamp, fused_position, pose, ca.plane_depth, stamp, ca.delta_t,
+                                           ca.conf_thresh, ca.zmin, ca.zmax);
+            if (st == 2) M.conf[m] = -1.0f;
+            state_vis[m] = (uint8_t)st;
+            const int vb = (int)(m >> 8);
+            atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + st], 1u);
+            atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
+        }
+    } else {
+        const int ch = min(l & 3, 2), l0 = l & ~3;        // (the fourth lane repeats the third channel; its results are unused)
+        const V3 frame_lab = ld3(F.lab, f), model_lab = ld3(M.lab, m);
+        const V3 lin = lab_to_linear_rgb(scale(ratio, add(scale(f_conf, frame_lab), scale(m_conf, model_lab))));
+        const float c255 = srgb_to_255(pick3(lin, ch));
+        const V3 fused_color = v3(__shfl(c255, l0, 64), __shfl(c255, l0 + 1, 64), __shfl(c255, l0 + 2, 64));
+        const float e = srgb_expand(c255 / 255.0f);
+        const V3 q = xyz_from_linear(__shfl(e, l0, 64), __shfl(e, l0 + 1, 64), __shfl(e, l0 + 2, 64));
+        const float fq = lab_f(pick3(q, ch));
+        const V3 lab = lab_from_f(__shfl(fq, l0, 64), __shfl(fq, l0 + 1, 64), __shfl(fq, l0 + 2, 64));
+        if ((l & 3) == 0) { st3(M.col, m, fused_color); st3(M.lab, m, lab); }
     }
-    if (!info) {
-        fused_shape = sym_scale(ratio, sym_add(sym_scale(f_conf, frame_shape), sym_scale(m_conf, model_shape)));
-        fused_position = scale(ratio, add(scale(f_conf, frame_position), scale(m_conf, model_position)));
-    }
-    M3 vecs; V3 vals;
-    principal_frame(fused_shape, vecs, vals);
-    st3(M.pos, m, fused_position);
-    M.conf[m] = m_conf + f_conf;
-    st6(M.shape, m, fused_shape);
-    st3(M.r0, m, vecs.r0); st3(M.r1, m, vecs.r1); st3(M.r2, m, vecs.r2);
-    st3(M.col, m, fused_color);
-    st3(M.lab, m, rgb_to_lab(fused_color));
-    M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
-    M.stamps[2 * m + 1] = stamp;
-    atomicAdd(&cnt->n_updated, 1);
-    new_pos = fused_position; new_conf = m_conf + f_conf;
-    return local;
 }
 
 // spatial-tile owner of a frame supersurfel (multi-GPU sharding)
@@ -497,7 +533,6 @@ __device__ __forceinline__ bool insert_flag(const SurfelSoA& F, int f, int S, co
                                             int rank, int nranks, float tile) {
     return f < S && (F.conf[f] > 0.0f) && !matched[f] && shard_owner(F, f, pose, nranks, tile) == rank;
 }
-struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
 __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, const uint8_t* __restrict__ matched,
                                              int S, int capacity, int rank, int nranks, float tile, Counters* cnt, int* wave_tot,
                                              int chunk, int nchunks, const ClassifyArgs& ca, uint8_t* __restrict__ state_vis,
@@ -554,8 +589,8 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
         __hip_atomic_store(&cnt->n_inserted, min(base_total + before + total, capacity) - base_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The fuse launch.  Blocks, in this order:
-//   update     nchunks blocks, one frame supersurfel per thread (updateModel); the thread also classifies the row
-//              it rewrote
+//   update     nupd blocks of UPD_PER_WG frame supersurfels (updateModel, update_group); also classifies the rows
+//              it rewrites
 //   insert     nchunks blocks, one chunk each (insertSupersurfels); classifies the rows it inserts
 //   classify   nb_vis blocks of 256 old visible rows (filterModel), minus the rows the update rewrites (a row knows
 //              from cand / best whether it won its frame supersurfel)
@@ -569,7 +604,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, const int32_t* __restrict__ cand, int S,
                                                        int do_update, int capacity, int rank, int nranks, float tile, Counters* cnt,
-                                                       int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
+                                                       int nupd, int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
                                                        uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
                                                        uint32_t* __restrict__ bc_oov, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
     __shared__ int wave_tot[16];
@@ -577,11 +612,11 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
     __shared__ int s_last;
     __shared__ uint32_t tot[8];
     const int b = blockIdx.x;
-    if (b >= 2 * nchunks + nb_vis)
+    if (b >= nupd + nchunks + nb_vis)
         classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
-                           ws, cnt, b - 2 * nchunks - nb_vis, nb_oov, hist);
-    else if (b >= 2 * nchunks) {
-        const int vb = b - 2 * nchunks, i = vb * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
+                           ws, cnt, b - nupd - nchunks - nb_vis, nb_oov, hist);
+    else if (b >= nupd + nchunks) {
+        const int vb = b - nupd - nchunks, i = vb * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
         int cls = 7;
         if (i < n_visible) {
             const int f = cand[i];
@@ -601,23 +636,10 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                 atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
             }
         }
-    } else if (b >= nchunks)
-        insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, b - nchunks, nchunks, ca, state_vis, ws);
-    else if (do_update) {
-        V3 new_pos; float new_conf;
-        const long long m = update_one(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * blockDim.x + threadIdx.x,
-                                       new_pos, new_conf);
-        if (m >= 0) {
-            // (classified from the values just stored: the row is not read back; it was seen in this frame)
-            const int st = classify_values(ca.cam, new_conf, stamp, new_pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh,
-                                           ca.zmin, ca.zmax);
-            if (st == 2) M.conf[m] = -1.0f;
-            state_vis[m] = (uint8_t)st;
-            const int vb = (int)(m >> 8);
-            atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + st], 1u);
-            atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
-        }
-    }
+    } else if (b >= nupd)
+        insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, b - nupd, nchunks, ca, state_vis, ws);
+    else if (do_update)
+        update_group(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * UPD_PER_WG, ca, state_vis, ws);
     // the atomics above (and cnt->n_updated / n_inserted) are device-scope, complete (vmcnt(0) + barrier) before this
     // block counts its arrival; the last block reads them back with device-scope atomic loads (same protocol as the
     // ICP record)
@@ -1051,9 +1073,10 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
     ScopedKernel sk("update_insert", st);
     const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256, nb_vis = (n_visible + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
-    hipLaunchKernelGGL(k_update_insert, dim3(2 * nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
+    const int nupd = (S + UPD_PER_WG - 1) / UPD_PER_WG;
+    hipLaunchKernelGGL(k_update_insert, dim3(nupd + nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
                        frame, pose, stamp, id_offset,
-                       n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nchunks, nb_vis, nb_oov, oov, ca,
+                       n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nupd, nchunks, nb_vis, nb_oov, oov, ca,
                        state_vis, state_oov, bc_oov, ws, mb, seq);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
