@@ -1075,7 +1075,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
     h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
-    bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 128);
+    bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 512);
     // working set of one frame, carved out of a slab (256 B aligned pieces); a context owns `batch` slabs
     auto carve = [&](ExtractCtx& c, char* base) -> size_t {
         size_t off = 0;
@@ -1145,7 +1145,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         (void)hipMemcpy(h->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     }
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
-    (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_cand, 0xFF, N * sizeof(int32_t), h->stream);
@@ -1676,7 +1676,7 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
-    (void)hipMemsetAsync(h->d_tickets, 0, 128 * sizeof(unsigned int), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
     (void)hipStreamSynchronize(h->stream);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 1000.0 * ms / reps;

@@ -874,19 +874,40 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
     if (ICP) {
         // (the barrier after the class histogram also ordered the zeroing of `red`)
         if (keep) icp_row(nx.cam, nx.pix2, nx.fpack, nx.T.R, nx.T.t, pos, lab, nrm, red, lane() & (ICP_SLOTS - 1), 0);
-        // only workgroups that hold rows of the new visible array take part; arrivals are counted in ROWS, and the
-        // workgroup that completes cnt->n_visible (written by the scan kernel before this launch) is the last
-        // (row counter: ticket word 65, next to the grid arrival counters of k_icp).
-        // No such rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
+        // Arrivals are counted in ROWS: the workgroup that completes cnt->n_visible (written by the fuse launch) is
+        // the last.  Two levels, as in k_icp (thousands of returning atomics on one word serialise at L2): the
+        // blocks of the visible array that hold rows at all (index < nbr) arrive at one of 64 group words packed
+        // (rows << 32 | arrivals); the last of a group (its size follows from nbr) takes the group's rows to the
+        // global row counter.  The few out-of-view blocks with rows that come back into view go there directly.
+        // No rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
         const int nkeep = __syncthreads_count(keep);
-        if (nkeep == 0) return;
+        const bool vis = (int)blockIdx.x < nb_vis;
+        const int nbr = (cnt->mv_nv + cnt->last[3] + 255) / 256;
+        if (vis ? (int)blockIdx.x >= nbr : nkeep == 0) return;
         __shared__ int s_last;
         icp_fold(red, nx.replicas);
         if (threadIdx.x == 0) {
-            const unsigned int total = (unsigned int)cnt->n_visible;
-            const unsigned int before = __hip_atomic_fetch_add(&nx.ticket[65], (unsigned int)nkeep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = before + (unsigned int)nkeep == total;
-            if (s_last) __hip_atomic_store(&nx.ticket[65], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned int rows = (unsigned int)nkeep;
+            bool report = true;
+            if (vis) {
+                const unsigned int g = blockIdx.x & 63u, in_group = ((unsigned int)nbr - g + 63u) / 64u;
+                unsigned long long* gw = reinterpret_cast<unsigned long long*>(nx.ticket + 128) + g;
+                const unsigned long long before = __hip_atomic_fetch_add(gw, ((unsigned long long)rows << 32) | 1ull, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT);
+                report = (unsigned int)(before & 0xFFFFFFFFull) == in_group - 1;
+                if (report) {
+                    rows += (unsigned int)(before >> 32);
+                    __hip_atomic_store(gw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            int last = 0;
+            if (report) {
+                const unsigned int total = (unsigned int)cnt->n_visible;
+                const unsigned int before = rows ? __hip_atomic_fetch_add(&nx.ticket[65], rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                last = rows != 0u && before + rows == total;
+                if (last) __hip_atomic_store(&nx.ticket[65], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_last = last;
         }
         __syncthreads();
         if (s_last) icp_publish(nx.replicas, nx.sums, nx.mb, nx.seq);
