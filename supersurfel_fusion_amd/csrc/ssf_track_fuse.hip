@@ -343,22 +343,32 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
 // filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
-__device__ __forceinline__ int classify_values(const Cam& cam, float conf, int last_seen, const V3& pos, const Rt& pose,
-                                               const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
-                                               float zmin, float zmax) {
+// in two steps, so that a thread that classifies several rows can issue all its plane-depth gathers together:
+// classify_pre decides what it can without the frame (st >= 0) or names the pixel to look at (st < 0)
+struct ClsPre { int st; int pix; float pz; };
+__device__ __forceinline__ ClsPre classify_pre(const Cam& cam, float conf, int last_seen, const V3& pos, const Rt& pose, int stamp,
+                                               int delta_t, float conf_thresh, float zmin, float zmax) {
+    ClsPre r; r.pix = 0; r.pz = 0.0f;
     const int time_diff = stamp - last_seen;
-    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) return 2;
+    if ((time_diff > delta_t && conf < conf_thresh && stamp > delta_t) || conf <= 0.0f) { r.st = 2; return r; }
     const M3 Rv = m3_transpose(pose.R);
     const V3 tv = negate(m3_mulv(Rv, pose.t));
     const V3 p = add(m3_mulv(Rv, pos), tv);
+    r.st = 1;
     if (p.z > zmin && p.z < zmax) {
         const float u = cam.fx * p.x / p.z + cam.cx, v = cam.fy * p.y / p.z + cam.cy;
         if (u >= 0.0f && u < (float)cam.W && v >= 0.0f && v < (float)cam.H) {
-            const float z = plane_depth[(size_t)((int)floorf(v)) * cam.W + (int)floorf(u)];
-            return p.z < 0.8f * z ? 2 : 0;
+            r.st = -1; r.pix = ((int)floorf(v)) * cam.W + (int)floorf(u); r.pz = p.z;
         }
     }
-    return 1;
+    return r;
+}
+__device__ __forceinline__ int classify_post(const ClsPre& r, float z) { return r.st >= 0 ? r.st : (r.pz < 0.8f * z ? 2 : 0); }
+__device__ __forceinline__ int classify_values(const Cam& cam, float conf, int last_seen, const V3& pos, const Rt& pose,
+                                               const float* __restrict__ plane_depth, int stamp, int delta_t, float conf_thresh,
+                                               float zmin, float zmax) {
+    const ClsPre r = classify_pre(cam, conf, last_seen, pos, pose, stamp, delta_t, conf_thresh, zmin, zmax);
+    return r.st >= 0 ? r.st : classify_post(r, plane_depth[r.pix]);
 }
 // the same for a row in memory; a removed row gets conf := -1
 __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, size_t idx, const Rt& pose,
@@ -384,13 +394,31 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
     __shared__ int h2[OOV_PER_WG][4][2];
     const int wv = threadIdx.x >> 6;
     const long long head = cnt->oov_head, tail = cnt->oov_tail;
+    // every load of a step for all OOV_PER_WG slots before the next step (a dead slot's row is read and ignored)
     int cls[OOV_PER_WG];
+    uint8_t lv[OOV_PER_WG]; float conf[OOV_PER_WG]; int seen[OOV_PER_WG]; V3 pos[OOV_PER_WG]; ClsPre pre[OOV_PER_WG]; float z[OOV_PER_WG];
 #pragma unroll
     for (int j = 0; j < OOV_PER_WG; j++) {
         const long long phys = head + ((long long)wg * OOV_PER_WG + j) * blockDim.x + threadIdx.x;
-        cls[j] = 7;
-        if (phys < tail && O.live[phys]) {
-            cls[j] = classify_row(cam, O.rows, (size_t)phys, pose, plane_depth, stamp, delta_t, conf_thresh, zmin, zmax);
+        const bool in = phys < tail;
+        lv[j] = in ? O.live[phys] : (uint8_t)0;
+        conf[j] = in ? O.rows.conf[phys] : 0.0f;
+        seen[j] = in ? O.rows.stamps[2 * phys + 1] : 0;
+        pos[j] = in ? ld3(O.rows.pos, (size_t)phys) : v3(0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) {
+        pre[j] = classify_pre(cam, conf[j], seen[j], pos[j], pose, stamp, delta_t, conf_thresh, zmin, zmax);
+        if (!lv[j]) { pre[j].st = 7; pre[j].pix = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) z[j] = pre[j].st < 0 ? plane_depth[pre[j].pix] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) {
+        cls[j] = classify_post(pre[j], z[j]);
+        if (lv[j]) {
+            const long long phys = head + ((long long)wg * OOV_PER_WG + j) * blockDim.x + threadIdx.x;
+            if (cls[j] == 2) O.rows.conf[phys] = -1.0f;
             state_oov[phys] = (uint8_t)cls[j];
         }
     }
