@@ -43,9 +43,12 @@ P = W * H
 ALGO_BYTES = {
     # stable partition: only the rows that change place move (visible rows are compacted, view changes cross over)
     "reorder_move": lambda c: 2.0 * c["n_model"] + 208.0 * c["n_visible"],     # state + live byte per slot, visible rows read + written
-    "classify": lambda c: 28.0 * c["n_model"],                   # pos 12 + stamps 8 + conf 4 read, state 4 written
+    # the same launch when it also accumulates the next frame's first ICP iteration (rows are read once for both)
+    "reorder_move_icp": lambda c: 2.0 * c["n_model"] + 208.0 * c["n_visible"] + 8.0 * P + 28.0 * c["S"],
+    # fuse launch: classification of every row (pos 12 + stamps 8 + conf 4 read, state written) + candidate per visible row
+    "update_insert": lambda c: 28.0 * c["n_model"] + 4.0 * c["n_visible"],
     "icp_accumulate": lambda c: 36.0 * c["n_visible"] + 8.0 * P + 28.0 * c["S"],
-    "match": lambda c: 40.0 * c["n_visible"],
+    "match": lambda c: 44.0 * c["n_visible"],
     "update_pass_rgb": lambda c: c["batch"] * 9.0 * P,
     "update_pass_rgbd": lambda c: c["batch"] * 14.0 * P,
     "ingest": lambda c: c["batch"] * 23.0 * P,

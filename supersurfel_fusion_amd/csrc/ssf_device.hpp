@@ -184,10 +184,10 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
-// Sums the per-frame stable partition works from (k_classify in ssf_track_fuse.hip): per group of PART_GROUP blocks
+// Sums the per-frame stable partition works from (k_update_insert / k_move_rows in ssf_track_fuse.hip): per group of PART_GROUP blocks
 // the class counts (sup_vis: 6 per group, sup_oov: rows that come back into view), and the frame totals
 // a0 a1 a2 c0 c1 c2 b0 b2 in PART_REPLICAS copies of 8 words.  Two sets alternate by frame: `other` (all `words`
-// of it) is cleared by the frame that uses this one.  ticket: arrival counters of k_classify (65 words, zero at rest).
+// of it) is cleared by the frame that uses this one.  ticket: arrival counters of the fuse launch (65 words, zero at rest).
 #define PART_GROUP 32
 #define PART_REPLICAS 8
 struct PartitionWs { uint32_t* sup_vis; uint32_t* sup_oov; uint32_t* tot; uint32_t* ticket; uint32_t* other; int words; };

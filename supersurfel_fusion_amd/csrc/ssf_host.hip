@@ -818,7 +818,7 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
             const int nslot = h->pending.front().second;
             const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
             // (not finished yet: the track stream waits here instead of at the start of the next frame; the host
-            // does not, it continues on the counters the scan kernel has published before the move)
+            // does not, it continues on the counters the fuse launch has published before the move)
             if (nc.launched) {
                 if (multi && !nc.waited) { HCK(hipStreamWaitEvent(h->stream, nc.ev_done, 0)); nc.waited = true; }
                 const FrameMaps nm = batch_slot(nc.maps, nslot);
