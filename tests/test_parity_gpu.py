@@ -392,3 +392,55 @@ def test_soak_600_frames_pipelined(oracle_lib, product_lib):
         util.assert_same_bits(a["pose"], b["pose"], "pose of frame %d" % i)
     util.compare_state(fo, fh)
     assert want[-1]["n_model"] > 100
+
+
+def _emulated_ranks(lib, world, W, H, nframes, cap=4096):
+    """`world` handles of one library acting as the ranks of a sharded map in ONE process: the three exchanges
+    (ICP record SUM, association MIN / MAX, shard sizes) are done on the host between the stage calls."""
+    fs = [binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=cap, rank=r, nranks=world, shard_tile=0.25))
+          for r in range(world)]
+    counts = np.zeros((world, 2), np.int64)
+    out = []
+    for k in range(nframes):
+        rgb, depth = util.frame(k, W, H)
+        for f in fs:
+            f.stage_extract(rgb, depth)
+        g_model, g_vis = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+        for r, f in enumerate(fs):
+            f.set_shard(int(counts[:r, 1].sum()), g_model, g_vis)
+            f.icp_begin()
+        again = g_vis > 0 and fs[0].cfg.icp_iter > 0
+        while again:
+            total = sum(f.icp_accumulate() for f in fs)
+            agains = [f.icp_update(total) for f in fs]
+            assert len(set(agains)) == 1
+            again = agains[0]
+        valid = [f.icp_end() for f in fs]
+        assert len(set(valid)) == 1
+        bm = [f.match() for f in fs]
+        best = np.minimum.reduce([b for b, _ in bm])
+        matched = np.maximum.reduce([m for _, m in bm])
+        res = [f.fuse(best, matched) for f in fs]
+        counts = np.array([[r["n_model"], r["n_visible"]] for r in res], np.int64)
+        out.append(([r["pose"].copy() for r in res], counts.copy(), [[r[key] for key in ("n_removed", "n_inserted", "n_updated")] for r in res]))
+    return fs, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_emulated_ranks_bit_exact(world, oracle_lib, product_lib):
+    """nranks > 1 on the HIP engine (global ids, shard offsets, winners that live on another rank) against the
+    oracle doing the same exchanges, rank by rank."""
+    W, H, NF = 320, 240, 6
+    fh, oh = _emulated_ranks(product_lib, world, W, H, NF)
+    fo, oo = _emulated_ranks(oracle_lib, world, W, H, NF)
+    for k in range(NF):
+        for r in range(world):
+            assert np.array_equal(oh[k][0][r].view(np.uint32), oo[k][0][r].view(np.uint32)), ("pose", k, r)
+        assert np.array_equal(oh[k][1], oo[k][1]), ("counts", k, oh[k][1], oo[k][1])
+        assert oh[k][2] == oo[k][2], ("frame counters", k)
+    assert all(len(f.get_model()["confidences"]) > 0 for f in fh)
+    for r in range(world):
+        mh, mo = fh[r].get_model(), fo[r].get_model()
+        for name in mh:
+            assert np.array_equal(mh[name].view(np.uint32), mo[name].view(np.uint32)), (name, r)
