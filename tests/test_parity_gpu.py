@@ -444,3 +444,30 @@ def test_emulated_ranks_bit_exact(world, oracle_lib, product_lib):
         mh, mo = fh[r].get_model(), fo[r].get_model()
         for name in mh:
             assert np.array_equal(mh[name].view(np.uint32), mo[name].view(np.uint32)), (name, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth_ahead,batch", [(2, 2), (1, 4)])
+def test_pipelined_with_priors_blank_frames_and_pose_changes(depth_ahead, batch, oracle_lib, product_lib):
+    """The first ICP iteration of a frame may have been accumulated ahead by the previous frame's row moves; that
+    record must be dropped whenever it is not this frame's: a pose prior on the call, a pose set in between, a frame
+    in which nothing is visible (blank depth: no rows, no record), frames after it (model still there, all out of
+    view or re-entering)."""
+    W, H, nf = 320, 240, 14
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+    frames = [list(util.frame(k, W, H, noise=True, holes=0.02)) for k in range(nf)]
+    frames[6][1] = np.zeros_like(frames[6][1])                      # blank frame: no frame supersurfels at all
+    frames[10] = list(util.frame(40, W, H))                         # a jump: most of the map leaves the view
+    priors = {3: synthetic.pose12(*synthetic.relative_pose(3)), 11: synthetic.pose12(*synthetic.relative_pose(40))}
+    set_pose_before = {8: synthetic.pose12(*synthetic.relative_pose(8))}
+    nsub = 0
+    for k in range(nf):
+        while nsub < nf and fh.can_submit():
+            fh.submit_frame(frames[nsub][0], frames[nsub][1]); nsub += 1
+        if k in set_pose_before:
+            fo.set_pose(set_pose_before[k]); fh.set_pose(set_pose_before[k])
+        want = fo.process_frame(frames[k][0], frames[k][1], prior_pose=priors.get(k))
+        got = fh.process_submitted(prior_pose=priors.get(k)).as_dict()
+        util.same_result(want, got)
+    util.compare_state(fo, fh)
