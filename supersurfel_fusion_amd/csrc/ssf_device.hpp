@@ -193,7 +193,8 @@ struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view
 struct PartitionWs { uint32_t* sup_vis; uint32_t* sup_oov; uint32_t* tot; uint32_t* ticket; uint32_t* other; int words; };
 // The fuse launch (k_update_insert in ssf_track_fuse.hip): update of the matched rows | ordered insertion of the
 // unmatched frame supersurfels | classification (filterModel) of every row of the model store, and publication of the
-// frame's counters by the last block to finish.  do_update = 0 skips the update (no visible rows anywhere);
+// frame's counters by the last block to finish (cnt[0] = what the next frame starts from, cnt[1] = what
+// launch_move_rows sends to the host: sequence number cnt_seq there).  do_update = 0 skips the update (no visible rows anywhere);
 // span_upper = host upper bound of the out-of-view span; cand = launch_match's per-row candidate.
 void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
@@ -219,7 +220,7 @@ struct NextFrameIcp {
 // first ICP iteration
 void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
                       const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
-                      const Counters* cnt, Mailbox* mb, const NextFrameIcp* next);
+                      const Counters* cnt /* [2]: see launch_fuse */, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next);
 // stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
 // new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,

@@ -836,7 +836,7 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         // frame overlap the host-side launch work of the next one (stream order keeps every later reader of the
         // model behind them)
         launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S, h->oov_tail - h->oov_head,
-                         h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, have_next ? &next : nullptr);
+                         h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
         h->mcur ^= 1;
     } else {
         launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
@@ -1131,7 +1131,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
-         dalloc(h, &h->d_cnt, 1) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
+         dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
              hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;

@@ -627,7 +627,8 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
 // per group of PART_GROUP blocks, and replicated frame totals) with atomics.  The LAST block to finish turns the
 // totals into the frame's counters and publishes them; the move kernel that follows derives its prefixes from the
 // group sums and the states themselves.  No scan kernel, no separate classify kernel.
-__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
+__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed);
+__device__ __forceinline__ void mailbox_counters(const Counters& c, Mailbox* mb, unsigned long long seq);
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, const int32_t* __restrict__ cand, int S,
@@ -699,9 +700,10 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
         c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
         c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
-        // the frame's counters are final here: publish them now, the host overlaps its next launches
-        // with the row moves that follow in the stream
-        publish_counters_value(cnt, c, 1, mb, seq);
+        // the frame's counters are final here; the move kernel that follows in the stream sends them to the host first
+        // thing (cnt[1]), so that this launch does not end on the acknowledgement of writes to host memory
+        cnt[1] = finalise_counters(cnt, c, 1);
+        (void)mb; (void)seq;
     }
 }
 
@@ -802,7 +804,10 @@ template <bool ICP>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
                                                    const uint8_t* __restrict__ state_oov,
                                                    const uint32_t* __restrict__ bc_oov, PartitionWs ws,
-                                                   const Counters* __restrict__ cnt, int nb_vis, NextIcp nx) {
+                                                   const Counters* __restrict__ cnt, int nb_vis, NextIcp nx, Mailbox* mb,
+                                                   unsigned long long cnt_seq) {
+    // the frame's counters (finalised by the fuse launch, cnt[1]) go to the host while the rows move
+    if (blockIdx.x == 0 && threadIdx.x == 255) mailbox_counters(cnt[1], mb, cnt_seq);
     __shared__ int hist[4][6];
     __shared__ uint32_t base[6];                  // rows of each class in the blocks before this one
     __shared__ unsigned long long red[ICP ? 29 * ICP_SLOTS : 1];
@@ -979,12 +984,17 @@ __global__ void k_oov_set_span(Counters* cnt, int new_head) { cnt->oov_head = ne
 
 // end of the fuse stage: nbSupersurfels -= nbRemoved (supersurfel_fusion.cu:474), publish the
 // counters to the host-mapped mailbox, reset the per-frame ones for the next frame
-__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+// finalise_counters: the frame's counters become final in device memory (cnt[0] = the values the next frame starts
+// from, per-frame ones reset; cnt[1] = the values to publish); mailbox_counters writes a set of values to the host
+__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed) {
     if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
     c.last[0] = c.n_model; c.last[1] = c.n_visible; c.last[2] = c.n_removed; c.last[3] = c.n_inserted; c.last[4] = c.n_updated;
     Counters next = c;
     next.n_inserted = 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
-    *cnt = next;
+    cnt[0] = next;
+    return c;
+}
+__device__ __forceinline__ void mailbox_counters(const Counters& c, Mailbox* mb, unsigned long long seq) {
     int* dst = reinterpret_cast<int*>(&mb->cnt);
     const int* src = reinterpret_cast<const int*>(&c);
     unsigned long long check = seq;
@@ -995,6 +1005,9 @@ __device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c
     __hip_atomic_store(&mb->cnt_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // payload write-through stores acknowledged
     __hip_atomic_store(&mb->cnt_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void publish_counters_value(Counters* cnt, Counters c, int shrink_by_removed, Mailbox* mb, unsigned long long seq) {
+    mailbox_counters(finalise_counters(cnt, c, shrink_by_removed), mb, seq);
 }
 // a 29-value device record (e.g. the rank-reduced ICP system) -> mailbox, as the ICP kernel's tail does
 __global__ void k_publish_icp(const long long* __restrict__ rec, Mailbox* mb, unsigned long long seq) {
@@ -1135,7 +1148,7 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 }
 void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
                       const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
-                      const Counters* cnt, Mailbox* mb, const NextFrameIcp* next) {
+                      const Counters* cnt, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
     NextIcp nx{};
     if (next) {
@@ -1143,11 +1156,11 @@ void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelS
         nx.ticket = next->ticket; nx.sums = next->sums; nx.mb = mb; nx.seq = next->seq;
         ScopedKernel sk("reorder_move_icp", st);
         hipLaunchKernelGGL(k_move_rows<true>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_oov, ws, cnt, nb_vis, nx);
+                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq);
     } else {
         ScopedKernel sk("reorder_move", st);
         hipLaunchKernelGGL(k_move_rows<false>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_oov, ws, cnt, nb_vis, nx);
+                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq);
     }
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
