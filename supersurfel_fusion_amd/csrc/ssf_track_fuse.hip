@@ -771,23 +771,33 @@ __device__ __forceinline__ void block_scan_counts(uint32_t* __restrict__ bc, int
     }
 }
 
-__device__ __forceinline__ void copy_row(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j) {
-    st3(B.pos, j, ld3(A.pos, i)); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, ld3(A.lab, i));
-    B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
-    st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, ld3(A.r2, i));
-    st6(B.shape, j, ld6(A.shape, i));
-    B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
-    B.conf[j] = A.conf[i];
+// one model row in registers: all loads are issued before the first store (source and destination arrays may alias as
+// far as the compiler knows, so a field-by-field copy is a chain of dependent round trips)
+struct RowRegs { V3 pos, col, lab, r0, r1, r2; Sym3 shape; int s0, s1; float d0, d1, conf; };
+__device__ __forceinline__ RowRegs load_row(const SurfelSoA& A, size_t i) {
+    RowRegs r;
+    r.pos = ld3(A.pos, i); r.col = ld3(A.col, i); r.lab = ld3(A.lab, i);
+    r.s0 = A.stamps[2 * i]; r.s1 = A.stamps[2 * i + 1];
+    r.r0 = ld3(A.r0, i); r.r1 = ld3(A.r1, i); r.r2 = ld3(A.r2, i);
+    r.shape = ld6(A.shape, i);
+    r.d0 = A.dims[2 * i]; r.d1 = A.dims[2 * i + 1];
+    r.conf = A.conf[i];
+    return r;
 }
+__device__ __forceinline__ void store_row(const SurfelSoA& B, size_t j, const RowRegs& r) {
+    st3(B.pos, j, r.pos); st3(B.col, j, r.col); st3(B.lab, j, r.lab);
+    B.stamps[2 * j] = r.s0; B.stamps[2 * j + 1] = r.s1;
+    st3(B.r0, j, r.r0); st3(B.r1, j, r.r1); st3(B.r2, j, r.r2);
+    st6(B.shape, j, r.shape);
+    B.dims[2 * j] = r.d0; B.dims[2 * j + 1] = r.d1;
+    B.conf[j] = r.conf;
+}
+__device__ __forceinline__ void copy_row(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j) { store_row(B, j, load_row(A, i)); }
 // copy of a row that enters the new visible array; hands back the three fields the ICP terms read
 __device__ __forceinline__ void copy_row_keep(const SurfelSoA& A, size_t i, const SurfelSoA& B, size_t j, V3& pos, V3& lab, V3& nrm) {
-    pos = ld3(A.pos, i); lab = ld3(A.lab, i); nrm = ld3(A.r2, i);
-    st3(B.pos, j, pos); st3(B.col, j, ld3(A.col, i)); st3(B.lab, j, lab);
-    B.stamps[2 * j] = A.stamps[2 * i]; B.stamps[2 * j + 1] = A.stamps[2 * i + 1];
-    st3(B.r0, j, ld3(A.r0, i)); st3(B.r1, j, ld3(A.r1, i)); st3(B.r2, j, nrm);
-    st6(B.shape, j, ld6(A.shape, i));
-    B.dims[2 * j] = A.dims[2 * i]; B.dims[2 * j + 1] = A.dims[2 * i + 1];
-    B.conf[j] = A.conf[i];
+    const RowRegs r = load_row(A, i);
+    pos = r.pos; lab = r.lab; nrm = r.r2;
+    store_row(B, j, r);
 }
 // what the fused form of k_move_rows needs to accumulate the first ICP iteration of the NEXT frame
 struct NextIcp {
@@ -821,6 +831,9 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         const int nv = cnt->mv_nv, n_rows = nv + cnt->last[3];            // last[3] = insertions of this frame (published)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
+        // the row itself is requested now: its loads travel while the prefix below is worked out
+        RowRegs row;
+        if (cls == 0 || cls == 1 || cls == 3 || cls == 4) row = load_row(V, i);
         // prefix: the sums of the groups before this block's group (6 counters wide: word w belongs to class w % 6),
         // then the states of the rows of the earlier blocks of its own group, 16 per load
         const int g0 = (int)(blockIdx.x / PART_GROUP), ng = 6 * g0;
@@ -872,11 +885,11 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             const size_t r = (size_t)base[cls] + before + in_wave;
             if (cls == 0 || cls == 3) {
                 const size_t j = cls == 0 ? r : (size_t)cnt->mv_a0 + cnt->mv_b0 + r;
-                if (ICP) { copy_row_keep(V, i, Vn, j, pos, lab, nrm); keep = true; }
-                else copy_row(V, i, Vn, j);
+                store_row(Vn, j, row);
+                if (ICP) { pos = row.pos; lab = row.lab; nrm = row.r2; keep = true; }
             } else {
                 const size_t j = (cls == 1 ? (size_t)cnt->mv_head_new : (size_t)cnt->mv_tail_old) + r;
-                copy_row(V, i, O.rows, j);
+                store_row(O.rows, j, row);
                 O.live[j] = 1;
             }
         }
