@@ -498,18 +498,17 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
         if (which == 0) {
             M3 vecs; V3 vals;
             principal_finish(fused_shape, r0, r2, vecs, vals);
+            // classification (from the values in registers: the row is not read back; it was seen in this frame)
+            const int st = classify_values(ca.cam, m_conf + f_conf, stamp, fused_position, pose, ca.plane_depth, stamp, ca.delta_t,
+                                           ca.conf_thresh, ca.zmin, ca.zmax);
             st3(M.pos, m, fused_position);
-            M.conf[m] = m_conf + f_conf;
+            M.conf[m] = st == 2 ? -1.0f : m_conf + f_conf;
             st6(M.shape, m, fused_shape);
             st3(M.r0, m, vecs.r0); st3(M.r1, m, vecs.r1); st3(M.r2, m, vecs.r2);
             M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
             M.stamps[2 * m + 1] = stamp;
-            atomicAdd(&cnt->n_updated, 1);
-            // classification (from the values just stored: the row is not read back; it was seen in this frame)
-            const int st = classify_values(ca.cam, m_conf + f_conf, stamp, fused_position, pose, ca.plane_depth, stamp, ca.delta_t,
-                                           ca.conf_thresh, ca.zmin, ca.zmax);
-            if (st == 2) M.conf[m] = -1.0f;
             state_vis[m] = (uint8_t)st;
+            atomicAdd(&cnt->n_updated, 1);
             const int vb = (int)(m >> 8);
             atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + st], 1u);
             atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
@@ -585,22 +584,27 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
     const int k = base + before + r;
     const int g_first = ((base + before) >> 8) / PART_GROUP;        // partition group of the chunk's first row
     if (flag && base_total + before + r < capacity) {
-        const V3 new_pos = add(m3_mulv(R, ld3(F.pos, f)), t);
+        // every load (the frame row, then the classification's depth lookup) before the first store: the arrays may
+        // alias as far as the compiler knows, and a load behind a store waits for it
+        const V3 f_pos = ld3(F.pos, f), f_col = ld3(F.col, f), f_lab = ld3(F.lab, f);
+        const V3 f_r0 = ld3(F.r0, f), f_r1 = ld3(F.r1, f), f_r2 = ld3(F.r2, f);
+        const Sym3 f_shape = ld6(F.shape, f);
+        const float f_d0 = F.dims[2 * f], f_d1 = F.dims[2 * f + 1];
         const float new_conf = F.conf[f];
-        st3(M.pos, k, new_pos);
-        M.conf[k] = new_conf;
-        st3(M.col, k, ld3(F.col, f));
-        st3(M.lab, k, ld3(F.lab, f));
-        M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
-        M.dims[2 * k] = F.dims[2 * f]; M.dims[2 * k + 1] = F.dims[2 * f + 1];
-        st3(M.r0, k, row_mul(ld3(F.r0, f), Rt_));
-        st3(M.r1, k, row_mul(ld3(F.r1, f), Rt_));
-        st3(M.r2, k, row_mul(ld3(F.r2, f), Rt_));
-        st6(M.shape, k, rot_sym(R, ld6(F.shape, f)));
-        // classification (class C) of the row just written, for the partition
+        const V3 new_pos = add(m3_mulv(R, f_pos), t);
+        // classification (class C) of the new row, for the partition
         const int st = classify_values(ca.cam, new_conf, stamp, new_pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh,
                                        ca.zmin, ca.zmax);
-        if (st == 2) M.conf[k] = -1.0f;
+        st3(M.pos, k, new_pos);
+        M.conf[k] = st == 2 ? -1.0f : new_conf;
+        st3(M.col, k, f_col);
+        st3(M.lab, k, f_lab);
+        M.stamps[2 * k] = stamp; M.stamps[2 * k + 1] = stamp;
+        M.dims[2 * k] = f_d0; M.dims[2 * k + 1] = f_d1;
+        st3(M.r0, k, row_mul(f_r0, Rt_));
+        st3(M.r1, k, row_mul(f_r1, Rt_));
+        st3(M.r2, k, row_mul(f_r2, Rt_));
+        st6(M.shape, k, rot_sym(R, f_shape));
         state_vis[k] = (uint8_t)st;
         atomicAdd(&s_cls[(k >> 8) / PART_GROUP - g_first][st], 1u);
     }
