@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
+    __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
     __syncthreads();
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
                                                uint8_t* __restrict__ matched, int32_t* __restrict__ cand) {
+    __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_visible) return;
     cand[id] = match_row(cam, model, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                                                        int nupd, int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
                                                        uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
                                                        uint32_t* __restrict__ bc_oov, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
+    __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
     __shared__ int s_last;
@@ -820,6 +823,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
                                                    const uint32_t* __restrict__ bc_oov, PartitionWs ws,
                                                    const Counters* __restrict__ cnt, int nb_vis, NextIcp nx, Mailbox* mb,
                                                    unsigned long long cnt_seq) {
+    __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     // the frame's counters (finalised by the fuse launch, cnt[1]) go to the host while the rows move
     if (blockIdx.x == 0 && threadIdx.x == 255) mailbox_counters(cnt[1], mb, cnt_seq);
     __shared__ int hist[4][6];
