@@ -7,6 +7,7 @@
 //
 // There is NO CPU fallback here: without a gfx950 device ssf_create fails with SSF_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <deque>
@@ -17,6 +18,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -281,6 +283,40 @@ static RcclApi* rccl_api() {
     return &api;
 }
 
+// ---- upload of host frames ahead of the pipeline (ssf_process_sequence with host buffers) --------------------------
+// The caller of the reference hands over host images (cv::Mat).  Copying them inside the submit call costs the thread
+// that also drives the track chain 30-70 us per frame (two hipMemcpyAsync, for pageable memory incl. the staging
+// copy).  In ssf_process_sequence the frames are known ahead, so a worker thread copies them into a ring of device
+// buffers on a stream of its own; the submitting thread only makes the extract stream wait for the copy's event.
+struct Uploader {
+    std::thread th;
+    std::atomic<int> uploaded{0};             // frames whose copies are enqueued (events recorded)
+    std::atomic<int> processed{0};            // frames the caller has finished with (their ring slots may be reused)
+    std::atomic<int> failed{0}, stop{0};
+    int n = 0, ring = 0, device = 0;
+    const void* const* rgb = nullptr; const void* const* depth = nullptr;
+    size_t rgb_bytes = 0, depth_bytes = 0;
+    // frame i is copied on the stream of the extract context that will take it (contexts take batches in turn): the
+    // copy precedes that batch's launch in stream order, and no further hardware queue becomes active (a 5th one
+    // halves the throughput of the others)
+    std::vector<hipStream_t> ctx_stream; int ctx0 = 0, batch = 1;
+    std::vector<uint8_t*> d_rgb; std::vector<float*> d_depth;
+    void run() {
+        if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
+        for (int i = 0; i < n && !stop.load(std::memory_order_relaxed); i++) {
+            while (i >= processed.load(std::memory_order_acquire) + ring) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::sleep_for(std::chrono::microseconds(100));      // (the ring is a dozen frames ahead)
+            }
+            const int sl = i % ring;
+            hipStream_t st = ctx_stream[(size_t)(ctx0 + i / batch) % ctx_stream.size()];
+            if (hipMemcpyAsync(d_rgb[sl], rgb[i], rgb_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_depth[sl], depth[i], depth_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { failed.store(1); return; }
+            uploaded.store(i + 1, std::memory_order_release);
+        }
+    }
+};
+
 // ---- handle -----------------------------------------------------------------------------------------
 struct IcpLoop {
     bool active = false, valid = true, done = true;
@@ -329,6 +365,7 @@ struct ssf_handle {
     // ssf_process_sequence: frames still to be submitted; do_fuse submits them between its launches and its wait for
     // the counters (the ~40 us of host work of a batch launch hide behind the ~55 us fuse chain on the GPU)
     const void* const* seq_rgb = nullptr; const void* const* seq_depth = nullptr; int seq_next = 0, seq_n = 0, seq_on_device = 0, stamp_bias = 0;
+    Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
     ncclComm_t comm = nullptr; int* d_all5 = nullptr;
@@ -571,6 +608,28 @@ static int activate_oldest(ssf_handle* h) {
     a.ctx = &c; a.slot = fr.second;
     h->have_frame = true;
     return SSF_OK;
+}
+// submit the next frame of the sequence being processed (ssf_process_sequence)
+static int seq_submit(ssf_handle* h) {
+    const int i = h->seq_next;
+    if (h->seq_on_device || !h->seq_upload) {
+        int rc = submit_extract(h, h->seq_rgb[i], h->seq_depth[i], h->seq_on_device, nullptr);
+        if (!rc) h->seq_next++;
+        return rc;
+    }
+    Uploader& u = *h->up;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 0; u.uploaded.load(std::memory_order_acquire) <= i; spins++) {
+        if (u.failed.load()) { h->err = "upload of a host frame failed"; return SSF_ERR_DEVICE; }
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+            h->err = "upload of a host frame never finished"; return SSF_ERR_DEVICE;
+        }
+        std::this_thread::yield();
+    }
+    const int sl = i % u.ring;                    // (its copies are already in the stream of the context it goes to)
+    int rc = submit_extract(h, u.d_rgb[sl], u.d_depth[sl], 1, nullptr);
+    if (!rc) h->seq_next++;
+    return rc;
 }
 static int do_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
@@ -847,9 +906,8 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     { int rr = retire_active(h); if (rr) return rr; }     // last reader of this frame's buffers is enqueued
     h->stamp_bias = 1;                                     // the frame being fused still holds h->stamp
     while (h->seq_next < h->seq_n && !h->ctx[h->open_ctx].launched) {      // see seq_rgb
-        int rs = submit_extract(h, h->seq_rgb[h->seq_next], h->seq_depth[h->seq_next], h->seq_on_device, nullptr);
+        int rs = seq_submit(h);
         if (rs) { h->stamp_bias = 0; return rs; }
-        h->seq_next++;
     }
     h->stamp_bias = 0;
     int rc = wait_seq(h, &h->mb_host->cnt_seq, seq);
@@ -1015,6 +1073,11 @@ void ssf_default_config(ssf_config* c) {       // default arguments of initializ
 
 void ssf_destroy(ssf_handle* h) {
     if (!h) return;
+    if (h->up) {
+        h->up->stop.store(1);
+        if (h->up->th.joinable()) h->up->th.join();
+        delete h->up; h->up = nullptr;
+    }
     for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
@@ -1195,17 +1258,43 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
     if (!h || !rgb || !depth || n < 0) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
     for (int i = 0; i < n; i++) if (!rgb[i] || !depth[i]) return SSF_ERR_INVALID_ARG;
-    h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device;
     int rc = SSF_OK;
+    const bool ahead = !on_device && h->ctx.size() > 1 && n > 1;       // host frames, pipelined: copy them ahead
+    if (ahead) {
+        const size_t P = (size_t)h->cfg.width * h->cfg.height;
+        if (!h->up) {
+            Uploader* u = new (std::nothrow) Uploader();
+            if (!u) { h->err = "out of memory"; return SSF_ERR_DEVICE; }
+            u->ring = (int)h->ctx.size() * h->batch + h->batch + 2;
+            u->rgb_bytes = 3 * P; u->depth_bytes = 4 * P;
+            (void)hipGetDevice(&u->device);
+            bool ok = true;
+            u->d_rgb.assign(u->ring, nullptr); u->d_depth.assign(u->ring, nullptr);
+            for (int i = 0; i < u->ring && ok; i++) ok = dalloc(h, &u->d_rgb[i], 3 * P) && dalloc(h, &u->d_depth[i], P);
+            for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream);
+            u->batch = h->batch;
+            h->up = u;
+            if (!ok) { h->err = "allocation of the upload ring failed"; return SSF_ERR_DEVICE; }
+        }
+        Uploader& u = *h->up;
+        u.n = n; u.rgb = rgb; u.depth = depth; u.ctx0 = h->open_ctx;
+        u.uploaded.store(0); u.processed.store(0); u.failed.store(0); u.stop.store(0);
+        u.th = std::thread([&u] { u.run(); });
+    }
+    h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device; h->seq_upload = ahead;
     for (int k = 0; k < n && !rc; k++) {
         while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
             TimerScope ts(h);
-            rc = submit_extract(h, rgb[h->seq_next], depth[h->seq_next], on_device, nullptr);
-            if (!rc) h->seq_next++;
+            rc = seq_submit(h);
         }
         if (!rc) rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
+        if (ahead) h->up->processed.store(k + 1, std::memory_order_release);
     }
-    h->seq_rgb = nullptr; h->seq_depth = nullptr; h->seq_n = 0; h->seq_next = 0;
+    if (ahead) {
+        h->up->stop.store(1);
+        if (h->up->th.joinable()) h->up->th.join();
+    }
+    h->seq_rgb = nullptr; h->seq_depth = nullptr; h->seq_n = 0; h->seq_next = 0; h->seq_upload = false;
     return rc;
 }
 int ssf_pending_frames(const ssf_handle* h) { return h ? (int)h->pending.size() : 0; }
