@@ -1,0 +1,146 @@
+/* ssf.hpp -- header-only C++ surface over the C ABI of ssf.h, with the method names of the reference's
+ * supersurfel_fusion::SupersurfelFusion (core/include/supersurfel_fusion/supersurfel_fusion.hpp:40-143) for the
+ * hot path: initialize / processFrame / getPose / getnbSupersurfels / getStamp / getModel / exportModel.
+ * A node that owns a `supersurfel_fusion::SupersurfelFusion ssf;` member includes this header instead of the
+ * reference's and links libssf_hip.so.  No OpenCV needed: processFrame takes raw pointers; the
+ * cv::Mat overloads appear when <opencv2/core.hpp> has been included before this header.
+ *
+ * Sparse VO, MOD and loop closure stay with the caller; their outputs enter as `vo_pose` and `dynamic`.
+ * Errors: the reference exits the process on a CUDA failure (cuda_error_check.h:30-66); this surface throws
+ * std::runtime_error with the library's message. */
+#ifndef SSF_HPP
+#define SSF_HPP
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "ssf.h"
+
+namespace supersurfel_fusion {
+
+struct CamParam { float fx, fy, cx, cy; int height, width; };          /* cam_param.hpp:27-31 */
+struct Transform3 { float R[9]; float t[3]; };                          /* matrix_types.h:38-42, row-major */
+
+/* host copy of a supersurfel set in the reference's SoA layout (supersurfels.hpp:34-40) */
+struct HostSupersurfels {
+    std::vector<float> positions, colors, orientations, shapes, dims, confidences;
+    std::vector<int32_t> stamps;
+    int size = 0;
+    void resize(int n) {
+        size = n; const size_t m = (size_t)(n > 0 ? n : 1);
+        positions.resize(3 * m); colors.resize(3 * m); stamps.resize(2 * m); orientations.resize(9 * m);
+        shapes.resize(6 * m); dims.resize(2 * m); confidences.resize(m);
+    }
+    ssf_surfels view() {
+        ssf_surfels v; v.positions = positions.data(); v.colors = colors.data(); v.stamps = stamps.data();
+        v.orientations = orientations.data(); v.shapes = shapes.data(); v.dims = dims.data(); v.confidences = confidences.data();
+        return v;
+    }
+};
+
+class SupersurfelFusion {
+public:
+    SupersurfelFusion() = default;
+    SupersurfelFusion(const SupersurfelFusion&) = delete;
+    SupersurfelFusion& operator=(const SupersurfelFusion&) = delete;
+    ~SupersurfelFusion() { if (h_) ssf_destroy(h_); }
+
+    /* initialize(): supersurfel_fusion.hpp:46-74 -- the 21 path-relevant arguments map 1:1 onto ssf_config.
+     * pipeline_depth / extract_batch: see ssf_config (0 / 1 = the reference's one-frame-in-flight behaviour). */
+    void initialize(const CamParam& cam, int cell_size = 16, float lambda_pos = 50.f, float lambda_bound = 1000.f,
+                    float lambda_size = 10000.f, float lambda_disp = 1e6f, float thresh_disp = 1e-4f,
+                    int seg_iter = 10, bool seg_use_ransac = true, int nb_samples = 16, int filter_iter = 4,
+                    float filter_alpha = 0.1f, float filter_beta = 1.0f, float filter_threshold = 0.05f,
+                    float range_min = 0.2f, float range_max = 5.0f, int delta_t = 20, float conf_thresh = 2500.f,
+                    int nb_supersurfels_max = 50000, int icp_iter = 10, double icp_cov_thresh = 0.04,
+                    int pipeline_depth = 0, int extract_batch = 1) {
+        ssf_config c; ssf_default_config(&c);
+        c.width = cam.width; c.height = cam.height; c.fx = cam.fx; c.fy = cam.fy; c.cx = cam.cx; c.cy = cam.cy;
+        c.cell_size = cell_size; c.lambda_pos = lambda_pos; c.lambda_bound = lambda_bound; c.lambda_size = lambda_size;
+        c.lambda_disp = lambda_disp; c.thresh_disp = thresh_disp; c.seg_iter = seg_iter; c.seg_use_ransac = seg_use_ransac ? 1 : 0;
+        c.nb_samples = nb_samples; c.filter_iter = filter_iter; c.filter_alpha = filter_alpha; c.filter_beta = filter_beta;
+        c.filter_threshold = filter_threshold; c.range_min = range_min; c.range_max = range_max; c.delta_t = delta_t;
+        c.conf_thresh = conf_thresh; c.nb_supersurfels_max = nb_supersurfels_max; c.icp_iter = icp_iter;
+        c.icp_cov_thresh = icp_cov_thresh; c.pipeline_depth = pipeline_depth; c.extract_batch = extract_batch;
+        initialize(c);
+    }
+    void initialize(const ssf_config& c) {
+        if (h_) { ssf_destroy(h_); h_ = nullptr; }
+        if (ssf_create(&c, &h_) != SSF_OK) { h_ = nullptr; throw std::runtime_error(ssf_last_error(nullptr)); }
+        width_ = c.width; height_ = c.height;
+    }
+    bool isInitialized() const { return h_ != nullptr; }
+
+    /* processFrame(): supersurfel_fusion.hpp:75-76.  rgb: H x W x 3 bytes in RGB order, depth: H x W floats in
+     * metres (0 = hole) -- what RGBDCallback / run() build (convertTo(CV_32FC1, depthScale)).  vo_pose: the sparse-VO
+     * pose prior (supersurfel_fusion.cu:225-228; row-major R then t; nullptr = previous pose); dynamic: the MOD
+     * mask, one byte per superpixel (motion_detection.cu:573-578; nullptr = none). */
+    void processFrame(const uint8_t* rgb, const float* depth_m, const float* vo_pose = nullptr, const uint8_t* dynamic = nullptr) {
+        check(ssf_process_frame(need(), rgb, depth_m, vo_pose, dynamic, &last_));
+    }
+    /* replay of a recorded sequence (SupersurfelFusionRGBDBenchmarkNode::run): host images of n frames, results in
+     * order; with pipeline_depth / extract_batch > 0 / 1 the extract stage runs ahead (bit-identical results) */
+    std::vector<ssf_frame_result> processSequence(const std::vector<const uint8_t*>& rgb, const std::vector<const float*>& depth_m) {
+        if (rgb.size() != depth_m.size()) throw std::invalid_argument("processSequence: rgb / depth counts differ");
+        std::vector<const void*> r(rgb.begin(), rgb.end()), d(depth_m.begin(), depth_m.end());
+        std::vector<ssf_frame_result> out(rgb.size());
+        check(ssf_process_sequence(need(), r.data(), d.data(), (int)rgb.size(), 0, out.data()));
+        if (!out.empty()) last_ = out.back();
+        return out;
+    }
+#ifdef CV_VERSION
+    void processFrame(const cv::Mat& rgb_h, const cv::Mat& depth_h, const float* vo_pose = nullptr, const uint8_t* dynamic = nullptr) {
+        const cv::Mat rgb = rgb_h.isContinuous() ? rgb_h : rgb_h.clone(), d = depth_h.isContinuous() ? depth_h : depth_h.clone();
+        processFrame(rgb.ptr<uint8_t>(), d.ptr<float>(), vo_pose, dynamic);
+    }
+#endif
+    Transform3 getPose() const {
+        Transform3 p; float v[12];
+        check(ssf_get_pose(need(), v));
+        for (int i = 0; i < 9; i++) p.R[i] = v[i];
+        for (int i = 0; i < 3; i++) p.t[i] = v[9 + i];
+        return p;
+    }
+    void setPose(const Transform3& p) {
+        float v[12];
+        for (int i = 0; i < 9; i++) v[i] = p.R[i];
+        for (int i = 0; i < 3; i++) v[9 + i] = p.t[i];
+        check(ssf_set_pose(need(), v));
+    }
+    int getnbSupersurfels() const { int n = 0; check(ssf_get_counts(need(), &n, nullptr, nullptr, nullptr)); return n; }
+    int getnbVisible() const { int n = 0; check(ssf_get_counts(need(), nullptr, &n, nullptr, nullptr)); return n; }
+    int getStamp() const { int s = 0; check(ssf_get_counts(need(), nullptr, nullptr, &s, nullptr)); return s; }
+    int getnbSuperpixels() const { int s = 0; check(ssf_get_counts(need(), nullptr, nullptr, nullptr, &s)); return s; }
+    /* getModel() / getFrame(): the reference returns device-resident thrust vectors and the node copies
+     * [0, nbSupersurfels) to the host (supersurfel_fusion_node.cpp:306-310); here the copy comes back directly */
+    HostSupersurfels getModel() {
+        HostSupersurfels m; m.resize(getnbSupersurfels());
+        ssf_surfels v = m.view();
+        check(ssf_get_model(need(), 0, m.size, &v));
+        return m;
+    }
+    HostSupersurfels getFrame() {
+        HostSupersurfels m; m.resize(getnbSuperpixels());
+        ssf_surfels v = m.view();
+        check(ssf_get_frame(need(), &v));
+        return m;
+    }
+    void exportModel(const std::string& file) { check(ssf_export_model_txt(need(), file.c_str())); }   /* supersurfel_fusion.cu:595-633 */
+    /* computeSuperpixelSegIm's data (supersurfel_fusion.hpp:103): the label of every pixel */
+    std::vector<int32_t> getIndexImage() {
+        std::vector<int32_t> v((size_t)width_ * height_);
+        check(ssf_get_index_map(need(), v.data()));
+        return v;
+    }
+    const ssf_frame_result& lastResult() const { return last_; }
+    ssf_handle* handle() { return h_; }
+
+private:
+    ssf_handle* need() const { if (!h_) throw std::logic_error("SupersurfelFusion: initialize() first"); return h_; }
+    void check(int rc) const { if (rc != SSF_OK) throw std::runtime_error(std::string(ssf_last_error(h_))); }
+    ssf_handle* h_ = nullptr;
+    ssf_frame_result last_{};
+    int width_ = 0, height_ = 0;
+};
+
+}  /* namespace supersurfel_fusion */
+#endif
