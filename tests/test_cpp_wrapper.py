@@ -4,6 +4,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 import util
 from conftest import ORACLE_LIB, ROOT
@@ -11,6 +12,16 @@ from supersurfel_fusion_amd import binding, synthetic
 
 
 def test_cpp_wrapper_builds_and_matches_the_python_mirror(oracle_lib, tmp_path):
+    _run(oracle_lib, ORACLE_LIB, "ssf_oracle", tmp_path)
+
+
+@pytest.mark.gpu
+def test_cpp_wrapper_on_the_hip_library(oracle_lib, product_lib, tmp_path):
+    """the same C++ program linked against libssf_hip.so on the GPU box, checked against the oracle"""
+    _run(oracle_lib, os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
+
+
+def _run(oracle_lib, lib_path, lib_name, tmp_path):
     W, H, n = 160, 128, 3
     frames = [util.frame(k, W, H) for k in range(n)]
     raw = tmp_path / "frames.bin"
@@ -18,9 +29,9 @@ def test_cpp_wrapper_builds_and_matches_the_python_mirror(oracle_lib, tmp_path):
         for rgb, depth in frames:
             f.write(np.ascontiguousarray(rgb, np.uint8).tobytes()); f.write(np.ascontiguousarray(depth, np.float32).tobytes())
     exe = tmp_path / "wrapper_smoke"
-    libdir = os.path.dirname(ORACLE_LIB)
+    libdir = os.path.dirname(lib_path)
     cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "wrapper_smoke.cpp"), "-o", str(exe), "-L", libdir, "-lssf_oracle",
+           os.path.join(ROOT, "tests", "cpp", "wrapper_smoke.cpp"), "-o", str(exe), "-L", libdir, "-l" + lib_name,
            "-Wl,-rpath," + libdir]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
