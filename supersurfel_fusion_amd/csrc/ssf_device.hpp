@@ -99,8 +99,10 @@ struct FrameMaps {
 // The extract kernels take the batch index from the grid (blockIdx.z, or .y for 1-D kernels): one
 // launch relabels the tiles of all frames of the batch.  srgb_lut is shared.
 #define SSF_MAX_BATCH 8
+// (byte arithmetic on a char pointer, not on an integer: a pointer that went through an integer loses its address
+// space, and every access through it becomes a FLAT instruction -- which also ties LDS waits to outstanding loads)
 template <typename T> SSF_HD T* slab_shift(T* p, size_t off) {
-    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + off);
+    return reinterpret_cast<T*>(const_cast<char*>(reinterpret_cast<const char*>(p)) + off);
 }
 SSF_HD SpSums batch_slot(SpSums s, size_t o) { s.r = slab_shift(s.r, o); return s; }
 SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {

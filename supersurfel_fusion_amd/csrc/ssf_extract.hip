@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
         const int ws = win.slot(l);
         // (a ballot/popcount aggregation per (label, sample) instead of replicas was measured slower: 41 us)
         for (int sk = 0; sk < ns; sk++) {
-            const float4 th = ws >= 0 ? w_plane[ws * ns + sk] : m.samples[(size_t)l * ns + sk];
+            float4 th;                          // (two loads in two branches: a select of an LDS and a global address is a FLAT load)
+            if (ws >= 0) th = w_plane[ws * ns + sk]; else th = m.samples[(size_t)l * ns + sk];
             if (isfinite(th.z)) {
                 const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
                 const float dd = (d - dp) * (d - dp);
@@ -741,7 +742,8 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const size_t q = (size_t)y * p.W + x;
         const int label = tile[(ly + 1) * TW + lx + 1];
         const int ws = win.slot(label);
-        const SpRow sp = ws >= 0 ? w_row[ws] : m.sp[label];
+        SpRow sp;
+        if (ws >= 0) sp = w_row[ws]; else sp = m.sp[label];
         const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
         const float depth = 1.f / disp;
         m.plane_depth[q] = depth;
