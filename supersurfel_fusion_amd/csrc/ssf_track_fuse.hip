@@ -63,7 +63,10 @@ __device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict_
     const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
     const int tid = (int)pl.x;
     const float zt = __uint_as_float(pl.y);
-    const float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];   // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
+    float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];         // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
+    // (keeps the gather whole: left alone, the compiler fetches the confidence first, tests it, and only then the
+    // rest -- a second dependent round trip)
+    asm volatile("" : "+v"(f0.y), "+v"(f1.x));
     if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) return;
     const float dist_color = len3(sub(mlab, v3(f0.y, f0.z, f0.w)));
     const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
@@ -308,24 +311,29 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
-    if (!(model.conf[id] > 0.0f)) return -1;
+    // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
+    // row -> pixel -> frame supersurfel -> atomic, three dependent round trips instead of five
+    float m_conf = model.conf[id];
+    V3 mp = ld3(model.pos, id), m_r2 = ld3(model.r2, id), m_lab = ld3(model.lab, id);
+    asm volatile("" : "+v"(m_conf), "+v"(mp.x), "+v"(m_r2.x), "+v"(m_lab.x));
+    if (!(m_conf > 0.0f)) return -1;
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
     const V3 tview = negate(m3_mulv(Rt_, t));
-    const V3 mp = ld3(model.pos, id);
     const V3 pv = add(m3_mulv(Rt_, mp), tview);
     if (!(pv.z > zmin && pv.z < zmax)) return -1;
     const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
     if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return -1;
     const int f = (int)pix2[(size_t)py * cam.W + px].x;
     matched[f] = 1;
-    const float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];     // (conf, lab) (normal) (pos): one line
+    float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];           // (conf, lab) (normal) (pos): one line
+    asm volatile("" : "+v"(f0.y), "+v"(f1.x), "+v"(f2.x));       // (one gather, not confidence first and the rest later: see icp_row)
     if (!(f0.x > 0.0f)) return -1;
     const V3 fp = add(m3_mulv(R, v3(f2.x, f2.y, f2.z)), t);
     const V3 fn = unit3(row_mul(v3(f1.x, f1.y, f1.z), Rt_));    // third row of frame_orientation * R^T
-    const V3 mn = unit3(ld3(model.r2, id));
+    const V3 mn = unit3(m_r2);
     const float dist = len3(sub(mp, fp));
-    const float lab_dist = len3(sub(ld3(model.lab, id), v3(f0.y, f0.z, f0.w)));
+    const float lab_dist = len3(sub(m_lab, v3(f0.y, f0.z, f0.w)));
     const float delta_norm = fabsf(dot3(mn, fn));
     if (!(lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f)) return -1;
     const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
