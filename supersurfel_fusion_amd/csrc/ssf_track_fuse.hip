@@ -404,30 +404,40 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
     __shared__ int h2[OOV_PER_WG][4][2];
     const int wv = threadIdx.x >> 6;
     const long long head = cnt->oov_head, tail = cnt->oov_tail;
-    // every load of a step for all OOV_PER_WG slots before the next step (a dead slot's row is read and ignored)
+    // Every load of a step for all OOV_PER_WG slots before the next step.  The loads are unconditional (index clamped
+    // into the span; a dead or out-of-span slot's row is read and ignored) and pinned together: with `in ? load : 0`
+    // the compiler made each slot's loads a branch of its own, one dependent round trip per slot and step.
     int cls[OOV_PER_WG];
     uint8_t lv[OOV_PER_WG]; float conf[OOV_PER_WG]; int seen[OOV_PER_WG]; V3 pos[OOV_PER_WG]; ClsPre pre[OOV_PER_WG]; float z[OOV_PER_WG];
+    bool in[OOV_PER_WG];
 #pragma unroll
     for (int j = 0; j < OOV_PER_WG; j++) {
-        const long long phys = head + ((long long)wg * OOV_PER_WG + j) * blockDim.x + threadIdx.x;
-        const bool in = phys < tail;
-        lv[j] = in ? O.live[phys] : (uint8_t)0;
-        conf[j] = in ? O.rows.conf[phys] : 0.0f;
-        seen[j] = in ? O.rows.stamps[2 * phys + 1] : 0;
-        pos[j] = in ? ld3(O.rows.pos, (size_t)phys) : v3(0.f, 0.f, 0.f);
+        const long long phys = head + ((long long)wg * OOV_PER_WG + j) * 256 /* block size of the fuse launch */ + threadIdx.x;
+        in[j] = phys < tail;
+        const size_t q = (size_t)(in[j] ? phys : tail - 1);
+        lv[j] = O.live[q]; conf[j] = O.rows.conf[q]; seen[j] = O.rows.stamps[2 * q + 1]; pos[j] = ld3(O.rows.pos, q);
+    }
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) {
+        int lvj = lv[j];
+        asm volatile("" : "+v"(lvj), "+v"(conf[j]), "+v"(seen[j]), "+v"(pos[j].x), "+v"(pos[j].y), "+v"(pos[j].z));
+        lv[j] = in[j] ? (uint8_t)lvj : (uint8_t)0;
     }
 #pragma unroll
     for (int j = 0; j < OOV_PER_WG; j++) {
         pre[j] = classify_pre(cam, conf[j], seen[j], pos[j], pose, stamp, delta_t, conf_thresh, zmin, zmax);
         if (!lv[j]) { pre[j].st = 7; pre[j].pix = 0; }
+        if (pre[j].st >= 0) pre[j].pix = 0;
     }
 #pragma unroll
-    for (int j = 0; j < OOV_PER_WG; j++) z[j] = pre[j].st < 0 ? plane_depth[pre[j].pix] : 0.0f;
+    for (int j = 0; j < OOV_PER_WG; j++) z[j] = plane_depth[pre[j].pix];
+#pragma unroll
+    for (int j = 0; j < OOV_PER_WG; j++) asm volatile("" : "+v"(z[j]));
 #pragma unroll
     for (int j = 0; j < OOV_PER_WG; j++) {
         cls[j] = classify_post(pre[j], z[j]);
         if (lv[j]) {
-            const long long phys = head + ((long long)wg * OOV_PER_WG + j) * blockDim.x + threadIdx.x;
+            const long long phys = head + ((long long)wg * OOV_PER_WG + j) * 256 /* block size of the fuse launch */ + threadIdx.x;
             if (cls[j] == 2) O.rows.conf[phys] = -1.0f;
             state_oov[phys] = (uint8_t)cls[j];
         }
@@ -833,7 +843,15 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
                                                    unsigned long long cnt_seq) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     // the frame's counters (finalised by the fuse launch, cnt[1]) go to the host while the rows move
-    if (blockIdx.x == 0 && threadIdx.x == 255) mailbox_counters(cnt[1], mb, cnt_seq);
+    if (blockIdx.x == 0 && threadIdx.x == 255) {
+        int w[sizeof(Counters) / sizeof(int)];                    // (all words requested before the first store to the host)
+        const int* src = reinterpret_cast<const int*>(&cnt[1]);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) w[i] = __builtin_nontemporal_load(&src[i]);
+        Counters c;
+        __builtin_memcpy(&c, w, sizeof(c));
+        mailbox_counters(c, mb, cnt_seq);
+    }
     __shared__ int hist[4][6];
     __shared__ uint32_t base[6];                  // rows of each class in the blocks before this one
     __shared__ unsigned long long red[ICP ? 29 * ICP_SLOTS : 1];
