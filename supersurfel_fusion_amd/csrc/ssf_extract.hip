@@ -77,6 +77,21 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
 // means (+ plane) of one superpixel from its exact sums: mergeTPSRGBCoeffs_kernel /
 // mergeTPSRGBDCoeffs_kernel, TPS_RGBD_kernels.cu:224-276.  `prev` supplies the plane that an RGB-only
 // merge leaves untouched.
+// Loads for the rare "outside the LDS window" paths.  Written as nontemporal loads so that the compiler cannot fold
+// "LDS copy if inside the window, else global" into ONE load through a selected address -- that is a FLAT load, slower
+// than either and tied to both wait counters.
+__device__ __forceinline__ float4 ld_global_f4(const float4* p) {
+    const float* q = reinterpret_cast<const float*>(p);
+    return make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
+                       __builtin_nontemporal_load(q + 3));
+}
+__device__ __forceinline__ SpRow ld_global_row(const SpRow* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = ld_global_f4(q), b = ld_global_f4(q + 1), c = ld_global_f4(q + 2);
+    SpRow r; r.cx = a.x; r.cy = a.y; r.r = a.z; r.g = a.w; r.b = b.x; r.ta = b.y; r.tb = b.z; r.tc = b.w;
+    r.size = c.x; r.pad0 = c.y; r.pad1 = c.z; r.pad2 = c.w;
+    return r;
+}
 __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with_planes, SpRow prev) {
     SpRow row = prev;
     // the record is read as whole 16-byte pieces (two cache lines per superpixel)
@@ -509,8 +524,8 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
         const int ws = win.slot(l);
         // (a ballot/popcount aggregation per (label, sample) instead of replicas was measured slower: 41 us)
         for (int sk = 0; sk < ns; sk++) {
-            float4 th;                          // (two loads in two branches: a select of an LDS and a global address is a FLAT load)
-            if (ws >= 0) th = w_plane[ws * ns + sk]; else th = m.samples[(size_t)l * ns + sk];
+            float4 th = w_plane[(ws >= 0 ? ws : 0) * ns + sk];      // (LDS read always: see k_render_moments)
+            if (ws < 0) th = ld_global_f4(&m.samples[(size_t)l * ns + sk]);
             if (isfinite(th.z)) {
                 const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
                 const float dd = (d - dp) * (d - dp);
@@ -721,6 +736,10 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         if (l >= 0) w_row[i] = m.sp[l];
     }
     for (int i = threadIdx.x; i < win.size() * 13 * ACC_REP; i += blockDim.x) w_acc[i] = 0ull;
+    // the gamma table in LDS: three lookups per pixel would otherwise be global loads queued behind this thread's
+    // stores (the maps may alias as far as the compiler knows)
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = m.srgb_lut[threadIdx.x];
     // this thread's pixels: inlier flag and colour requested up front (in flight while the tile is staged)
     constexpr int PX = TILE * TILE / 256;
     unsigned char pin[PX]; uint32_t prgba[PX];
@@ -733,26 +752,26 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
     }
     load_label_tile(tile, m.label, X0, Y0, p.W, p.H);
     __syncthreads();
+    float out_depth[PX]; int out_label[PX];
 #pragma unroll
     for (int k = 0; k < PX; k++) {
         const int i = threadIdx.x + 256 * k;
         const int lx = i % TILE, ly = i / TILE;
         const int x = X0 + lx, y = Y0 + ly;
+        out_label[k] = -1; out_depth[k] = 0.f;
         if (x >= p.W || y >= p.H) continue;
-        const size_t q = (size_t)y * p.W + x;
         const int label = tile[(ly + 1) * TW + lx + 1];
         const int ws = win.slot(label);
-        SpRow sp;
-        if (ws >= 0) sp = w_row[ws]; else sp = m.sp[label];
+        SpRow sp = w_row[ws >= 0 ? ws : 0];      // (LDS read always, global row on top when outside the window: a select
+        if (ws < 0) sp = ld_global_row(&m.sp[label]);     //  between an LDS and a global ADDRESS would be one FLAT load)
         const float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
         const float depth = 1.f / disp;
-        m.plane_depth[q] = depth;
-        m.pix2[q] = make_uint2((uint32_t)label, __float_as_uint(depth));
+        out_label[k] = label; out_depth[k] = depth;
         const int bound = tile_boundary(tile, lx + 1, ly + 1);
         if (!(pin[k] && isfinite(depth) && depth > 0.0f && bound == 0)) continue;
         const V3 pos = v3(((float)x - cam.cx) * depth / cam.fx, ((float)y - cam.cy) * depth / cam.fy, depth);
         const uint32_t px = prgba[k];
-        const V3 lab = rgb8_to_lab(m.srgb_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
+        const V3 lab = rgb8_to_lab(s_lut, px & 255u, (px >> 8) & 255u, (px >> 16) & 255u);
         const Sym3 c = sym_outer(pos);
         const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
         if (ws >= 0) {
@@ -765,6 +784,15 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
             for (int j = 0; j < 12; j++) atomic_add_i64(&m.moments[(size_t)label * 13 + j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
             atomic_add_i64(&m.moments[(size_t)label * 13 + 12], 1);
         }
+    }
+    // the rendered depth and the packed (label, depth) table of ICP / association: stored after all loads
+#pragma unroll
+    for (int k = 0; k < PX; k++) {
+        if (out_label[k] < 0) continue;
+        const int i = threadIdx.x + 256 * k;
+        const size_t q = (size_t)(Y0 + i / TILE) * p.W + (X0 + i % TILE);
+        m.plane_depth[q] = out_depth[k];
+        m.pix2[q] = make_uint2((uint32_t)out_label[k], __float_as_uint(out_depth[k]));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) {

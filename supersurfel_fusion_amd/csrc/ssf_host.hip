@@ -393,7 +393,7 @@ struct ssf_handle {
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
     bool icp_ahead = true;
-    bool graph_failed = false;
+    bool graph_failed = false; hipStream_t capture_stream = nullptr;
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
     int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
@@ -490,9 +490,8 @@ struct TimerScope {
 // Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
 // kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
 // only materialised where a later stage wants it: before the plane filter.
-static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c) {
+static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st) {
     const SegParams& p = h->seg;
-    hipStream_t st = c.stream;
     const int nb = c.count;
     const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
@@ -516,17 +515,20 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
     if (use_graph) {
         hipGraphExec_t& ex = c.exec[c.count];
         if (!ex) {
-            bool ok = hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            // captured on a stream of its own, not on the context's: the upload thread (Uploader) may be enqueueing
+            // copies on the context's stream at this very moment
+            bool ok = (h->capture_stream || hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) == hipSuccess) &&
+                      hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                enqueue_segmentation(h, c);
-                ok = hipStreamEndCapture(c.stream, &c.graph[c.count]) == hipSuccess && c.graph[c.count] != nullptr;
+                enqueue_segmentation(h, c, h->capture_stream);
+                ok = hipStreamEndCapture(h->capture_stream, &c.graph[c.count]) == hipSuccess && c.graph[c.count] != nullptr;
             }
             if (ok) ok = hipGraphInstantiate(&ex, c.graph[c.count], nullptr, nullptr, 0) == hipSuccess;
             if (!ok) { h->graph_failed = true; ex = nullptr; (void)hipGetLastError(); }
         }
         if (ex) { HCK(hipGraphLaunch(ex, c.stream)); return SSF_OK; }
     }
-    enqueue_segmentation(h, c);
+    enqueue_segmentation(h, c, c.stream);
     return SSF_OK;
 }
 
@@ -1087,6 +1089,7 @@ void ssf_destroy(ssf_handle* h) {
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
         if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     }
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
