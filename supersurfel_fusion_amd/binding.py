@@ -235,14 +235,21 @@ class Fusion:
         mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
         self._ck(self.L.lib.ssf_submit_frame(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_submit_frame")
 
+    def prepare_sequence(self, rgb_ptrs, depth_ptrs):
+        """ctypes argument arrays of a sequence (built ahead, e.g. outside a timed region): (rgb, depth, results, n)"""
+        n = len(rgb_ptrs)
+        return (C.c_void_p * n)(*rgb_ptrs), (C.c_void_p * n)(*depth_ptrs), (SsfFrameResult * n)(), n
+
+    def process_prepared(self, prepared, on_device=True):
+        """ssf_process_sequence on arrays from prepare_sequence; returns the raw SsfFrameResult array (as_dict() each)."""
+        pr, pd, res, n = prepared
+        self._ck(self.L.lib.ssf_process_sequence(self.h, pr, pd, n, 1 if on_device else 0, res), "ssf_process_sequence")
+        return res
+
     def process_sequence(self, rgb_ptrs, depth_ptrs, on_device=True):
         """The whole submit-ahead / process-in-order loop in native code.  rgb_ptrs / depth_ptrs: raw addresses
         (device pointers when on_device, else addresses of contiguous host arrays).  Returns a list of result dicts."""
-        n = len(rgb_ptrs)
-        pr = (C.c_void_p * n)(*rgb_ptrs); pd = (C.c_void_p * n)(*depth_ptrs)
-        res = (SsfFrameResult * n)()
-        self._ck(self.L.lib.ssf_process_sequence(self.h, pr, pd, n, 1 if on_device else 0, res), "ssf_process_sequence")
-        return [r.as_dict() for r in res]
+        return [r.as_dict() for r in self.process_prepared(self.prepare_sequence(rgb_ptrs, depth_ptrs), on_device)]
 
     def process_submitted(self, prior_pose=None):
         """ICP + association + fusion of the oldest submitted frame; returns its SsfFrameResult."""

@@ -482,19 +482,30 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
     if (wv == 3) return;
     const int f = wv == 0 ? f0 + (l >> 1) : f0 + (wv - 1) * 16 + (l >> 2);
     if (f >= S) return;                                   // (uniform over a supersurfel's lanes, like every test below)
-    if (!matched[f] || best[f] == SSF_NO_MATCH) return;
-    const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
+    // Two dependent round trips instead of four: everything that hangs on the frame supersurfel alone is requested at
+    // once (association result and the frame row), then everything that hangs on the model row it won.
+    unsigned int mt = matched[f];
+    unsigned long long bk = best[f];
+    float f_conf = F.conf[f];
+    V3 f_pos = v3(0.f, 0.f, 0.f), f_lab = v3(0.f, 0.f, 0.f);
+    Sym3 f_shape = sym3(0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    if (wv == 0) { f_pos = ld3(F.pos, f); f_shape = ld6(F.shape, f); } else f_lab = ld3(F.lab, f);
+    asm volatile("" : "+v"(mt), "+v"(bk), "+v"(f_conf), "+v"(f_pos.x), "+v"(f_shape.xx), "+v"(f_lab.x));
+    if (!mt || bk == SSF_NO_MATCH) return;
+    const long long local = (long long)(uint32_t)(bk & 0xFFFFFFFFull) - id_offset;
     if (local < 0 || local >= n_visible) return;
     const size_t m = (size_t)local;
-    const float m_conf = M.conf[m], f_conf = F.conf[f];
+    float m_conf = M.conf[m];
+    V3 model_position = v3(0.f, 0.f, 0.f), model_lab = v3(0.f, 0.f, 0.f);
+    Sym3 model_shape = sym3(0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    if (wv == 0) { model_position = ld3(M.pos, m); model_shape = ld6(M.shape, m); } else model_lab = ld3(M.lab, m);
+    asm volatile("" : "+v"(m_conf), "+v"(model_position.x), "+v"(model_shape.xx), "+v"(model_lab.x));
     const float ratio = 1.0f / (m_conf + f_conf);
     if (wv == 0) {
         const int which = l & 1;
         const M3 R = pose.R; const V3 t = pose.t;
-        const V3 model_position = ld3(M.pos, m);
-        const V3 frame_position = add(m3_mulv(R, ld3(F.pos, f)), t);
-        const Sym3 frame_shape = rot_sym(R, ld6(F.shape, f));
-        const Sym3 model_shape = ld6(M.shape, m);
+        const V3 frame_position = add(m3_mulv(R, f_pos), t);
+        const Sym3 frame_shape = rot_sym(R, f_shape);
         Sym3 f1, m1, fused_shape, fused_1;
         V3 fused_position;
         const float w = ratio * f_conf;
@@ -535,7 +546,7 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
         }
     } else {
         const int ch = min(l & 3, 2), l0 = l & ~3;        // (the fourth lane repeats the third channel; its results are unused)
-        const V3 frame_lab = ld3(F.lab, f), model_lab = ld3(M.lab, m);
+        const V3 frame_lab = f_lab;
         const V3 lin = lab_to_linear_rgb(scale(ratio, add(scale(f_conf, frame_lab), scale(m_conf, model_lab))));
         const float c255 = srgb_to_255(pick3(lin, ch));
         const V3 fused_color = v3(__shfl(c255, l0, 64), __shfl(c255, l0 + 1, 64), __shfl(c255, l0 + 2, 64));
@@ -673,10 +684,14 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         const int vb = b - nupd - nchunks, i = vb * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
         int cls = 7;
         if (i < n_visible) {
-            const int f = cand[i];
+            // the row's own fields travel together with its candidate (then: association result, then the depth lookup)
+            int f = cand[i];
+            float conf = M.conf[i]; int seen = M.stamps[2 * (size_t)i + 1]; V3 pos = ld3(M.pos, (size_t)i);
+            asm volatile("" : "+v"(f), "+v"(conf), "+v"(seen), "+v"(pos.x));
             const bool rewritten = do_update && f >= 0 && (uint32_t)(best[f] & 0xFFFFFFFFull) == (uint32_t)(id_offset + i);
             if (!rewritten) {
-                cls = classify_row(ca.cam, M, (size_t)i, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax);
+                cls = classify_values(ca.cam, conf, seen, pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax);
+                if (cls == 2) M.conf[i] = -1.0f;
                 state_vis[i] = (uint8_t)cls;
             }
         }
