@@ -471,3 +471,23 @@ def test_pipelined_with_priors_blank_frames_and_pose_changes(depth_ahead, batch,
         got = fh.process_submitted(prior_pose=priors.get(k)).as_dict()
         util.same_result(want, got)
     util.compare_state(fo, fh)
+
+
+@pytest.mark.gpu
+def test_host_frame_sequences_on_fresh_handles(oracle_lib, product_lib):
+    """ssf_process_sequence with HOST frames uploads them from a worker thread while the calling thread launches --
+    and, on a fresh handle, captures -- the extract graphs: every (depth, batch) on a new handle, partial last batches,
+    a second sequence on the same handle."""
+    W, H, nf = 160, 128, 9
+    frames = [util.frame(k, W, H, noise=True) for k in range(2 * nf)]
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    want = [fo.process_frame(*fr) for fr in frames]
+    for depth_ahead, batch in [(1, 1), (1, 2), (2, 2), (2, 3), (1, 4), (2, 4), (3, 2), (1, 5), (2, 8)]:
+        fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+        keep = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+        got = fh.process_sequence([r.ctypes.data for r, _ in keep[:nf]], [d.ctypes.data for _, d in keep[:nf]], on_device=False)
+        got += fh.process_sequence([r.ctypes.data for r, _ in keep[nf:]], [d.ctypes.data for _, d in keep[nf:]], on_device=False)
+        for a, b in zip(want, got):
+            util.same_result(a, b)
+        util.compare_state(fo, fh, maps=False, frame_surfels=False)
+        fh.close()
