@@ -190,7 +190,7 @@ struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view
 // the class counts (sup_vis: 6 per group, sup_oov: rows that come back into view), and the frame totals
 // a0 a1 a2 c0 c1 c2 b0 b2 in PART_REPLICAS copies of 8 words.  Two sets alternate by frame: `other` (all `words`
 // of it) is cleared by the frame that uses this one.  ticket: arrival counters of the fuse launch (65 words, zero at rest).
-#define PART_GROUP 32
+#define PART_GROUP 16
 #define PART_REPLICAS 8
 struct PartitionWs { uint32_t* sup_vis; uint32_t* sup_oov; uint32_t* tot; uint32_t* ticket; uint32_t* other; int words; };
 // The fuse launch (k_update_insert in ssf_track_fuse.hip): update of the matched rows | ordered insertion of the
