@@ -202,7 +202,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, Mailbox* mb, unsigned long long seq);
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // first ICP iteration of the next frame, accumulated by the row-move kernel of this one (launch_classify_reorder)

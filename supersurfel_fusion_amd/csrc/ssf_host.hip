@@ -868,7 +868,7 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         launch_fuse(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->d_cand,
                     h->S, nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
                     h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
-                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->mb_dev, seq);
+                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws);
         // The rows the move kernel writes to the new visible array are the rows the next frame's first ICP iteration
         // reads, under a transform that is known now (the pose just estimated, when the caller supplies no prior):
         // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).

@@ -399,7 +399,7 @@ __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, 
 __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStore& O, const Rt& pose, const float* __restrict__ plane_depth,
                                                    int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
                                                    uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, PartitionWs ws,
-                                                   const Counters* __restrict__ cnt, int wg, int nb_oov, int (*hist)[6]) {
+                                                   const Counters* __restrict__ cnt, int wg, int nb_oov) {
     // OOV_PER_WG blocks of 256 slots per workgroup (fewer arrivals at the end of the launch)
     __shared__ int h2[OOV_PER_WG][4][2];
     const int wv = threadIdx.x >> 6;
@@ -447,7 +447,6 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
         const int k0 = __popcll(__ballot(cls[j] == 0)), k2 = __popcll(__ballot(cls[j] == 2));
         if (lane() == 0) { h2[j][wv][0] = k0; h2[j][wv][1] = k2; }
     }
-    (void)hist;
     __syncthreads();
     if (threadIdx.x < 2 * OOV_PER_WG) {
         const int j = threadIdx.x >> 1, which = threadIdx.x & 1, ob = wg * OOV_PER_WG + j;
@@ -670,7 +669,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                                                        int do_update, int capacity, int rank, int nranks, float tile, Counters* cnt,
                                                        int nupd, int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
                                                        uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
-                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws, Mailbox* mb, unsigned long long seq) {
+                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
     const int b = blockIdx.x;
     if (b >= nupd + nchunks + nb_vis)
         classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
-                           ws, cnt, b - nupd - nchunks - nb_vis, nb_oov, hist);
+                           ws, cnt, b - nupd - nchunks - nb_vis, nb_oov);
     else if (b >= nupd + nchunks) {
         const int vb = b - nupd - nchunks, i = vb * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
         int cls = 7;
@@ -743,7 +742,6 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         // the frame's counters are final here; the move kernel that follows in the stream sends them to the host first
         // thing (cnt[1]), so that this launch does not end on the acknowledgement of writes to host memory
         cnt[1] = finalise_counters(cnt, c, 1);
-        (void)mb; (void)seq;
     }
 }
 
@@ -1193,7 +1191,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, Mailbox* mb, unsigned long long seq) {
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws) {
     ScopedKernel sk("update_insert", st);
     const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256, nb_vis = (n_visible + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
@@ -1201,7 +1199,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
     hipLaunchKernelGGL(k_update_insert, dim3(nupd + nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
                        frame, pose, stamp, id_offset,
                        n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nupd, nchunks, nb_vis, nb_oov, oov, ca,
-                       state_vis, state_oov, bc_oov, ws, mb, seq);
+                       state_vis, state_oov, bc_oov, ws);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {
