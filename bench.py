@@ -69,6 +69,9 @@ def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_
     kw.update(PARAMS)
     if stream is not None:
         kw["stream"] = stream
+    # one process per GPU: the library works on the device this process has selected (LOCAL_RANK under torchrun)
+    if lib.backend.startswith("hip") and torch.cuda.is_available():
+        kw["device_id"] = torch.cuda.current_device()
     return lib.default_config(**kw)
 
 
