@@ -9,13 +9,18 @@ import bench, util
 from conftest import ORACLE_LIB
 from supersurfel_fusion_amd import binding, synthetic
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+if len(sys.argv) > 4 and sys.argv[4] == "config3":            # BASELINE config 3: 1280x960, all seeded supersurfels in view, forced iterations
+    bench.W, bench.H = 1280, 960
 olib = binding.Library(ORACLE_LIB); plib = binding.load_product()
 frames = bench.render_frames(32)
 order = [(i % 62) if (i % 62) < 32 else 62 - (i % 62) for i in range(nf)]
 seq = [(np.ascontiguousarray(frames[k][0]), np.ascontiguousarray(frames[k][1])) for k in order]
-model, nvis = synthetic.seed_model_cam0(bench.N_MODEL, bench.W, bench.H, stamp=30)
-fo = binding.Fusion(olib, bench.make_cfg(olib, bench.N_MODEL + 65536))
-fh = binding.Fusion(plib, bench.make_cfg(plib, bench.N_MODEL + 65536, pipeline_depth=2, extract_batch=4))
+c3 = bench.W == 1280
+model, nvis = (synthetic.seed_model_cam0_visible if c3 else synthetic.seed_model_cam0)(bench.N_MODEL, bench.W, bench.H, stamp=30)
+fo = binding.Fusion(olib, bench.make_cfg(olib, bench.N_MODEL + 65536, force_icp=c3))
+fh = binding.Fusion(plib, bench.make_cfg(plib, bench.N_MODEL + 65536, force_icp=c3, pipeline_depth=depth, extract_batch=batch))
 fo.set_model(model, nvis, 30); fh.set_model(model, nvis, 30)
 t0 = time.time()
 want = [fo.process_frame(r, d) for r, d in seq]
@@ -26,4 +31,4 @@ for i, (a, b) in enumerate(zip(want, got)):
         assert a[key] == b[key], (i, key, a[key], b[key])
     util.assert_same_bits(a["pose"], b["pose"], "pose of frame %d" % i)
 util.compare_state(fo, fh)
-print("ok: %d frames, n_model %d n_visible %d, oracle %.0f s" % (nf, want[-1]["n_model"], want[-1]["n_visible"], t1 - t0))
+print("ok (%dx%d, depth %d, batch %d): %d frames, n_model %d n_visible %d, oracle %.0f s" % (bench.W, bench.H, depth, batch, nf, want[-1]["n_model"], want[-1]["n_visible"], t1 - t0))
