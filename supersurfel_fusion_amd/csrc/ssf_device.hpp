@@ -179,9 +179,18 @@ void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* labe
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
 // replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: 65 zeroed u32 (global + 64 group arrival counters)
 // pix2 / fpack: FrameMaps::pix2 / fpack of the frame
+// go != nullptr: the launch is made AHEAD of its transform (while the previous iteration is still running, so that its
+// launch latency is off the host round trip): the workgroups wait until the host stores go->flag == go_seq (then
+// the transform is in go->T) or go_seq | SSF_ICP_GO_ABORT (no further iteration: leave at once).  IcpGo lives in
+// fine-grained DEVICE memory that the host writes directly (large BAR): ~1 us from the host's store to the kernel's
+// eyes (tools/probe/bar_write.hip), against ~5 us for a launch to start.
+struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; };       // one 128-byte slot
+#define SSF_ICP_GO_ABORT (1ull << 63)
+#define SSF_ICP_GO_SLOTS 4
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
-                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1);
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, const IcpGo* go = nullptr,
+                unsigned long long go_seq = 0);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);

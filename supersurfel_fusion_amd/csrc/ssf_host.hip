@@ -393,6 +393,9 @@ struct ssf_handle {
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
     bool icp_ahead = true;
+    // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
+    // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
+    IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
     bool graph_failed = false; hipStream_t capture_stream = nullptr;
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
@@ -983,6 +986,32 @@ static int comm_counts(ssf_handle* h) {
     return SSF_OK;
 }
 
+// ---- chained ICP launches --------------------------------------------------------------------------------
+// launch the NEXT iteration now, to wait on the device for its transform; returns the sequence number of its record
+static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo** slot_out, unsigned long long* go_seq_out) {
+    const unsigned long long seq = ++h->icp_seq;
+    const unsigned long long go_seq = ++h->go_count;
+    IcpGo* slot = h->go + (go_seq % SSF_ICP_GO_SLOTS);
+    Rt none; none.R = m3_identity(); none.t = v3(0, 0, 0);
+    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, none,
+               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq);
+    HCK(hipGetLastError());
+    *seq_out = seq; *slot_out = slot; *go_seq_out = go_seq;
+    return SSF_OK;
+}
+// the host's word to a waiting launch: its transform and "go", or "no further iteration"
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T) {
+    volatile IcpGo* s = slot;
+    if (T) {
+        const float v[12] = {T->R.r0.x, T->R.r0.y, T->R.r0.z, T->R.r1.x, T->R.r1.y, T->R.r1.z, T->R.r2.x, T->R.r2.y, T->R.r2.z,
+                             T->t.x, T->t.y, T->t.z};
+        for (int i = 0; i < 12; i++) s->T[i] = v[i];
+        __builtin_ia32_sfence();                  // (the mapping is write-combining: transform before flag, flag out now)
+        s->flag = go_seq;
+    } else s->flag = go_seq | SSF_ICP_GO_ABORT;
+    __builtin_ia32_sfence();
+}
+
 // ICP + association + fusion of the oldest submitted frame, on the track stream
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* out) {
@@ -998,7 +1027,37 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (h->comm) { rc = comm_counts(h); if (rc) return rc; }
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
+    // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
+    // already launched and waits on the device for its transform
+    const bool chain = h->icp_chain && h->go && !h->comm && h->cfg.nranks == 1 && h->cfg.profile != 1;
+    bool waiting = false; unsigned long long wait_seq_rec = 0, wait_go_seq = 0; IcpGo* wait_slot = nullptr;
     while (again) {
+        if (chain) {
+            unsigned long long seq_rec;
+            if (h->icp.ahead_seq) { seq_rec = h->icp.ahead_seq; h->icp.ahead_seq = 0; }     // iteration 1 came from the move kernel
+            else if (waiting) {                                                                 // this iteration is already on the device
+                const Rt T = icp_transform(h->icp);
+                icp_release_waiting(wait_slot, wait_go_seq, &T);
+                seq_rec = wait_seq_rec; waiting = false;
+            } else {
+                const Rt T = icp_transform(h->icp);
+                seq_rec = ++h->icp_seq;
+                launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
+                           h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec);
+                HCK(hipGetLastError());
+            }
+            // the next iteration, should there be one (the loop may run cfg.icp_iter iterations at most)
+            if (h->icp.iter + 1 < h->cfg.icp_iter) {
+                rc = icp_launch_waiting(h, &wait_seq_rec, &wait_slot, &wait_go_seq);
+                if (rc) return rc;
+                waiting = true;
+            }
+            rc = icp_fetch(h, seq_rec);
+            if (rc) { if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr); return rc; }
+            if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
+            icp_update(h, (const int64_t*)h->h_icp, &again);
+            continue;
+        }
         if (h->comm) {
             // shard record -> SUM over the ranks in HBM (exact: int64) -> mailbox -> host solve
             rc = icp_accumulate(h, false);
@@ -1018,6 +1077,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
         icp_update(h, (const int64_t*)h->h_icp, &again);
     }
+    if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr);     // no further iteration: the launch made ahead leaves
     icp_end(h, &valid);
     const double t_b = now_us();
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
@@ -1117,7 +1177,8 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int W = cfg->width, H = cfg->height, c = cfg->cell_size;
     h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
-    if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switch (tools/)
+    if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switches (tools/)
+    if (const char* e = getenv("SSF_ICP_CHAIN")) h->icp_chain = atoi(e) != 0;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
@@ -1192,6 +1253,14 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     h->part_sup_oov = (int)(((OC + 255) / 256 + 8) / PART_GROUP + 1);
     h->part_words = h->part_sup_vis + h->part_sup_oov + 8 * PART_REPLICAS;
     ok = ok && dalloc(h, &h->d_part, 2 * (size_t)h->part_words) && dalloc(h, &h->d_part_ticket, 128);
+    if (ok) {
+        // host-writable device memory for the chained ICP launches; without it (no large BAR) the launches are not chained
+        void* q = nullptr;
+        if (hipExtMallocWithFlags(&q, SSF_ICP_GO_SLOTS * sizeof(IcpGo), hipDeviceMallocFinegrained) == hipSuccess) {
+            h->allocs.push_back(q); h->go = (IcpGo*)q;
+            (void)hipMemset(q, 0, SSF_ICP_GO_SLOTS * sizeof(IcpGo));
+        } else { (void)hipGetLastError(); h->go = nullptr; }
+    }
     ok = ok && alloc_surfels(h, h->model[0], N) && alloc_surfels(h, h->model[1], N) && alloc_surfels(h, h->dense, N) &&
          alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&

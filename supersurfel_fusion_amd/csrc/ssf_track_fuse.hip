@@ -158,10 +158,32 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
-                                             long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg) {
+                                             long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
+                                             const IcpGo* go, unsigned long long go_seq) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
+    __shared__ float s_T[12];
+    __shared__ int s_go;
     for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
+    if (go) {
+        // launched ahead of its transform: wait for the host's word (bounded: a lost word must not hang the device)
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            for (int spin = 0; spin < (1 << 22); spin++) {
+                const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (v == go_seq) { ok = 1; break; }
+                if (v == (go_seq | SSF_ICP_GO_ABORT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok)
+                for (int i = 0; i < 12; i++) s_T[i] = __hip_atomic_load(&go->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_go = ok;
+        }
+        __syncthreads();
+        if (!s_go) return;
+        T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
+        T.t = v3(s_T[9], s_T[10], s_T[11]);
+    }
     __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
     const int slot = lane() & (ICP_SLOTS - 1);
@@ -1166,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
 // ---- launchers -----------------------------------------------------------------------------------
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
-                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg) {
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, const IcpGo* go, unsigned long long go_seq) {
     ScopedKernel sk("icp_accumulate", st);
     static int per_lane = 0;             // supersurfels per lane before the wave reduction
     if (!per_lane) { const char* e = getenv("SSF_ICP_PER_LANE"); per_lane = e ? atoi(e) : 1; if (per_lane < 1) per_lane = 1; }
@@ -1176,7 +1198,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     if (grid > 4096) grid = 4096;
     const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
     hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
-                       ticket, sums29, mb, seq, dbg);
+                       ticket, sums29, mb, seq, dbg, go, go_seq);
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
