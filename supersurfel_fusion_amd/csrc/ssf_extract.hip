@@ -102,9 +102,12 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
     row.r = (float)i0.z / n; row.g = (float)i0.w / n; row.b = (float)i1.x / n;
     row.size = n;
     if (with_planes) {
-        const int dn_i = s.r[k].dn;
+        int dn_i = s.r[k].dn;
         const longlong2* __restrict__ q = reinterpret_cast<const longlong2*>(&s.r[k].dxx);
-        const longlong2 q0 = q[0], q1 = q[1], q2 = q[2];   // dxx dyy | dxy dxd | dyd dd
+        longlong2 q0 = q[0], q1 = q[1], q2 = q[2];         // dxx dyy | dxy dxd | dyd dd
+        // the whole record in ONE round trip: left alone, the compiler fetches dxd / dyd / dd only behind the first
+        // test of the plane solve, a second dependent trip to memory in every RGB-D pass
+        asm volatile("" : "+v"(dn_i), "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y));
         const double inv = 1.0 / SSF_DISP_SCALE;
         const float dx = (float)i1.z, dy = (float)i1.w, dn = (float)dn_i;
         const float dxx = (float)q0.x, dyy = (float)q0.y, dxy = (float)q1.x;
