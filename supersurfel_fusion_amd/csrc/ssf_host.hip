@@ -1256,7 +1256,9 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     if (ok) {
         // host-writable device memory for the chained ICP launches; without it (no large BAR) the launches are not chained
         void* q = nullptr;
-        if (hipExtMallocWithFlags(&q, SSF_ICP_GO_SLOTS * sizeof(IcpGo), hipDeviceMallocFinegrained) == hipSuccess) {
+        int large_bar = 0;
+        (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, cfg->device_id);
+        if (large_bar && hipExtMallocWithFlags(&q, SSF_ICP_GO_SLOTS * sizeof(IcpGo), hipDeviceMallocFinegrained) == hipSuccess) {
             h->allocs.push_back(q); h->go = (IcpGo*)q;
             (void)hipMemset(q, 0, SSF_ICP_GO_SLOTS * sizeof(IcpGo));
         } else { (void)hipGetLastError(); h->go = nullptr; }
