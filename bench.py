@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
-    ap.add_argument("--extract-batch", type=int, default=4, help="frames per extract launch chain")
+    ap.add_argument("--extract-batch", type=int, default=8, help="frames per extract launch chain")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU exchanges (collectives included) even on one rank: exercises the N > 1 code path")
     ap.add_argument("--py-driver", action="store_true",
