@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
-    ap.add_argument("--extract-batch", type=int, default=8, help="frames per extract launch chain")
+    ap.add_argument("--extract-batch", type=int, default=None, help="frames per extract launch chain (default 8; 4 at 1280x960)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU exchanges (collectives included) even on one rank: exercises the N > 1 code path")
     ap.add_argument("--py-driver", action="store_true",
@@ -156,6 +156,8 @@ def main():
         model_local, nvis_local = model, nvis
     n_local = len(model_local["confidences"])
     cap = n_local + 65536
+    if a.extract_batch is None:
+        a.extract_batch = 4 if a.config == 3 else 8        # measured optima
     depth, batch = a.pipeline_depth, a.extract_batch
     # N > 1: the map is sharded and the library exchanges natively over RCCL on its track stream
     # (ssf_comm_attach; torch.distributed only ships the communicator id and provides the barrier).
