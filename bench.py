@@ -95,7 +95,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
                     help="2 (default): the configuration the metric is quoted on, 640x480 / ~1M supersurfels; 3: the HBM-bound "
                          "stress of BASELINE.json, 1280x960, ~1M supersurfels all visible, 10 forced ICP iterations")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=None,
+                    help="frames of the bounded cpu_baseline sample (0 = skip; default 80, 12 at 1280x960: 10-15 s of CPU work)")
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches the extract stage may run ahead of ICP/fusion (0 = strictly sequential)")
@@ -158,6 +159,8 @@ def main():
     cap = n_local + 65536
     if a.extract_batch is None:
         a.extract_batch = 4 if a.config == 3 else 8        # measured optima
+    if a.cpu_frames is None:
+        a.cpu_frames = 12 if a.config == 3 else 80
     depth, batch = a.pipeline_depth, a.extract_batch
     # N > 1: the map is sharded and the library exchanges natively over RCCL on its track stream
     # (ssf_comm_attach; torch.distributed only ships the communicator id and provides the barrier).
@@ -327,8 +330,8 @@ def main():
                 fo.process_frame(*h_frames[i])
             cdt = time.perf_counter() - t1
             cpu = dict(value=a.cpu_frames / cdt, unit="frames/s", cores=1, kind="port",
-                       sample="%d frames of the same 640x480 / ~1M-supersurfel workload, oracle/libssf_oracle.so "
-                              "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, cdt))
+                       sample="%d frames of the same %dx%d / ~1M-supersurfel workload, oracle/libssf_oracle.so "
+                              "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, W, H, cdt))
             fo.close()
 
     # whole-frame view: algorithmic bytes of one frame over the measured frame time
