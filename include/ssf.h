@@ -212,7 +212,10 @@ int ssf_can_submit(const ssf_handle* h);
 
 /* A whole recorded sequence in one call: the submit-ahead / process-in-order loop above in native code (what
  * SupersurfelFusionRGBDBenchmarkNode::run does frame by frame).  rgb[i] / depth_m[i]: the n frames (host or
- * device pointers, see ssf_submit_frame); out[i]: result of frame i.  No pose priors, no dynamic masks. */
+ * device pointers, see ssf_submit_frame); out[i]: result of frame i.  No pose priors, no dynamic masks.
+ * Host frames (on_device = 0) of a pipelined handle are copied to the device ahead of their turn by a worker
+ * thread of the library, which lives for the duration of the call; the frame buffers must stay valid until the
+ * call returns (they need not be page-locked). */
 int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth_m, int n, int on_device,
                          ssf_frame_result* out);
 
