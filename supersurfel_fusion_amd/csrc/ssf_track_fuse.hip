@@ -474,7 +474,10 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
         const int j = threadIdx.x >> 1, which = threadIdx.x & 1, ob = wg * OOV_PER_WG + j;
         const uint32_t k = h2[j][0][which] + h2[j][1][which] + h2[j][2][which] + h2[j][3][which];
         if (ob < nb_oov) {
-            if (which == 0) bc_oov[ob] = k;
+            // bc_oov: rows that come back into view (low half) | removed rows (high half); 0 = nothing for the move
+            // kernel to do in these 256 slots
+            const uint32_t other = __shfl_xor(k, 1, 64);
+            if (which == 0) bc_oov[ob] = k | (other << 16);
             if (k) {
                 atomicAdd(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + 6 + which], k);
                 if (which == 0) atomicAdd(&ws.sup_oov[ob / PART_GROUP], k);
@@ -887,6 +890,8 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         __builtin_memcpy(&c, w, sizeof(c));
         mailbox_counters(c, mb, cnt_seq);
     }
+    // out-of-view blocks: nothing moves in most of them (bc_oov: see classify_oov_block) -- leave at once
+    if ((int)blockIdx.x >= nb_vis && bc_oov[blockIdx.x - nb_vis] == 0u) return;
     __shared__ int hist[4][6];
     __shared__ uint32_t base[6];                  // rows of each class in the blocks before this one
     __shared__ unsigned long long red[ICP ? 29 * ICP_SLOTS : 1];
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         if (__syncthreads_count(cls == 0)) {      // (few blocks have rows that come back into view)
             const int g0 = ob / PART_GROUP, nw = g0 + (ob - g0 * PART_GROUP);
             for (int w = threadIdx.x; w < nw; w += blockDim.x) {
-                const uint32_t v = w < g0 ? ws.sup_oov[w] : bc_oov[g0 * PART_GROUP + (w - g0)];
+                const uint32_t v = w < g0 ? ws.sup_oov[w] : (bc_oov[g0 * PART_GROUP + (w - g0)] & 0xFFFFu);
                 if (v) atomicAdd(&base[0], v);
             }
             __syncthreads();
