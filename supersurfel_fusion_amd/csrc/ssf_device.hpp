@@ -154,7 +154,7 @@ struct Mailbox {
     unsigned long long all_check;
     unsigned long long all_seq;
 };
-#define SSF_ICP_REPLICAS 32
+#define SSF_ICP_REPLICAS 8
 // word w of Mailbox::icp_rec for payload p[0..29] (29 sums + checksum) and sequence number seq
 #define SSF_ICP_REC_WORD(w, p, seq) ((((w) & 7) == 7) ? (unsigned long long)(seq) : ((7 * ((w) >> 3) + ((w) & 7)) < 30 ? (unsigned long long)(p)[7 * ((w) >> 3) + ((w) & 7)] : 0ull))
 

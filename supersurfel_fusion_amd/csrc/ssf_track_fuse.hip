@@ -131,10 +131,12 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
     const int field = threadIdx.x & 31, group = threadIdx.x >> 5;
     long long v = 0;
 #pragma unroll
-    for (int j = 0; j < SSF_ICP_REPLICAS / 8; j++) {
+    for (int j = 0; j < (SSF_ICP_REPLICAS + 7) / 8; j++) {
         const int r = group + 8 * j;
-        v += __hip_atomic_load(&replicas[r * 32 + field], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&replicas[r * 32 + field], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r < SSF_ICP_REPLICAS) {
+            v += __hip_atomic_load(&replicas[r * 32 + field], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&replicas[r * 32 + field], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     part[group * 32 + field] = v;
     __syncthreads();
