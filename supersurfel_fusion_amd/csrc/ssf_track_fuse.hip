@@ -110,9 +110,12 @@ __device__ __forceinline__ void icp_fold(unsigned long long* red, long long* __r
 // ... count the arrival (is this the last workgroup?) ...
 // two-level arrival count over all workgroups of the grid (a single counter serialises thousands of same-address
 // atomics at L2): 64 group counters, the last workgroup of a group reports to the global counter.  Thread 0 only.
+#ifndef ARRIVE_GROUPS
+#define ARRIVE_GROUPS 64u
+#endif
 __device__ __forceinline__ int grid_arrive(unsigned int* ticket) {
-    const unsigned int g = blockIdx.x & 63u;
-    const unsigned int in_group = (gridDim.x - g + 63u) / 64u, groups = min(gridDim.x, 64u);
+    const unsigned int g = blockIdx.x & (ARRIVE_GROUPS - 1u);
+    const unsigned int in_group = (gridDim.x - g + ARRIVE_GROUPS - 1u) / ARRIVE_GROUPS, groups = min(gridDim.x, ARRIVE_GROUPS);
     int last = 0;
     const unsigned int tk = __hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk == in_group - 1) {
