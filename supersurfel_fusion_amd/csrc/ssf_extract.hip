@@ -488,7 +488,7 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
 // planes of the window's superpixels are staged in LDS, every pixel tests its label's planes and
 // counts with LDS integer atomics; the tile flushes non-zero counts with one global atomic each.
 #define EVAL_WIN 64
-#define ACC_REP 4
+#define ACC_REP 8
 #define EVAL_NS 16
 #define EVAL_REP 8
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
@@ -566,7 +566,7 @@ __device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int n
 // the 9 exact integer sums of every inlier go into LDS accumulators of the window's superpixels and
 // are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
 __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int ransac) {
-    __shared__ unsigned long long w_acc[WIN_MAX * 9 * ACC_REP];     // ACC_REP replicas (lane & 3) against same-address serialisation
+    __shared__ unsigned long long w_acc[WIN_MAX * 9 * ACC_REP];     // ACC_REP replicas (lane id) against same-address serialisation
     __shared__ float4 w_theta[WIN_MAX];
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m,
 __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m) {
     __shared__ int tile[TW * TW];
     __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * 13 * ACC_REP];    // ACC_REP replicas (lane & 3) against same-address serialisation
+    __shared__ unsigned long long w_acc[WIN_MAX * 13 * ACC_REP];    // ACC_REP replicas (lane id) against same-address serialisation
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
