@@ -236,11 +236,15 @@ def main():
         return res
 
     run(0, Wm)
-    # the extract graph of every batch size the timed region will launch is built lazily on first use (like a JIT):
-    # the tail batch of K frames has K % batch of them -- build that graph now, with warm-up frames, not inside the timing
-    if batch > 1 and K % batch and not (depth == 0 and batch == 1):
-        run(Wm, K % batch)
-        Wm += K % batch                             # (reported as config.warmup_extra)
+    # the extract graph of every batch size the timed region will launch is built lazily on first use (like a JIT).  A
+    # sequence starts with batches of batch/4 and batch/2 frames, continues with full ones and ends with what is left
+    # (ssf_process_sequence): one short untimed sequence with exactly those sizes builds the graphs before the timing
+    if batch > 1 and not (depth == 0 and batch == 1):
+        r0, r1 = max(1, batch // 4), max(1, batch // 2)
+        tail = (K - r0 - r1) % batch if K > r0 + r1 else 0
+        extra = r0 + r1 + batch + tail
+        run(Wm, extra)
+        Wm += extra                                 # (reported as warmup_extra_frames)
     native_seq = not (depth == 0 and batch == 1) and drv is None
     if native_seq:
         # the harness's own work (argument arrays before, result structs -> dicts after) stays outside the timed

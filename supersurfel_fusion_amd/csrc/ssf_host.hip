@@ -288,6 +288,13 @@ static RcclApi* rccl_api() {
 // that also drives the track chain 30-70 us per frame (two hipMemcpyAsync, for pageable memory incl. the staging
 // copy).  In ssf_process_sequence the frames are known ahead, so a worker thread copies them into a ring of device
 // buffers on a stream of its own; the submitting thread only makes the extract stream wait for the copy's event.
+// A sequence starts with small batches (a quarter, then half of extract_batch, then full ones): the first frame can
+// only be tracked when the whole first batch has been extracted, and a full batch of 8 takes twice as long as one of 2.
+static inline int seq_batch_size(int b, int batch) { return b == 0 ? std::max(1, batch / 4) : (b == 1 ? std::max(1, batch / 2) : batch); }
+static inline int seq_batch_of(int i, int batch) {
+    const int r0 = seq_batch_size(0, batch), r1 = seq_batch_size(1, batch);
+    return i < r0 ? 0 : (i < r0 + r1 ? 1 : 2 + (i - r0 - r1) / batch);
+}
 struct Uploader {
     std::thread th;
     std::atomic<int> uploaded{0};             // frames whose copies are enqueued (events recorded)
@@ -309,7 +316,7 @@ struct Uploader {
                 std::this_thread::sleep_for(std::chrono::microseconds(100));      // (the ring is a dozen frames ahead)
             }
             const int sl = i % ring;
-            hipStream_t st = ctx_stream[(size_t)(ctx0 + i / batch) % ctx_stream.size()];
+            hipStream_t st = ctx_stream[(size_t)(ctx0 + seq_batch_of(i, batch)) % ctx_stream.size()];
             if (hipMemcpyAsync(d_rgb[sl], rgb[i], rgb_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipMemcpyAsync(d_depth[sl], depth[i], depth_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { failed.store(1); return; }
             uploaded.store(i + 1, std::memory_order_release);
@@ -365,6 +372,7 @@ struct ssf_handle {
     // ssf_process_sequence: frames still to be submitted; do_fuse submits them between its launches and its wait for
     // the counters (the ~40 us of host work of a batch launch hide behind the ~55 us fuse chain on the GPU)
     const void* const* seq_rgb = nullptr; const void* const* seq_depth = nullptr; int seq_next = 0, seq_n = 0, seq_on_device = 0, stamp_bias = 0;
+    int seq_batches = 0;                      // batches launched by the running ssf_process_sequence (see seq_batch_size)
     Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
@@ -561,6 +569,7 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     if (multi) HCK(hipEventRecord(c.ev_done, st));
     c.launched = true; c.waited = false; c.inflight = nb; c.nb_launched = nb;
     h->open_ctx = (int)((&c - h->ctx.data() + 1) % (ptrdiff_t)h->ctx.size());
+    if (h->seq_n > 0) h->seq_batches++;
     return SSF_OK;
 }
 // Add one frame to the open batch; the batch is launched when it is full (or when its first frame is needed).
@@ -581,7 +590,8 @@ static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int
     if (mask) { HCK(hipMemcpyAsync(slab_shift(c.d_mask, off), mask, h->S, hipMemcpyHostToDevice, c.stream)); c.mask_bits |= 1u << b; }
     c.count = b + 1;
     h->pending.push_back(std::make_pair(h->open_ctx, b));
-    if (c.count == h->batch) return launch_batch(h, c);
+    // (inside ssf_process_sequence the first two batches are smaller: seq_batch_size)
+    if (c.count == (h->seq_n > 0 ? seq_batch_size(h->seq_batches, h->batch) : h->batch)) return launch_batch(h, c);
     return SSF_OK;
 }
 // the frame held by h->active will not be fused (or has been): its slot is free again
@@ -1356,6 +1366,7 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
         u.th = std::thread([&u] { u.run(); });
     }
     h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device; h->seq_upload = ahead;
+    h->seq_batches = 0;
     for (int k = 0; k < n && !rc; k++) {
         while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
             TimerScope ts(h);
