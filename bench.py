@@ -217,14 +217,16 @@ def main():
 
     cap_frames = f.pipeline_capacity()
 
-    def run(first, count):
-        """Process frames [first, first + count): every frame's extract, ICP and fusion complete inside."""
+    def run(first, count, native=True):
+        """Process frames [first, first + count): every frame's extract, ICP and fusion complete inside.
+        native=False: the same loop through ssf_submit_frame / ssf_process_submitted (full batches from the first
+        frame on: the per-kernel profile wants every launch to cover extract_batch frames)."""
         res = []
         if depth == 0 and batch == 1:
             for i in range(first, first + count):
                 res.append(step(i))
             return res
-        if drv is None:                             # the submit-ahead / process-in-order loop, natively
+        if drv is None and native:                  # the submit-ahead / process-in-order loop, natively
             return f.process_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)],
                                       [d_depth[i].data_ptr() for i in range(first, first + count)], on_device=True)
         nsub = first
@@ -290,11 +292,11 @@ def main():
     stage = np.zeros(3)
     ns = npk = -(-max(a.profile_frames // 2, 1) // batch) * batch     # whole batches
     f.set_profile(2)                                  # stage split only (one event synchronise per frame)
-    for r in run(base, ns):
+    for r in run(base, ns, native=False):
         stage += np.array(r["stage_ms"]) / ns
     f.set_profile(1); f.reset_kernel_times()          # per-kernel hipEvent brackets
     cnt_before = f.counts()
-    run(base + ns, npk)
+    run(base + ns, npk, native=False)
     torch.cuda.synchronize(dev)
     kt = f.kernel_times()
     f.set_profile(0)
