@@ -61,11 +61,14 @@ ALGO_BYTES = {
 EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
 
 
-def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1):
+def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1, prefilter=0):
+    """prefilter = 0: the metric's path starts at "depth after the pre-filter" (the
+    bilateral filter is OpenCV's, third party, a "next" row); the rate WITH the library's own filter inside the frame
+    is reported beside it (extra key "with_depth_prefilter")."""
     K = synthetic.intrinsics(W, H)
     kw = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=cap,
               rank=rank, nranks=nranks, icp_force_iters=1 if force_icp else 0, pipeline_depth=pipeline_depth,
-              extract_batch=extract_batch)
+              extract_batch=extract_batch, depth_prefilter=prefilter)
     kw.update(PARAMS)
     if stream is not None:
         kw["stream"] = stream

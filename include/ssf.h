@@ -113,9 +113,10 @@ typedef struct ssf_config {
     void* stream;              /* hipStream_t to launch on, NULL = library-owned stream */
     int   rank, nranks;        /* model shard of this handle; 0/1 = unsharded */
     float shard_tile;          /* world-space tile edge (m) hashed to the owning rank, 0.5 */
-    int   depth_prefilter;     /* 1: run the bilateral depth pre-filter inside process_frame, as the reference's
-                                  processFrame does (supersurfel_fusion.cu:180); 0 (default): the caller passes
-                                  the depth it wants segmented */
+    int   depth_prefilter;     /* 1 (default): run the bilateral depth pre-filter inside process_frame, as the
+                                  reference's processFrame always does (supersurfel_fusion.cu:180: in-place
+                                  cv::cuda::bilateralFilter, third party); 0: the caller passes the depth it wants
+                                  segmented as is (already filtered, or synthetic) */
     float prefilter_sigma_color;   /* 0.03 m  */
     float prefilter_sigma_space;   /* 4.5 px  */
     int   profile;             /* 0: none (fastest); 2: stage_ms split (one event synchronise per frame);
@@ -320,13 +321,19 @@ int ssf_get_plane_depth(ssf_handle* h, float* out /* H*W */);
 /* SuperpixelRGBD table (TPS_RGBD.hpp:32-37) as 9 floats per superpixel:
  * cx, cy, r, g, b, theta_a, theta_b, theta_c, size. */
 int ssf_get_superpixels(ssf_handle* h, float* out /* 9*S */);
-/* Device-resident view of the whole model in the reference's order [visible | out-of-view]
- * (getModel() returns device vectors, supersurfel_fusion.hpp:87).  The product keeps the two classes
- * in separate stores and materialises this dense copy on demand: n_model rows,
- * device pointers in ssf_surfels; `orientations` points at the stream of FIRST rows (3 floats per
- * supersurfel: the major axis) -- the product stores the three rows of the reference's Mat33 as
- * three separate streams and this view exposes only the first; use ssf_get_model for full 3x3
- * orientations.  Valid until the next call on the handle.  Product only. */
+/* computeSuperpixelSegIm (supersurfel_fusion.hpp:79, supersurfel_fusion.cu:635-640 -> TPS_RGBD::computePreviewImage,
+ * TPS_RGBD.cu:527-541, renderBoundaryImage_kernel TPS_RGBD_kernels.cu:616-644): the CV_8UC3 preview of the
+ * segmentation of the last frame -- white where the label of the right or lower-right neighbour differs, otherwise
+ * 0.8 x the pixel's colour, channels in the order the reference writes them (B, G, R).
+ * computeSlantedPlaneIm (supersurfel_fusion.hpp:80, :642-647) is ssf_get_plane_depth: the CV_32FC1 plane-rendered depth. */
+int ssf_get_preview_image(ssf_handle* h, uint8_t* out /* H*W*3 */);
+/* Device-resident view of the whole model in the reference's order [visible | out-of-view] and in the reference's
+ * layout (getModel() returns device vectors which the node copies out array by array,
+ * supersurfel_fusion.hpp:87, supersurfel_fusion_node.cpp:306-310): n_model rows, device pointers in ssf_surfels,
+ * `orientations` = packed row-major Mat33 (9 floats per supersurfel), as supersurfels.hpp:37.  The product keeps the
+ * two visibility classes in separate stores and the three rows of the Mat33 as separate streams (DESIGN.md section
+ * 3); this call materialises the dense, packed copy on demand.  Valid until the next call on the handle.  (For the
+ * CPU checker "device" pointers are host pointers.) */
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_model);
 int ssf_export_model_txt(ssf_handle* h, const char* path);
 

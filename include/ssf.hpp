@@ -45,14 +45,16 @@ public:
     ~SupersurfelFusion() { if (h_) ssf_destroy(h_); }
 
     /* initialize(): supersurfel_fusion.hpp:46-74 -- the 21 path-relevant arguments map 1:1 onto ssf_config.
-     * pipeline_depth / extract_batch: see ssf_config (0 / 1 = the reference's one-frame-in-flight behaviour). */
+     * pipeline_depth / extract_batch: see ssf_config (0 / 1 = the reference's one-frame-in-flight behaviour).
+     * depth_prefilter: true (default) = processFrame filters the depth image first, as the reference's does
+     * (supersurfel_fusion.cu:180); false = the caller hands over the depth it wants segmented. */
     void initialize(const CamParam& cam, int cell_size = 16, float lambda_pos = 50.f, float lambda_bound = 1000.f,
                     float lambda_size = 10000.f, float lambda_disp = 1e6f, float thresh_disp = 1e-4f,
                     int seg_iter = 10, bool seg_use_ransac = true, int nb_samples = 16, int filter_iter = 4,
                     float filter_alpha = 0.1f, float filter_beta = 1.0f, float filter_threshold = 0.05f,
                     float range_min = 0.2f, float range_max = 5.0f, int delta_t = 20, float conf_thresh = 2500.f,
                     int nb_supersurfels_max = 50000, int icp_iter = 10, double icp_cov_thresh = 0.04,
-                    int pipeline_depth = 0, int extract_batch = 1) {
+                    int pipeline_depth = 0, int extract_batch = 1, bool depth_prefilter = true) {
         ssf_config c; ssf_default_config(&c);
         c.width = cam.width; c.height = cam.height; c.fx = cam.fx; c.fy = cam.fy; c.cx = cam.cx; c.cy = cam.cy;
         c.cell_size = cell_size; c.lambda_pos = lambda_pos; c.lambda_bound = lambda_bound; c.lambda_size = lambda_size;
@@ -61,6 +63,7 @@ public:
         c.filter_threshold = filter_threshold; c.range_min = range_min; c.range_max = range_max; c.delta_t = delta_t;
         c.conf_thresh = conf_thresh; c.nb_supersurfels_max = nb_supersurfels_max; c.icp_iter = icp_iter;
         c.icp_cov_thresh = icp_cov_thresh; c.pipeline_depth = pipeline_depth; c.extract_batch = extract_batch;
+        c.depth_prefilter = depth_prefilter ? 1 : 0;
         initialize(c);
     }
     void initialize(const ssf_config& c) {
@@ -88,11 +91,32 @@ public:
         return out;
     }
 #ifdef CV_VERSION
+    /* the reference's own signatures (supersurfel_fusion.hpp:75-80); compiled against a cv::Mat test double by
+     * tests/test_cpp_wrapper.py (tests/cpp/cv_double.hpp) since OpenCV is not in the build image */
     void processFrame(const cv::Mat& rgb_h, const cv::Mat& depth_h, const float* vo_pose = nullptr, const uint8_t* dynamic = nullptr) {
         const cv::Mat rgb = rgb_h.isContinuous() ? rgb_h : rgb_h.clone(), d = depth_h.isContinuous() ? depth_h : depth_h.clone();
         processFrame(rgb.ptr<uint8_t>(), d.ptr<float>(), vo_pose, dynamic);
     }
+    void computeSuperpixelSegIm(cv::Mat& seg_im) {                     /* CV_8UC3, supersurfel_fusion.cu:635-640 */
+        seg_im.create(height_, width_, CV_8UC3);
+        check(ssf_get_preview_image(need(), seg_im.ptr<uint8_t>()));
+    }
+    void computeSlantedPlaneIm(cv::Mat& slanted_plane_im) {            /* CV_32FC1, supersurfel_fusion.cu:642-647 */
+        slanted_plane_im.create(height_, width_, CV_32FC1);
+        check(ssf_get_plane_depth(need(), slanted_plane_im.ptr<float>()));
+    }
 #endif
+    /* the same two images without OpenCV */
+    std::vector<uint8_t> getSuperpixelSegIm() {
+        std::vector<uint8_t> v((size_t)3 * width_ * height_);
+        check(ssf_get_preview_image(need(), v.data()));
+        return v;
+    }
+    std::vector<float> getSlantedPlaneIm() {
+        std::vector<float> v((size_t)width_ * height_);
+        check(ssf_get_plane_depth(need(), v.data()));
+        return v;
+    }
     Transform3 getPose() const {
         Transform3 p; float v[12];
         check(ssf_get_pose(need(), v));
@@ -124,8 +148,12 @@ public:
         check(ssf_get_frame(need(), &v));
         return m;
     }
+    /* getModel() as the reference returns it: device-resident arrays in the reference's layout (orientations =
+     * packed Mat33), n rows, valid until the next call (supersurfel_fusion.hpp:87; the node copies
+     * [0, nbSupersurfels) out array by array, supersurfel_fusion_node.cpp:306-310) */
+    ssf_surfels getModelDevice(int* n = nullptr) { ssf_surfels v; check(ssf_get_model_device(need(), &v, n)); return v; }
     void exportModel(const std::string& file) { check(ssf_export_model_txt(need(), file.c_str())); }   /* supersurfel_fusion.cu:595-633 */
-    /* computeSuperpixelSegIm's data (supersurfel_fusion.hpp:103): the label of every pixel */
+    /* TPS_RGBD::getIndexImage (TPS_RGBD.hpp:77): the label of every pixel */
     std::vector<int32_t> getIndexImage() {
         std::vector<int32_t> v((size_t)width_ * height_);
         check(ssf_get_index_map(need(), v.data()));

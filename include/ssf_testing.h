@@ -32,6 +32,18 @@ int ssf_dbg_lab_to_rgb(const float* lab3, float* rgb3);
 int ssf_dbg_sym_inverse(const float* cov6, float* inv6);            /* returns 1 when invertible */
 int ssf_dbg_principal_frame(const float* cov6, float* vecs9, float* vals3);
 int ssf_dbg_plane_solve(const float* rows12, float* theta3);        /* returns 1 when accepted */
+/* the matrix helpers the fuse / deformation kernels are built from, pinned against the reference's own headers by
+ * tests/golden/ref_math_vectors.npz (oracle/ref_math_vectors.cpp): square(Cov3) (matrix_math.cuh:184), Cov3 * float3
+ * (:164), mult_ABAt (:442), Mat33 * Mat33 (:381), Mat33 * float3 (:484), float3 * Mat33 (:491), rotMatToQuat (:529),
+ * quatToRotMat (:512, with its wy = q.w*q.z).  Matrices are 9 floats row-major, quaternions (x, y, z, w). */
+int ssf_dbg_sym_square(const float* cov6, float* out6);
+int ssf_dbg_sym_mulv(const float* cov6, const float* v3, float* out3);
+int ssf_dbg_mult_abat(const float* R9, const float* cov6, float* out6);
+int ssf_dbg_m3_mul(const float* A9, const float* B9, float* out9);
+int ssf_dbg_m3_mulv(const float* A9, const float* v3, float* out3);
+int ssf_dbg_row_mul(const float* v3, const float* A9, float* out3);
+int ssf_dbg_rot_to_quat(const float* R9, float* q4);
+int ssf_dbg_quat_to_rot(const float* q4, float* R9);
 #ifdef __cplusplus
 }
 #endif

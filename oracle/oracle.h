@@ -121,6 +121,8 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
 void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
                        const float* w4, const int32_t* idx4);
 int  shard_owner(const State& s, int f, const Pose& pose);
+void rot_to_quat(const Mat33& m, float* q /* x, y, z, w */);    // matrix_math.cuh:529-618
+Mat33 quat_to_rot(const float* q);                              // matrix_math.cuh:512-527 (wy quirk kept)
 // host solvers (pinned against the reference's vendored Eigen by oracle/_ref)
 bool ldlt_solve6(const double* A /*36 row-major, symmetric*/, const double* b, double* x);
 bool lu_inverse6(const double* A, double* Ainv);

@@ -40,7 +40,7 @@ void ssf_default_config(ssf_config* c) {      // supersurfel_fusion.hpp:46-74 de
     c->conf_thresh = 2500.f; c->nb_supersurfels_max = 50000; c->icp_iter = 10; c->icp_cov_thresh = 0.04;
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
-    c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
+    c->depth_prefilter = 1; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
     c->pipeline_depth = 0; c->extract_batch = 1;
 }
 
@@ -308,7 +308,32 @@ int ssf_get_superpixels(ssf_handle* h, float* o) {
     }
     return SSF_OK;
 }
-int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) { (void)h; (void)o; (void)n; return SSF_ERR_NO_DEVICE; }
+// for the checker a device pointer is a host pointer: its arrays already have the reference's layout
+int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    Surfels& M = h->s.model;
+    static_assert(sizeof(f3) == 12 && sizeof(Mat33) == 36 && sizeof(Cov3) == 24, "SoA rows are packed floats");
+    o->positions = &M.pos[0].x; o->colors = &M.col[0].x; o->stamps = M.stamps.data(); o->orientations = &M.orient[0].r[0].x;
+    o->shapes = &M.shape[0].xx; o->dims = M.dims.data(); o->confidences = M.conf.data();
+    if (n) *n = h->s.n_model;
+    return SSF_OK;
+}
+// renderBoundaryImage_kernel, TPS_RGBD_kernels.cu:616-644 (computePreviewImage, TPS_RGBD.cu:527-541)
+int ssf_get_preview_image(ssf_handle* h, uint8_t* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    const State& s = h->s;
+    for (int y = 0; y < s.H; y++)
+        for (int x = 0; x < s.W; x++) {
+            const size_t p = (size_t)y * s.W + x;
+            const int index = s.label[p];
+            uint8_t* px = &o[3 * p];
+            if (x < s.W - 1 && y < s.H - 1 && (s.label[p + 1] != index || s.label[p + s.W + 1] != index)) { px[0] = px[1] = px[2] = 255; continue; }
+            const uint32_t c = s.rgba[p];       // texel (R, G, B, 255): the reference writes 0.8 * z, y, x = B, G, R
+            px[0] = (uint8_t)(0.8f * (float)((c >> 16) & 255u)); px[1] = (uint8_t)(0.8f * (float)((c >> 8) & 255u));
+            px[2] = (uint8_t)(0.8f * (float)(c & 255u));
+        }
+    return SSF_OK;
+}
 
 // exportModel, supersurfel_fusion.cu:595-633 (std::to_string == "%f")
 int ssf_export_model_txt(ssf_handle* h, const char* path) {
@@ -393,5 +418,19 @@ int ssf_dbg_plane_solve(const float* r, float* th) {
     const bool ok = solvePlaneEquations(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
     th[0] = a; th[1] = b; th[2] = c; return ok ? 1 : 0;
 }
+
+static Mat33 mat_from9(const float* a) { Mat33 m; for (int r = 0; r < 3; r++) m.r[r] = mk3(a[3 * r], a[3 * r + 1], a[3 * r + 2]); return m; }
+static void mat_to9(const Mat33& m, float* o) { for (int r = 0; r < 3; r++) { o[3 * r] = m.r[r].x; o[3 * r + 1] = m.r[r].y; o[3 * r + 2] = m.r[r].z; } }
+static void cov_to6(const Cov3& s, float* o) { o[0] = s.xx; o[1] = s.xy; o[2] = s.xz; o[3] = s.yy; o[4] = s.yz; o[5] = s.zz; }
+int ssf_dbg_sym_square(const float* c, float* o) { cov_to6(square(mkcov(c[0], c[1], c[2], c[3], c[4], c[5])), o); return 0; }
+int ssf_dbg_sym_mulv(const float* c, const float* v, float* o) { f3 r = mkcov(c[0], c[1], c[2], c[3], c[4], c[5]) * mk3(v[0], v[1], v[2]); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_mult_abat(const float* R9, const float* c, float* o) { cov_to6(mult_ABAt(mat_from9(R9), mkcov(c[0], c[1], c[2], c[3], c[4], c[5])), o); return 0; }
+int ssf_dbg_m3_mul(const float* A9, const float* B9, float* o) { mat_to9(mat_from9(A9) * mat_from9(B9), o); return 0; }
+int ssf_dbg_m3_mulv(const float* A9, const float* v, float* o) { f3 r = mat_from9(A9) * mk3(v[0], v[1], v[2]); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_row_mul(const float* v, const float* A9, float* o) {     // float3 * Mat33, matrix_math.cuh:491-496
+    const Mat33 t = transpose(mat_from9(A9)); f3 r = t * mk3(v[0], v[1], v[2]); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0;
+}
+int ssf_dbg_rot_to_quat(const float* R9, float* q4) { rot_to_quat(mat_from9(R9), q4); return 0; }
+int ssf_dbg_quat_to_rot(const float* q4, float* R9) { mat_to9(quat_to_rot(q4), R9); return 0; }
 
 }  // extern "C"

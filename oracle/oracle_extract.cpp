@@ -69,8 +69,15 @@ static inline void disp_terms(SpSums& c, int x, int y, float d, int sign) {
     c.dd += sign * fx_quant((double)d, DISP_SCALE, DISP_LIM);
 }
 
+static inline void sums_add(SpSums& a, const SpSums& d) {
+    a.sx += d.sx; a.sy += d.sy; a.sr += d.sr; a.sg += d.sg; a.sb += d.sb; a.n += d.n;
+    a.dx += d.dx; a.dy += d.dy; a.dn += d.dn; a.dxx += d.dxx; a.dyy += d.dyy; a.dxy += d.dxy;
+    a.dxd += d.dxd; a.dyd += d.dyd; a.dd += d.dd;
+}
+
 // mergeTPSRGBCoeffs_kernel, TPS_RGBD_kernels.cu:224-242
 static void merge_rgb(State& s) {
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < s.S; k++) {
         const SpSums& c = s.sums[k]; Superpixel& sp = s.sp[k];
         float n = (float)c.n;
@@ -83,6 +90,7 @@ static void merge_rgb(State& s) {
 static void merge_rgbd(State& s) {
     merge_rgb(s);
     const double inv = 1.0 / DISP_SCALE;
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < s.S; k++) {
         const SpSums& c = s.sums[k]; Superpixel& sp = s.sp[k];
         float dx = (float)c.dx, dy = (float)c.dy, dn = (float)c.dn;
@@ -107,7 +115,15 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
     std::vector<int32_t>& dst = s.label_tmp;
     dst = src;                                                                  // decision A1
     const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};                    // neighbors[8], .cuh:350
-    for (int raw_y = 0; 2 * raw_y + OY < H; raw_y++) {
+    // Rows of a pass are independent (all reads are pre-pass values, decision A1) and the sums are exact integers, so
+    // the OpenMP build (libssf_oracle_omp.so, the timed CPU baseline) splits the rows over threads, each with its own
+    // delta table, and adds the tables up afterwards: bit-identical to the serial order.
+    const int n_rows = (H - OY + 1) / 2;
+#pragma omp parallel
+    {
+    std::vector<SpSums> delta(s.S, SpSums{});
+#pragma omp for schedule(static)
+    for (int raw_y = 0; raw_y < n_rows; raw_y++) {
         const int y = 2 * raw_y + OY;
         for (int raw_x = 0; 2 * raw_x < W; raw_x++) {
             const int x = 2 * raw_x + ((raw_x + OX) & 1);                       // .cuh:264
@@ -170,18 +186,21 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
                 }
                 if (new_index != index) {                                       // .cuh:400-440
                     dst[p] = new_index;
-                    SpSums& a = s.sums[index]; SpSums& bsum = s.sums[new_index];
+                    SpSums& a = delta[index]; SpSums& bsum = delta[new_index];
                     const int ir = (int)(px & 255u), ig = (int)((px >> 8) & 255u), ib = (int)((px >> 16) & 255u);
                     a.sx -= x; a.sy -= y; a.sr -= ir; a.sg -= ig; a.sb -= ib; a.n -= 1;
                     bsum.sx += x; bsum.sy += y; bsum.sr += ir; bsum.sg += ig; bsum.sb += ib; bsum.n += 1;
                 }
             }
             if (rgbd) {                                                         // .cuh:443-472
-                if (inlier && (!prev_inlier || index != new_index)) disp_terms(s.sums[new_index], x, y, disp, +1);
-                if (prev_inlier && (!inlier || (inlier && index != new_index))) disp_terms(s.sums[index], x, y, disp, -1);
+                if (inlier && (!prev_inlier || index != new_index)) disp_terms(delta[new_index], x, y, disp, +1);
+                if (prev_inlier && (!inlier || (inlier && index != new_index))) disp_terms(delta[index], x, y, disp, -1);
                 if (inlier != prev_inlier) s.inlier[p] = inlier;
             }
         }
+    }
+#pragma omp critical
+    for (int k = 0; k < s.S; k++) sums_add(s.sums[k], delta[k]);
     }
     s.label.swap(s.label_tmp);
 }
@@ -199,6 +218,7 @@ static void init_samples(State& s) {
     const float radius = (float)s.cfg.cell_size / 2.f;                          // TPS_RGBD.cu:288
     const float wdx[4] = {-1.f, 0.f, 1.f, 0.f}, wdy[4] = {0.f, -1.f, 0.f, 1.f};
     const int ns = s.cfg.nb_samples;
+#pragma omp parallel for schedule(static)
     for (int index = 0; index < s.S; index++)
         for (int t = 0; t < ns; t++) {
             const uint32_t idx = (uint32_t)(index * ns + t);
@@ -240,19 +260,29 @@ static void init_samples(State& s) {
 // evalSamples_kernel, TPS_RGBD_kernels.cu:403-433 (scores are integer counts)
 static void eval_samples(State& s) {
     const int ns = s.cfg.nb_samples;
+    // scores are counts (the reference adds 1.f per hit: exact in float below 2^24), kept as integers per thread
+    std::vector<int32_t> score((size_t)s.S * ns, 0);
+#pragma omp parallel
+    {
+    std::vector<int32_t> local((size_t)s.S * ns, 0);
+#pragma omp for schedule(static)
     for (int y = 0; y < s.H; y++)
         for (int x = 0; x < s.W; x++) {
             size_t p = (size_t)y * s.W + x;
             int index = s.label[p]; float d = s.disp[p];
             for (int k = 0; k < ns; k++) {
-                float* th = &s.samples[4 * ((size_t)index * ns + k)];
+                const float* th = &s.samples[4 * ((size_t)index * ns + k)];
                 if (std::isfinite(th[2])) {
                     float dp = (th[0] * (float)x + th[1] * (float)y) + th[2];
                     float dd = (d - dp) * (d - dp);
-                    if (dd < s.cfg.thresh_disp) th[3] += 1.f;
+                    if (dd < s.cfg.thresh_disp) local[(size_t)index * ns + k] += 1;
                 }
             }
         }
+#pragma omp critical
+    for (size_t i = 0; i < score.size(); i++) score[i] += local[i];
+    }
+    for (size_t i = 0; i < score.size(); i++) s.samples[4 * i + 3] += (float)score[i];
 }
 
 // selectSamples_kernel, TPS_RGBD_kernels.cu:435-467
@@ -272,6 +302,10 @@ static void select_samples(State& s) {
 
 // initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190)
 static void init_disp_coeffs(State& s, bool ransac) {
+#pragma omp parallel
+    {
+    std::vector<SpSums> delta(s.S, SpSums{});
+#pragma omp for schedule(static)
     for (int y = 0; y < s.H; y++)
         for (int x = 0; x < s.W; x++) {
             size_t p = (size_t)y * s.W + x;
@@ -284,10 +318,13 @@ static void init_disp_coeffs(State& s, bool ransac) {
                     float dd = (dp - d) * (dp - d);
                     if (std::isfinite(dd) && dd < s.cfg.thresh_disp && dp > 0.f) inl = 0xff;
                 } else inl = 0xff;
-                if (inl) disp_terms(s.sums[index], x, y, d, +1);
+                if (inl) disp_terms(delta[index], x, y, d, +1);
             }
             s.inlier[p] = inl;
         }
+#pragma omp critical
+    for (int k = 0; k < s.S; k++) sums_add(s.sums[k], delta[k]);
+    }
 }
 
 // TPS_RGBD::filter, TPS_RGBD.cu:480-505; kernels TPS_RGBD_kernels.cu:510-614.  Jacobi sweeps (A9).
@@ -344,6 +381,7 @@ static void plane_filter(State& s) {
 
 // renderDepthImage_kernel, TPS_RGBD_kernels.cu:469-508 (inlier mask ignored: `if(true || inlier)`)
 static void render_depth(State& s) {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < s.H; y++)
         for (int x = 0; x < s.W; x++) {
             size_t p = (size_t)y * s.W + x;
@@ -360,6 +398,10 @@ static void generate_supersurfels(State& s) {
     s.frame.zero(S);
     std::vector<int64_t> acc((size_t)S * 13, 0);                                // p(3) lab(3) pp(6) count
     // computeSupersurfelCoeffs, supersurfel_fusion_kernels.cu:113-167
+#pragma omp parallel
+    {
+    std::vector<int64_t> lacc((size_t)S * 13, 0);
+#pragma omp for schedule(static)
     for (int y = 0; y < s.H; y++)
         for (int x = 0; x < s.W; x++) {
             size_t p = (size_t)y * s.W + x;
@@ -372,14 +414,18 @@ static void generate_supersurfels(State& s) {
                 uint32_t px = s.rgba[p];
                 f3 lab = rgbToLab(mk3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)));
                 Cov3 cov = outer(pos);
-                int64_t* a = &acc[(size_t)index * 13];
+                int64_t* a = &lacc[(size_t)index * 13];
                 const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, cov.xx, cov.xy, cov.xz, cov.yy, cov.yz, cov.zz};
                 for (int k = 0; k < 12; k++) a[k] += fx_quant((double)v[k], MOM_SCALE, MOM_LIM);
                 a[12] += 1;
             }
         }
+#pragma omp critical
+    for (size_t i = 0; i < acc.size(); i++) acc[i] += lacc[i];
+    }
     // computeSupersurfels, supersurfel_fusion_kernels.cu:169-224
     const double inv = 1.0 / MOM_SCALE;
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < S; k++) {
         const int64_t* a = &acc[(size_t)k * 13];
         float sum[12];
@@ -422,6 +468,7 @@ void bilateral_filter(const float* in, float* out, int W, int H, float sigma_col
     if (radius < 1) radius = 1;
     const float r2 = (float)(radius * radius);
     const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const float center = in[(size_t)y * W + x];

@@ -67,6 +67,12 @@ void icp_accumulate(State& s, int64_t* sums) {
     I.t_corres = I.R_inc * I.t_init + I.t_inc;
     const Mat33 R = I.R_corres; const f3 t = I.t_corres;
     const int W = s.W, H = s.H;
+    // (exact integer sums: the OpenMP build accumulates per thread and adds the partial records, same bits)
+#pragma omp parallel
+    {
+    int64_t part[SSF_ICP_RECORD];
+    for (int i = 0; i < SSF_ICP_RECORD; i++) part[i] = 0;
+#pragma omp for schedule(static)
     for (int id = 0; id < s.n_visible; id++) {
         f3 ps = R * s.model.pos[id] + t;
         int u = project_round(ps.x * c.fx / ps.z + c.cx);
@@ -88,11 +94,14 @@ void icp_accumulate(State& s, int64_t* sums) {
         int k = 0;
         for (int i = 0; i < 6; i++)
             for (int j = i; j < 6; j++, k++)
-                sums[k] += (int64_t)fx_quant32(x1[i] * x1[j] + x2[i] * x2[j], (float)SSF_ICP_SCALE_JTJ);
+                part[k] += (int64_t)fx_quant32(x1[i] * x1[j] + x2[i] * x2[j], (float)SSF_ICP_SCALE_JTJ);
         for (int i = 0; i < 6; i++)
-            sums[21 + i] += (int64_t)fx_quant32(dn1 * x1[i] + dn2 * x2[i], (float)SSF_ICP_SCALE_JTR);
-        sums[27] += fx_quant((double)(dn2 * dn2), SSF_ICP_SCALE_R, 4611686018427387904.0);
-        sums[28] += 1;
+            part[21 + i] += (int64_t)fx_quant32(dn1 * x1[i] + dn2 * x2[i], (float)SSF_ICP_SCALE_JTR);
+        part[27] += fx_quant((double)(dn2 * dn2), SSF_ICP_SCALE_R, 4611686018427387904.0);
+        part[28] += 1;
+    }
+#pragma omp critical
+    for (int i = 0; i < SSF_ICP_RECORD; i++) sums[i] += part[i];
     }
 }
 
@@ -336,6 +345,12 @@ void match(State& s, uint64_t* best, uint8_t* matched) {
     const Mat33 Rview = transpose(R);
     const f3 tview = neg(Rview * t);
     const Mat33 Rt = transpose(R);
+    // (MIN of packed keys / OR of flags: order-free, so the OpenMP build keeps a table per thread and folds them)
+#pragma omp parallel
+    {
+    std::vector<uint64_t> lbest(s.S, SSF_NO_MATCH);
+    std::vector<uint8_t> lmatched(s.S, 0);
+#pragma omp for schedule(static)
     for (int id = 0; id < s.n_visible; id++) {
         if (!(s.model.conf[id] > 0.0f)) continue;
         const f3 mp = s.model.pos[id];
@@ -344,7 +359,7 @@ void match(State& s, uint64_t* best, uint8_t* matched) {
         int px = project_round(pv.x * c.fx / pv.z + c.cx), py = project_round(pv.y * c.fy / pv.z + c.cy);
         if (!(px >= 0 && px < s.W && py >= 0 && py < s.H)) continue;
         const int f = s.label[(size_t)py * s.W + px];
-        matched[f] = 1;                                     // unconditional (:570)
+        lmatched[f] = 1;                                    // unconditional (:570)
         if (!(s.frame.conf[f] > 0.0f)) continue;
         const f3 fp = R * s.frame.pos[f] + t;
         const Mat33 frot = s.frame.orient[f] * Rt;
@@ -356,8 +371,11 @@ void match(State& s, uint64_t* best, uint8_t* matched) {
         if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
             uint32_t bits; std::memcpy(&bits, &dist, 4);
             uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)(s.id_offset + id);
-            if (key < best[f]) best[f] = key;
+            if (key < lbest[f]) lbest[f] = key;
         }
+    }
+#pragma omp critical
+    for (int f = 0; f < s.S; f++) { if (lbest[f] < best[f]) best[f] = lbest[f]; matched[f] |= lmatched[f]; }
     }
 }
 
@@ -448,6 +466,7 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
         const f3 tview = neg(Rview * t);
         std::vector<int> state(s.n_model);
         int n_vis = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_vis, n_removed)
         for (int i = 0; i < s.n_model; i++) {
             int st = 0;
             const int time_diff = s.stamp - M.stamps[2 * i + 1];
@@ -468,12 +487,27 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
             state[i] = st;
         }
         // thrust::sort_by_key(states, model) -- stable 3-way partition (supersurfel_fusion.cu:469-472)
+        // (written as count / prefix / ordered scatter over fixed chunks of rows so that the OpenMP build can run the
+        // chunks in parallel: within a state, rows keep their order -- the same permutation as three serial sweeps)
         Surfels tmp; tmp.resize(s.n_model);
         std::vector<f3> lab_tmp(s.n_model);
+        const int NCH = 64, chunk = (s.n_model + NCH - 1) / NCH;
+        int cnt[NCH][3], off[NCH][3];
+#pragma omp parallel for schedule(static)
+        for (int ch = 0; ch < NCH; ch++) {
+            cnt[ch][0] = cnt[ch][1] = cnt[ch][2] = 0;
+            for (int i = ch * chunk; i < std::min(s.n_model, (ch + 1) * chunk); i++) cnt[ch][state[i]]++;
+        }
         int w = 0;
         for (int pass = 0; pass < 3; pass++)
-            for (int i = 0; i < s.n_model; i++)
-                if (state[i] == pass) { tmp.copy_row(w, M, i); lab_tmp[w] = s.model_lab[i]; w++; }
+            for (int ch = 0; ch < NCH; ch++) { off[ch][pass] = w; w += cnt[ch][pass]; }
+#pragma omp parallel for schedule(static)
+        for (int ch = 0; ch < NCH; ch++)
+            for (int i = ch * chunk; i < std::min(s.n_model, (ch + 1) * chunk); i++) {
+                const int d = off[ch][state[i]]++;
+                tmp.copy_row(d, M, i); lab_tmp[d] = s.model_lab[i];
+            }
+#pragma omp parallel for schedule(static)
         for (int i = 0; i < s.n_model; i++) { M.copy_row(i, tmp, i); s.model_lab[i] = lab_tmp[i]; }
         s.n_model -= n_removed;                                                 // :474
         s.n_visible = n_vis;
@@ -501,7 +535,7 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
 }
 
 // rotMatToQuat matrix_math.cuh:529-618, quatToRotMat :512-527 (the wy = q.w*q.z quirk is kept)
-static void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
+void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
     float s, tr = (m.r[0].x + m.r[1].y) + m.r[2].z;
     if (tr > 0) {
         s = sqrtf(tr + 1);
@@ -526,7 +560,7 @@ static void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
         }
     }
 }
-static Mat33 quat_to_rot(const float* q) {
+Mat33 quat_to_rot(const float* q) {
     const float x2 = q[0] * q[0], y2 = q[1] * q[1], z2 = q[2] * q[2];
     const float xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
     const float wx = q[3] * q[0], wy = q[3] * q[2] /* sic */, wz = q[3] * q[2];
@@ -541,6 +575,7 @@ static Mat33 quat_to_rot(const float* q) {
 void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
                        const float* w4, const int32_t* idx4) {
     (void)m;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < s.n_model; i++) {
         const f3 pi = s.model.pos[i];
         f3 po = mk3(0, 0, 0);

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -115,7 +115,7 @@ class Library:
         L.ssf_get_frame.argtypes = [vp, C.POINTER(SsfSurfels)]
         L.ssf_set_model.argtypes = [vp, C.POINTER(SsfSurfels), C.c_int, C.c_int, C.c_int]
         for nm in ("ssf_get_index_map", "ssf_get_boundary_map", "ssf_get_inlier_map",
-                   "ssf_get_plane_depth", "ssf_get_superpixels"):
+                   "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_preview_image"):
             getattr(L, nm).argtypes = [vp, vp]
         L.ssf_get_model_device.argtypes = [vp, C.POINTER(SsfSurfels), C.POINTER(C.c_int)]
         L.ssf_export_model_txt.argtypes = [vp, C.c_char_p]
@@ -446,6 +446,20 @@ class Fusion:
 
     def plane_depth(self):
         return self._map("ssf_get_plane_depth", np.float32, (self.H, self.W))
+
+    def preview_image(self):
+        """computeSuperpixelSegIm: H x W x 3 uint8 (B, G, R), boundaries white"""
+        return self._map("ssf_get_preview_image", np.uint8, (self.H, self.W, 3))
+
+    def slanted_plane_image(self):
+        """computeSlantedPlaneIm: the plane-rendered depth, H x W float32"""
+        return self.plane_depth()
+
+    def model_device(self):
+        """ssf_get_model_device: (SsfSurfels of device pointers in the reference's layout, n_model)"""
+        st, n = SsfSurfels(), C.c_int(0)
+        self._ck(self.L.lib.ssf_get_model_device(self.h, C.byref(st), C.byref(n)), "ssf_get_model_device")
+        return st, n.value
 
     def superpixels(self):
         return self._map("ssf_get_superpixels", np.float32, (self.S, 9))

@@ -175,6 +175,7 @@ void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, i
                              unsigned long long* best, uint8_t* matched);
 void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space);
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
+void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const uint32_t* rgba, uint8_t* out /* 3P */);
 
 // ---- ICP + fuse (ssf_track_fuse.hip) -----------------------------------------------------------
 // replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: 65 zeroed u32 (global + 64 group arrival counters)
@@ -246,6 +247,7 @@ void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mail
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);
+void launch_pack_orient(hipStream_t st, SurfelSoA s, int n, float* out9);
 void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
                         const float* ntrans, const float* w4, const int32_t* idx4);
 

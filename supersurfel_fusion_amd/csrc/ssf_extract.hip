@@ -869,6 +869,24 @@ __global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t
     }
 }
 
+// renderBoundaryImage_kernel, TPS_RGBD_kernels.cu:616-644 (computeSuperpixelSegIm's image)
+__global__ __launch_bounds__(256) void k_preview(int W, int H, const int32_t* __restrict__ label, const uint32_t* __restrict__ rgba,
+                                                 uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    const int index = label[p];
+    uint8_t b0 = 255, b1 = 255, b2 = 255;
+    if (!(x < W - 1 && y < H - 1 && (label[p + 1] != index || label[p + W + 1] != index))) {
+        const uint32_t c = rgba[p];
+        b0 = (uint8_t)(0.8f * (float)((c >> 16) & 255u)); b1 = (uint8_t)(0.8f * (float)((c >> 8) & 255u)); b2 = (uint8_t)(0.8f * (float)(c & 255u));
+    }
+    out[3 * p] = b0; out[3 * p + 1] = b1; out[3 * p + 2] = b2;
+}
+void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const uint32_t* rgba, uint8_t* out) {
+    hipLaunchKernelGGL(k_preview, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, W, H, label, rgba, out);
+}
+
 // ---- depth pre-filter ("next" row f3) ---------------------------------------------------------------
 // Out-of-place restatement of cv::cuda::bilateralFilter(depth, depth, -1, sigma_color, sigma_space)
 // (supersurfel_fusion.cu:180; OpenCV cudaimgproc is third party, algorithm as published): circular

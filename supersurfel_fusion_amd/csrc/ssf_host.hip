@@ -381,7 +381,7 @@ struct ssf_handle {
     long long all_cnt[5 * SSF_MAX_RANKS];
     SurfelSoA model[2]; int mcur = 0;
     std::vector<void*> allocs;
-    float* d_bf_in = nullptr; float* d_bf_out = nullptr;
+    float* d_bf_in = nullptr; float* d_bf_out = nullptr; float* d_orient9 = nullptr;
     long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
     // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
@@ -1146,7 +1146,7 @@ void ssf_default_config(ssf_config* c) {       // default arguments of initializ
     c->conf_thresh = 2500.f; c->nb_supersurfels_max = 50000; c->icp_iter = 10; c->icp_cov_thresh = 0.04;
     c->rng_seed = 1234; c->icp_force_iters = 0; c->device_id = 0; c->stream = nullptr;
     c->rank = 0; c->nranks = 1; c->shard_tile = 0.5f; c->profile = 0;
-    c->depth_prefilter = 0; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
+    c->depth_prefilter = 1; c->prefilter_sigma_color = 0.03f; c->prefilter_sigma_space = 4.5f;
     c->pipeline_depth = 0; c->extract_batch = 1;
 }
 
@@ -1728,12 +1728,24 @@ int ssf_get_superpixels(ssf_handle* h, float* o) {
 }
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    { int rc = materialise(h); if (rc) return rc; HCK(hipStreamSynchronize(h->stream)); }
+    if (!h->d_orient9 && !dalloc(h, &h->d_orient9, 9 * (size_t)h->cfg.nb_supersurfels_max)) { h->err = "allocation failed"; return SSF_ERR_DEVICE; }
+    { int rc = materialise(h); if (rc) return rc; }
     const SurfelSoA& s = h->dense;                 // a dense copy: [visible | out-of-view], valid until the next call
-    o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = s.r0; o->shapes = s.shape;
-    o->dims = s.dims; o->confidences = s.conf;     // orientations: r0 stream (r1, r2 follow the SoA layout of DESIGN.md)
+    launch_pack_orient(h->stream, s, h->n_model, h->d_orient9);
+    HCK(hipGetLastError());
+    HCK(hipStreamSynchronize(h->stream));
+    o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = h->d_orient9; o->shapes = s.shape;
+    o->dims = s.dims; o->confidences = s.conf;
     if (n) *n = h->n_model;
     return SSF_OK;
+}
+int ssf_get_preview_image(ssf_handle* h, uint8_t* o) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    const size_t P = (size_t)h->cfg.width * h->cfg.height;
+    uint8_t* d = reinterpret_cast<uint8_t*>(h->d_scratch_map);      // P x int32 of scratch: 3P bytes fit
+    launch_preview(h->stream, h->cfg.width, h->cfg.height, h->cc->maps.label, h->cc->maps.rgba, d);
+    HCK(hipGetLastError());
+    return copy_map(h, o, d, 3 * P);
 }
 
 // exportModel, supersurfel_fusion.cu:595-633 (std::to_string == "%f"/"%d")
@@ -1906,5 +1918,17 @@ int ssf_dbg_plane_solve(const float* r, float* th) {
     const bool ok = plane_solve(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
     th[0] = a; th[1] = b; th[2] = c; return ok ? 1 : 0;
 }
+
+static M3 m3_from9(const float* a) { return m3(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(a[6], a[7], a[8])); }
+static void m3_to9(const M3& m, float* o) { o[0] = m.r0.x; o[1] = m.r0.y; o[2] = m.r0.z; o[3] = m.r1.x; o[4] = m.r1.y; o[5] = m.r1.z; o[6] = m.r2.x; o[7] = m.r2.y; o[8] = m.r2.z; }
+static void sym_to6(const Sym3& s, float* o) { o[0] = s.xx; o[1] = s.xy; o[2] = s.xz; o[3] = s.yy; o[4] = s.yz; o[5] = s.zz; }
+int ssf_dbg_sym_square(const float* c, float* o) { sym_to6(sym_square(sym3(c[0], c[1], c[2], c[3], c[4], c[5])), o); return 0; }
+int ssf_dbg_sym_mulv(const float* c, const float* v, float* o) { V3 r = sym_mul(sym3(c[0], c[1], c[2], c[3], c[4], c[5]), v3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_mult_abat(const float* R9, const float* c, float* o) { sym_to6(rot_sym(m3_from9(R9), sym3(c[0], c[1], c[2], c[3], c[4], c[5])), o); return 0; }
+int ssf_dbg_m3_mul(const float* A9, const float* B9, float* o) { m3_to9(m3_mul(m3_from9(A9), m3_from9(B9)), o); return 0; }
+int ssf_dbg_m3_mulv(const float* A9, const float* v, float* o) { V3 r = m3_mulv(m3_from9(A9), v3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_row_mul(const float* v, const float* A9, float* o) { V3 r = row_mul(v3(v[0], v[1], v[2]), m3_from9(A9)); o[0] = r.x; o[1] = r.y; o[2] = r.z; return 0; }
+int ssf_dbg_rot_to_quat(const float* R9, float* q4) { rot_to_quat(m3_from9(R9), q4); return 0; }
+int ssf_dbg_quat_to_rot(const float* q4, float* R9) { m3_to9(quat_to_rot_quirk(q4), R9); return 0; }
 
 }  // extern "C"

@@ -88,6 +88,38 @@ SSF_HD Sym3 rot_sym(M3 A, Sym3 B) {                                             
     return sym3(dot3(A.r0, t0), dot3(A.r0, t1), dot3(A.r0, t2), dot3(A.r1, t1), dot3(A.r1, t2), dot3(A.r2, t2));
 }
 
+// rotMatToQuat, matrix_math.cuh:529-618
+SSF_HD void rot_to_quat(M3 m, float* q) {
+    float s; const float tr = (m.r0.x + m.r1.y) + m.r2.z;
+    if (tr > 0) {
+        s = sqrtf(tr + 1); q[3] = 0.5f * s; s = 0.5f / s;
+        q[0] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.z - m.r2.x) * s; q[2] = (m.r1.x - m.r0.y) * s;
+    } else {
+        int i = 0;
+        if (m.r1.y > m.r0.x) i = 1;
+        if (m.r2.z > m.r0.x || m.r2.z > m.r1.y) i = 2;
+        if (i == 0) {
+            s = sqrtf(((1.0f + m.r0.x) - m.r1.y) - m.r2.z); q[0] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.y + m.r1.x) * s; q[2] = (m.r0.z + m.r2.x) * s;
+        } else if (i == 1) {
+            s = sqrtf(((1.0f + m.r1.y) - m.r0.x) - m.r2.z); q[1] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r0.z - m.r2.x) * s; q[0] = (m.r0.y + m.r1.x) * s; q[2] = (m.r1.z + m.r2.y) * s;
+        } else {
+            s = sqrtf(((1.0f + m.r2.z) - m.r0.x) - m.r1.y); q[2] = 0.5f * s; s = 0.5f / s;
+            q[3] = (m.r1.x - m.r0.y) * s; q[0] = (m.r0.z + m.r2.x) * s; q[1] = (m.r1.z + m.r2.y) * s;
+        }
+    }
+}
+// quatToRotMat, matrix_math.cuh:512-527, with its `wy = q.w*q.z` (sic, :521) reproduced: applyDeformation's rotation
+SSF_HD M3 quat_to_rot_quirk(const float* q /* x, y, z, w */) {
+    const float x2 = q[0] * q[0], y2 = q[1] * q[1], z2 = q[2] * q[2];
+    const float xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
+    const float wx = q[3] * q[0], wy = q[3] * q[2] /* sic */, wz = q[3] * q[2];
+    return m3(v3(1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy)),
+              v3(2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx)),
+              v3(2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)));
+}
+
 // ---- specified roots: IEEE double ops only (see DESIGN.md "arithmetic spec") -----------------
 SSF_HD double bits_to_f64(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 SSF_HD uint64_t f64_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }

@@ -1128,6 +1128,17 @@ __global__ void k_publish_counts(Counters* cnt, int shrink_by_removed, Mailbox* 
     publish_counters_value(cnt, *cnt, shrink_by_removed, mb, seq);
 }
 
+// the three row streams of the orientations -> packed row-major Mat33 (the reference's layout, supersurfels.hpp:37)
+__global__ void k_pack_orient(SurfelSoA s, int n, float* __restrict__ out9) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 a = ld3(s.r0, i), b = ld3(s.r1, i), c = ld3(s.r2, i);
+    float* o = out9 + 9 * (size_t)i;
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = b.x; o[4] = b.y; o[5] = b.z; o[6] = c.x; o[7] = c.y; o[8] = c.z;
+}
+void launch_pack_orient(hipStream_t st, SurfelSoA s, int n, float* out9) {
+    if (n > 0) hipLaunchKernelGGL(k_pack_orient, dim3((n + 255) / 256), dim3(256), 0, st, s, n, out9);
+}
 __global__ void k_lab_refresh(SurfelSoA s, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) st3(s.lab, i, rgb_to_lab(ld3(s.col, i)));
@@ -1135,27 +1146,6 @@ __global__ void k_lab_refresh(SurfelSoA s, int n) {
 
 // ---- deformation apply ("next" row) -----------------------------------------------------------------
 // rotMatToQuat matrix_math.cuh:529-618; quatToRotMat :512-527 (its wy = q.w*q.z is reproduced)
-__device__ __forceinline__ void rot_to_quat(M3 m, float* q) {
-    float s; const float tr = (m.r0.x + m.r1.y) + m.r2.z;
-    if (tr > 0) {
-        s = sqrtf(tr + 1); q[3] = 0.5f * s; s = 0.5f / s;
-        q[0] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.z - m.r2.x) * s; q[2] = (m.r1.x - m.r0.y) * s;
-    } else {
-        int i = 0;
-        if (m.r1.y > m.r0.x) i = 1;
-        if (m.r2.z > m.r0.x || m.r2.z > m.r1.y) i = 2;
-        if (i == 0) {
-            s = sqrtf(((1.0f + m.r0.x) - m.r1.y) - m.r2.z); q[0] = 0.5f * s; s = 0.5f / s;
-            q[3] = (m.r2.y - m.r1.z) * s; q[1] = (m.r0.y + m.r1.x) * s; q[2] = (m.r0.z + m.r2.x) * s;
-        } else if (i == 1) {
-            s = sqrtf(((1.0f + m.r1.y) - m.r0.x) - m.r2.z); q[1] = 0.5f * s; s = 0.5f / s;
-            q[3] = (m.r0.z - m.r2.x) * s; q[0] = (m.r0.y + m.r1.x) * s; q[2] = (m.r1.z + m.r2.y) * s;
-        } else {
-            s = sqrtf(((1.0f + m.r2.z) - m.r0.x) - m.r1.y); q[2] = 0.5f * s; s = 0.5f / s;
-            q[3] = (m.r1.x - m.r0.y) * s; q[0] = (m.r0.z + m.r2.x) * s; q[1] = (m.r1.z + m.r2.y) * s;
-        }
-    }
-}
 __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const float* __restrict__ npos,
                                                      const float* __restrict__ nrot, const float* __restrict__ ntrans,
                                                      const float* __restrict__ w4, const int32_t* __restrict__ idx4) {
@@ -1181,12 +1171,7 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
     const float inv = 1.0f / len;
 #pragma unroll
     for (int a = 0; a < 4; a++) bq[a] *= inv;
-    const float x2 = bq[0] * bq[0], y2 = bq[1] * bq[1], z2 = bq[2] * bq[2];
-    const float xy = bq[0] * bq[1], xz = bq[0] * bq[2], yz = bq[1] * bq[2];
-    const float wx = bq[3] * bq[0], wy = bq[3] * bq[2] /* sic, matrix_math.cuh:521 */, wz = bq[3] * bq[2];
-    const M3 av = m3(v3(1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy)),
-                     v3(2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx)),
-                     v3(2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)));
+    const M3 av = quat_to_rot_quirk(bq);
     const M3 avT = m3_transpose(av);
     st3(M.r0, i, row_mul(ld3(M.r0, i), avT));
     st3(M.r1, i, row_mul(ld3(M.r1, i), avT));

@@ -9,13 +9,22 @@ call process_frame once per line and append `stamp tx ty tz qx qy qz qw` to the 
 the model is exported in the reference's text format at the end (exportModel,
 core/src/supersurfel_fusion.cu:595-633).
 
-Sparse VO, MOD and loop closure of the reference are out of scope: the pose prior is the previous
-pose.  Pre-decoded frames (np.savez archives produced by `pack_frames`) replace the PNG files on
+The depth pre-filter of processFrame (cv::cuda::bilateralFilter(depth, -1, 0.03, 4.5), supersurfel_fusion.cu:180)
+is ON, as in the reference (BENCHMARK_LAUNCH below).  Sparse VO, MOD and loop closure of the reference are out of
+scope: the pose prior is the previous pose.  Pre-decoded frames (np.savez archives produced by `pack_frames`) replace the PNG files on
 boxes without the dataset."""
 import argparse
 import os
 
 import numpy as np
+
+# The rgbd_benchmark launch column (launch/supersurfel_fusion_rgbd_benchmark.launch; SURVEY.md Appendix B) with TUM fr1
+# intrinsics (rgbd_benchmark/fr1_cam.yaml): what SupersurfelFusionRGBDBenchmarkNode hands to initialize().
+BENCHMARK_LAUNCH = dict(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, cell_size=16, seg_iter=10,
+                        lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, thresh_disp=1e-4,
+                        filter_iter=3, filter_alpha=0.1, filter_beta=1.0, filter_threshold=0.05, range_min=0.2, range_max=5.0,
+                        delta_t=20, conf_thresh=2560.0, nb_supersurfels_max=100000, icp_iter=10, icp_cov_thresh=0.05,
+                        depth_prefilter=1, prefilter_sigma_color=0.03, prefilter_sigma_space=4.5)
 
 
 def read_associations(path, max_frames=None):
@@ -98,6 +107,7 @@ def replay(fusion, frames, out_path=None, export_model=None, pipelined=False):
             lines.append(tum_line(stamp, r["pose"]))
     else:
         it, stamps, done = iter(frames), [], False
+        held = []                                         # submitted host buffers stay alive until their frame is processed
         while True:
             while not done and fusion.can_submit():
                 try:
@@ -105,11 +115,14 @@ def replay(fusion, frames, out_path=None, export_model=None, pipelined=False):
                 except StopIteration:
                     done = True
                     break
-                fusion.submit_frame(rgb, depth)           # host buffers are copied at submit
+                rgb, depth = np.ascontiguousarray(rgb, np.uint8), np.ascontiguousarray(depth, np.float32)
+                fusion.submit_frame(rgb, depth)           # (the copy is asynchronous: ssf.h, ssf_submit_frame)
+                held.append((rgb, depth))
                 stamps.append(stamp)
             if fusion.pending_frames() == 0:
                 break
             r = fusion.process_submitted().as_dict()
+            held.pop(0)
             results.append(r)
             lines.append(tum_line(stamps[len(lines)], r["pose"]))
     if out_path:
@@ -133,6 +146,13 @@ def frames_from_npz(path, depth_scale=0.0002):
         stamp = str(z["lines"][i]).split()[0]
         yield stamp, z["rgb%d" % i], convert_depth(z["depth%d" % i], depth_scale)
         i += 1
+
+
+def read_trajectory(path):
+    """TUM trajectory file -> (stamps, xyz (n,3), quat xyzw (n,4)); '#' lines skipped"""
+    rows = [l.split() for l in open(path) if l.strip() and not l.startswith("#")]
+    v = np.array([[float(x) for x in r[1:8]] for r in rows])
+    return [r[0] for r in rows], v[:, :3], v[:, 3:7]
 
 
 def ate_rmse(est_xyz, gt_xyz):
@@ -161,11 +181,7 @@ def main():
     a = ap.parse_args()
     from . import binding
     lib = binding.load_product()
-    # rgbd_benchmark launch column of SURVEY.md Appendix B, TUM fr1 intrinsics (rgbd_benchmark/fr1_cam.yaml)
-    cfg = lib.default_config(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, lambda_pos=10.0,
-                             lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, filter_iter=3, delta_t=20,
-                             conf_thresh=2560.0, nb_supersurfels_max=100000, icp_cov_thresh=0.05,
-                             pipeline_depth=2 if a.pipelined else 0, extract_batch=4 if a.pipelined else 1)
+    cfg = lib.default_config(pipeline_depth=2 if a.pipelined else 0, extract_batch=4 if a.pipelined else 1, **BENCHMARK_LAUNCH)
     f = binding.Fusion(lib, cfg)
     frames = frames_from_npz(a.npz, a.depth_scale) if a.npz else frames_from_dataset(a.dataset, a.depth_scale, a.max_frames)
     lines, res = replay(f, frames, a.out, a.export_model, pipelined=a.pipelined)

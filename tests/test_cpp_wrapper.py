@@ -58,3 +58,70 @@ def _run(oracle_lib, lib_path, lib_name, tmp_path):
     assert lines[n + 1].startswith("sequence n=%d" % n)
     assert lines[n + 2] == "sequence_equals_frames 1"
     assert lines[n + 3] == "uninitialised_throws 1"
+
+
+def _run_cv(oracle_lib, lib_path, lib_name, tmp_path):
+    """tests/cpp/wrapper_cv_smoke.cpp: the cv::Mat overloads (against the cv::Mat test double), the two image getters
+    of supersurfel_fusion.hpp:79-80, getModelDevice and initialize()'s depth_prefilter switch."""
+    W, H, n = 160, 128, 3
+    frames = [util.frame(k, W, H) for k in range(n)]
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        for rgb, depth in frames:
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes()); f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+    exe = tmp_path / "wrapper_cv_smoke"
+    libdir = os.path.dirname(lib_path)
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "wrapper_cv_smoke.cpp"), "-o", str(exe), "-L", libdir, "-l" + lib_name, "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    K = synthetic.intrinsics(W, H)
+    r = subprocess.run([str(exe), str(W), str(H), str(n), str(raw)] + [repr(float(K[k])) for k in ("fx", "fy", "cx", "cy")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    out = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    fo = binding.Fusion(oracle_lib, oracle_lib.default_config(nb_supersurfels_max=50000, lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0,
+                                                              lambda_disp=1e8, depth_prefilter=0, **{k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}))
+    for rgb, depth in frames:
+        res = fo.process_frame(rgb, depth)
+    seg = fo.preview_image()
+    h = 0
+    for v in seg.reshape(-1).tolist():
+        h = (h * 1315423911 + v) & 0xFFFFFFFFFFFFFFFF
+    assert out["seg"] == "%dx%d type=16 hash=%d" % (W, H, h)
+    # the preview: boundaries white, elsewhere 0.8 x the colour in B, G, R order
+    lab = fo.index_map()
+    edge = np.zeros((H, W), bool); edge[:-1, :-1] = (lab[:-1, 1:] != lab[:-1, :-1]) | (lab[1:, 1:] != lab[:-1, :-1])
+    assert (seg[edge] == 255).all() and 0.05 < edge.mean() < 0.5
+    assert np.array_equal(seg[~edge], (np.float32(0.8) * frames[-1][0][~edge][:, ::-1].astype(np.float32)).astype(np.uint8))
+    pd = fo.plane_depth()
+    ok = np.isfinite(pd) & (pd > 0) & (pd < 100)
+    tok = out["plane"].split()
+    assert tok[0] == "%dx%d" % (W, H) and tok[1] == "type=5" and tok[2] == "finite=%d" % int(ok.sum())
+    assert abs(float(tok[3].split("=")[1]) - float(pd[ok].astype(np.float64).sum())) < 1e-3 * float(ok.sum())
+    assert out["same_as_raw"] == "1"
+    assert out["model_device"] == "n=%d ptrs=1" % res["n_model"]
+    assert out["n=%d" % res["n_model"]] == "vis=%d" % res["n_visible"]
+
+
+def test_cv_mat_surface_builds_and_runs(oracle_lib, tmp_path):
+    _run_cv(oracle_lib, ORACLE_LIB, "ssf_oracle", tmp_path)
+
+
+@pytest.mark.gpu
+def test_cv_mat_surface_on_the_hip_library(oracle_lib, product_lib, tmp_path):
+    _run_cv(oracle_lib, os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
+
+
+def test_model_device_view_has_the_reference_layout(oracle_lib):
+    """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
+    import ctypes as C
+    W, H = 160, 128
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
+    for k in range(2):
+        fo.process_frame(*util.frame(k, W, H))
+    st, n = fo.model_device()
+    m = fo.get_model()
+    assert n == len(m["confidences"]) > 0
+    ori = np.ctypeslib.as_array(C.cast(st.orientations, C.POINTER(C.c_float)), shape=(n, 9))
+    pos = np.ctypeslib.as_array(C.cast(st.positions, C.POINTER(C.c_float)), shape=(n, 3))
+    assert np.array_equal(ori, m["orientations"]) and np.array_equal(pos, m["positions"])

@@ -111,6 +111,19 @@ def test_seeded_model_50k_bit_exact(oracle_lib, product_lib):
     util.compare_state(fo, fh)
 
 
+def test_model_device_view_has_the_reference_layout(product_lib):
+    """ssf_get_model_device on the product: dense [visible | out-of-view] rows, orientations as packed Mat33"""
+    fh, _ = seeded(product_lib, 30000, 640, 480)
+    for k in range(2):
+        fh.process_frame(*util.frame(k, 640, 480))
+    st, n = fh.model_device()
+    m = fh.get_model()
+    assert n == len(m["confidences"]) > 20000
+    for name, k, dt in binding.SURFEL_FIELDS:
+        got = util.device_to_host(getattr(st, name), (n, k) if k > 1 else (n,), dt)
+        util.assert_same_bits(got, m[name], "device view " + name)
+
+
 def test_deformation_bit_exact(oracle_lib, product_lib):
     fo, _ = seeded(oracle_lib, 20000, 640, 480)
     fh, _ = seeded(product_lib, 20000, 640, 480)

@@ -9,8 +9,11 @@ BENCH_PARAMS = dict(lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0, la
 
 
 def make_cfg(lib, W, H, **kw):
+    """Test configuration.  depth_prefilter is OFF here unless a test asks for it: the path under test takes "depth after
+    the pre-filter" as its input and the filter is covered on its own (tests/test_prefilter.py,
+    tests/test_replay.py run it inside process_frame); the library default is ON, as in the reference."""
     K = synthetic.intrinsics(W, H)
-    args = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=20000)
+    args = dict({k: K[k] for k in ("width", "height", "fx", "fy", "cx", "cy")}, nb_supersurfels_max=20000, depth_prefilter=0)
     args.update(BENCH_PARAMS)
     args.update(kw)
     return lib.default_config(**args)
@@ -49,6 +52,7 @@ def compare_state(fa, fb, maps=True, frame_surfels=True):
         assert_same_bits(fa.inlier_map(), fb.inlier_map(), "inlier map")
         assert_same_bits(fa.plane_depth(), fb.plane_depth(), "plane depth")
         assert_same_bits(fa.superpixels(), fb.superpixels(), "superpixel table")
+        assert_same_bits(fa.preview_image(), fb.preview_image(), "preview image (computeSuperpixelSegIm)")
     if frame_surfels:
         a, b = fa.get_frame(), fb.get_frame()
         assert_same_bits(a["confidences"], b["confidences"], "frame confidences")
@@ -70,3 +74,14 @@ def same_result(ra, rb):
     for k in RESULT_KEYS:
         assert ra[k] == rb[k], (k, ra[k], rb[k])
     assert_same_bits(ra["pose"], rb["pose"], "result pose")
+
+
+def device_to_host(ptr, shape, dtype):
+    """copy a raw device pointer (ssf_get_model_device) to a numpy array through the HIP runtime already in the process"""
+    import ctypes as C
+    path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]
+    hip = C.CDLL(path)
+    out = np.zeros(shape, dtype)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) == 0
+    return out
