@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SSF_ABI_VERSION 2
+#define SSF_ABI_VERSION 3
 /* "no candidate" key of the association tables: the largest value that orders the same as a signed
  * and as an unsigned 64-bit integer (valid keys are < 2^63: the distance is a positive float), so a
  * MIN all-reduce works on backends without unsigned types */
@@ -248,6 +248,27 @@ int ssf_stage_match(ssf_handle* h, uint64_t* best, uint8_t* matched);
 int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched,
                    ssf_frame_result* out);
 
+/* Fusion in two halves around the exchange of rows between shards ("halo exchange": a supersurfel belongs to the rank
+ * that owns the world tile of its position, cfg.shard_tile; updateSupersurfels moves the fused position,
+ * supersurfel_fusion_kernels.cu:601-682, so an updated row can cross a tile edge):
+ *   ssf_stage_fuse_begin  update of the winners this shard owns + ordered insertion of the unmatched frame
+ *                         supersurfels it owns.  An updated row whose new position hashes to another rank -- and that this
+ *                         frame's filterModel keeps -- leaves the shard: it is written to slot f (the frame supersurfel
+ *                         that updated it) of `table`, SSF_MIGRANT_WORDS int32 words per slot, S slots, all other slots
+ *                         zero.  Slot layout: [0] destination rank + 1 (0 = empty), [1] 0, [2..27] the row in the
+ *                         reference's layout (position 3, colour 3, stamps 2, orientation 9 row-major, shape 6, dims 2,
+ *                         confidence 1; floats as their bits).  A frame supersurfel updates at most ONE model row in the
+ *                         whole map, so an int32 SUM all-reduce of the tables over the ranks is exactly their union.
+ *   ssf_stage_fuse_end    rows addressed to this rank in the (reduced) table are appended behind this frame's
+ *                         insertions in ascending f, then classification (filterModel) of every row and the stable
+ *                         reorder.  table = NULL: nothing arrives.  Per-shard n_removed does not count emigrants and
+ *                         n_inserted does not count immigrants, so the sums over the ranks are the unsharded counters.
+ * ssf_stage_fuse = begin (no migration: every row stays where it is) + end.  The native RCCL mode
+ * (ssf_comm_attach) always migrates.  After every frame each row then lives on the rank that owns its tile. */
+#define SSF_MIGRANT_WORDS 28
+int ssf_stage_fuse_begin(ssf_handle* h, const uint64_t* best, const uint8_t* matched, int32_t* table);
+int ssf_stage_fuse_end(ssf_handle* h, const int32_t* table, ssf_frame_result* out);
+
 /* Device-resident variants for the multi-GPU driver: the exchanged records stay in HBM, where the
  * RCCL collectives run on them (the buffers are the caller's, e.g. torch tensors; for the CPU
  * checker "device" pointers are host pointers).  All work is enqueued on the handle's stream
@@ -264,6 +285,10 @@ int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums);
 int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched);
 int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched,
                           ssf_frame_result* out);
+/*   ssf_stage_fuse_begin_device / _end_device   the two halves above with the migrant table in HBM (d_table:
+ *                                SSF_MIGRANT_WORDS * S int32, the caller's buffer: the all-reduce runs on it in between) */
+int ssf_stage_fuse_begin_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, int32_t* d_table);
+int ssf_stage_fuse_end_device(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out);
 
 /* ---- loop-closure registration -----------------------------------
  * DenseRegistration::align (dense_registration.cu:52-243; makeCorrespondences,
@@ -295,7 +320,8 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
  * (e.g. a torch.distributed broadcast); every rank then calls ssf_comm_attach.  From then on
  * ssf_process_frame* / ssf_process_submitted run the exchange steps themselves, all in HBM on the
  * track stream: SUM all-reduce of the 29 x int64 ICP record per iteration, MIN / MAX all-reduce of
- * the association tables, one all-gather of the shard sizes per frame (read lazily at the start of
+ * the association tables, SUM all-reduce of the migrant table (rows that crossed a tile edge move to their new
+ * owner, see ssf_stage_fuse_begin), one all-gather of the shard sizes per frame (read lazily at the start of
  * the next frame).  All ranks must process the same frames in the same order.
  * ssf_get_global_counts: (n_model, n_visible, n_removed, n_inserted, n_updated) of the last frame
  * summed over the ranks.  The CPU checker exports these symbols and returns SSF_ERR_DEVICE (it has

@@ -100,6 +100,9 @@ struct State {
     int64_t id_offset = 0, global_n_model = -1, global_n_visible = -1;
     bool have_frame = false;
     int last_icp_valid = 0, last_icp_iters = 0;
+    // between fuse_begin and fuse_end
+    int f_updated = 0, f_inserted = 0, f_old_rows = 0; bool f_first = false;
+    std::vector<uint8_t> emigrant;       // per model row: leaves this shard in this frame (multi-GPU migration)
 };
 
 // oracle_extract.cpp
@@ -118,6 +121,9 @@ void icp_update(State& s, const int64_t* sums, int* again);
 void icp_end(State& s, int* valid);
 void match(State& s, uint64_t* best, uint8_t* matched);
 void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out);
+// the same in two halves around the exchange of rows between shards (see ssf_stage_fuse_begin in ssf.h)
+void fuse_begin(State& s, const uint64_t* best, const uint8_t* matched, int migrate, int32_t* table);
+void fuse_end(State& s, const int32_t* table, ssf_frame_result* out);
 void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
                        const float* w4, const int32_t* idx4);
 int  shard_owner(const State& s, int f, const Pose& pose);

@@ -17,7 +17,7 @@
 using namespace orc;
 
 struct PendingFrame { std::vector<uint8_t> rgb; std::vector<float> depth; std::vector<uint8_t> mask; bool has_mask; };
-struct ssf_handle { State s; std::deque<PendingFrame> pending; };
+struct ssf_handle { State s; std::deque<PendingFrame> pending; bool fusing = false; };
 static std::string g_create_err;
 
 static void pose_to12(const Pose& p, float* o) {
@@ -168,6 +168,18 @@ int ssf_stage_icp_fetch(ssf_handle* h, const int64_t* d_sums, int64_t* sums) {
     std::memcpy(sums, d_sums, SSF_ICP_RECORD * sizeof(int64_t)); return SSF_OK;
 }
 int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched) { return ssf_stage_match(h, d_best, d_matched); }
+int ssf_stage_fuse_begin(ssf_handle* h, const uint64_t* best, const uint8_t* matched, int32_t* table) {
+    if (!h || !best || !matched || !table) return SSF_ERR_INVALID_ARG;
+    if (!h->s.have_frame) return SSF_ERR_STATE;
+    fuse_begin(h->s, best, matched, 1, table); h->fusing = true; return SSF_OK;
+}
+int ssf_stage_fuse_end(ssf_handle* h, const int32_t* table, ssf_frame_result* out) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (!h->fusing) return SSF_ERR_STATE;
+    fuse_end(h->s, table, out); h->fusing = false; return SSF_OK;
+}
+int ssf_stage_fuse_begin_device(ssf_handle* h, const uint64_t* b, const uint8_t* m, int32_t* t) { return ssf_stage_fuse_begin(h, b, m, t); }
+int ssf_stage_fuse_end_device(ssf_handle* h, const int32_t* t, ssf_frame_result* out) { return ssf_stage_fuse_end(h, t, out); }
 int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, ssf_frame_result* out) {
     return ssf_stage_fuse(h, d_best, d_matched, out);
 }

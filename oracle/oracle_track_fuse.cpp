@@ -429,61 +429,137 @@ static void update_one(State& s, int f, int m) {
     M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
 }
 
-void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
+// spatial-tile owner of a world position (the same hash as shard_owner)
+static int owner_of(const State& s, const f3& pw) {
+    const int n = s.cfg.nranks;
+    if (n <= 1) return 0;
+    const float tile = s.cfg.shard_tile;
+    const int32_t ix = (int32_t)floorf(pw.x / tile), iy = (int32_t)floorf(pw.y / tile), iz = (int32_t)floorf(pw.z / tile);
+    const uint32_t h = ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u);
+    return (int)(h % (uint32_t)n);
+}
+
+// filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed
+static int classify_row(const State& s, const Surfels& M, int i, const Mat33& Rview, const f3& tview) {
+    const ssf_config& c = s.cfg;
+    const int time_diff = s.stamp - M.stamps[2 * i + 1];
+    if ((time_diff > c.delta_t && M.conf[i] < c.conf_thresh && s.stamp > c.delta_t) || M.conf[i] <= 0.0f) return 2;
+    const f3 p = Rview * M.pos[i] + tview;
+    if (p.z > c.range_min && p.z < c.range_max) {
+        const float u = c.fx * p.x / p.z + c.cx, v = c.fy * p.y / p.z + c.cy;
+        if (u >= 0.0f && u < (float)s.W && v >= 0.0f && v < (float)s.H) {
+            const float z = s.plane_depth[(size_t)((int)floorf(v)) * s.W + (int)floorf(u)];
+            return (p.z < 0.8f * z) ? 2 : 0;
+        }
+    }
+    return 1;
+}
+
+// One slot of the migrant table (multi-GPU "halo exchange", no reference counterpart): 28 words per frame
+// supersurfel f -- word 0 = destination rank + 1 (0: nothing in this slot), word 1 unused, words 2..27 = the row in
+// the reference's layout (pos 3, colour 3, stamps 2, orientation 9, shape 6, dims 2, confidence 1; floats as their
+// bits).  A frame supersurfel updates at most one model row in the whole map, so over all ranks at most one
+// contributes a non-zero slot f: an int32 SUM all-reduce of the tables is their union, exactly.
+static void row_to_slot(const Surfels& M, int m, int dest, int32_t* w) {
+    w[0] = dest + 1; w[1] = 0;
+    float v[26];
+    v[0] = M.pos[m].x; v[1] = M.pos[m].y; v[2] = M.pos[m].z; v[3] = M.col[m].x; v[4] = M.col[m].y; v[5] = M.col[m].z;
+    std::memcpy(&v[6], &M.stamps[2 * m], 8);
+    for (int r = 0; r < 3; r++) { v[8 + 3 * r] = M.orient[m].r[r].x; v[9 + 3 * r] = M.orient[m].r[r].y; v[10 + 3 * r] = M.orient[m].r[r].z; }
+    const Cov3& c = M.shape[m];
+    v[17] = c.xx; v[18] = c.xy; v[19] = c.xz; v[20] = c.yy; v[21] = c.yz; v[22] = c.zz;
+    v[23] = M.dims[2 * m]; v[24] = M.dims[2 * m + 1]; v[25] = M.conf[m];
+    std::memcpy(&w[2], v, sizeof(v));
+}
+static void slot_to_row(Surfels& M, int k, const int32_t* w) {
+    float v[26];
+    std::memcpy(v, &w[2], sizeof(v));
+    M.pos[k] = mk3(v[0], v[1], v[2]); M.col[k] = mk3(v[3], v[4], v[5]);
+    std::memcpy(&M.stamps[2 * k], &v[6], 8);
+    for (int r = 0; r < 3; r++) M.orient[k].r[r] = mk3(v[8 + 3 * r], v[9 + 3 * r], v[10 + 3 * r]);
+    M.shape[k] = mkcov(v[17], v[18], v[19], v[20], v[21], v[22]);
+    M.dims[2 * k] = v[23]; M.dims[2 * k + 1] = v[24]; M.conf[k] = v[25];
+}
+
+// First half of the fuse block (supersurfel_fusion.cu:351-395): update of the matched rows and ordered insertion.
+// migrate != 0 (sharded maps): an updated row whose fused position now hashes to another rank's world tile -- and
+// that this frame's filterModel would keep -- leaves this shard: it goes to slot f of `table` (SSF_MIGRANT_WORDS * S
+// words, zeroed here) and is dropped from the local model by fuse_end.
+void fuse_begin(State& s, const uint64_t* best, const uint8_t* matched, int migrate, int32_t* table) {
     const ssf_config& c = s.cfg;
     const int64_t nmodel_g = (c.nranks > 1 && s.global_n_model >= 0) ? s.global_n_model : s.n_model;
     const int64_t nvis_g = (c.nranks > 1 && s.global_n_visible >= 0) ? s.global_n_visible : s.n_visible;
-    int n_updated = 0, n_inserted = 0, n_removed = 0;
+    s.f_updated = 0; s.f_inserted = 0; s.f_first = !(nmodel_g > 0);
+    s.f_old_rows = s.n_model;
+    s.emigrant.assign(s.n_model, 0);
+    if (table) for (size_t i = 0; i < (size_t)SSF_MIGRANT_WORDS * s.S; i++) table[i] = 0;
     Surfels& M = s.model;
-    if (nmodel_g > 0) {                                                         // supersurfel_fusion.cu:351
-        const Mat33 R = s.pose.R; const f3 t = s.pose.t;
-        if (nvis_g > 0)                                                         // :356, update (:386)
-            for (int f = 0; f < s.S; f++) {
-                if (!matched[f] || best[f] == SSF_NO_MATCH) continue;             // model_id >= 0 (:626)
-                int64_t local = (int64_t)(uint32_t)(best[f] & 0xFFFFFFFFull) - s.id_offset;
-                if (local < 0 || local >= s.n_visible) continue;                // owned by another shard
-                update_one(s, f, (int)local); n_updated++;
-            }
-        // insertSupersurfels, supersurfel_fusion_kernels.cu:348-395 (decision A14)
-        const Mat33 Rt = transpose(R);
+    if (s.f_first) return;
+    const Mat33 R = s.pose.R; const f3 t = s.pose.t;
+    const Mat33 Rview = transpose(R);
+    const f3 tview = neg(Rview * t);
+    if (nvis_g > 0)                                                             // :356, update (:386)
         for (int f = 0; f < s.S; f++) {
-            if (!(s.frame.conf[f] > 0.0f) || matched[f]) continue;
-            if (shard_owner(s, f, s.pose) != c.rank) continue;
-            if (s.n_model >= c.nb_supersurfels_max) continue;
-            const int k = s.n_model++;
-            M.pos[k] = R * s.frame.pos[f] + t;
-            M.conf[k] = s.frame.conf[f];
-            M.col[k] = s.frame.col[f];
-            s.model_lab[k] = s.frame_lab[f];
-            M.stamps[2 * k] = s.stamp; M.stamps[2 * k + 1] = s.stamp;
-            M.dims[2 * k] = s.frame.dims[2 * f]; M.dims[2 * k + 1] = s.frame.dims[2 * f + 1];
-            M.orient[k] = s.frame.orient[f] * Rt;
-            M.shape[k] = mult_ABAt(R, s.frame.shape[f]);
-            n_inserted++;
+            if (!matched[f] || best[f] == SSF_NO_MATCH) continue;                 // model_id >= 0 (:626)
+            int64_t local = (int64_t)(uint32_t)(best[f] & 0xFFFFFFFFull) - s.id_offset;
+            if (local < 0 || local >= s.n_visible) continue;                    // owned by another shard
+            const int m = (int)local;
+            update_one(s, f, m); s.f_updated++;
+            if (migrate && c.nranks > 1 && table) {
+                const int dest = owner_of(s, M.pos[m]);
+                if (dest != c.rank && classify_row(s, M, m, Rview, tview) != 2) { row_to_slot(M, m, dest, &table[(size_t)SSF_MIGRANT_WORDS * f]); s.emigrant[m] = 1; }
+            }
         }
+    // insertSupersurfels, supersurfel_fusion_kernels.cu:348-395 (decision A14)
+    const Mat33 Rt = transpose(R);
+    for (int f = 0; f < s.S; f++) {
+        if (!(s.frame.conf[f] > 0.0f) || matched[f]) continue;
+        if (shard_owner(s, f, s.pose) != c.rank) continue;
+        if (s.n_model >= c.nb_supersurfels_max) continue;
+        const int k = s.n_model++;
+        M.pos[k] = R * s.frame.pos[f] + t;
+        M.conf[k] = s.frame.conf[f];
+        M.col[k] = s.frame.col[f];
+        s.model_lab[k] = s.frame_lab[f];
+        M.stamps[2 * k] = s.stamp; M.stamps[2 * k + 1] = s.stamp;
+        M.dims[2 * k] = s.frame.dims[2 * f]; M.dims[2 * k + 1] = s.frame.dims[2 * f + 1];
+        M.orient[k] = s.frame.orient[f] * Rt;
+        M.shape[k] = mult_ABAt(R, s.frame.shape[f]);
+        s.f_inserted++;
+    }
+}
+
+// Second half (supersurfel_fusion.cu:397-483): rows arriving from other shards (slots of the reduced migrant table
+// addressed to this rank, ascending f) are appended behind this frame's insertions, then filterModel over every row
+// and the stable 3-way reorder; emigrants are dropped without counting as removed.
+void fuse_end(State& s, const int32_t* table, ssf_frame_result* out) {
+    const ssf_config& c = s.cfg;
+    int n_removed = 0;
+    Surfels& M = s.model;
+    if (!s.f_first) {                                                           // supersurfel_fusion.cu:351
+        const Mat33 R = s.pose.R; const f3 t = s.pose.t;
+        if (table)
+            for (int f = 0; f < s.S; f++) {
+                const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * f];
+                if (w[0] - 1 != c.rank) continue;
+                if (s.n_model >= c.nb_supersurfels_max) continue;               // no room: dropped, like an insertion
+                const int k = s.n_model++;
+                slot_to_row(M, k, w);
+                s.model_lab[k] = rgbToLab(M.col[k]);
+            }
+        s.emigrant.resize(s.n_model, 0);
         // filterModel, supersurfel_fusion_kernels.cu:397-467
         const Mat33 Rview = transpose(R);
         const f3 tview = neg(Rview * t);
         std::vector<int> state(s.n_model);
-        int n_vis = 0;
-#pragma omp parallel for schedule(static) reduction(+ : n_vis, n_removed)
+        int n_vis = 0, n_gone = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_vis, n_removed, n_gone)
         for (int i = 0; i < s.n_model; i++) {
-            int st = 0;
-            const int time_diff = s.stamp - M.stamps[2 * i + 1];
-            if ((time_diff > c.delta_t && M.conf[i] < c.conf_thresh && s.stamp > c.delta_t) || M.conf[i] <= 0.0f) {
-                M.conf[i] = -1.0f; st = 2;
-            } else {
-                const f3 p = Rview * M.pos[i] + tview;
-                if (p.z > c.range_min && p.z < c.range_max) {
-                    const float u = c.fx * p.x / p.z + c.cx, v = c.fy * p.y / p.z + c.cy;
-                    if (u >= 0.0f && u < (float)s.W && v >= 0.0f && v < (float)s.H) {
-                        const float z = s.plane_depth[(size_t)((int)floorf(v)) * s.W + (int)floorf(u)];
-                        if (p.z < 0.8f * z) { M.conf[i] = -1.0f; st = 2; }
-                    } else st = 1;
-                } else st = 1;
-            }
+            int st = classify_row(s, M, i, Rview, tview);
+            if (st == 2) M.conf[i] = -1.0f;
+            if (s.emigrant[i] && st != 2) { st = 2; n_gone++; }                // leaves the shard: dropped, not "removed"
+            else if (st == 2) n_removed++;
             if (st == 0) n_vis++;
-            if (st == 2) n_removed++;
             state[i] = st;
         }
         // thrust::sort_by_key(states, model) -- stable 3-way partition (supersurfel_fusion.cu:469-472)
@@ -509,7 +585,7 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
             }
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < s.n_model; i++) { M.copy_row(i, tmp, i); s.model_lab[i] = lab_tmp[i]; }
-        s.n_model -= n_removed;                                                 // :474
+        s.n_model -= n_removed + n_gone;                                        // :474
         s.n_visible = n_vis;
     } else {
         // first frame: thrust::copy(frame -> model), supersurfel_fusion.cu:477-483
@@ -527,11 +603,16 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
         out->pose[9] = s.pose.t.x; out->pose[10] = s.pose.t.y; out->pose[11] = s.pose.t.z;
         out->icp_valid = s.last_icp_valid; out->icp_iters = s.last_icp_iters;
         out->n_model = s.n_model; out->n_visible = s.n_visible; out->n_removed = n_removed;
-        out->n_inserted = n_inserted; out->n_updated = n_updated; out->stamp = s.stamp;
+        out->n_inserted = s.f_inserted; out->n_updated = s.f_updated; out->stamp = s.stamp;
     }
     s.stamp++;                                                                  // :522
     s.global_n_model = -1; s.global_n_visible = -1;
     s.have_frame = false;
+}
+
+void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
+    fuse_begin(s, best, matched, 0, nullptr);
+    fuse_end(s, nullptr, out);
 }
 
 // rotMatToQuat matrix_math.cuh:529-618, quatToRotMat :512-527 (the wy = q.w*q.z quirk is kept)

@@ -11,6 +11,7 @@ import os
 import numpy as np
 
 ICP_RECORD = 29
+MIGRANT_WORDS = 28
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(_HERE, "csrc", "libssf_hip.so")
 
@@ -65,7 +66,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -140,6 +141,10 @@ class Library:
         L.ssf_stage_icp_fetch.argtypes = [vp, vp, vp]
         L.ssf_stage_match_device.argtypes = [vp, vp, vp]
         L.ssf_stage_fuse_device.argtypes = [vp, vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_stage_fuse_begin.argtypes = [vp, vp, vp, vp]
+        L.ssf_stage_fuse_end.argtypes = [vp, vp, C.POINTER(SsfFrameResult)]
+        L.ssf_stage_fuse_begin_device.argtypes = [vp, vp, vp, vp]
+        L.ssf_stage_fuse_end_device.argtypes = [vp, vp, C.POINTER(SsfFrameResult)]
 
     @property
     def backend(self):
@@ -321,6 +326,30 @@ class Fusion:
         matched = np.ascontiguousarray(matched, np.uint8)
         res = SsfFrameResult()
         self._ck(self.L.lib.ssf_stage_fuse(self.h, _ptr(best), _ptr(matched), C.byref(res)), "ssf_stage_fuse")
+        return res.as_dict()
+
+    def fuse_begin(self, best, matched):
+        """first half of the fuse stage; returns this shard's migrant table (S x MIGRANT_WORDS int32, see ssf.h)"""
+        best = np.ascontiguousarray(best, np.uint64)
+        matched = np.ascontiguousarray(matched, np.uint8)
+        table = np.zeros((self.S, MIGRANT_WORDS), np.int32)
+        self._ck(self.L.lib.ssf_stage_fuse_begin(self.h, _ptr(best), _ptr(matched), _ptr(table)), "ssf_stage_fuse_begin")
+        return table
+
+    def fuse_end(self, table=None):
+        """second half: rows addressed to this rank in the (rank-reduced) table arrive, then classify + reorder"""
+        table = None if table is None else np.ascontiguousarray(table, np.int32)
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_stage_fuse_end(self.h, _ptr(table), C.byref(res)), "ssf_stage_fuse_end")
+        return res.as_dict()
+
+    def fuse_begin_device(self, d_best_ptr, d_matched_ptr, d_table_ptr):
+        self._ck(self.L.lib.ssf_stage_fuse_begin_device(self.h, C.c_void_p(d_best_ptr), C.c_void_p(d_matched_ptr), C.c_void_p(d_table_ptr)),
+                 "ssf_stage_fuse_begin_device")
+
+    def fuse_end_device(self, d_table_ptr):
+        res = SsfFrameResult()
+        self._ck(self.L.lib.ssf_stage_fuse_end_device(self.h, C.c_void_p(d_table_ptr), C.byref(res)), "ssf_stage_fuse_end_device")
         return res.as_dict()
 
     # ---- loop closure: registration of a keyframe's supersurfels against the current frame ---------

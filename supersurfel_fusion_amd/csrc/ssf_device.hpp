@@ -51,6 +51,10 @@ struct Counters {
     // frozen inputs of the move kernel: old visible count, class totals A0 (visible staying), B0 (out-of-view
     // becoming visible), new head / old tail of the out-of-view span
     int mv_nv, mv_a0, mv_b0, mv_head_new, mv_tail_old, mv_head_old;
+    // rows appended behind the old visible rows in this frame: insertions + rows that arrived from other shards
+    int mv_nc;
+    // multi-GPU migration: updated rows that left this shard in this frame (dropped by the partition, not "removed")
+    int n_emigrated;
     // the published counters of the last frame (n_model, n_visible, n_removed, n_inserted, n_updated): never reset,
     // the source of the per-frame RCCL all-gather of the shard sizes
     int last[5];
@@ -212,7 +216,18 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws);
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate = 0);
+// Multi-GPU migration (ssf_stage_fuse_begin / _end in ssf.h).  launch_fuse(migrate = 1) marks an updated row whose new
+// position belongs to another rank's world tile as leaving (partition class "dropped", confidence kept);
+// launch_pack_emigrants writes those rows to slot f of the migrant table (SSF_MIGRANT_WORDS words per slot, other
+// slots zero); after the tables of all ranks have been summed, launch_migrate_in appends the rows addressed to this
+// rank behind this frame's insertions (ascending f), classifies them and corrects the partition sums and both
+// counter sets; launch_move_rows then treats them like inserted rows.
+void launch_pack_emigrants(hipStream_t st, SurfelSoA model, const unsigned long long* best, const uint8_t* matched, long long id_offset,
+                           int n_visible, const uint8_t* state_vis, int S, int do_update, int nranks, float tile, int32_t* table);
+void launch_migrate_in(hipStream_t st, SurfelSoA model, const int32_t* table, int S, int rank, int capacity, Counters* cnt,
+                       const Cam& cam, Rt pose, int stamp, const float* plane_depth, int delta_t, float conf_thresh, float zmin,
+                       float zmax, uint8_t* state_vis, const PartitionWs& ws);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // first ICP iteration of the next frame, accumulated by the row-move kernel of this one (launch_classify_reorder)

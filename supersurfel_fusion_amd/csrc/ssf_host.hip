@@ -384,6 +384,8 @@ struct ssf_handle {
     float* d_bf_in = nullptr; float* d_bf_out = nullptr; float* d_orient9 = nullptr;
     long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
+    // multi-GPU migration: this shard's migrant table (SSF_MIGRANT_WORDS x S int32), state between the two fuse halves
+    int32_t* d_migrants = nullptr; PartitionWs fuse_ws{}; bool fuse_first = false, fuse_migrate = false, fusing = false;
     // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
     // with live flags, host mirror of the span below), dense = materialised [visible | out-of-view] view for the
     // consumers of the whole model (get/set model, export, deformation)
@@ -863,21 +865,24 @@ static int do_match(ssf_handle* h) {
 }
 
 // update | insert | classify | reorder, all stream-ordered through the device-side counters; the
-// final counters come back through the mailbox (no D2H copy, no stream synchronise)
-static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
+// final counters come back through the mailbox (no D2H copy, no stream synchronise).  In two halves: between them a
+// sharded map exchanges the rows that crossed a tile edge (migrate: fuse_begin leaves this shard's migrant table in
+// h->d_migrants; fuse_end takes the rank-reduced table, or nullptr when nothing can arrive).
+static int fuse_begin(ssf_handle* h, int migrate) {
     const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis_g = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     SurfelSoA& M = h->model[h->mcur];
-    const unsigned long long seq = ++h->cnt_seq;
+    h->fuse_first = !(nmodel_g > 0);
+    h->fuse_migrate = migrate && h->cfg.nranks > 1 && !h->fuse_first;
     if (nmodel_g > 0) {
         // out-of-view store upkeep before the frame's launches: room in front for the rows that leave the view (at
         // most all visible rows), room behind for out-of-view insertions, and not too many dead slots in the span
         {
             const int span = h->oov_tail - h->oov_head;
-            if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < h->S + 256 ||
+            if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < 2 * h->S + 256 ||
                 span > h->oov_live + h->oov_live / 4 + 65536) { int rc2 = oov_recentre(h); if (rc2) return rc2; }
         }
-        PartitionWs ws;
+        PartitionWs& ws = h->fuse_ws;
         {
             uint32_t* set = h->d_part + (size_t)h->part_set * h->part_words;
             ws.sup_vis = set; ws.sup_oov = set + h->part_sup_vis; ws.tot = ws.sup_oov + h->part_sup_oov;
@@ -888,7 +893,26 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         launch_fuse(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, h->n_visible, h->cc->d_best, h->cc->d_matched, h->d_cand,
                     h->S, nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
                     h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
-                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws);
+                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws,
+                    h->fuse_migrate ? 1 : 0);
+        if (h->fuse_migrate)
+            launch_pack_emigrants(h->stream, M, h->cc->d_best, h->cc->d_matched, h->id_offset, h->n_visible, h->d_state, h->S,
+                                  nvis_g > 0 ? 1 : 0, h->cfg.nranks, h->cfg.shard_tile, h->d_migrants);
+    }
+    HCK(hipGetLastError());
+    h->fusing = true;
+    return SSF_OK;
+}
+static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out) {
+    SurfelSoA& M = h->model[h->mcur];
+    const unsigned long long seq = ++h->cnt_seq;
+    h->fusing = false;
+    if (!h->fuse_first) {
+        const PartitionWs& ws = h->fuse_ws;
+        if (h->fuse_migrate && d_table)
+            launch_migrate_in(h->stream, M, d_table, h->S, h->cfg.rank, h->cfg.nb_supersurfels_max, h->d_cnt, h->cam, h->pose, h->stamp,
+                              h->cc->maps.plane_depth, h->cfg.delta_t, h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max,
+                              h->d_state, ws);
         // The rows the move kernel writes to the new visible array are the rows the next frame's first ICP iteration
         // reads, under a transform that is known now (the pose just estimated, when the caller supplies no prior):
         // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).
@@ -916,7 +940,7 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
         // move: the host continues once the counters arrive (published by the fuse launch), the row moves of this
         // frame overlap the host-side launch work of the next one (stream order keeps every later reader of the
         // model behind them)
-        launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + h->S, h->oov_tail - h->oov_head,
+        launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + (h->fuse_migrate ? 2 : 1) * h->S, h->oov_tail - h->oov_head,
                          h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
         h->mcur ^= 1;
     } else {
@@ -963,6 +987,11 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {
     h->global_n_model = -1; h->global_n_visible = -1;
     if (h->cfg.profile == 1) { HCK(hipStreamSynchronize(h->stream)); timer_collect(&h->timer); }
     return SSF_OK;
+}
+
+static int do_fuse(ssf_handle* h, ssf_frame_result* out) {          // no exchange of rows (single shard, or ssf_stage_fuse)
+    int rc = fuse_begin(h, 0);
+    return rc ? rc : fuse_end(h, nullptr, out);
 }
 
 // ---- multi-GPU exchanges (native RCCL on the track stream) -------------------------------------------------
@@ -1106,7 +1135,15 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         NCK(api->AllReduce(h->cc->d_matched, h->cc->d_matched, h->S, ncclUint8, ncclMax, h->comm, h->stream));
     }
     ssf_frame_result r;
-    rc = do_fuse(h, &r);
+    if (h->comm) {
+        // rows whose fused position crossed a tile edge move to the rank that owns their new tile: every rank's
+        // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
+        rc = fuse_begin(h, 1);
+        if (rc) return rc;
+        if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
+        rc = fuse_end(h, h->d_migrants, &r);
+    } else
+        rc = do_fuse(h, &r);
     if (rc) return rc;
     if (h->comm) { rc = comm_gather_counts(h); if (rc) return rc; }     // read at the start of the next frame
     h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
@@ -1265,7 +1302,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
              hipEventCreate(&c.ev_t0) == hipSuccess && hipEventCreate(&c.ev_t1) == hipSuccess;
     }
-    const size_t OC = 3 * N + 2 * S + 1024;        // out-of-view store: home of the span = N + S + 256, room for N rows either side
+    const size_t OC = 3 * N + 4 * S + 1024;        // out-of-view store: home of the span = N + S + 256, room for N rows either side (+ 2 S appended per frame)
     h->part_sup_vis = 6 * (int)(((N + 255) / 256 + 2) / PART_GROUP + 1);
     h->part_sup_oov = (int)(((OC + 255) / 256 + 8) / PART_GROUP + 1);
     h->part_words = h->part_sup_vis + h->part_sup_oov + 8 * PART_REPLICAS;
@@ -1285,7 +1322,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
-         dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
+         dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
              hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;
@@ -1622,6 +1659,44 @@ int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* 
     HCK(hipMemcpyAsync(h->cc->d_best, d_best, (size_t)h->S * 8, hipMemcpyDeviceToDevice, h->stream));
     HCK(hipMemcpyAsync(h->cc->d_matched, d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
     return do_fuse(h, out);
+}
+int ssf_stage_fuse_begin_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, int32_t* d_table) {
+    if (!h || !d_best || !d_matched || !d_table) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame || h->fusing) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    HCK(hipMemcpyAsync(h->cc->d_best, d_best, (size_t)h->S * 8, hipMemcpyDeviceToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->cc->d_matched, d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
+    int rc = fuse_begin(h, 1);
+    if (rc) return rc;
+    if (h->fuse_migrate) HCK(hipMemcpyAsync(d_table, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S * 4, hipMemcpyDeviceToDevice, h->stream));
+    else HCK(hipMemsetAsync(d_table, 0, (size_t)SSF_MIGRANT_WORDS * h->S * 4, h->stream));
+    return SSF_OK;
+}
+int ssf_stage_fuse_end_device(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (!h->fusing) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    return fuse_end(h, d_table, out);
+}
+int ssf_stage_fuse_begin(ssf_handle* h, const uint64_t* best, const uint8_t* matched, int32_t* table) {
+    if (!h || !best || !matched || !table) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame || h->fusing) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    HCK(hipMemcpyAsync(h->cc->d_best, best, (size_t)h->S * 8, hipMemcpyHostToDevice, h->stream));
+    HCK(hipMemcpyAsync(h->cc->d_matched, matched, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+    int rc = fuse_begin(h, 1);
+    if (rc) return rc;
+    const size_t bytes = (size_t)SSF_MIGRANT_WORDS * h->S * 4;
+    if (h->fuse_migrate) { HCK(hipMemcpyAsync(table, h->d_migrants, bytes, hipMemcpyDeviceToHost, h->stream)); HCK(hipStreamSynchronize(h->stream)); }
+    else std::memset(table, 0, bytes);
+    return SSF_OK;
+}
+int ssf_stage_fuse_end(ssf_handle* h, const int32_t* table, ssf_frame_result* out) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (!h->fusing) return SSF_ERR_STATE;
+    TimerScope ts(h);
+    if (table && h->fuse_migrate) HCK(hipMemcpyAsync(h->d_migrants, table, (size_t)SSF_MIGRANT_WORDS * h->S * 4, hipMemcpyHostToDevice, h->stream));
+    return fuse_end(h, (table && h->fuse_migrate) ? h->d_migrants : nullptr, out);
 }
 int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
     if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;

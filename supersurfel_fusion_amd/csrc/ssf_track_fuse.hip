@@ -502,11 +502,13 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
 // (the two kinds of work sit in different waves, so neither waits for the other's instruction stream)
 #define UPD_PER_WG 32
 struct ClassifyArgs { Cam cam; const float* plane_depth; int delta_t; float conf_thresh, zmin, zmax; };
+struct ShardArgs { int rank, nranks, migrate; float tile; };
+__device__ __forceinline__ int tile_owner(const V3& pw, int nranks, float tile);
 __device__ __forceinline__ float pick3(const V3& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset, int n_visible,
                                              const unsigned long long* __restrict__ best, const uint8_t* __restrict__ matched,
                                              int S, Counters* cnt, int f0, const ClassifyArgs& ca, uint8_t* __restrict__ state_vis,
-                                             PartitionWs ws) {
+                                             PartitionWs ws, const ShardArgs& sh) {
     const int wv = threadIdx.x >> 6, l = lane();
     if (wv == 3) return;
     const int f = wv == 0 ? f0 + (l >> 1) : f0 + (wv - 1) * 16 + (l >> 2);
@@ -559,10 +561,17 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
             M3 vecs; V3 vals;
             principal_finish(fused_shape, r0, r2, vecs, vals);
             // classification (from the values in registers: the row is not read back; it was seen in this frame)
-            const int st = classify_values(ca.cam, m_conf + f_conf, stamp, fused_position, pose, ca.plane_depth, stamp, ca.delta_t,
-                                           ca.conf_thresh, ca.zmin, ca.zmax);
+            int st = classify_values(ca.cam, m_conf + f_conf, stamp, fused_position, pose, ca.plane_depth, stamp, ca.delta_t,
+                                     ca.conf_thresh, ca.zmin, ca.zmax);
+            const bool removed = st == 2;
+            // sharded map: a row that is kept but whose new position belongs to another rank's tile leaves this shard --
+            // the partition drops it (class 2) with its confidence intact; launch_pack_emigrants ships it
+            if (sh.migrate && !removed && tile_owner(fused_position, sh.nranks, sh.tile) != sh.rank) {
+                st = 2;
+                atomicAdd(&cnt->n_emigrated, 1);
+            }
             st3(M.pos, m, fused_position);
-            M.conf[m] = st == 2 ? -1.0f : m_conf + f_conf;
+            M.conf[m] = removed ? -1.0f : m_conf + f_conf;
             st6(M.shape, m, fused_shape);
             st3(M.r0, m, vecs.r0); st3(M.r1, m, vecs.r1); st3(M.r2, m, vecs.r2);
             M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
@@ -587,14 +596,16 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
     }
 }
 
-// spatial-tile owner of a frame supersurfel (multi-GPU sharding)
-__device__ __forceinline__ int shard_owner(const SurfelSoA& F, int f, const Rt& pose, int nranks, float tile) {
-    if (nranks <= 1) return 0;
-    if (!(F.conf[f] > 0.0f)) return f % nranks;
-    const V3 pw = add(m3_mulv(pose.R, ld3(F.pos, f)), pose.t);
+// spatial-tile owner of a world position / of a frame supersurfel (multi-GPU sharding)
+__device__ __forceinline__ int tile_owner(const V3& pw, int nranks, float tile) {
     const int ix = (int)floorf(pw.x / tile), iy = (int)floorf(pw.y / tile), iz = (int)floorf(pw.z / tile);
     const uint32_t h = ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)iz * 83492791u);
     return (int)(h % (uint32_t)nranks);
+}
+__device__ __forceinline__ int shard_owner(const SurfelSoA& F, int f, const Rt& pose, int nranks, float tile) {
+    if (nranks <= 1) return 0;
+    if (!(F.conf[f] > 0.0f)) return f % nranks;
+    return tile_owner(add(m3_mulv(pose.R, ld3(F.pos, f)), pose.t), nranks, tile);
 }
 
 // ordered compaction helper: exclusive rank of `flag` among the block's threads (blockDim <= 1024)
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
                                                        int do_update, int capacity, int rank, int nranks, float tile, Counters* cnt,
                                                        int nupd, int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
                                                        uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
-                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws) {
+                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws, int migrate) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
@@ -736,8 +747,10 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         }
     } else if (b >= nupd)
         insert_chunk(M, F, pose, stamp, matched, S, capacity, rank, nranks, tile, cnt, wave_tot, b - nupd, nchunks, ca, state_vis, ws);
-    else if (do_update)
-        update_group(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * UPD_PER_WG, ca, state_vis, ws);
+    else if (do_update) {
+        ShardArgs sh; sh.rank = rank; sh.nranks = nranks; sh.migrate = (migrate && nranks > 1) ? 1 : 0; sh.tile = tile;
+        update_group(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * UPD_PER_WG, ca, state_vis, ws, sh);
+    }
     // the atomics above (and cnt->n_updated / n_inserted) are device-scope, complete (vmcnt(0) + barrier) before this
     // block counts its arrival; the last block reads them back with device-scope atomic loads (same protocol as the
     // ICP record)
@@ -759,13 +772,14 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         Counters c_in = *cnt;
         c_in.n_inserted = __hip_atomic_load(&cnt->n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written in this launch
         c_in.n_updated = __hip_atomic_load(&cnt->n_updated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c_in.n_emigrated = __hip_atomic_load(&cnt->n_emigrated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
         const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
         Counters c = c_in;
         c.n_model = c_in.n_model + c_in.n_inserted;   // the insertion reports its rows in n_inserted only
         c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
-        c.n_visible = a0 + b0 + c0; c.n_removed = a2 + b2 + c2;
-        c.mv_nv = c_in.n_visible; c.mv_a0 = a0; c.mv_b0 = b0;
+        c.n_visible = a0 + b0 + c0; c.n_removed = (a2 + b2 + c2) - c_in.n_emigrated;     // emigrants are dropped, not removed
+        c.mv_nv = c_in.n_visible; c.mv_a0 = a0; c.mv_b0 = b0; c.mv_nc = c_in.n_inserted;
         c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
         c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
         c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
@@ -907,7 +921,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
     bool keep = false;
     V3 pos, lab, nrm;
     if ((int)blockIdx.x < nb_vis) {
-        const int nv = cnt->mv_nv, n_rows = nv + cnt->last[3];            // last[3] = insertions of this frame (published)
+        const int nv = cnt->mv_nv, n_rows = nv + cnt->mv_nc;              // mv_nc = rows appended in this frame (insertions + arrivals)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
         // the row itself is requested now: its loads travel while the prefix below is worked out
@@ -1007,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         // No rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
         const int nkeep = __syncthreads_count(keep);
         const bool vis = (int)blockIdx.x < nb_vis;
-        const int nbr = (cnt->mv_nv + cnt->last[3] + 255) / 256;
+        const int nbr = (cnt->mv_nv + cnt->mv_nc + 255) / 256;
         if (vis ? (int)blockIdx.x >= nbr : nkeep == 0) return;
         __shared__ int s_last;
         icp_fold(red, nx.replicas);
@@ -1036,6 +1050,95 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         }
         __syncthreads();
         if (s_last) icp_publish(nx.replicas, nx.sums, nx.mb, nx.seq);
+    }
+}
+
+// ---- multi-GPU migration: rows that crossed a tile edge move to the rank that owns their new tile -----------------
+// slot f of the migrant table <- the model row that frame supersurfel f updated, if the fuse launch marked it as
+// leaving (partition state 2 with its confidence intact); every other slot is zeroed.  One thread per slot.
+__global__ __launch_bounds__(256) void k_pack_emigrants(SurfelSoA M, const unsigned long long* __restrict__ best,
+                                                        const uint8_t* __restrict__ matched, long long id_offset, int n_visible,
+                                                        const uint8_t* __restrict__ state_vis, int S, int do_update, int nranks,
+                                                        float tile, int32_t* __restrict__ table) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= S) return;
+    int32_t w[SSF_MIGRANT_WORDS];
+#pragma unroll
+    for (int i = 0; i < SSF_MIGRANT_WORDS; i++) w[i] = 0;
+    if (do_update && matched[f] && best[f] != SSF_NO_MATCH) {
+        const long long local = (long long)(uint32_t)(best[f] & 0xFFFFFFFFull) - id_offset;
+        if (local >= 0 && local < n_visible) {
+            const size_t m = (size_t)local;
+            const float conf = M.conf[m];
+            if (state_vis[m] == 2 && conf > 0.0f) {
+                const RowRegs r = load_row(M, m);
+                w[0] = tile_owner(r.pos, nranks, tile) + 1;
+                const float v[26] = {r.pos.x, r.pos.y, r.pos.z, r.col.x, r.col.y, r.col.z, __int_as_float(r.s0), __int_as_float(r.s1),
+                                     r.r0.x, r.r0.y, r.r0.z, r.r1.x, r.r1.y, r.r1.z, r.r2.x, r.r2.y, r.r2.z,
+                                     r.shape.xx, r.shape.xy, r.shape.xz, r.shape.yy, r.shape.yz, r.shape.zz, r.d0, r.d1, r.conf};
+#pragma unroll
+                for (int i = 0; i < 26; i++) w[2 + i] = __float_as_int(v[i]);
+            }
+        }
+    }
+    int32_t* o = table + (size_t)SSF_MIGRANT_WORDS * f;
+#pragma unroll
+    for (int i = 0; i < SSF_MIGRANT_WORDS; i++) o[i] = w[i];
+}
+// rows of the (rank-reduced) table addressed to this rank -> appended behind this frame's insertions in the visible
+// array (ascending f), classified like any inserted row; partition sums and both counter sets corrected.  One
+// workgroup: at most S rows arrive, a handful in practice.
+__global__ __launch_bounds__(1024) void k_migrate_in(SurfelSoA M, const int32_t* __restrict__ table, int S, int rank, int capacity,
+                                                     Counters* cnt, ClassifyArgs ca, Rt pose, int stamp,
+                                                     uint8_t* __restrict__ state_vis, PartitionWs ws) {
+    __shared__ int wave_tot[16];
+    __shared__ int s_in[3];
+    if (threadIdx.x < 3) s_in[threadIdx.x] = 0;
+    const Counters c1 = cnt[1];
+    const int base_row = c1.mv_nv + c1.mv_nc;                  // first free row behind the insertions
+    const int total_before = c1.n_model + c1.n_state2;         // rows in the store before this frame's removals
+    int running = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < S; f0 += 1024) {
+        const int f = f0 + threadIdx.x;
+        const bool flag = f < S && table[(size_t)SSF_MIGRANT_WORDS * f] - 1 == rank;
+        int total;
+        const int r = block_rank_1024(flag, wave_tot, total);
+        if (flag && total_before + running + r < capacity) {
+            const int32_t* w = table + (size_t)SSF_MIGRANT_WORDS * f;
+            float v[26];
+#pragma unroll
+            for (int i = 0; i < 26; i++) v[i] = __int_as_float(w[2 + i]);
+            RowRegs row;
+            row.pos = v3(v[0], v[1], v[2]); row.col = v3(v[3], v[4], v[5]); row.lab = rgb_to_lab(row.col);
+            row.s0 = __float_as_int(v[6]); row.s1 = __float_as_int(v[7]);
+            row.r0 = v3(v[8], v[9], v[10]); row.r1 = v3(v[11], v[12], v[13]); row.r2 = v3(v[14], v[15], v[16]);
+            row.shape = sym3(v[17], v[18], v[19], v[20], v[21], v[22]); row.d0 = v[23]; row.d1 = v[24]; row.conf = v[25];
+            const int st = classify_values(ca.cam, row.conf, row.s1, row.pos, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh,
+                                           ca.zmin, ca.zmax);
+            if (st == 2) row.conf = -1.0f;
+            const size_t k = (size_t)base_row + running + r;
+            store_row(M, k, row);
+            state_vis[k] = (uint8_t)st;
+            atomicAdd(&ws.sup_vis[((k >> 8) / PART_GROUP) * 6 + 3 + st], 1u);
+            atomicAdd(&s_in[st], 1);
+        }
+        running += min(total, max(0, capacity - total_before - running));
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int in0 = s_in[0], in1 = s_in[1], in2 = s_in[2], n_in = in0 + in1 + in2;
+        if (n_in) {
+            for (int q = 0; q < 2; q++) {
+                Counters c = cnt[q];
+                c.n_model += in0 + in1; c.n_visible += in0;
+                c.oov_tail += in1; c.oov_live += in1; c.mv_nc += n_in;
+                if (q == 1) { c.n_state0 += in0; c.n_state1 += in1; c.n_state2 += in2; c.n_removed += in2; }
+                c.last[0] = c.n_model; c.last[1] = c.n_visible; if (q == 1) c.last[2] = c.n_removed; else c.last[2] += in2;
+                cnt[q] = c;
+            }
+        }
     }
 }
 
@@ -1083,6 +1186,7 @@ __device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c,
     c.last[0] = c.n_model; c.last[1] = c.n_visible; c.last[2] = c.n_removed; c.last[3] = c.n_inserted; c.last[4] = c.n_updated;
     Counters next = c;
     next.n_inserted = 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
+    next.n_emigrated = 0;
     cnt[0] = next;
     return c;
 }
@@ -1208,7 +1312,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws) {
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate) {
     ScopedKernel sk("update_insert", st);
     const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256, nb_vis = (n_visible + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
@@ -1216,7 +1320,20 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
     hipLaunchKernelGGL(k_update_insert, dim3(nupd + nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
                        frame, pose, stamp, id_offset,
                        n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nupd, nchunks, nb_vis, nb_oov, oov, ca,
-                       state_vis, state_oov, bc_oov, ws);
+                       state_vis, state_oov, bc_oov, ws, migrate);
+}
+void launch_pack_emigrants(hipStream_t st, SurfelSoA model, const unsigned long long* best, const uint8_t* matched, long long id_offset,
+                           int n_visible, const uint8_t* state_vis, int S, int do_update, int nranks, float tile, int32_t* table) {
+    ScopedKernel sk("pack_emigrants", st);
+    hipLaunchKernelGGL(k_pack_emigrants, dim3((S + 255) / 256), dim3(256), 0, st, model, best, matched, id_offset, n_visible, state_vis, S,
+                       do_update, nranks, tile, table);
+}
+void launch_migrate_in(hipStream_t st, SurfelSoA model, const int32_t* table, int S, int rank, int capacity, Counters* cnt,
+                       const Cam& cam, Rt pose, int stamp, const float* plane_depth, int delta_t, float conf_thresh, float zmin,
+                       float zmax, uint8_t* state_vis, const PartitionWs& ws) {
+    ScopedKernel sk("migrate_in", st);
+    ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
+    hipLaunchKernelGGL(k_migrate_in, dim3(1), dim3(1024), 0, st, model, table, S, rank, capacity, cnt, ca, pose, stamp, state_vis, ws);
 }
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt) {

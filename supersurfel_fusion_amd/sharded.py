@@ -8,6 +8,9 @@ work is a model supersurfel run on the local shard with three real exchange step
               (exact: integer addition is associative, so 1/2/4/8 ranks give identical bits)
   association MIN all-reduce of S packed (dist_bits<<32 | global id) keys + MAX of the S matched
               bytes; the shard that owns the winner applies the update
+  migration   ("halo exchange") SUM all-reduce of the migrant table (S slots x 28 int32): an updated row whose
+              fused position now hashes to another rank's world tile moves there; a frame supersurfel updates
+              at most one row in the whole map, so at most one rank fills a slot and the sum is the union
   counts      one all-gather of the per-rank frame counters at the end of the frame: their sums
               are the global counts, their prefix gives the next frame's global id offsets
 
@@ -53,6 +56,7 @@ class ShardedFusion:
             # keys are < 2^63 (SSF_NO_MATCH = INT64_MAX): exchanged as int64, MIN order is preserved
             self._best = torch.zeros(S, dtype=torch.int64, device=self.device)
             self._matched = torch.zeros(S, dtype=torch.uint8, device=self.device)
+            self._migrants = torch.zeros(S * 28, dtype=torch.int32, device=self.device)       # binding.MIGRANT_WORDS per slot
             self._mine = torch.zeros(len(COUNT_KEYS), dtype=torch.int64, device=self.device)
             self._all = torch.zeros(self.world * len(COUNT_KEYS), dtype=torch.int64, device=self.device)
         self._counts = None                       # per-rank (n_model, n_visible) after the previous frame
@@ -108,7 +112,13 @@ class ShardedFusion:
             if self.reduce:
                 dist.all_reduce(self._best, op=dist.ReduceOp.MIN, group=self.group)
                 dist.all_reduce(self._matched, op=dist.ReduceOp.MAX, group=self.group)
-            res = f.fuse_device(self._best.data_ptr(), self._matched.data_ptr())
+            # ---- fusion in two halves around the exchange of the rows that crossed a tile edge ----
+            if self.world > 1:
+                f.fuse_begin_device(self._best.data_ptr(), self._matched.data_ptr(), self._migrants.data_ptr())
+                dist.all_reduce(self._migrants, op=dist.ReduceOp.SUM, group=self.group)
+                res = f.fuse_end_device(self._migrants.data_ptr())
+            else:
+                res = f.fuse_device(self._best.data_ptr(), self._matched.data_ptr())
         res["icp_valid"], res["icp_iters"] = int(valid), iters
         allc = self._gather_counts([res[k] for k in COUNT_KEYS])
         # host-side split of the exchange-bound stages (extract: the library's own per-batch events)

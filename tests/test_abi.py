@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(which, product_lib, oracle_lib):
     lib = product_lib if which == "product" else oracle_lib
     for sym in declared_symbols():
         assert hasattr(lib.lib, sym), "%s does not export %s" % (lib.path, sym)
-    assert lib.lib.ssf_abi_version() == 2
+    assert lib.lib.ssf_abi_version() == 3
     assert lib.backend == ("hip-gfx950" if which == "product" else "cpu-oracle")
 
 

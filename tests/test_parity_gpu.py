@@ -408,8 +408,8 @@ def test_soak_600_frames_pipelined(oracle_lib, product_lib):
 
 
 def _emulated_ranks(lib, world, W, H, nframes, cap=4096):
-    """`world` handles of one library acting as the ranks of a sharded map in ONE process: the three exchanges
-    (ICP record SUM, association MIN / MAX, shard sizes) are done on the host between the stage calls."""
+    """`world` handles of one library acting as the ranks of a sharded map in ONE process: the exchanges (ICP record
+    SUM, association MIN / MAX, migrant table SUM, shard sizes) are done on the host between the stage calls."""
     fs = [binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=cap, rank=r, nranks=world, shard_tile=0.25))
           for r in range(world)]
     counts = np.zeros((world, 2), np.int64)
@@ -433,8 +433,12 @@ def _emulated_ranks(lib, world, W, H, nframes, cap=4096):
         bm = [f.match() for f in fs]
         best = np.minimum.reduce([b for b, _ in bm])
         matched = np.maximum.reduce([m for _, m in bm])
-        res = [f.fuse(best, matched) for f in fs]
+        res = util.exchange_and_fuse(fs, best, matched)       # rows that crossed a tile edge move to their new owner
         counts = np.array([[r["n_model"], r["n_visible"]] for r in res], np.int64)
+        for r, f in enumerate(fs):                            # every row lives on the rank that owns its world tile
+            m = f.get_model()
+            ok = m["confidences"] > 0                         # (the first frame copies invalid frame rows too: they are culled next frame)
+            assert (synthetic.tile_owner(m["positions"][ok], world, 0.25) == r).all(), (k, r)
         out.append(([r["pose"].copy() for r in res], counts.copy(), [[r[key] for key in ("n_removed", "n_inserted", "n_updated")] for r in res]))
     return fs, out
 

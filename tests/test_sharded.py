@@ -16,7 +16,7 @@ import util
 from conftest import ORACLE_LIB
 from supersurfel_fusion_amd import binding, sharded
 
-W, H, NF = 160, 128, 4
+W, H, NF = 160, 128, 6
 
 
 def _free_port():
@@ -35,7 +35,9 @@ def _worker(rank, world, port, outdir):
         r = drv.process_frame(rgb, depth)
         poses.append(r["pose"]); glob.append([r["global_n_model"], r["global_n_visible"], r["icp_valid"], r["icp_iters"]])
     m = f.get_model()
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), poses=np.array(poses), glob=np.array(glob), **m)
+    from supersurfel_fusion_amd import synthetic
+    at_home = bool((synthetic.tile_owner(m["positions"][m["confidences"] > 0], world, 0.25) == rank).all())     # migration keeps rows with their tile's owner
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), poses=np.array(poses), glob=np.array(glob), at_home=at_home, **m)
     dist.destroy_process_group()
 
 
@@ -62,6 +64,7 @@ def test_sharded_map_equals_single_rank_map(world, oracle_lib, tmp_path):
     single = f.get_model()
     ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for r in ranks:
+        assert bool(r["at_home"]), "a row lives on a rank that does not own its world tile"
         assert np.array_equal(r["poses"].view(np.uint32), np.array(poses).view(np.uint32)), "pose differs across shard counts"
         assert np.array_equal(r["glob"], np.array(glob))
     merged = {name: np.concatenate([r[name] for r in ranks]) for name, _, _ in binding.SURFEL_FIELDS}

@@ -85,3 +85,13 @@ def device_to_host(ptr, shape, dtype):
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) == 0
     return out
+
+
+def exchange_and_fuse(ranks, best, matched):
+    """The fuse stage of a sharded map with the ranks emulated in one process: first halves, SUM of the migrant tables
+    (what the int32 all-reduce does: at most one rank fills a slot), second halves.  Returns the per-rank results."""
+    tables = [f.fuse_begin(best, matched) for f in ranks]
+    filled = np.stack([t[:, 0] != 0 for t in tables]).sum(axis=0)
+    assert (filled <= 1).all(), "two ranks filled the same slot of the migrant table"
+    total = np.sum(np.stack(tables).astype(np.int64), axis=0).astype(np.int32)
+    return [f.fuse_end(total) for f in ranks]
