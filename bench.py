@@ -61,6 +61,16 @@ ALGO_BYTES = {
 EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
 
 
+def kernel_source_sha():
+    """hash of the product's kernel sources: ties a PMC profile under profiles/ to the binary it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "supersurfel_fusion_amd", "csrc")
+    for f in ("ssf_extract.hip", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1, prefilter=0):
     """prefilter = 0: the metric's path starts at "depth after the pre-filter" (the
     bilateral filter is OpenCV's, third party, a "next" row); the rate WITH the library's own filter inside the frame
@@ -76,6 +86,55 @@ def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_
     if lib.backend.startswith("hip") and torch.cuda.is_available():
         kw["device_id"] = torch.cuda.current_device()
     return lib.default_config(**kw)
+
+
+def next_kernel_times(lib, dev, model, nvis, cap):
+    """The "next" rows of SURVEY.md section 8f on their own: achieved GB/s of the deformation apply (176 B per
+    supersurfel), the depth pre-filter (8 B per pixel) and one loop-closure registration call, hipEvent-timed by the
+    library (cfg.profile = 1)."""
+    out = {}
+    rng = np.random.default_rng(5)
+    f = binding.Fusion(lib, make_cfg(lib, cap))
+    f.set_model(model, nvis, 30)
+    n = len(model["confidences"]); m = max(n // 50, 4)
+    npos = rng.uniform(-3, 3, (m, 3)).astype(np.float32)
+    nrot = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (m, 1)); ntr = rng.uniform(-1e-3, 1e-3, (m, 3)).astype(np.float32)
+    w4 = rng.dirichlet(np.ones(4), n).astype(np.float32); idx = rng.integers(0, m, (n, 4)).astype(np.int32)
+    f.set_profile(1)
+    for rep in range(3):
+        if rep == 1:
+            f.reset_kernel_times()
+        f.apply_deformation(npos, nrot, ntr, w4, idx)
+    ms, calls = f.kernel_times().get("apply_deformation", (0.0, 0))
+    if calls:
+        us = 1000.0 * ms / calls
+        out["apply_deformation"] = dict(rows=n, nodes=m, avg_us=us, algo_bytes=176.0 * n, achieved_GBs=176.0 * n / (us * 1e-6) / 1e9,
+                                        frac_of_hbm_peak=176.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+    R, t = synthetic.orbit_pose(0)
+    rgb, depth, _ = synthetic.render(R, t, W, H, noise=True, rng=np.random.default_rng(1000))
+    d_in = torch.from_numpy(depth).to(dev); d_out = torch.empty_like(d_in)
+    import ctypes as C
+    f.reset_kernel_times()
+    for rep in range(6):
+        if rep == 2:
+            f.reset_kernel_times()
+        f._ck(lib.lib.ssf_bilateral_filter(f.h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), 1), "ssf_bilateral_filter")
+    ms, calls = f.kernel_times().get("bilateral_prefilter", (0.0, 0))
+    if calls:
+        us = 1000.0 * ms / calls
+        out["bilateral_prefilter"] = dict(width=W, height=H, taps=177, avg_us=us, algo_bytes=8.0 * W * H, achieved_GBs=8.0 * W * H / (us * 1e-6) / 1e9,
+                                          frac_of_hbm_peak=8.0 * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                          note="compute bound: 177 taps x a specified (bit-reproducible) exp per pixel")
+    f.process_frame(rgb, depth)
+    src = f.get_frame()
+    f.reset_kernel_times()
+    res = f.align(src)
+    ms, calls = f.kernel_times().get("align_iteration", (0.0, 0))
+    if calls:
+        out["align"] = dict(sources=int(f.S), iterations=int(res["iters"]), avg_us_per_iteration=1000.0 * ms / calls, pairs=int(res["pairs"]),
+                            note="one single-workgroup launch per iteration (LDS-sized problem): latency, not bandwidth")
+    f.close()
+    return out
 
 
 def render_frames(n):
@@ -95,9 +154,14 @@ def main():
     ap.add_argument("--rendered-frames", type=int, default=64,
                     help="distinct orbit frames rendered; the sequence sweeps them back and forth (consecutive frames stay 1 degree apart)")
     ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
-                    help="2 (default): the configuration the metric is quoted on, 640x480 / ~1M supersurfels; 3: the HBM-bound "
-                         "stress of BASELINE.json, 1280x960, ~1M supersurfels all visible, 10 forced ICP iterations")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="2 (default): the configuration the metric is quoted on, 640x480 / ~1M supersurfels (N > 1: the same map "
+                         "sharded, strong scaling); 3: the HBM-bound stress of BASELINE.json, 1280x960, ~1M supersurfels all "
+                         "visible, 10 forced ICP iterations; 4: BASELINE config 4, 640x480 with 500 k supersurfels PER RANK "
+                         "(2 M over 4 GPUs), weak scaling")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1 (default, N = 1 only): also measure the same workload with host-resident frames (PCIe-inclusive) and "
+                         "with the depth pre-filter inside the frame, and the 'next' kernels (deformation, pre-filter, align); 0: skip")
     ap.add_argument("--cpu-frames", type=int, default=None,
                     help="frames of the bounded cpu_baseline sample (0 = skip; default 80, 12 at 1280x960: 10-15 s of CPU work)")
     ap.add_argument("--profile-frames", type=int, default=8)
@@ -113,7 +177,7 @@ def main():
     # stderr until the result is ready
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    global W, H, P
+    global W, H, P, N_MODEL
     if a.config == 3:
         W, H, a.force_icp = 1280, 960, True
         a.steps, a.warmup, a.rendered_frames = min(a.steps, 64), min(a.warmup, 8), min(a.rendered_frames, 16)
@@ -121,6 +185,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if a.config == 4:
+        N_MODEL = 500000 * world                       # BASELINE config 4: ~2 M supersurfels over 4 GPUs -> 500 k per rank
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
     torch.cuda.set_device(local)
@@ -318,35 +384,80 @@ def main():
     if dom is not None and "achieved_GBs" in per_kernel[dom]:
         ach = per_kernel[dom]["achieved_GBs"]
         # HBM traffic of the kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KB; separate rocprofv3
-        # --pmc passes of this same command, recorded in profiles/pmc_r01.json -- bench.py cannot run the
-        # profiler on itself)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_r01.json")
+        # --pmc passes of this same command, recorded in profiles/pmc_r02.json by tools/pmc_summary.py together with
+        # a hash of the kernel sources it was taken at -- bench.py cannot run the profiler on itself).  A file taken
+        # at other sources, or at another extract batch, does not describe this binary: traffic = null then.
+        traffic, traffic_note = None, "profiles/pmc_r02.json absent"
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc.get("extract_batch", 1) == batch or dom not in EXTRACT_KERNELS:     # per-launch traffic depends on the batch
+            if pmc.get("source_sha") != kernel_source_sha():
+                traffic_note = "profiles/pmc_r02.json was recorded at other kernel sources (%s)" % pmc.get("source_sha")
+            elif pmc.get("extract_batch", 1) != batch and dom in EXTRACT_KERNELS:     # per-launch traffic depends on the batch
+                traffic_note = "profiles/pmc_r02.json was recorded at extract_batch %s" % pmc.get("extract_batch")
+            else:
                 traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_r02.json @ %s" % pmc.get("source_sha")
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=traffic, avg_launch_us=per_kernel[dom]["avg_us"],
+                        traffic=traffic, traffic_note=traffic_note, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
 
-    # ---- CPU baseline: the oracle (single-threaded port), rank 0, bounded sample --------------------
+    # ---- CPU baseline: the reference has no CPU implementation of this path, so the baseline
+    # is the oracle restatement built -O3 -march=native ON THIS BOX, timed (i) single-threaded and (ii) with OpenMP over
+    # all host cores; rank 0, bounded samples of the same workload --------------------------------------------------
     cpu = None
     if rank == 0 and a.cpu_frames > 0:
-        olib_path = os.path.join(ROOT, "oracle", "_build", "libssf_oracle.so")
-        if os.path.exists(olib_path):
+        import subprocess
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        mk = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp", "native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        legs = {}
+        for key, so, nfr in (("single_thread", "libssf_oracle_native.so", max(4, a.cpu_frames // 4)), ("openmp", "libssf_oracle_omp.so", a.cpu_frames)):
+            olib_path = os.path.join(ROOT, "oracle", "_build", so)
+            if mk.returncode != 0 or not os.path.exists(olib_path):
+                continue
             olib = binding.Library(olib_path)
             fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp))
             fo.set_model(model, nvis, 30)
             fo.process_frame(*h_frames[0])                    # warm-up frame
             t1 = time.perf_counter()
-            for i in range(1, 1 + a.cpu_frames):
+            for i in range(1, 1 + nfr):
                 fo.process_frame(*h_frames[i])
-            cdt = time.perf_counter() - t1
-            cpu = dict(value=a.cpu_frames / cdt, unit="frames/s", cores=1, kind="port",
-                       sample="%d frames of the same %dx%d / ~1M-supersurfel workload, oracle/libssf_oracle.so "
-                              "(g++ -O2, single thread), %.1f s" % (a.cpu_frames, W, H, cdt))
+            legs[key] = (nfr / (time.perf_counter() - t1), nfr, time.perf_counter() - t1)
             fo.close()
+        if legs:
+            best = "openmp" if "openmp" in legs else "single_thread"
+            cpu = dict(value=legs[best][0], unit="frames/s", cores=ncpu if best == "openmp" else 1, kind="port", host_cores=ncpu,
+                       single_thread_frames_per_sec=legs.get("single_thread", (None,))[0],
+                       openmp_frames_per_sec=legs.get("openmp", (None,))[0], openmp_threads=ncpu,
+                       sample="the same %dx%d / ~%d-supersurfel workload on the CPU oracle (the build's restatement of the reference "
+                              "algorithm; the reference has no CPU path), g++ -O3 -march=native: %s" %
+                              (W, H, N_MODEL, "; ".join("%s %d frames in %.1f s" % (k, v[1], v[2]) for k, v in legs.items())))
+
+    # ---- the same workload handed over differently (N = 1): host-resident frames (what the reference's caller has: cv::Mat,
+    # PCIe-inclusive) and with the library's depth pre-filter inside the frame (what the reference's processFrame does with
+    # OpenCV's bilateralFilter).  Never `value`: extra keys. -------------------------------------------------------------------
+    extras = None
+    if rank == 0 and world == 1 and a.extras and not exchange and native_seq:
+        extras = {}
+        nx = min(K, 240)
+        host_frames = [(np.ascontiguousarray(h_frames[i][0]), np.ascontiguousarray(h_frames[i][1])) for i in range(nr)]
+        hsweep = Sweep(host_frames)
+        for key, kw, on_dev in (("host_frames_pageable", dict(), False), ("with_depth_prefilter", dict(prefilter=1), True)):
+            fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, depth, batch, **kw))
+            fx.set_model(model_local, nvis_local, 30)
+            def seq(first, count):
+                if on_dev:
+                    return fx.prepare_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)], [d_depth[i].data_ptr() for i in range(first, first + count)])
+                return fx.prepare_sequence([hsweep[i][0].ctypes.data for i in range(first, first + count)], [hsweep[i][1].ctypes.data for i in range(first, first + count)])
+            fx.process_prepared(seq(0, a.warmup + 3 * batch), on_device=on_dev)
+            prep = seq(a.warmup + 3 * batch, nx)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fx.process_prepared(prep, on_device=on_dev)
+            torch.cuda.synchronize(dev)
+            extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx)
+            fx.close()
+        extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
 
     # whole-frame view: algorithmic bytes of one frame over the measured frame time
     it_mean = float(np.mean(iters))
@@ -362,11 +473,11 @@ def main():
         gn, gv = gcounts["n_model"], gcounts["n_visible"]
         out = {
             "metric": "frames_per_sec", "value": K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
-            "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": 1000.0 * dt / K, "higher_is_better": True, "scaling": "weak" if a.config == 4 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic RGB-D orbit (seed 1234), map seeded with 1,000,000 supersurfels "
+            "config": {"workload": "%dx%d synthetic RGB-D orbit (seed 1234), map seeded with %d supersurfels "
                                    "(~%d live, ~%d visible), reference rgbd_benchmark parameters, extract+ICP+fuse per frame%s"
-                                   % (W, H, gn, gv, " (BASELINE config 3: all seeded supersurfels visible, 10 forced ICP iterations)"
+                                   % (W, H, N_MODEL, gn, gv, " (BASELINE config 3: all seeded supersurfels visible, 10 forced ICP iterations)"
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
@@ -375,7 +486,8 @@ def main():
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
-            "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "per_kernel": per_kernel,
+            "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "extras": extras, "kernel_source_sha": kernel_source_sha(),
+            "per_kernel": per_kernel,
         }
     f.close()
     if dist.is_initialized():

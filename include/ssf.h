@@ -196,7 +196,9 @@ int ssf_process_frame_device(ssf_handle* h, const void* d_rgb, const void* d_dep
  * returned.  At most ssf_pipeline_capacity() frames may be pending (SSF_ERR_STATE beyond that).
  * With extract_batch = b the launches happen once b frames have been submitted (or when the
  * first of them is asked for by ssf_process_submitted).
- * Device input buffers (on_device = 1) must stay valid until the frame has been processed.  The
+ * Input buffers -- device (on_device = 1) AND host (on_device = 0: the copy to the device is enqueued, not waited
+ * for; page-locked memory is read asynchronously) -- must stay valid and unmodified until the frame has been
+ * processed; the same holds for dynamic_mask.  The
  * per-frame getters below refer to the last processed frame and are invalidated by the next
  * ssf_submit_frame once the pipeline wraps around (always valid with pipeline_depth = 0).
  * Replaces the loop body of the replay node (supersurfel_fusion_rgbd_benchmark_node.cpp, one

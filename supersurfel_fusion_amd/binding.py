@@ -190,6 +190,7 @@ class Fusion:
             raise SsfError("ssf_create failed (%d): %s" % (rc, library.lib.ssf_last_error(None).decode()))
         self.W, self.H = cfg.width, cfg.height
         self.S = self.counts()["n_superpixels"]
+        self._held = []          # host buffers of submitted frames: they must outlive the asynchronous copy (ssf.h)
 
     def close(self):
         if self.h:
@@ -239,6 +240,7 @@ class Fusion:
             rp, dp = _ptr(rgb), _ptr(depth)
         mask = None if dynamic_mask is None else np.ascontiguousarray(dynamic_mask, np.uint8)
         self._ck(self.L.lib.ssf_submit_frame(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_submit_frame")
+        self._held.append((rgb, depth, mask))
 
     def prepare_sequence(self, rgb_ptrs, depth_ptrs):
         """ctypes argument arrays of a sequence (built ahead, e.g. outside a timed region): (rgb, depth, results, n)"""
@@ -261,6 +263,8 @@ class Fusion:
         prior = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float32)
         res = SsfFrameResult()
         self._ck(self.L.lib.ssf_process_submitted(self.h, _ptr(prior), C.byref(res)), "ssf_process_submitted")
+        if self._held:
+            self._held.pop(0)
         return res
 
     def pending_frames(self):

@@ -167,6 +167,7 @@ struct Mailbox {
 // frame k of the batch is frame number epoch0 + k of this handle (keys its RANSAC draws)
 void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameMaps& m, int nb, uint32_t epoch0);
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
+int pass_tile_npx(int nb);     // 1: 32-wide relabelling tiles, 2: 64-wide (log regions of 512 entries per tile)
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0);
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb);
@@ -194,7 +195,7 @@ struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; 
 #define SSF_ICP_GO_SLOTS 4
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
-                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, const IcpGo* go = nullptr,
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
                 unsigned long long go_seq = 0);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,

@@ -232,9 +232,14 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 // exactly.  The rows of the superpixels around the tile (a window of grid cells) are computed by
 // the first threads of the workgroup into LDS while the label tile is being staged; the energy
 // then reads rows from LDS.  Labels that have drifted out of the window take an exact slow path.
-template <bool RGBD>
-__global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
-    __shared__ int tile[TW * TW];
+// NPX = pass pixels per thread: the tile is 32 * NPX pixels wide (32 rows).  NPX = 2 halves the number of workgroups of a
+// launch: with 8 frames per launch the 32-wide grid is 2520 workgroups = 10080 waves, more than the 8192 the part
+// holds at once (a second, mostly empty round of workgroups); the 64-wide grid fits in one round and amortises the
+// window's row computation and the flush over twice the pixels.  NPX = 1 stays for single-frame launches (latency).
+template <bool RGBD, int NPX>
+__global__ __launch_bounds__(256, 6) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
+    constexpr int TWX = TILE * NPX, TWW = TWX + 2, LOGN = 256 * NPX;
+    __shared__ int tile[TWW * TW];
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];   // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
@@ -242,48 +247,63 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
-    const int X0 = blockIdx.x * TILE - (OX ? 0 : 30), Y0 = blockIdx.y * TILE;  // OX = 0: tiles start at 2 (mod 4)
+    const int X0 = blockIdx.x * TWX - (OX ? 0 : TWX - 2), Y0 = blockIdx.y * TILE;  // OX = 0: tiles start at 2 (mod 4)
     int32_t* __restrict__ lab = m.label;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;          // pass pixels: local columns 4j+1, 4j+2
-    const int x = X0 + lx0, y = Y0 + ly0;
-    const bool in_image = x >= 0 && x < p.W && y < p.H;
-    const size_t q = in_image ? (size_t)y * p.W + x : 0;
+    // this thread's pass pixels: local columns 4j+1, 4j+2 of pass rows; pixel s of the thread is element threadIdx.x + 256 s
+    int x[NPX], y[NPX], lxh[NPX], lyh[NPX]; bool in_image[NPX]; size_t q[NPX];
+#pragma unroll
+    for (int s = 0; s < NPX; s++) {
+        const int e = threadIdx.x + 256 * s;
+        const int tx = e % (16 * NPX), ty = e / (16 * NPX);
+        const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;
+        x[s] = X0 + lx0; y[s] = Y0 + ly0; lxh[s] = lx0 + 1; lyh[s] = ly0 + 1;      // lxh / lyh: halo coordinates
+        in_image[s] = x[s] >= 0 && x[s] < p.W && y[s] < p.H;
+        q[s] = in_image[s] ? (size_t)y[s] * p.W + x[s] : 0;
+    }
     // this tile's log of the previous pass is replayed at the very end; its entry count (uniform, a scalar load)
-    // is requested first so that only the valid entries are fetched (an unconditional 256-entry fetch costs 5 B
-    // per pixel of HBM)
+    // is requested first so that only the valid entries are fetched (an unconditional fetch of the whole region costs
+    // 5 B per pixel of HBM)
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int lp = (pass + 2) % 3, lc = pass % 3;
     const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
     const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
     // operands that do not depend on the label tile: in flight while the tile is staged
-    const uint32_t px = m.rgba[q];
-    float disp = 0.f; unsigned char prev_inlier = 0;
-    if (RGBD) { disp = m.disp[q]; prev_inlier = m.inlier[q]; }
-    // the label tile + halo: requested into registers NOW (5 independent loads per thread), stored to LDS after the
-    // superpixel rows have been computed -- one memory round trip for tile, pixel operands, sums and log instead of two
-    constexpr int TILE_LOADS = (TW * TW + 255) / 256;
+    uint32_t px[NPX]; float disp[NPX]; unsigned char prev_inlier[NPX];
+#pragma unroll
+    for (int s = 0; s < NPX; s++) {
+        px[s] = m.rgba[q[s]];
+        disp[s] = 0.f; prev_inlier[s] = 0;
+        if (RGBD) { disp[s] = m.disp[q[s]]; prev_inlier[s] = m.inlier[q[s]]; }
+    }
+    // the label tile + halo: requested into registers NOW (independent loads), stored to LDS after the superpixel rows
+    // have been computed -- one memory round trip for tile, pixel operands, sums and log instead of two
+    constexpr int TILE_LOADS = (TWW * TW + 255) / 256;
     int tile_reg[TILE_LOADS];
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) {
         const int i = threadIdx.x + 256 * k;
-        const int lx = i % TW, ly = i / TW;
+        const int lx = i % TWW, ly = i / TWW;
         const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
         tile_reg[k] = -1;
-        if (!(dbg & 32) && i < TW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
+        if (!(dbg & 32) && i < TWW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
     }
     // the valid entries of the previous pass' log (replayed at the very end)
     const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
     const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    int4 prev_ent = make_int4(0, 0, 0, 0); float prev_disp = 0.f;
-    if (threadIdx.x < n_prev) {
-        prev_ent = pent[(size_t)tile_id * 256 + threadIdx.x];
-        if (RGBD) prev_disp = pdis[(size_t)tile_id * 256 + threadIdx.x];
+    int4 prev_ent[NPX]; float prev_disp[NPX];
+#pragma unroll
+    for (int s = 0; s < NPX; s++) {
+        prev_ent[s] = make_int4(0, 0, 0, 0); prev_disp[s] = 0.f;
+        const unsigned int e = threadIdx.x + 256u * s;
+        if (e < n_prev) {
+            prev_ent[s] = pent[(size_t)tile_id * LOGN + e];
+            if (RGBD) prev_disp[s] = pdis[(size_t)tile_id * LOGN + e];
+        }
     }
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
     const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
-    const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
+    const int tcx1 = min(X0 + TWX - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
     while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
     const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
     const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
     if (threadIdx.x == 0) s_nlog = 0;
     if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
 #pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) { const int i = threadIdx.x + 256 * k; if (i < TW * TW) tile[i] = tile_reg[k]; }
+    for (int k = 0; k < TILE_LOADS; k++) { const int i = threadIdx.x + 256 * k; if (i < TWW * TW) tile[i] = tile_reg[k]; }
     __syncthreads();
     const float inv_gx = 1.0f / (float)p.gx;
     auto slot_of = [&](int l) -> int {
@@ -329,92 +349,99 @@ __global__ __launch_bounds__(256) void k_update_pass(SegParams p, FrameMaps m, i
         if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
     };
     if (dbg & 2) return;
-    const int lx = lx0 + 1, ly = ly0 + 1;                                     // halo coordinates
-    const int index = in_image ? tile[ly * TW + lx] : 0;
-    int new_index = index;
-    const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-    int nl[4];
+    int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
+    float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TW + lx + nx[k]];
-    const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
-    bool eligible = in_image && bounds != 0 && !(dbg & 4);
-    if (eligible) {
-        // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
-        const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-        bool prev = tile[(ly + oy[0]) * TW + lx + ox[0]] == index;
-        int jump = 0;
+    for (int s = 0; s < NPX; s++) {
+        const int lx = lxh[s], ly = lyh[s];
+        const int index = in_image[s] ? tile[ly * TWW + lx] : 0;
+        int new_index = index;
+        const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
+        int nl[4];
 #pragma unroll
-        for (int k = 1; k < 8; k++) {
-            const bool cur = tile[(ly + oy[k]) * TW + lx + ox[k]] == index;
-            if (prev != cur) { jump++; prev = cur; }
-        }
-        eligible = !(jump > 2);
-    }
-    SpRow own = zero_row;
-    if (in_image && (RGBD || eligible)) own = row_of(index);
-    float disp_energy = 0.f;
-    unsigned char inlier = 0xff;
-    if (RGBD && in_image) {
-        const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-        disp_energy = (dp - disp) * (dp - disp);
-        if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
-    }
-    if (eligible) {
-        const float cr = (float)(px & 255u), cg = (float)((px >> 8) & 255u), cb = (float)((px >> 16) & 255u);
-        const float posx = (float)x, posy = (float)y;
-        const float size = own.size;
-        const float sc = size / (size - 1.f);
-        const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
-        const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
-        const float dsize = size - (float)p.min_size;
-        float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
-        if (RGBD) best = best + p.lambda_disp * disp_energy;
-        best = best - p.lambda_size * fminf(dsize, 0.f);
-        best = best + p.lambda_bound * (float)bounds;
+        for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TWW + lx + nx[k]];
+        const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
+        bool eligible = in_image[s] && bounds != 0 && !(dbg & 4);
+        if (eligible) {
+            // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
+            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+            bool prev = tile[(ly + oy[0]) * TWW + lx + ox[0]] == index;
+            int jump = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i_n = nl[k];
-            if (i_n == -1 || i_n == index) continue;
-            const SpRow nb = row_of(i_n);
-            const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-            const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-            const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-            float n_de = 0.f; unsigned char n_inlier = 0xff;
-            if (RGBD) {
-                const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
-                n_de = (dp - disp) * (dp - disp);
-                if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+            for (int k = 1; k < 8; k++) {
+                const bool cur = tile[(ly + oy[k]) * TWW + lx + ox[k]] == index;
+                if (prev != cur) { jump++; prev = cur; }
             }
-            const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-            float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-            if (RGBD) e = e + p.lambda_disp * n_de;
-            e = e - p.lambda_size * fminf(ndsize, 0.f);
-            e = e + p.lambda_bound * (float)b;
-            if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
+            eligible = !(jump > 2);
         }
-    }
-    unsigned flags = 0u;
-    if (in_image) {
-        if (new_index != index) lab[q] = new_index;
-        flags = (new_index != index) ? 1u : 0u;
-        if (RGBD) {
-            if (inlier && (!prev_inlier || index != new_index)) flags |= 2u;
-            if (prev_inlier && (!inlier || (inlier && index != new_index))) flags |= 4u;
-            if (inlier != prev_inlier) m.inlier[q] = inlier;
+        SpRow own = zero_row;
+        if (in_image[s] && (RGBD || eligible)) own = row_of(index);
+        float disp_energy = 0.f;
+        unsigned char inlier = 0xff;
+        if (RGBD && in_image[s]) {
+            const float dp = (own.ta * (float)x[s] + own.tb * (float)y[s]) + own.tc;
+            disp_energy = (dp - disp[s]) * (dp - disp[s]);
+            if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
         }
-    }
-    if (flags) {
-        const uint32_t rgbf = (px & 0x00FFFFFFu) | (flags << 24);
-        add_delta(index, new_index, x, y, rgbf, disp);
-        int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
-        float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
-        const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < 256 by construction
-        cent[(size_t)tile_id * 256 + slot] = make_int4(index, new_index, x | (y << 16), (int)rgbf);
-        if (RGBD) cdis[(size_t)tile_id * 256 + slot] = disp;
+        if (eligible) {
+            const float cr = (float)(px[s] & 255u), cg = (float)((px[s] >> 8) & 255u), cb = (float)((px[s] >> 16) & 255u);
+            const float posx = (float)x[s], posy = (float)y[s];
+            const float size = own.size;
+            const float sc = size / (size - 1.f);
+            const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
+            const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
+            const float dsize = size - (float)p.min_size;
+            float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
+            if (RGBD) best = best + p.lambda_disp * disp_energy;
+            best = best - p.lambda_size * fminf(dsize, 0.f);
+            best = best + p.lambda_bound * (float)bounds;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i_n = nl[k];
+                if (i_n == -1 || i_n == index) continue;
+                const SpRow nb = row_of(i_n);
+                const float ndx = posx - nb.cx, ndy = posy - nb.cy;
+                const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
+                const float ndsize = (nb.size + 1.f) - (float)p.min_size;
+                float n_de = 0.f; unsigned char n_inlier = 0xff;
+                if (RGBD) {
+                    const float dp = (nb.ta * (float)x[s] + nb.tb * (float)y[s]) + nb.tc;
+                    n_de = (dp - disp[s]) * (dp - disp[s]);
+                    if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+                }
+                const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
+                float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
+                if (RGBD) e = e + p.lambda_disp * n_de;
+                e = e - p.lambda_size * fminf(ndsize, 0.f);
+                e = e + p.lambda_bound * (float)b;
+                if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
+            }
+        }
+        unsigned flags = 0u;
+        if (in_image[s]) {
+            if (new_index != index) lab[q[s]] = new_index;
+            flags = (new_index != index) ? 1u : 0u;
+            if (RGBD) {
+                if (inlier && (!prev_inlier[s] || index != new_index)) flags |= 2u;
+                if (prev_inlier[s] && (!inlier || (inlier && index != new_index))) flags |= 4u;
+                if (inlier != prev_inlier[s]) m.inlier[q[s]] = inlier;
+            }
+        }
+        if (flags) {
+            const uint32_t rgbf = (px[s] & 0x00FFFFFFu) | (flags << 24);
+            add_delta(index, new_index, x[s], y[s], rgbf, disp[s]);
+            const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < LOGN by construction
+            cent[(size_t)tile_id * LOGN + slot] = make_int4(index, new_index, x[s] | (y[s] << 16), (int)rgbf);
+            if (RGBD) cdis[(size_t)tile_id * LOGN + slot] = disp[s];
+        }
     }
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
-    if (threadIdx.x < n_prev && !(dbg & 8))
-        add_delta(prev_ent.x, prev_ent.y, prev_ent.z & 0xFFFF, (prev_ent.z >> 16) & 0xFFFF, (uint32_t)prev_ent.w, prev_disp);
+    if (!(dbg & 8)) {
+#pragma unroll
+        for (int s = 0; s < NPX; s++)
+            if (threadIdx.x + 256u * s < n_prev)
+                add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
+    }
     __syncthreads();
     if (window_ok)
         for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) {
@@ -945,6 +972,13 @@ void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameM
     ScopedKernel sk("ingest", st);
     hipLaunchKernelGGL(k_ingest, dim3(p.S, nb), dim3(256), 0, st, p, in, m, epoch0);
 }
+// pass pixels per thread (tile width / 32) for a launch over nb frames; SSF_PASS_NPX = 1 / 2 forces it (measurement)
+int pass_tile_npx(int nb) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SSF_PASS_NPX"); forced = e ? atoi(e) : 0; }
+    if (forced == 1 || forced == 2) return forced;
+    return nb >= 2 ? 2 : 1;
+}
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
     static const char* per_pass_names[64] = {nullptr};
     static int per_pass = -1;
@@ -954,13 +988,21 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
         for (int i = 0; i < 64; i++) { snprintf(buf[i], 16, "pass_%02d", i); per_pass_names[i] = buf[i]; }
     }
     ScopedKernel sk(per_pass ? per_pass_names[k & 63] : (rgbd ? "update_pass_rgbd" : "update_pass_rgb"), st);
-    // OX = 0: tiles shifted left by 30: [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
-    // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.
+    // OX = 0: tiles shifted left by (tile width - 2): [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
+    // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.  All passes of a
+    // frame use the same tile width (the log layout depends on it): 64 when the launch covers several frames.
+    const int npx = pass_tile_npx(nb);
+    const int twx = TILE * npx;
     dim3 grid = tile_grid(p);
-    grid.x = (p.W + 30 + TILE - 1) / TILE;
+    grid.x = (p.W + (twx - 2) + twx - 1) / twx;
     grid.z = nb;
-    if (rgbd) hipLaunchKernelGGL(k_update_pass<true>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-    else hipLaunchKernelGGL(k_update_pass<false>, grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    if (npx == 2) {
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        else hipLaunchKernelGGL((k_update_pass<false, 2>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    } else {
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        else hipLaunchKernelGGL((k_update_pass<false, 1>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    }
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

@@ -1045,6 +1045,24 @@ static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo*
     *seq_out = seq; *slot_out = slot; *go_seq_out = go_seq;
     return SSF_OK;
 }
+// drain the write-combining buffers: the stores above become visible to the device in order, now
+static inline void store_fence() {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+// A chained launch that never got its word (host stalled past the kernel's bound, or the record never arrived) may
+// have left the arrival counters / replica records of the ICP reduction half filled: drain the stream, put them back
+// to rest and stop chaining launches on this handle.
+static void icp_chain_reset(ssf_handle* h) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    h->icp_chain = false; h->ahead.valid = false;
+}
 // the host's word to a waiting launch: its transform and "go", or "no further iteration"
 static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T) {
     volatile IcpGo* s = slot;
@@ -1052,10 +1070,10 @@ static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt
         const float v[12] = {T->R.r0.x, T->R.r0.y, T->R.r0.z, T->R.r1.x, T->R.r1.y, T->R.r1.z, T->R.r2.x, T->R.r2.y, T->R.r2.z,
                              T->t.x, T->t.y, T->t.z};
         for (int i = 0; i < 12; i++) s->T[i] = v[i];
-        __builtin_ia32_sfence();                  // (the mapping is write-combining: transform before flag, flag out now)
+        store_fence();                            // (the mapping is write-combining: transform before flag, flag out now)
         s->flag = go_seq;
     } else s->flag = go_seq | SSF_ICP_GO_ABORT;
-    __builtin_ia32_sfence();
+    store_fence();
 }
 
 // ICP + association + fusion of the oldest submitted frame, on the track stream
@@ -1099,7 +1117,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
                 waiting = true;
             }
             rc = icp_fetch(h, seq_rec);
-            if (rc) { if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr); return rc; }
+            if (rc) { if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr); icp_chain_reset(h); return rc; }
             if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
             icp_update(h, (const int64_t*)h->h_icp, &again);
             continue;
@@ -1166,6 +1184,18 @@ static int process_frame_impl(ssf_handle* h, const void* rgb, const void* depth,
     { TimerScope ts(h); rc = submit_extract(h, rgb, depth, on_device, mask); }
     return rc ? rc : process_oldest(h, prior, out);
 }
+
+// device temporaries of one call: freed on every exit path
+struct DevTemps {
+    std::vector<void*> p;
+    template <typename T> hipError_t take(T** out, size_t bytes) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+        if (e == hipSuccess) { p.push_back(q); *out = (T*)q; }
+        return e;
+    }
+    ~DevTemps() { for (void* q : p) (void)hipFree(q); }
+};
 
 // ---- C ABI ----------------------------------------------------------------------------------------------
 extern "C" {
@@ -1252,7 +1282,10 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
-    const size_t NT = (size_t)((W + 30 + 31) / 32) * ((H + 31) / 32);   // relabelling tiles (shifted grid has one more column)
+    // relabelling tiles (the shifted grid has one more column): 32-wide tiles with 256 log entries each, or 64-wide
+    // ones with 512 (ssf_extract.hip, k_update_pass<., NPX>); the log regions are sized for whichever needs more
+    const size_t NT32 = (size_t)((W + 30 + 31) / 32) * ((H + 31) / 32), NT64 = (size_t)((W + 62 + 63) / 64) * ((H + 31) / 32);
+    const size_t NT = std::max(NT32, 2 * NT64);
     const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
     h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
@@ -1401,8 +1434,8 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
             for (int i = 0; i < u->ring && ok; i++) ok = dalloc(h, &u->d_rgb[i], 3 * P) && dalloc(h, &u->d_depth[i], P);
             for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream);
             u->batch = h->batch;
+            if (!ok) { delete u; h->err = "allocation of the upload ring failed"; return SSF_ERR_DEVICE; }    // (buffers taken so far stay in h->allocs)
             h->up = u;
-            if (!ok) { h->err = "allocation of the upload ring failed"; return SSF_ERR_DEVICE; }
         }
         Uploader& u = *h->up;
         u.n = n; u.rgb = rgb; u.depth = depth; u.ctx0 = h->open_ctx;
@@ -1444,12 +1477,13 @@ int ssf_align(ssf_handle* h, const ssf_surfels* src, int n, const float* init_po
         for (int c = 0; c < 3; c++) nrm[3 * i + c] = src->orientations[9 * i + 6 + c];
     }
     float *d_pos = nullptr, *d_lab = nullptr, *d_nrm = nullptr, *d_conf = nullptr; long long* d_out = nullptr;
-    HCK(hipMalloc((void**)&d_pos, 12 * N)); HCK(hipMalloc((void**)&d_lab, 12 * N)); HCK(hipMalloc((void**)&d_nrm, 12 * N));
-    HCK(hipMalloc((void**)&d_out, 40 * sizeof(long long)));
-    if (src->confidences) HCK(hipMalloc((void**)&d_conf, 4 * N));
+    DevTemps tmp;
+    HCK(tmp.take(&d_pos, 12 * N)); HCK(tmp.take(&d_lab, 12 * N)); HCK(tmp.take(&d_nrm, 12 * N));
+    HCK(tmp.take(&d_out, 40 * sizeof(long long)));
+    if (src->confidences) HCK(tmp.take(&d_conf, 4 * N));
     hipStream_t st = h->stream;
     int rc = SSF_OK;
-    auto cleanup = [&]() { (void)hipFree(d_pos); (void)hipFree(d_lab); (void)hipFree(d_nrm); (void)hipFree(d_out); if (d_conf) (void)hipFree(d_conf); };
+    auto cleanup = [&]() {};
     if (n > 0) {
         if (hipMemcpyAsync(d_pos, src->positions, 12 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(d_lab, lab.data(), 12 * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -1516,8 +1550,9 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
     if (n == 0) return SSF_OK;
     const size_t P = (size_t)width * height;
     uint8_t *d_rgb = nullptr, *d_frgb = nullptr, *d_codes = nullptr; float *d_depth = nullptr, *d_fd = nullptr; uint32_t* d_fp = nullptr;
-    HCK(hipMalloc((void**)&d_rgb, 3 * P)); HCK(hipMalloc((void**)&d_depth, 4 * P)); HCK(hipMalloc((void**)&d_fp, 8 * (size_t)n));
-    HCK(hipMalloc((void**)&d_frgb, 3 * (size_t)n)); HCK(hipMalloc((void**)&d_fd, 4 * (size_t)n)); HCK(hipMalloc((void**)&d_codes, (size_t)n));
+    DevTemps tmp;
+    HCK(tmp.take(&d_rgb, 3 * P)); HCK(tmp.take(&d_depth, 4 * P)); HCK(tmp.take(&d_fp, 8 * (size_t)n));
+    HCK(tmp.take(&d_frgb, 3 * (size_t)n)); HCK(tmp.take(&d_fd, 4 * (size_t)n)); HCK(tmp.take(&d_codes, (size_t)n));
     hipStream_t st = h->stream;
     bool ok = hipMemcpyAsync(d_rgb, rgb, 3 * P, hipMemcpyHostToDevice, st) == hipSuccess &&
               hipMemcpyAsync(d_depth, depth, 4 * P, hipMemcpyHostToDevice, st) == hipSuccess &&
@@ -1529,7 +1564,6 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(codes, d_codes, (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
     }
-    (void)hipFree(d_rgb); (void)hipFree(d_depth); (void)hipFree(d_fp); (void)hipFree(d_frgb); (void)hipFree(d_fd); (void)hipFree(d_codes);
     if (!ok) { h->err = "fern encoding failed on the device"; return SSF_ERR_DEVICE; }
     return SSF_OK;
 }
@@ -1855,8 +1889,9 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     const size_t n = h->n_model;
     if (n == 0) return SSF_OK;
     float *d_np, *d_nr, *d_nt, *d_w; int32_t* d_i;
-    HCK(hipMalloc((void**)&d_np, 12 * (size_t)m)); HCK(hipMalloc((void**)&d_nr, 36 * (size_t)m)); HCK(hipMalloc((void**)&d_nt, 12 * (size_t)m));
-    HCK(hipMalloc((void**)&d_w, 16 * n)); HCK(hipMalloc((void**)&d_i, 16 * n));
+    DevTemps tmp;
+    HCK(tmp.take(&d_np, 12 * (size_t)m)); HCK(tmp.take(&d_nr, 36 * (size_t)m)); HCK(tmp.take(&d_nt, 12 * (size_t)m));
+    HCK(tmp.take(&d_w, 16 * n)); HCK(tmp.take(&d_i, 16 * n));
     hipStream_t st = h->stream;
     HCK(hipMemcpyAsync(d_np, np, 12 * (size_t)m, hipMemcpyHostToDevice, st));
     HCK(hipMemcpyAsync(d_nr, nr, 36 * (size_t)m, hipMemcpyHostToDevice, st));
@@ -1869,7 +1904,6 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     { int rc = store_from_dense(h, h->n_model, h->n_visible); if (rc) return rc; }
     HCK(hipStreamSynchronize(st));
     if (h->cfg.profile == 1) timer_collect(&h->timer);
-    (void)hipFree(d_np); (void)hipFree(d_nr); (void)hipFree(d_nt); (void)hipFree(d_w); (void)hipFree(d_i);
     return SSF_OK;
 }
 

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
-                                             const IcpGo* go, unsigned long long go_seq) {
+                                             IcpGo* go, unsigned long long go_seq) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
@@ -180,6 +180,9 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                 if (v == (go_seq | SSF_ICP_GO_ABORT)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            // gave up waiting (the host stalled): make that the decision of the whole launch -- workgroups dispatched
+            // later must not find a word that arrives after all and start accumulating into a record nobody completes
+            if (!ok) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (ok)
                 for (int i = 0; i < 12; i++) s_T[i] = __hip_atomic_load(&go->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_go = ok;
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
 // ---- launchers -----------------------------------------------------------------------------------
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
-                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, const IcpGo* go, unsigned long long go_seq) {
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq) {
     ScopedKernel sk("icp_accumulate", st);
     static int per_lane = 0;             // supersurfels per lane before the wave reduction
     if (!per_lane) { const char* e = getenv("SSF_ICP_PER_LANE"); per_lane = e ? atoi(e) : 1; if (per_lane < 1) per_lane = 1; }

@@ -10,7 +10,7 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = [("k_update_pass<true>", "update_pass_rgbd"), ("k_update_pass<false>", "update_pass_rgb"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
+NAMES = [("k_update_pass<true", "update_pass_rgbd"), ("k_update_pass<false", "update_pass_rgb"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
          ("k_classify", "classify"), ("k_icp", "icp_accumulate"), ("k_match", "match"), ("k_render_moments", "render_moments"),
          ("k_ingest", "ingest"), ("k_eval_samples", "eval_samples"), ("k_init_disp", "init_disp"), ("k_init_samples", "init_samples"),
          ("k_plane_filter", "plane_filter"), ("k_finalize_surfels", "finalize_surfels"), ("k_update_insert", "update_insert"),
@@ -45,7 +45,10 @@ def main(fetch_dir, write_dir, out, note):
         w = sum(wr[nm]) / max(len(wr[nm]), 1)
         kernels[nm] = dict(FETCH_SIZE_KB_mean=f, WRITE_SIZE_KB_mean=w, launches=len(fe[nm]),
                            hbm_bytes_per_launch=1024.0 * (2.0 * f + w))
-    json.dump(dict(note=note, kernels=kernels), open(out, "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    eb = int(os.environ.get("PMC_EXTRACT_BATCH", "8"))
+    json.dump(dict(note=note, source_sha=bench.kernel_source_sha(), extract_batch=eb, kernels=kernels), open(out, "w"), indent=1)
     for nm, k in kernels.items():
         print("%-20s %6d launches  fetch %10.1f KB  write %10.1f KB  -> %8.2f MB / launch" %
               (nm, k["launches"], k["FETCH_SIZE_KB_mean"], k["WRITE_SIZE_KB_mean"], k["hbm_bytes_per_launch"] / 1e6))
