@@ -1,11 +1,20 @@
 // oracle.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
 //
 // State of the deterministic single-threaded restatement of the supersurfel_fusion hot path.
-// PARITY STATUS: the reference ships no tests/golden vectors for this path and its CUDA sources
-// cannot be built or run here (no nvcc/OpenCV/ROS/GPU), so the kernel-level restatement is
-// "parity unpinned" against a reference execution.  What IS pinned: the host solvers (6x6 LDLT,
-// LU inverse, quaternion re-normalisation) against the reference's vendored Eigen 3.3.7
-// (oracle/_ref, built from /root/reference/third_party/eigen3 by oracle/Makefile).
+// PARITY STATUS: the reference ships no unit tests or golden vectors for this path and its CUDA sources cannot be
+// built or run here (no nvcc / OpenCV / ROS / NVIDIA GPU), so a kernel-by-kernel comparison with a reference
+// EXECUTION is not obtainable: in that sense the restatement is "parity unpinned".  What IS pinned to material the
+// reference holds:
+//   * the host solvers (6x6 LDLT, LU inverse, quaternion re-normalisation, angle-axis increment, the align step)
+//     against the reference's vendored Eigen 3.3.7 (oracle/_ref/eigen_vectors -> tests/golden/eigen_vectors.json);
+//   * the per-element helpers against the reference's own vector_math.cuh / matrix_math.cuh compiled where they lie
+//     (oracle/_ref/math_vectors -> tests/golden/ref_math_vectors.npz): inverse, square, Cov3 * v, mult_ABAt, Mat33
+//     products, rotMatToQuat, quatToRotMat bit for bit; rgbToLab / labToRgb to 2e-4 Lab / 2e-3 grey levels (libm
+//     powf / cbrtf there, a specified IEEE sequence here);
+//   * the whole path, loosely, against the only end-to-end artefact the reference commits: over all 790 frames of the
+//     rgbd_dataset_freiburg1_xyz sequence it ships, run the way its benchmark node runs it, this oracle's trajectory
+//     has ATE 0.0226 m against ground truth (the reference's committed estimated.txt: 0.0195 m) and stays within
+//     0.0102 m RMSE of that file (tests/golden/fr1_xyz_*, tests/test_replay.py).
 //
 // Schedule decisions where the reference is racy / non-deterministic:
 //   A1  relabelling pass reads the pre-pass label map only (double buffer)

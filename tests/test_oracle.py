@@ -194,3 +194,44 @@ def test_submit_process_is_the_sequential_order(oracle_lib):
     for a, b in zip(want, got):
         util.same_result(a, b)
     util.compare_state(fa, fb)
+
+
+def test_openmp_build_equals_single_thread(oracle_lib):
+    """oracle/_build/libssf_oracle_omp.so (the timed CPU baseline of bench.py and the checker of the full-size GPU
+    tests) is the same source with OpenMP over loops whose results are exact integer sums or order-free minima: every
+    map, table, result and model row equals the single-threaded checker bit for bit -- seeded model (ICP / association /
+    update / partition over tens of thousands of rows), pre-filter on, holes, sharded fuse halves included."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    omp = binding.Library(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_omp.so"))
+    W, H = 320, 240
+    model, nvis = synthetic.seed_model_cam0(60000, W, H, stamp=30)
+    fa = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=80000, depth_prefilter=1))
+    fb = binding.Fusion(omp, util.make_cfg(omp, W, H, nb_supersurfels_max=80000, depth_prefilter=1))
+    fa.set_model(model, nvis, 30); fb.set_model(model, nvis, 30)
+    for k in range(4):
+        rgb, depth = util.frame(k, W, H, noise=True, holes=0.05)
+        util.same_result(fa.process_frame(rgb, depth), fb.process_frame(rgb, depth))
+        util.compare_state(fa, fb)
+    # a sharded rank through the two fuse halves (migration table included)
+    ga = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=80000, rank=1, nranks=2, shard_tile=0.25))
+    gb = binding.Fusion(omp, util.make_cfg(omp, W, H, nb_supersurfels_max=80000, rank=1, nranks=2, shard_tile=0.25))
+    own = synthetic.tile_owner(model["positions"], 2, 0.25) == 1
+    sub = {k_: v[own] for k_, v in model.items()}
+    nv = int((own & (np.arange(len(own)) < nvis)).sum())
+    for g in (ga, gb):
+        g.set_model(sub, nv, 30)
+    rgb, depth = util.frame(1, W, H)
+    tables = []
+    for g in (ga, gb):
+        g.stage_extract(rgb, depth); g.set_shard(0, len(sub["confidences"]), nv); g.icp_begin()
+        again = True
+        while again:
+            again = g.icp_update(g.icp_accumulate())
+        g.icp_end()
+        best, matched = g.match()
+        tables.append(g.fuse_begin(best, matched))
+        g.fuse_end(tables[-1] * 0)
+    assert np.array_equal(tables[0], tables[1]) and (tables[0][:, 0] != 0).sum() > 0     # some rows do leave the shard
+    util.compare_state(ga, gb, maps=False, frame_surfels=False)
