@@ -137,6 +137,31 @@ def next_kernel_times(lib, dev, model, nvis, cap):
     return out
 
 
+def pin_to_gpu_numa_node(local):
+    """Run this process on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does): the track
+    chain is a sequence of host <-> device round trips (mailbox polls, doorbells, BAR stores), and on a two-socket host a
+    far node adds an inter-socket hop to every one of them.  Returns a description for the JSON line."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        cpus = open(base + "/local_cpulist").read().strip()
+        if node < 0 or not cpus:
+            return dict(pinned=False, reason="no NUMA affinity reported for %s" % bdf)
+        want = set()
+        for part in cpus.split(","):
+            lo, _, hi = part.partition("-")
+            want.update(range(int(lo), int(hi or lo) + 1))
+        want &= os.sched_getaffinity(0)
+        if not want:
+            return dict(pinned=False, reason="local cpus of %s not in this process's affinity mask" % bdf)
+        os.sched_setaffinity(0, want)
+        return dict(pinned=True, gpu=bdf, numa_node=node, cpus=cpus, n_cpus=len(want))
+    except Exception as e:          # no sysfs, old torch: run unpinned
+        return dict(pinned=False, reason=repr(e))
+
+
 def render_frames(n):
     frames = []
     for k in range(n):
@@ -159,6 +184,7 @@ def main():
                          "sharded, strong scaling); 3: the HBM-bound stress of BASELINE.json, 1280x960, ~1M supersurfels all "
                          "visible, 10 forced ICP iterations; 4: BASELINE config 4, 640x480 with 500 k supersurfels PER RANK "
                          "(2 M over 4 GPUs), weak scaling")
+    ap.add_argument("--pin", type=int, default=1, help="1 (default): bind the process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--extras", type=int, default=1,
                     help="1 (default, N = 1 only): also measure the same workload with host-resident frames (PCIe-inclusive) and "
                          "with the depth pre-filter inside the frame, and the 'next' kernels (deformation, pre-filter, align); 0: skip")
@@ -191,6 +217,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = pin_to_gpu_numa_node(local) if a.pin else dict(pinned=False, reason="--pin 0")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -410,25 +437,38 @@ def main():
         import subprocess
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         mk = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp", "native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        legs = {}
-        for key, so, nfr in (("single_thread", "libssf_oracle_native.so", max(4, a.cpu_frames // 4)), ("openmp", "libssf_oracle_omp.so", a.cpu_frames)):
-            olib_path = os.path.join(ROOT, "oracle", "_build", so)
-            if mk.returncode != 0 or not os.path.exists(olib_path):
-                continue
-            olib = binding.Library(olib_path)
+        legs, omp_probe = {}, {}
+
+        def time_oracle(olib, nfr, first=1):
             fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp))
             fo.set_model(model, nvis, 30)
             fo.process_frame(*h_frames[0])                    # warm-up frame
             t1 = time.perf_counter()
-            for i in range(1, 1 + nfr):
+            for i in range(first, first + nfr):
                 fo.process_frame(*h_frames[i])
-            legs[key] = (nfr / (time.perf_counter() - t1), nfr, time.perf_counter() - t1)
+            dt_ = time.perf_counter() - t1
             fo.close()
+            return nfr / dt_, nfr, dt_
+
+        if mk.returncode == 0 and os.path.exists(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_native.so")):
+            legs["single_thread"] = time_oracle(binding.Library(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_native.so")), max(4, a.cpu_frames // 4))
+        omp_threads = 1
+        if mk.returncode == 0 and os.path.exists(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_omp.so")):
+            olib = binding.Library(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_omp.so"))
+            # all host cores is not the fastest team on a many-core host (the per-frame loops are short: 1200 superpixels,
+            # 480 image rows): a short probe over team sizes, then the sample with the best one; every probe is reported
+            for nt in sorted({min(ncpu, 8), min(ncpu, 16), min(ncpu, 32), min(ncpu, 64), ncpu}):
+                olib.lib.ssf_oracle_set_threads(nt)
+                omp_probe[nt] = time_oracle(olib, 4)[0]
+            omp_threads = max(omp_probe, key=omp_probe.get)
+            olib.lib.ssf_oracle_set_threads(omp_threads)
+            legs["openmp"] = time_oracle(olib, a.cpu_frames)
         if legs:
             best = "openmp" if "openmp" in legs else "single_thread"
-            cpu = dict(value=legs[best][0], unit="frames/s", cores=ncpu if best == "openmp" else 1, kind="port", host_cores=ncpu,
+            cpu = dict(value=legs[best][0], unit="frames/s", cores=omp_threads if best == "openmp" else 1, kind="port", host_cores=ncpu,
                        single_thread_frames_per_sec=legs.get("single_thread", (None,))[0],
-                       openmp_frames_per_sec=legs.get("openmp", (None,))[0], openmp_threads=ncpu,
+                       openmp_frames_per_sec=legs.get("openmp", (None,))[0], openmp_threads=omp_threads,
+                       openmp_probe_frames_per_sec_by_threads={str(k): v for k, v in omp_probe.items()},
                        sample="the same %dx%d / ~%d-supersurfel workload on the CPU oracle (the build's restatement of the reference "
                               "algorithm; the reference has no CPU path), g++ -O3 -march=native: %s" %
                               (W, H, N_MODEL, "; ".join("%s %d frames in %.1f s" % (k, v[1], v[2]) for k, v in legs.items())))
@@ -486,7 +526,7 @@ def main():
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
-            "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "extras": extras, "kernel_source_sha": kernel_source_sha(),
+            "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "extras": extras, "kernel_source_sha": kernel_source_sha(), "host_affinity": affinity,
             "per_kernel": per_kernel,
         }
     f.close()

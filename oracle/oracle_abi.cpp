@@ -13,6 +13,9 @@
 #include <new>
 #include <string>
 #include "oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace orc;
 
@@ -384,6 +387,17 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
 }
 int ssf_reset_kernel_times(ssf_handle* h) { (void)h; return SSF_OK; }
 int ssf_set_profile(ssf_handle* h, int enable) { (void)h; (void)enable; return SSF_OK; }
+
+// OpenMP build only (the timed CPU baseline): number of threads of the parallel loops; returns the number in effect
+// (1 for the single-threaded checker).  Not part of ssf.h.
+int ssf_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
 
 // test hooks of include/ssf_testing.h
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); return 0; }

@@ -920,6 +920,9 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // support of radius round(1.5 sigma_space), BORDER_REFLECT_101, taps in row-major order.  The tile and
 // its halo are staged in LDS once; every pixel then reads its (2r+1)^2 window from LDS.
 #define BIL_RMAX 16
+#define BIL_TILE 16      // 16 x 16 outputs per workgroup, one per thread: 1200 workgroups at 640x480 (4-5 waves per SIMD to
+                         // hide the dependent chain of the specified exp; with 32 x 32 tiles and four pixels per thread a
+                         // SIMD held one wave and the kernel took 0.4 ms)
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
@@ -927,43 +930,66 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ in, float* __restrict__ out, int W, int H,
                                                    int radius, float ss, float sc) {
-    __shared__ float tile[(TILE + 2 * BIL_RMAX) * (TILE + 2 * BIL_RMAX)];
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    const int tw = TILE + 2 * radius;
+    __shared__ float tile[(BIL_TILE + 2 * BIL_RMAX) * (BIL_TILE + 2 * BIL_RMAX)];
+    __shared__ int s_ext[2 * BIL_RMAX + 1];            // half-width of the circular support in row dy
+    const int X0 = blockIdx.x * BIL_TILE, Y0 = blockIdx.y * BIL_TILE;
+    const int tw = BIL_TILE + 2 * radius;
     const bool staged = radius <= BIL_RMAX;
-    if (staged)
+    if (staged) {
         for (int i = threadIdx.x; i < tw * tw; i += blockDim.x) {
             const int gx = reflect101(X0 - radius + i % tw, W), gy = reflect101(Y0 - radius + i / tw, H);
             tile[i] = in[(size_t)gy * W + gx];
         }
+        if ((int)threadIdx.x <= 2 * radius) {
+            const int dy = (int)threadIdx.x - radius;
+            int e = 0;
+            while ((e + 1) * (e + 1) + dy * dy <= radius * radius) e++;
+            s_ext[threadIdx.x] = e;
+        }
+    }
     __syncthreads();
+    const int lx = threadIdx.x % BIL_TILE, ly = threadIdx.x / BIL_TILE;
+    const int x = X0 + lx, y = Y0 + ly;
+    if (x >= W || y >= H) return;
     const float r2 = (float)(radius * radius);
-    for (int i = threadIdx.x; i < TILE * TILE; i += blockDim.x) {
-        const int lx = i % TILE, ly = i / TILE;
-        const int x = X0 + lx, y = Y0 + ly;
-        if (x >= W || y >= H) continue;
-        const float center = staged ? tile[(ly + radius) * tw + lx + radius] : in[(size_t)y * W + x];
-        float sum1 = 0.f, sum2 = 0.f;
-        for (int dy = -radius; dy <= radius; dy++)
-            for (int dx = -radius; dx <= radius; dx++) {
-                const float space2 = (float)(dx * dx + dy * dy);
-                if (space2 > r2) continue;
-                const float v = staged ? tile[(ly + radius + dy) * tw + lx + radius + dx]
-                                       : in[(size_t)reflect101(y + dy, H) * W + reflect101(x + dx, W)];
+    float sum1 = 0.f, sum2 = 0.f;
+    if (staged) {
+        // taps inside the circle in row-major order: the same sequence of additions as the definition's double loop
+        const float center = tile[(ly + radius) * tw + lx + radius];
+        for (int dy = -radius; dy <= radius; dy++) {
+            const int e = s_ext[dy + radius];
+            const float* __restrict__ row = &tile[(ly + radius + dy) * tw + lx + radius];
+            const float dy2 = (float)(dy * dy);
+            for (int dx = -e; dx <= e; dx++) {
+                const float space2 = (float)(dx * dx) + dy2;     // = (float)(dx*dx + dy*dy): small integers, exact either way
+                const float v = row[dx];
                 const float dv = fabsf(v - center);
                 const float w = exp_neg_spec(space2 * ss + (dv * dv) * sc);
                 sum1 = sum1 + w * v;
                 sum2 = sum2 + w;
             }
-        out[(size_t)y * W + x] = sum1 / sum2;
+        }
+    } else {
+        const float center = in[(size_t)y * W + x];
+        for (int dy = -radius; dy <= radius; dy++)
+            for (int dx = -radius; dx <= radius; dx++) {
+                const float space2 = (float)(dx * dx + dy * dy);
+                if (space2 > r2) continue;
+                const float v = in[(size_t)reflect101(y + dy, H) * W + reflect101(x + dx, W)];
+                const float dv = fabsf(v - center);
+                const float w = exp_neg_spec(space2 * ss + (dv * dv) * sc);
+                sum1 = sum1 + w * v;
+                sum2 = sum2 + w;
+            }
     }
+    out[(size_t)y * W + x] = sum1 / sum2;
 }
 void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
     ScopedKernel sk("bilateral_prefilter", st);
     int radius = (int)lrint((double)sigma_space * 1.5);
     if (radius < 1) radius = 1;
     const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
-    hipLaunchKernelGGL(k_bilateral, dim3((W + TILE - 1) / TILE, (H + TILE - 1) / TILE), dim3(256), 0, st, in, out, W, H, radius, ss, sc);
+    hipLaunchKernelGGL(k_bilateral, dim3((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE), dim3(256), 0, st, in, out, W, H, radius, ss, sc);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -977,7 +1003,10 @@ int pass_tile_npx(int nb) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("SSF_PASS_NPX"); forced = e ? atoi(e) : 0; }
     if (forced == 1 || forced == 2) return forced;
-    return nb >= 2 ? 2 : 1;
+    (void)nb;
+    return 1;       // measured (profiles/bench_r02_npx*.json): the 64-wide tiles cut the pass's HBM traffic from 1.25x to 1.01x of
+                    // the algorithmic bytes but not its time -- the kernel is bound by instruction issue, not by memory or by
+                    // how many workgroups are resident -- and cost a single-frame launch 50 % more (8 -> 12 us)
 }
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
     static const char* per_pass_names[64] = {nullptr};

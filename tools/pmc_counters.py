@@ -8,15 +8,26 @@ import sys
 from collections import defaultdict
 
 
-def main(d, filt):
-    acc = defaultdict(lambda: defaultdict(list))
+def rows_of(d):
+    """(kernel name, counter name, value) of every dispatch: rocprofv3 CSV output or its rocpd sqlite database"""
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                nm = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ssf::", "")
-                if filt and not any(x in nm for x in filt):
-                    continue
-                acc[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                yield r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
+    for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        import sqlite3
+        cur = sqlite3.connect(path).cursor()
+        for name, counter, value in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+            yield name, counter, float(value)
+
+
+def main(d, filt):
+    acc = defaultdict(lambda: defaultdict(list))
+    for name, counter, value in rows_of(d):
+        nm = name.split("(")[0].replace("void ", "").replace("ssf::", "")
+        if filt and not any(x in nm for x in filt):
+            continue
+        acc[nm][counter].append(value)
     for nm in sorted(acc):
         n = max(len(v) for v in acc[nm].values())
         print("%s  (%d launches)" % (nm, n))

@@ -10,7 +10,8 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = [("k_update_pass<true", "update_pass_rgbd"), ("k_update_pass<false", "update_pass_rgb"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
+NAMES = [("k_update_pass<true, 2", "update_pass_rgbd"), ("k_update_pass<false, 2", "update_pass_rgb"),
+         ("k_update_pass<true, 1", "update_pass_rgbd_1frame"), ("k_update_pass<false, 1", "update_pass_rgb_1frame"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
          ("k_classify", "classify"), ("k_icp", "icp_accumulate"), ("k_match", "match"), ("k_render_moments", "render_moments"),
          ("k_ingest", "ingest"), ("k_eval_samples", "eval_samples"), ("k_init_disp", "init_disp"), ("k_init_samples", "init_samples"),
          ("k_plane_filter", "plane_filter"), ("k_finalize_surfels", "finalize_surfels"), ("k_update_insert", "update_insert"),
@@ -25,15 +26,15 @@ def short(name):
 
 
 def collect(d, counter):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pmc_counters
     acc = defaultdict(list)
-    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        with open(path) as f:
-            for r in csv.DictReader(f):
-                if r.get("Counter_Name") != counter:
-                    continue
-                nm = short(r["Kernel_Name"])
-                if nm:
-                    acc[nm].append(float(r["Counter_Value"]))
+    for name, cname, value in pmc_counters.rows_of(d):
+        if cname != counter:
+            continue
+        nm = short(name)
+        if nm:
+            acc[nm].append(value)
     return acc
 
 
