@@ -121,6 +121,32 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
     }
     return row;
 }
+// the same in two independent halves, so that two waves of a workgroup can build a window row side by side (the plane
+// solve is a chain of three dependent IEEE divisions; the means are five independent ones): identical arithmetic
+__device__ __forceinline__ void row_means_from_sums(const SpSums& s, int k, SpRow& row) {
+    const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
+    const int4 i0 = rec[0], i1 = rec[1];             // sx sy sr sg | sb n dx dy
+    const float n = (float)i1.y;
+    row.cx = (float)i0.x / n; row.cy = (float)i0.y / n;
+    row.r = (float)i0.z / n; row.g = (float)i0.w / n; row.b = (float)i1.x / n;
+    row.size = n;
+}
+__device__ __forceinline__ void row_plane_from_sums(const SpSums& s, int k, float& ta, float& tb, float& tc) {
+    const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
+    int4 i1 = rec[1];
+    int dn_i = s.r[k].dn;
+    const longlong2* __restrict__ q = reinterpret_cast<const longlong2*>(&s.r[k].dxx);
+    longlong2 q0 = q[0], q1 = q[1], q2 = q[2];         // dxx dyy | dxy dxd | dyd dd
+    asm volatile("" : "+v"(i1.z), "+v"(i1.w), "+v"(dn_i), "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y));
+    const double inv = 1.0 / SSF_DISP_SCALE;
+    const float dx = (float)i1.z, dy = (float)i1.w, dn = (float)dn_i;
+    const float dxx = (float)q0.x, dyy = (float)q0.y, dxy = (float)q1.x;
+    const float dxd = (float)((double)q1.y * inv), dyd = (float)((double)q2.x * inv);
+    const float dd = (float)((double)q2.y * inv);
+    if (!plane_solve(ta, tb, tc, dxx, dxy, dx, dxd, dxy, dyy, dy, dyd, dx, dy, dn, dd)) {
+        ta = 0.f; tb = 0.f; tc = __uint_as_float(0xFFE00000u);
+    }
+}
 // ---- relabelling pass --------------------------------------------------------------------------
 #define TILE 32
 #define TW (TILE + 2)
@@ -236,8 +262,8 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 // launch: with 8 frames per launch the 32-wide grid is 2520 workgroups = 10080 waves, more than the 8192 the part
 // holds at once (a second, mostly empty round of workgroups); the 64-wide grid fits in one round and amortises the
 // window's row computation and the flush over twice the pixels.  NPX = 1 stays for single-frame launches (latency).
-template <bool RGBD, int NPX>
-__global__ __launch_bounds__(256, 6) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
+template <bool RGBD, int NPX, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     constexpr int TWX = TILE * NPX, TWW = TWX + 2, LOGN = 256 * NPX;
     __shared__ int tile[TWW * TW];
     __shared__ SpRow w_row[WIN_MAX];
@@ -309,11 +335,24 @@ __global__ __launch_bounds__(256, 6) void k_update_pass(SegParams p, FrameMaps m
     const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
     const bool window_ok = nwx * nwy <= WIN_MAX;
     const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (window_ok && !(dbg & 1))
-        for (int i = threadIdx.x; i < nwx * nwy; i += blockDim.x) {
-            const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
-            if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) w_row[i] = row_from_sums(sr, cy * p.gx + cx, RGBD, zero_row);
+    // (window <= 64 cells: wave 0 builds the means of cell `lane`, wave 1 -- RGB-D passes -- its plane, side by side)
+    if (window_ok && !(dbg & 1) && threadIdx.x < (RGBD ? 128 : 64)) {
+        const int i = threadIdx.x & 63;
+        const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
+        if (i < nwx * nwy && cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) {
+            const int k = cy * p.gx + cx;
+            if (threadIdx.x < 64) {
+                SpRow row = zero_row;
+                row_means_from_sums(sr, k, row);
+                w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
+                if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
+            } else {
+                float ta, tb, tc;
+                row_plane_from_sums(sr, k, ta, tb, tc);
+                w_row[i].ta = ta; w_row[i].tb = tb; w_row[i].tc = tc;
+            }
         }
+    }
     if (threadIdx.x == 0) s_nlog = 0;
     if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
 #pragma unroll
@@ -1025,13 +1064,17 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     dim3 grid = tile_grid(p);
     grid.x = (p.W + (twx - 2) + twx - 1) / twx;
     grid.z = nb;
+    // occupancy target of the RGB-D variant: 6 waves per SIMD (73 registers, no spills).  Forcing 8 (64 registers, 9 spilled
+    // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
+    static int waves = 0;
+    if (!waves) { const char* e = getenv("SSF_PASS_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 6; }
     if (npx == 2) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-        else hipLaunchKernelGGL((k_update_pass<false, 2>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-    } else {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-        else hipLaunchKernelGGL((k_update_pass<false, 1>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-    }
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    } else if (rgbd) {
+        if (waves == 8) hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        else hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+    } else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

@@ -173,16 +173,18 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     if (go) {
         // launched ahead of its transform: wait for the host's word (bounded: a lost word must not hang the device)
         if (threadIdx.x == 0) {
-            int ok = 0;
+            int ok = 0, told = 0;
             for (int spin = 0; spin < (1 << 22); spin++) {
                 const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v == go_seq) { ok = 1; break; }
-                if (v == (go_seq | SSF_ICP_GO_ABORT)) break;
+                if (v == go_seq) { ok = 1; told = 1; break; }
+                if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            // gave up waiting (the host stalled): make that the decision of the whole launch -- workgroups dispatched
-            // later must not find a word that arrives after all and start accumulating into a record nobody completes
-            if (!ok) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
+            // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
+            // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
+            // through the BAR cost the launch behind this one 3 us per frame.)
+            if (!told) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (ok)
                 for (int i = 0; i < 12; i++) s_T[i] = __hip_atomic_load(&go->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_go = ok;
