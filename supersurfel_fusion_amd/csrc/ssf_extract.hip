@@ -387,6 +387,10 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
         if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
     };
+    // (Measured and dropped, round 2: routing the boundary pixels that may change -- a quarter of the pass pixels, whose energy
+    // evaluation is the longest stretch of the kernel -- through a dense LDS list worked off by one or two full waves instead
+    // of four sparse ones.  Bit-exact, fewer VALU lanes wasted, but 1 us SLOWER per 8-frame launch: the kernel is bound by
+    // the latency chain of a wave, not by instruction issue -- profiles/pmc_r02_occupancy.txt.)
     if (dbg & 2) return;
     int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
     float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
