@@ -162,11 +162,16 @@ def pin_to_gpu_numa_node(local):
         return dict(pinned=False, reason=repr(e))
 
 
-def render_frames(n):
+def render_frames(n, tum_shaped=False):
+    """tum_shaped (BASELINE config 5): ~25 % of the pixels holes, depth quantised to 16 bits at 5000 counts per metre and
+    converted back as the benchmark node does (depth_scale 0.0002)"""
     frames = []
     for k in range(n):
         R, t = synthetic.orbit_pose(k)
-        rgb, depth, _ = synthetic.render(R, t, W, H, noise=True, rng=np.random.default_rng(1000 + k))
+        rgb, depth, _ = synthetic.render(R, t, W, H, noise=True, holes=0.25 if tum_shaped else 0.0, rng=np.random.default_rng(1000 + k))
+        if tum_shaped:
+            d16 = np.clip(np.rint(depth.astype(np.float64) * 5000.0), 0, 65535).astype(np.uint16)
+            depth = (d16.astype(np.float64) * 0.0002).astype(np.float32)
         frames.append((rgb, depth))
     return frames
 
@@ -179,11 +184,13 @@ def main():
     ap.add_argument("--rendered-frames", type=int, default=64,
                     help="distinct orbit frames rendered; the sequence sweeps them back and forth (consecutive frames stay 1 degree apart)")
     ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="2 (default): the configuration the metric is quoted on, 640x480 / ~1M supersurfels (N > 1: the same map "
                          "sharded, strong scaling); 3: the HBM-bound stress of BASELINE.json, 1280x960, ~1M supersurfels all "
                          "visible, 10 forced ICP iterations; 4: BASELINE config 4, 640x480 with 500 k supersurfels PER RANK "
-                         "(2 M over 4 GPUs), weak scaling")
+                         "(2 M over 4 GPUs), weak scaling; 5: BASELINE config 5, TUM-shaped input (u16 depth at 5000 / m, ~25 %% "
+                         "holes, depth pre-filter inside the frame) on the 1 M map, one loop-closure deformation (N / 50 nodes) "
+                         "applied before the timed region")
     ap.add_argument("--pin", type=int, default=1, help="1 (default): bind the process to the CPUs of the GPU's NUMA node")
     ap.add_argument("--extras", type=int, default=1,
                     help="1 (default, N = 1 only): also measure the same workload with host-resident frames (PCIe-inclusive) and "
@@ -226,7 +233,7 @@ def main():
     lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
     K, Wm = a.steps, a.warmup
     nr = max(2, a.rendered_frames)
-    frames = render_frames(nr)
+    frames = render_frames(nr, tum_shaped=a.config == 5)
     r_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     r_depth = [torch.from_numpy(f[1]).to(dev) for f in frames]
 
@@ -271,8 +278,15 @@ def main():
         if py_driver:
             tstream = torch.cuda.Stream(dev)       # the torch stream the collectives are ordered on
             stream = tstream.cuda_stream
-        fus = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch))
+        fus = binding.Fusion(lib, make_cfg(lib, cap, rank, world, stream, a.force_icp, depth, batch, prefilter=1 if a.config == 5 else 0))
         fus.set_model(model_local, nvis_local, 30)
+        if a.config == 5:                              # one loop-closure deformation of the whole map (applyDeformation)
+            rng = np.random.default_rng(5)
+            n_, m_ = n_local, max(n_local // 50, 4)
+            ang = rng.uniform(-0.002, 0.002, (m_, 3))
+            nrot = np.stack([(synthetic.rot_y(a_[1]) @ synthetic.rot_x(a_[0])).reshape(9) for a_ in ang]).astype(np.float32)
+            fus.apply_deformation(rng.uniform(-3, 3, (m_, 3)).astype(np.float32), nrot, rng.uniform(-1e-3, 1e-3, (m_, 3)).astype(np.float32),
+                                  rng.dirichlet(np.ones(4), n_).astype(np.float32), rng.integers(0, m_, (n_, 4)).astype(np.int32))
         if py_driver:
             return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
         if exchange:
@@ -361,7 +375,7 @@ def main():
     # N = 1, the same handle through the one-frame entry point otherwise
     nseq = a.profile_frames
     if not exchange:
-        fseq = binding.Fusion(lib, make_cfg(lib, cap, rank, world, None, a.force_icp, 0, 1))
+        fseq = binding.Fusion(lib, make_cfg(lib, cap, rank, world, None, a.force_icp, 0, 1, prefilter=1 if a.config == 5 else 0))
         fseq.set_model(model_local, nvis_local, 30)
         seq_step = lambda i: fseq.process_frame_device(d_rgb[i].data_ptr(), d_depth[i].data_ptr())  # noqa: E731
     else:
@@ -440,7 +454,7 @@ def main():
         legs, omp_probe = {}, {}
 
         def time_oracle(olib, nfr, first=1):
-            fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp))
+            fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp, prefilter=1 if a.config == 5 else 0))
             fo.set_model(model, nvis, 30)
             fo.process_frame(*h_frames[0])                    # warm-up frame
             t1 = time.perf_counter()
@@ -520,7 +534,7 @@ def main():
                                    % (W, H, N_MODEL, gn, gv, " (BASELINE config 3: all seeded supersurfels visible, 10 forced ICP iterations)"
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
-                       "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp),
+                       "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp), "baseline_config": a.config,
                        "exchange": ("native RCCL on the track stream" if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},

@@ -1942,6 +1942,7 @@ int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device
     { TimerScope ts(h); launch_bilateral(h->stream, d_in, d_out, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space); }
     if (!on_device) HCK(hipMemcpyAsync(out, d_out, 4 * P, hipMemcpyDeviceToHost, h->stream));
     HCK(hipStreamSynchronize(h->stream));
+    if (h->cfg.profile == 1) timer_collect(&h->timer);
     return SSF_OK;
 }
 int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t* calls, int max_k) {

@@ -508,3 +508,47 @@ def test_host_frame_sequences_on_fresh_handles(oracle_lib, product_lib):
             util.same_result(a, b)
         util.compare_state(fo, fh, maps=False, frame_surfels=False)
         fh.close()
+
+
+@pytest.mark.gpu
+def test_tracking_survives_a_starved_host(oracle_lib, product_lib):
+    """The track chain talks to the host through a polled mailbox and, for chained ICP launches, the device waits for the
+    host's next transform (bounded spin on a word the host stores through the BAR).  Here the host thread is starved:
+    the process is confined to ONE cpu shared with busy-looping children, so every round trip can be delayed by whole
+    scheduler quanta.  Results must still equal the oracle's, frame by frame -- late words, never wrong ones."""
+    import multiprocessing as mp
+    import os
+    W, H, nf = 160, 128, 10
+    frames = [util.frame(k, W, H, noise=True) for k in range(nf)]
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    want = [fo.process_frame(*fr) for fr in frames]
+    old = os.sched_getaffinity(0)
+    cpu = sorted(old)[0]
+
+    def burn(stop):
+        os.sched_setaffinity(0, {cpu})
+        while not stop.is_set():
+            pass
+
+    ctx = mp.get_context("fork")
+    stop = ctx.Event()
+    hogs = [ctx.Process(target=burn, args=(stop,), daemon=True) for _ in range(3)]
+    try:
+        os.sched_setaffinity(0, {cpu})
+        for p in hogs:
+            p.start()
+        fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=2, extract_batch=2))
+        keep = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+        got = fh.process_sequence([r.ctypes.data for r, _ in keep], [d.ctypes.data for _, d in keep], on_device=False)
+        fl = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H))            # one frame in flight: chained ICP launches
+        got_l = [fl.process_frame(*fr) for fr in frames]
+    finally:
+        stop.set()
+        os.sched_setaffinity(0, old)
+        for p in hogs:
+            p.join(timeout=5)
+    for a, b, c in zip(want, got, got_l):
+        util.same_result(a, b)
+        util.same_result(a, c)
+    util.compare_state(fo, fh, maps=False, frame_surfels=False)
+    util.compare_state(fo, fl, maps=False, frame_surfels=False)
