@@ -505,7 +505,7 @@ __device__ __forceinline__ size_t tex_index(float x, float y, int W, int H) {   
     return (size_t)iy * W + ix;
 }
 // initSamples_kernel, TPS_RGBD_kernels.cu:324-401: one thread per (superpixel, sample)
-__global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
+__global__ __launch_bounds__(256) void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(p.S * p.nb_samples)) return;
     const int index = (int)(idx / (uint32_t)p.nb_samples);
@@ -531,18 +531,40 @@ __global__ void k_init_samples(SegParams p, FrameMaps m, int true_buf) {
         }
         const float d0 = m.disp[tex_index(x, y, p.W, p.H)];
         float px[3] = {x, x, x}, py[3] = {y, y, y}, pd[3] = {d0, d0, d0};
+        // The three 10-step walks were a chain of 30 dependent label reads (21 us for a kernel of 19 200 threads).  But a
+        // step only ever moves while the walker stands on its own superpixel, and the directions come from the counter
+        // RNG alone: the path it WOULD take if it never left the superpixel ("free path") is known without touching
+        // memory.  So: free path first, then all its labels and disparities in one round of independent loads, then
+        // the walk is replayed from registers -- it follows the free path up to the first foreign pixel and stays there.
+        constexpr int NSTEP = 30;
+        float qx[NSTEP + 1], qy[NSTEP + 1];
+        uint32_t moved = 0u;                               // bit s: step s changes the position (its target is inside the image)
+        qx[0] = x; qy[0] = y;
+#pragma unroll
+        for (int s = 1; s <= NSTEP; s++) {
+            const int dir = (int)(rng_draw(p.seed, idx, ctr) & 3u);
+            const float ddx = (dir == 0) ? -1.f : ((dir == 2) ? 1.f : 0.f);
+            const float ddy = (dir == 1) ? -1.f : ((dir == 3) ? 1.f : 0.f);
+            const float nxp = qx[s - 1] + ddx, nyp = qy[s - 1] + ddy;
+            const bool inb = nxp >= 0 && nxp < (float)p.W && nyp >= 0 && nyp < (float)p.H;
+            qx[s] = inb ? nxp : qx[s - 1]; qy[s] = inb ? nyp : qy[s - 1];
+            moved |= inb ? (1u << s) : 0u;
+        }
+        int ql[NSTEP]; float qd[NSTEP + 1];
+#pragma unroll
+        for (int t = 0; t < NSTEP; t++) ql[t] = label[tex_index(qx[t], qy[t], p.W, p.H)];
+#pragma unroll
+        for (int s = 1; s <= NSTEP; s++) qd[s] = m.disp[tex_index(qx[s], qy[s], p.W, p.H)];
+        bool on = true;                                    // the walker still stands on its own superpixel
 #pragma unroll
         for (int j = 0; j < 3; j++)
+#pragma unroll
             for (int w = 0; w < 10; w++) {
-                const int dir = (int)(rng_draw(p.seed, idx, ctr) & 3u);
-                const float ddx = (dir == 0) ? -1.f : ((dir == 2) ? 1.f : 0.f);
-                const float ddy = (dir == 1) ? -1.f : ((dir == 3) ? 1.f : 0.f);
-                const float nxp = x + ddx, nyp = y + ddy;
-                i = label[tex_index(x, y, p.W, p.H)];
-                if (i == index && nxp >= 0 && nxp < (float)p.W && nyp >= 0 && nyp < (float)p.H) {
-                    x = nxp; y = nyp;
-                    const float dd = m.disp[tex_index(x, y, p.W, p.H)];
-                    if (isfinite(dd)) { px[j] = x; py[j] = y; pd[j] = dd; }
+                const int s = 10 * j + w + 1;
+                on = on && ql[s - 1] == index;             // label at the CURRENT position (:370)
+                if (on && ((moved >> s) & 1u)) {
+                    const float dd = qd[s];
+                    if (isfinite(dd)) { px[j] = qx[s]; py[j] = qy[s]; pd[j] = dd; }
                 }
             }
         float a, b, c;
@@ -876,36 +898,63 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
     }
 }
 
-// computeSupersurfels, supersurfel_fusion_kernels.cu:169-224 (+ the MOD mask hook)
-__global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp0,
-                                   const uint8_t* __restrict__ dyn_mask, unsigned mask_bits,
-                                   unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.S) return;
+// computeSupersurfels, supersurfel_fusion_kernels.cu:169-224 (+ the MOD mask hook).  64 superpixels per workgroup.  One
+// thread per superpixel ran a serial chain of ~3000 dependent instructions (two ten-fold normalised squarings for the
+// principal frame, double-precision roots for the colour: 11 us for 1200 threads); the three pieces are independent, so
+// they run side by side with identical arithmetic: waves 0-1, two lanes per superpixel, iterate towards the largest /
+// smallest axis; wave 2 converts the colour; wave 2 then assembles and stores the supersurfel.
+#define FIN_PER_WG 64
+__global__ __launch_bounds__(256) void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float zmin, float zmax, int stamp0,
+                                                          const uint8_t* __restrict__ dyn_mask, unsigned mask_bits,
+                                                          unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+    __shared__ float s_axis[2][FIN_PER_WG][3];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int kk = wv < 2 ? wv * 32 + (l >> 1) : l;
+    const int k = blockIdx.x * FIN_PER_WG + kk;
+    const bool active = k < p.S && wv < 3;
     const int fb = blockIdx.y;
     const size_t off = (size_t)fb * m.slab;
     m = batch_slot(m, fb); f = batch_slot(f, off);
     best = slab_shift(best, off); matched = slab_shift(matched, off);
     dyn_mask = ((mask_bits >> fb) & 1u) ? slab_shift(dyn_mask, off) : nullptr;
     const int stamp = stamp0 + fb;
-    best[k] = SSF_NO_MATCH; matched[k] = 0;         // association tables of this frame (findBestMatches init)
-    const long long* a = &m.moments[(size_t)k * 13];
-    const double inv = 1.0 / SSF_MOM_SCALE;
-    float sum[12];
+    float sum[12]; float conf = 0.f;
 #pragma unroll
-    for (int j = 0; j < 12; j++) sum[j] = (float)((double)a[j] * inv);
-    float conf = (float)a[12];
+    for (int j = 0; j < 12; j++) sum[j] = 0.f;
+    if (active) {
+        const long long* a = &m.moments[(size_t)k * 13];
+        const double inv = 1.0 / SSF_MOM_SCALE;
+#pragma unroll
+        for (int j = 0; j < 12; j++) sum[j] = (float)((double)a[j] * inv);
+        conf = (float)a[12];
+    }
     V3 pos = v3(sum[0], sum[1], sum[2]), col = v3(sum[3], sum[4], sum[5]);
     Sym3 shape = sym3(sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
+    const float z = pos.z / conf;
+    const bool valid = active && isfinite(z) && conf > 100.0f && z > zmin && z < zmax;
+    if (valid) {
+        pos = v3(pos.x / conf, pos.y / conf, z);
+        shape = sym_sub(sym_div(shape, conf), sym_outer(pos));
+    }
+    V3 lab = v3(0.f, 0.f, 0.f);
+    if (wv < 2) {
+        if (valid) {
+            const V3 axis = principal_power(principal_start(shape, (l & 1) == 1));
+            s_axis[l & 1][kk][0] = axis.x; s_axis[l & 1][kk][1] = axis.y; s_axis[l & 1][kk][2] = axis.z;
+        }
+    } else if (wv == 2 && active) {
+        if (valid) col = lab_to_rgb(v3(col.x / conf, col.y / conf, col.z / conf));
+        lab = rgb_to_lab(col);
+    }
+    __syncthreads();
+    if (wv != 2 || !active) return;
+    best[k] = SSF_NO_MATCH; matched[k] = 0;         // association tables of this frame (findBestMatches init)
     M3 vecs = m3(v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0));
     float d0 = 0.f, d1 = 0.f; int s0 = 0, s1 = 0;
-    const float z = pos.z / conf;
-    if (isfinite(z) && conf > 100.0f && z > zmin && z < zmax) {
-        pos = v3(pos.x / conf, pos.y / conf, z);
-        col = lab_to_rgb(v3(col.x / conf, col.y / conf, col.z / conf));
-        shape = sym_sub(sym_div(shape, conf), sym_outer(pos));
+    if (valid) {
         V3 vals;
-        principal_frame(shape, vecs, vals);
+        principal_finish(shape, v3(s_axis[0][kk][0], s_axis[0][kk][1], s_axis[0][kk][2]),
+                         v3(s_axis[1][kk][0], s_axis[1][kk][1], s_axis[1][kk][2]), vecs, vals);
         d0 = vals.x; d1 = vals.y; s0 = stamp; s1 = stamp;
         if (vals.x / vals.y > 50.0f) conf = -1.0f;
     } else
@@ -913,7 +962,6 @@ __global__ void k_finalize_surfels(SegParams p, FrameMaps m, SurfelSoA f, float 
     if (dyn_mask && dyn_mask[k]) conf = -1.0f;
     f.pos[3 * k] = pos.x; f.pos[3 * k + 1] = pos.y; f.pos[3 * k + 2] = pos.z;
     f.col[3 * k] = col.x; f.col[3 * k + 1] = col.y; f.col[3 * k + 2] = col.z;
-    const V3 lab = rgb_to_lab(col);
     f.lab[3 * k] = lab.x; f.lab[3 * k + 1] = lab.y; f.lab[3 * k + 2] = lab.z;
     f.stamps[2 * k] = s0; f.stamps[2 * k + 1] = s1;
     f.r0[3 * k] = vecs.r0.x; f.r0[3 * k + 1] = vecs.r0.y; f.r0[3 * k + 2] = vecs.r0.z;
@@ -1108,7 +1156,7 @@ void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, i
                              float zmax, int stamp0, const uint8_t* dynamic_mask, unsigned mask_bits,
                              unsigned long long* best, uint8_t* matched) {
     ScopedKernel sk("finalize_surfels", st);
-    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + 63) / 64, nb), dim3(64), 0, st, p, m, frame, zmin, zmax, stamp0,
+    hipLaunchKernelGGL(k_finalize_surfels, dim3((p.S + FIN_PER_WG - 1) / FIN_PER_WG, nb), dim3(256), 0, st, p, m, frame, zmin, zmax, stamp0,
                        dynamic_mask, mask_bits, best, matched);
 }
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out) {

@@ -360,6 +360,9 @@ struct ExtractCtx {
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
     hipStream_t stream = nullptr; bool own_stream = false;
+    // stream = the one the open / running batch uses: stream_lo (lowest priority: batches that run ahead of need) or
+    // stream_hi (middle priority, below the track stream: the batch the track chain is waiting for -- submit_extract)
+    hipStream_t stream_lo = nullptr, stream_hi = nullptr;
     hipEvent_t ev_done = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool consumed_valid = false, timed = false;
     hipGraph_t graph[SSF_MAX_BATCH + 1] = {}; hipGraphExec_t exec[SSF_MAX_BATCH + 1] = {};
@@ -418,7 +421,7 @@ struct ssf_handle {
     // first ICP iteration of the next submitted frame, accumulated ahead by the row-move kernel of the frame just
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
-    bool icp_ahead = true;
+    bool icp_ahead = true, urgent_first = true;
     // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
@@ -434,6 +437,7 @@ struct ssf_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     KernelTimer timer;
     std::vector<std::string> timer_names;
+    double seq_t0_us = 0, seq_done_us[64] = {0};      // debug: completion time of the first frames of the last ssf_process_sequence
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // debug: submit | icp loop | match+fuse | frames | extract ready at activation | first icp iteration
 };
 static std::string g_create_err;
@@ -595,7 +599,14 @@ static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int
     ExtractCtx& c = h->ctx[h->open_ctx];
     if (c.launched) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
     const int b = c.count;
-    if (b == 0) { c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal; }
+    if (b == 0) {
+        c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal;
+        // A batch opened while nothing older is pending is the one the track chain will wait for (the first batch of a
+        // sequence, or after the pipeline ran dry): it runs on the middle-priority stream, so that the batches submitted
+        // right behind it, which run ahead of need, do not slow it down (three batches started together took 0.95 ms to
+        // deliver the first frame, 0.47 ms alone).  Not with the upload workers: they have been told the streams.
+        if (c.stream_hi) c.stream = (h->urgent_first && h->pending.empty() && !h->seq_upload) ? c.stream_hi : c.stream_lo;
+    }
     h->extract_ordinal++;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, off = (size_t)b * c.maps.slab;
     c.in.rgb[b] = (const uint8_t*)rgb; c.in.depth[b] = (const float*)depth;
@@ -707,7 +718,7 @@ static void inc_to_float(const double* tf, M3& R, V3& t) {
     t = v3((float)tf[3], (float)tf[7], (float)tf[11]);
 }
 // device accumulate; the record lands in d_icp and in the mailbox (h_icp points at the mailbox copy)
-static int icp_fetch(ssf_handle* h, unsigned long long seq);
+static int icp_fetch(ssf_handle* h, unsigned long long seq, IcpGo* waiter = nullptr, unsigned long long waiter_go_seq = 0, bool* waiter_dismissed = nullptr);
 // model -> camera transform of the coming iteration
 static Rt icp_transform(IcpLoop& I) {
     M3 R_inc; V3 t_inc;
@@ -726,11 +737,15 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     return to_host ? icp_fetch(h, seq) : SSF_OK;
 }
 // wait for mailbox record `seq` and copy it to h->h_icp_local
-static int icp_fetch(ssf_handle* h, unsigned long long seq) {
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T);
+// waiter: a launch made ahead that is waiting on the device for the host's word (chained ICP launches).  Before the stream
+// is drained it is told to leave (*waiter_dismissed = true): it would otherwise hold the stream until its own bound expires.
+static int icp_fetch(ssf_handle* h, unsigned long long seq, IcpGo* waiter, unsigned long long waiter_go_seq, bool* waiter_dismissed) {
     // the record is five 64-byte lines that each end in the sequence number (Mailbox::icp_rec): accept it when all
     // five carry `seq` and the checksum over the payload matches; anything else is a record still in flight
     const volatile unsigned long long* rec = h->mb_host->icp_rec;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
+    bool drained = false;                     // the stream has been synchronised once after a timeout
     for (unsigned long long spins = 0;; spins++) {
         bool ok = true;
         for (int j = 0; j < 5 && ok; j++) ok = __atomic_load_n(&rec[8 * j + 7], __ATOMIC_ACQUIRE) == seq;
@@ -744,11 +759,15 @@ static int icp_fetch(ssf_handle* h, unsigned long long seq) {
             for (int j = 0; j < 5 && still; j++) still = __atomic_load_n(&rec[8 * j + 7], __ATOMIC_ACQUIRE) == seq;
             if (still && check == w29) break;
         }
-        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (drained ? 1.0 : 5.0)) {
+            // Nothing for 5 s.  The device may simply be slow or stalled (a cold box, a debugger, another tenant): drain the
+            // stream -- however long that takes -- and look again before calling it an error; only a record that is
+            // still missing once everything enqueued has run is one.
+            if (drained) { h->err = "ICP mailbox record never arrived"; return SSF_ERR_DEVICE; }
+            if (waiter) { icp_release_waiting(waiter, waiter_go_seq, nullptr); if (waiter_dismissed) *waiter_dismissed = true; waiter = nullptr; }
             hipError_t e = hipStreamSynchronize(h->stream);
-            h->err = e != hipSuccess ? std::string("device error while waiting for the ICP record: ") + hipGetErrorString(e)
-                                     : std::string("ICP mailbox record never arrived");
-            return SSF_ERR_DEVICE;
+            if (e != hipSuccess) { h->err = std::string("device error while waiting for the ICP record: ") + hipGetErrorString(e); return SSF_ERR_DEVICE; }
+            drained = true; t0 = std::chrono::steady_clock::now();
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1133,7 +1152,9 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
                 if (rc) return rc;
                 waiting = true;
             }
-            rc = icp_fetch(h, seq_rec);
+            bool dismissed = false;
+            rc = icp_fetch(h, seq_rec, waiting ? wait_slot : nullptr, wait_go_seq, &dismissed);
+            if (dismissed) waiting = false;           // (the next iteration, if any, is launched afresh)
             if (rc) { if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr); icp_chain_reset(h); return rc; }
             if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
             icp_update(h, (const int64_t*)h->h_icp, &again);
@@ -1243,14 +1264,15 @@ void ssf_destroy(ssf_handle* h) {
         for (auto q : h->up->p_depth) if (q) (void)hipHostFree(q);
         delete h->up; h->up = nullptr;
     }
-    for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
+    for (auto& c : h->ctx) { if (c.stream) (void)hipStreamSynchronize(c.stream); if (c.stream_hi) (void)hipStreamSynchronize(c.stream_hi); if (c.stream_lo) (void)hipStreamSynchronize(c.stream_lo); }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     for (auto& c : h->ctx) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+        if (c.own_stream && c.stream_lo) (void)hipStreamDestroy(c.stream_lo);
+        if (c.stream_hi) (void)hipStreamDestroy(c.stream_hi);
     }
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (void* p : h->allocs) (void)hipFree(p);
@@ -1282,6 +1304,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
     if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switches (tools/)
     if (const char* e = getenv("SSF_ICP_CHAIN")) h->icp_chain = atoi(e) != 0;
+    if (const char* e = getenv("SSF_URGENT_FIRST")) h->urgent_first = atoi(e) != 0;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
@@ -1349,6 +1372,10 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) == hipSuccess; c.own_stream = ok;
+            c.stream_lo = c.stream;
+            // a level strictly between the contexts' and the track stream's, where the device has one
+            const int mid = (least + greatest) / 2;
+            if (ok && mid != least && mid != greatest && hipStreamCreateWithPriority(&c.stream_hi, hipStreamNonBlocking, mid) != hipSuccess) { c.stream_hi = nullptr; (void)hipGetLastError(); }
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
@@ -1459,7 +1486,7 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
                           hipHostMalloc((void**)&u->p_depth[i], 4 * P, hipHostMallocDefault) == hipSuccess;
                 if (!pin) { for (auto q : u->p_rgb) if (q) (void)hipHostFree(q); for (auto q : u->p_depth) if (q) (void)hipHostFree(q); u->p_rgb.clear(); u->p_depth.clear(); (void)hipGetLastError(); }
             }
-            for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream);
+            for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream_lo ? c.stream_lo : c.stream);
             u->batch = h->batch;
             if (!ok) { delete u; h->err = "allocation of the upload ring failed"; return SSF_ERR_DEVICE; }    // (buffers taken so far stay in h->allocs)
             h->up = u;
@@ -1471,12 +1498,14 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
     }
     h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device; h->seq_upload = ahead;
     h->seq_batches = 0;
+    h->seq_t0_us = now_us();
     for (int k = 0; k < n && !rc; k++) {
         while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
             TimerScope ts(h);
             rc = seq_submit(h);
         }
         if (!rc) rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
+        if (k < 64) h->seq_done_us[k] = now_us() - h->seq_t0_us;
         if (ahead) h->up->processed.store(k + 1, std::memory_order_release);
     }
     if (ahead) {
@@ -1964,6 +1993,12 @@ int ssf_set_profile(ssf_handle* h, int enable) {
     return SSF_OK;
 }
 
+// completion times (us since the call started) of the first 64 frames of the last ssf_process_sequence (tools/startup_probe.py)
+int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
+    if (!h || !out64) return SSF_ERR_INVALID_ARG;
+    for (int i = 0; i < 64; i++) out64[i] = h->seq_done_us[i];
+    return SSF_OK;
+}
 // host-side time split of the pipelined loop (tools/pipeline_probe.py); reset on read
 int ssf_dbg_host_times(ssf_handle* h, double* out8) {
     if (!h || !out8) return SSF_ERR_INVALID_ARG;
@@ -1987,7 +2022,7 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
         if (activate_oldest(h) || retire_active(h)) return -1.0;
         h->stamp++;
     }
-    for (auto& c : h->ctx) (void)hipStreamSynchronize(c.stream);
+    for (auto& c : h->ctx) { (void)hipStreamSynchronize(c.stream); if (c.stream_hi) (void)hipStreamSynchronize(c.stream_hi); if (c.stream_lo) (void)hipStreamSynchronize(c.stream_lo); }
     (void)hipStreamSynchronize(h->stream);
     return (now_us() - t0) / (double)(n - n / 4);
 }

@@ -8,26 +8,34 @@ import sys
 from collections import defaultdict
 
 
-def rows_of(d):
-    """(kernel name, counter name, value) of every dispatch: rocprofv3 CSV output or its rocpd sqlite database"""
+def rows_of(d, with_grid=False):
+    """(kernel name, counter name, value[, grid size]) of every dispatch: rocprofv3 CSV output or its rocpd sqlite database"""
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                yield r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
+                row = (r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"]))
+                yield row + (int(r.get("Grid_Size", 0) or 0),) if with_grid else row
     for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
         import sqlite3
         cur = sqlite3.connect(path).cursor()
-        for name, counter, value in cur.execute("select kernel_name, counter_name, value from counters_collection"):
-            yield name, counter, float(value)
+        for name, counter, value, grid in cur.execute("select kernel_name, counter_name, value, grid_size from counters_collection"):
+            yield (name, counter, float(value), int(grid)) if with_grid else (name, counter, float(value))
 
 
 def main(d, filt):
-    acc = defaultdict(lambda: defaultdict(list))
-    for name, counter, value in rows_of(d):
+    """extract kernels are launched over 2, 4 and 8 frames (the batch ramp): only the full-size launches of a kernel are averaged"""
+    raw = defaultdict(lambda: defaultdict(list))
+    for name, counter, value, grid in rows_of(d, with_grid=True):
         nm = name.split("(")[0].replace("void ", "").replace("ssf::", "")
         if filt and not any(x in nm for x in filt):
             continue
-        acc[nm][counter].append(value)
+        raw[nm][counter].append((grid, value))
+    batched = ("k_update_pass", "k_ingest", "k_init_", "k_eval_samples", "k_plane_filter", "k_render_moments", "k_finalize_surfels", "k_bilateral")
+    acc = defaultdict(lambda: defaultdict(list))
+    for nm in raw:
+        for c, lst in raw[nm].items():
+            gmax = max(g for g, _ in lst)
+            acc[nm][c] = [v for g, v in lst if g == gmax or not nm.startswith(batched)]
     for nm in sorted(acc):
         n = max(len(v) for v in acc[nm].values())
         print("%s  (%d launches)" % (nm, n))

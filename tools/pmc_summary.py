@@ -10,8 +10,8 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = [("k_update_pass<true, 2", "update_pass_rgbd"), ("k_update_pass<false, 2", "update_pass_rgb"),
-         ("k_update_pass<true, 1", "update_pass_rgbd_1frame"), ("k_update_pass<false, 1", "update_pass_rgb_1frame"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
+NAMES = [("k_update_pass<true, 1", "update_pass_rgbd"), ("k_update_pass<false, 1", "update_pass_rgb"),
+         ("k_update_pass<true, 2", "update_pass_rgbd_wide"), ("k_update_pass<false, 2", "update_pass_rgb_wide"), ("k_move_rows", "reorder_move"), ("k_scatter", "reorder_scatter"),
          ("k_classify", "classify"), ("k_icp", "icp_accumulate"), ("k_match", "match"), ("k_render_moments", "render_moments"),
          ("k_ingest", "ingest"), ("k_eval_samples", "eval_samples"), ("k_init_disp", "init_disp"), ("k_init_samples", "init_samples"),
          ("k_plane_filter", "plane_filter"), ("k_finalize_surfels", "finalize_surfels"), ("k_update_insert", "update_insert"),
@@ -28,13 +28,19 @@ def short(name):
 def collect(d, counter):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import pmc_counters
-    acc = defaultdict(list)
-    for name, cname, value in pmc_counters.rows_of(d):
+    raw = defaultdict(list)
+    for name, cname, value, grid in pmc_counters.rows_of(d, with_grid=True):
         if cname != counter:
             continue
         nm = short(name)
         if nm:
-            acc[nm].append(value)
+            raw[nm].append((grid, value))
+    # extract kernels are launched over 2, 4 and 8 frames (the batch ramp): per-launch figures are those of the full batch
+    batched = ("update_pass", "ingest", "init_", "eval_samples", "plane_filter", "render_moments", "finalize_surfels")
+    acc = defaultdict(list)
+    for nm, lst in raw.items():
+        gmax = max(g for g, _ in lst)
+        acc[nm] = [v for g, v in lst if g == gmax or not nm.startswith(batched)]
     return acc
 
 
