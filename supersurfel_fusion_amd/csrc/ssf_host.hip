@@ -360,9 +360,6 @@ struct ExtractCtx {
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
     hipStream_t stream = nullptr; bool own_stream = false;
-    // stream = the one the open / running batch uses: stream_lo (lowest priority: batches that run ahead of need) or
-    // stream_hi (middle priority, below the track stream: the batch the track chain is waiting for -- submit_extract)
-    hipStream_t stream_lo = nullptr, stream_hi = nullptr;
     hipEvent_t ev_done = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool consumed_valid = false, timed = false;
     hipGraph_t graph[SSF_MAX_BATCH + 1] = {}; hipGraphExec_t exec[SSF_MAX_BATCH + 1] = {};
@@ -421,7 +418,7 @@ struct ssf_handle {
     // first ICP iteration of the next submitted frame, accumulated ahead by the row-move kernel of the frame just
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
-    bool icp_ahead = true, urgent_first = true;
+    bool icp_ahead = true;
     // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
@@ -601,11 +598,6 @@ static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int
     const int b = c.count;
     if (b == 0) {
         c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal;
-        // A batch opened while nothing older is pending is the one the track chain will wait for (the first batch of a
-        // sequence, or after the pipeline ran dry): it runs on the middle-priority stream, so that the batches submitted
-        // right behind it, which run ahead of need, do not slow it down (three batches started together took 0.95 ms to
-        // deliver the first frame, 0.47 ms alone).  Not with the upload workers: they have been told the streams.
-        if (c.stream_hi) c.stream = (h->urgent_first && h->pending.empty() && !h->seq_upload) ? c.stream_hi : c.stream_lo;
     }
     h->extract_ordinal++;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, off = (size_t)b * c.maps.slab;
@@ -1264,15 +1256,14 @@ void ssf_destroy(ssf_handle* h) {
         for (auto q : h->up->p_depth) if (q) (void)hipHostFree(q);
         delete h->up; h->up = nullptr;
     }
-    for (auto& c : h->ctx) { if (c.stream) (void)hipStreamSynchronize(c.stream); if (c.stream_hi) (void)hipStreamSynchronize(c.stream_hi); if (c.stream_lo) (void)hipStreamSynchronize(c.stream_lo); }
+    for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     for (auto& c : h->ctx) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        if (c.own_stream && c.stream_lo) (void)hipStreamDestroy(c.stream_lo);
-        if (c.stream_hi) (void)hipStreamDestroy(c.stream_hi);
+        if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (void* p : h->allocs) (void)hipFree(p);
@@ -1304,7 +1295,6 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
     if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switches (tools/)
     if (const char* e = getenv("SSF_ICP_CHAIN")) h->icp_chain = atoi(e) != 0;
-    if (const char* e = getenv("SSF_URGENT_FIRST")) h->urgent_first = atoi(e) != 0;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
@@ -1372,10 +1362,6 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) == hipSuccess; c.own_stream = ok;
-            c.stream_lo = c.stream;
-            // a level strictly between the contexts' and the track stream's, where the device has one
-            const int mid = (least + greatest) / 2;
-            if (ok && mid != least && mid != greatest && hipStreamCreateWithPriority(&c.stream_hi, hipStreamNonBlocking, mid) != hipSuccess) { c.stream_hi = nullptr; (void)hipGetLastError(); }
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
@@ -1486,7 +1472,7 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
                           hipHostMalloc((void**)&u->p_depth[i], 4 * P, hipHostMallocDefault) == hipSuccess;
                 if (!pin) { for (auto q : u->p_rgb) if (q) (void)hipHostFree(q); for (auto q : u->p_depth) if (q) (void)hipHostFree(q); u->p_rgb.clear(); u->p_depth.clear(); (void)hipGetLastError(); }
             }
-            for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream_lo ? c.stream_lo : c.stream);
+            for (auto& c : h->ctx) u->ctx_stream.push_back(c.stream);
             u->batch = h->batch;
             if (!ok) { delete u; h->err = "allocation of the upload ring failed"; return SSF_ERR_DEVICE; }    // (buffers taken so far stay in h->allocs)
             h->up = u;
@@ -2022,7 +2008,7 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
         if (activate_oldest(h) || retire_active(h)) return -1.0;
         h->stamp++;
     }
-    for (auto& c : h->ctx) { (void)hipStreamSynchronize(c.stream); if (c.stream_hi) (void)hipStreamSynchronize(c.stream_hi); if (c.stream_lo) (void)hipStreamSynchronize(c.stream_lo); }
+    for (auto& c : h->ctx) (void)hipStreamSynchronize(c.stream);
     (void)hipStreamSynchronize(h->stream);
     return (now_us() - t0) / (double)(n - n / 4);
 }
