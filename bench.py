@@ -55,6 +55,9 @@ ALGO_BYTES = {
     "init_disp": lambda c: c["batch"] * 9.0 * P,
     "eval_samples": lambda c: c["batch"] * 8.0 * P,
     "render_moments": lambda c: c["batch"] * 25.0 * P,
+    # depth pre-filter (config 5 / depth_prefilter = 1): one frame per launch, 4 B read + 4 B written per pixel; the kernel is
+    # bound by its 177 taps x a specified exp per pixel, not by these bytes
+    "bilateral_prefilter": lambda c: 8.0 * P,
 }
 
 

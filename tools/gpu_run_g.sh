@@ -27,7 +27,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p -- $P
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq -o p -- $PROF > $O/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU -d $O/pmc_sq2 -o p -- $PROF > $O/pmc_sq2.log 2>&1
 cd $R
-PMC_EXTRACT_BATCH=8 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_r02.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipeline_depth 2, extract_batch 8; the extract launches of the batch ramp cover 2 and 4 frames: the means below include them). Counters are KB; hbm_bytes_per_launch = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE reports half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section)" > $O/pmc_summary.txt 2>&1
+PMC_EXTRACT_BATCH=8 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_r02.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipeline_depth 2, extract_batch 8; extract kernels: only the launches over the full batch of 8 frames are averaged). Counters are KB; hbm_bytes_per_launch = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE reports half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section)" > $O/pmc_summary.txt 2>&1
 python tools/pmc_counters.py $O/pmc_sq > $O/pmc_sq.txt 2>&1
 python tools/pmc_counters.py $O/pmc_sq2 > $O/pmc_sq2.txt 2>&1
 DB=$(find $O/trace -name "*.db" | head -1)
