@@ -477,6 +477,8 @@ def main():
             for nt in sorted({min(ncpu, 8), min(ncpu, 16), min(ncpu, 32), min(ncpu, 64), ncpu}):
                 olib.lib.ssf_oracle_set_threads(nt)
                 omp_probe[nt] = time_oracle(olib, 4)[0]
+                if omp_probe[nt] < 0.5 * max(omp_probe.values()):      # past the knee (128 threads ran at 0.1 frames/s: 40 s of probe)
+                    break
             omp_threads = max(omp_probe, key=omp_probe.get)
             olib.lib.ssf_oracle_set_threads(omp_threads)
             legs["openmp"] = time_oracle(olib, a.cpu_frames)
