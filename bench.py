@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--extract-batch", type=int, default=None, help="frames per extract launch chain (default 8; 4 at 1280x960)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU exchanges (collectives included) even on one rank: exercises the N > 1 code path")
+    ap.add_argument("--comm", choices=["rccl", "p2p"], default="rccl",
+                    help="native exchange backend at N > 1 (or with --force-sharded): RCCL collectives on the track stream, or the "
+                         "peer-to-peer exchange regions of ssf_p2p_* (one node, no collective launches)")
     ap.add_argument("--py-driver", action="store_true",
                     help="N > 1 through supersurfel_fusion_amd/sharded.py (torch.distributed collectives) instead of native RCCL")
     a = ap.parse_args()
@@ -293,7 +296,10 @@ def main():
         if py_driver:
             return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
         if exchange:
-            fus.comm_attach()
+            if a.comm == "p2p":
+                fus.p2p_attach()                   # IPC handles of the exchange regions, all-gathered over torch.distributed
+            else:
+                fus.comm_attach()
         return fus, None
 
     native_ok = 1
@@ -540,7 +546,7 @@ def main():
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp), "baseline_config": a.config,
-                       "exchange": ("native RCCL on the track stream" if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
+                       "exchange": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,

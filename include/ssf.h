@@ -36,6 +36,7 @@
 #ifndef SSF_H
 #define SSF_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -332,6 +333,31 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
 int ssf_comm_unique_id(uint8_t* id128);
 int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
 int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
+
+/* ---- multi-GPU, native: peer to peer over xGMI, no collective launches ---------------------------
+ * The latency-tuned exchange SURVEY.md section 5 / 8e proposes for the ranks of ONE node (cfg.nranks <= 8): every
+ * handle owns an exchange region in its HBM; a rank stores its small records (29 x int64 ICP record per iteration,
+ * association tables, migrant table, shard sizes) straight into the other ranks' regions and sums what arrives in
+ * its own, in rank order (integers: the result is the SUM / MIN / MAX all-reduce of ssf_comm_attach, bit for bit).
+ * An ICP iteration is ONE launch whose last workgroup does the exchange -- as on a single GPU -- instead of kernel +
+ * all-reduce + publication.
+ *   ssf_p2p_export        allocates the region and returns its 64-byte IPC handle (hipIpcGetMemHandle); ship it to the
+ *                         other ranks out of band (e.g. a torch.distributed all_gather of 64 bytes)
+ *   ssf_p2p_attach        handles = nranks x 64 bytes in rank order (the own entry is ignored): opens the peers'
+ *                         regions (hipIpcOpenMemHandle) and switches ssf_process_frame* / ssf_process_submitted to the
+ *                         exchange protocol.  Mutually exclusive with ssf_comm_attach.
+ *   ssf_p2p_region / ssf_p2p_attach_local   the same for handles that live in ONE process (several shards on one
+ *                         GPU, or several GPUs driven by one process with peer access enabled): regions[r] = the
+ *                         pointer ssf_p2p_region returned for rank r.  Each rank must then be driven by its own
+ *                         host thread: a frame call returns only when every peer has made the same call.
+ * All ranks must process the same frames in the same order.  A peer that never arrives makes the waiting call fail
+ * with SSF_ERR_DEVICE after a bounded wait (seconds); it does not hang the device.  The CPU checker exports these
+ * symbols and returns SSF_ERR_DEVICE. */
+#define SSF_P2P_HANDLE_BYTES 64
+int ssf_p2p_export(ssf_handle* h, uint8_t* handle64);
+int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles);
+int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes);
+int ssf_p2p_attach_local(ssf_handle* h, void* const* regions);
 
 /* ---- read back -------------------------------------------------------------------------------- */
 int ssf_get_pose(const ssf_handle* h, float* pose12);

@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -135,6 +135,10 @@ class Library:
         L.ssf_fern_codes.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp]
         L.ssf_comm_unique_id.argtypes = [vp]
         L.ssf_comm_attach.argtypes = [vp, vp]
+        L.ssf_p2p_export.argtypes = [vp, vp]
+        L.ssf_p2p_attach.argtypes = [vp, vp]
+        L.ssf_p2p_region.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.ssf_p2p_attach_local.argtypes = [vp, C.POINTER(C.c_void_p)]
         L.ssf_get_global_counts.argtypes = [vp, vp]
         L.ssf_stage_begin_submitted.argtypes = [vp]
         L.ssf_stage_icp_accumulate_device.argtypes = [vp, vp]
@@ -401,6 +405,37 @@ class Fusion:
             raise SsfError(obj[1])
         ident = np.frombuffer(obj[0], np.uint8).copy()
         self._ck(self.L.lib.ssf_comm_attach(self.h, _ptr(ident)), "ssf_comm_attach")
+
+    # peer-to-peer exchange (ssf_p2p_* in ssf.h): the ranks of one node trade their records through each other's HBM
+    P2P_HANDLE_BYTES = 64
+
+    def p2p_export(self):
+        """64-byte IPC handle of this handle's exchange region (to be shipped to the other ranks)"""
+        out = np.zeros(self.P2P_HANDLE_BYTES, np.uint8)
+        self._ck(self.L.lib.ssf_p2p_export(self.h, _ptr(out)), "ssf_p2p_export")
+        return out
+
+    def p2p_attach(self, handles=None, group=None):
+        """handles: nranks x 64 bytes in rank order; None: all-gathered over torch.distributed (group)"""
+        if handles is None:
+            import torch.distributed as dist
+            mine = self.p2p_export().tobytes()
+            got = [None] * dist.get_world_size(group)
+            dist.all_gather_object(got, mine, group=group)
+            handles = np.concatenate([np.frombuffer(b, np.uint8) for b in got])
+        handles = np.ascontiguousarray(handles, np.uint8).reshape(-1)
+        assert handles.size == self.P2P_HANDLE_BYTES * self.cfg.nranks
+        self._ck(self.L.lib.ssf_p2p_attach(self.h, _ptr(handles)), "ssf_p2p_attach")
+
+    def p2p_region(self):
+        """(address, bytes) of this handle's exchange region: for ranks that live in one process"""
+        reg, nb = C.c_void_p(), C.c_size_t()
+        self._ck(self.L.lib.ssf_p2p_region(self.h, C.byref(reg), C.byref(nb)), "ssf_p2p_region")
+        return reg.value, nb.value
+
+    def p2p_attach_local(self, regions):
+        arr = (C.c_void_p * len(regions))(*regions)
+        self._ck(self.L.lib.ssf_p2p_attach_local(self.h, arr), "ssf_p2p_attach_local")
 
     def global_counts(self):
         out = np.zeros(5, np.int64)

@@ -196,7 +196,7 @@ struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; 
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
-                unsigned long long go_seq = 0);
+                unsigned long long go_seq = 0, const struct P2PView* pv = nullptr);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
@@ -258,6 +258,40 @@ void launch_align(hipStream_t st, const Cam& cam, const float* spos, const float
                   int n, SurfelSoA frame, const int32_t* label, const float* plane_depth, Rt T, long long* out40);
 void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, int W, int H, const uint32_t* fpos,
                        const uint8_t* frgb, const float* fdepth, int n, uint8_t* codes);
+// ---- peer-to-peer exchanges (ssf_p2p_* in ssf.h) ----------------------------------------------
+// The ranks of one node exchange their small per-frame records through memory instead of through collective launches:
+// every rank owns an exchange REGION in its HBM (fine-grained, exported to the other processes through an IPC handle)
+// with one slot per (exchange kind, parity of the exchange's sequence number, source rank).  A producer stores its
+// record straight into slot [.][.][me] of every peer's region (xGMI stores) and then waits in its OWN region for the
+// slots of the others -- an all-gather by remote stores followed by a local, fixed-order reduction.  Two parities are
+// enough: a rank can start exchange n + 2 of a kind only after every peer has produced n + 1, i.e. consumed n.
+//   ICP record   40 x u64 self-validating lines exactly as Mailbox::icp_rec (no ordering between the stores needed)
+//   shard sizes  one self-validating 64-byte line (Counters::last, checksum, sequence number)
+//   association  best u64[S] + matched u8[S], then a flag line (release) -- consumer: MIN / OR into its own tables
+//   migrants     the table of ssf_stage_fuse_begin (28 x i32 per slot; empty slots send their first word only),
+//                then a flag line -- consumer: adds the peers' slots into its own table (at most one rank fills a slot)
+// Everything a peer reads or writes in a region goes through system-scope atomic loads / stores (write-through,
+// cache-bypassing), so no cache write-back / invalidate is part of the protocol.
+#define SSF_P2P_MAX_RANKS 8
+struct P2PView { unsigned char* peer[SSF_P2P_MAX_RANKS]; int me, nranks, S; unsigned long long seq; };
+enum { P2P_FLAG_ASSOC = 0, P2P_FLAG_MIGR = 1 };
+#define SSF_P2P_HEADER 8192
+SSF_HD size_t p2p_slot(int par, int src) { return (size_t)(par * SSF_P2P_MAX_RANKS + src); }
+SSF_HD size_t p2p_spad(int S) { return ((size_t)S + 63) & ~(size_t)63; }
+SSF_HD size_t p2p_off_icp(int par, int src) { return p2p_slot(par, src) * 320; }
+SSF_HD size_t p2p_off_cnt(int par, int src) { return 16 * 320 + p2p_slot(par, src) * 64; }
+SSF_HD size_t p2p_off_flag(int kind, int par, int src) { return 16 * 384 + ((size_t)kind * 16 + p2p_slot(par, src)) * 64; }
+SSF_HD size_t p2p_off_best(int S, int par, int src) { return SSF_P2P_HEADER + p2p_slot(par, src) * (size_t)S * 8; }
+SSF_HD size_t p2p_off_matched(int S, int par, int src) { return SSF_P2P_HEADER + 16 * (size_t)S * 8 + p2p_slot(par, src) * p2p_spad(S); }
+SSF_HD size_t p2p_off_migr(int S, int par, int src) {
+    return SSF_P2P_HEADER + 16 * (size_t)S * 8 + 16 * p2p_spad(S) + p2p_slot(par, src) * (size_t)S * SSF_MIGRANT_WORDS * 4;
+}
+SSF_HD size_t p2p_region_bytes(int S) { return p2p_off_migr(S, 1, SSF_P2P_MAX_RANKS - 1) + (size_t)S * SSF_MIGRANT_WORDS * 4; }
+// launch_icp with pv != nullptr: the launch's last workgroup exchanges the shard record with the peers (pv->seq) and
+// publishes the SUM over the ranks (device record + mailbox), one launch per iteration as on a single GPU
+void launch_p2p_counts(hipStream_t st, const P2PView& pv, const Counters* cnt, Mailbox* mb, unsigned long long all_seq);
+void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched);
+void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket /* 65 zeroed words */);
 void launch_publish_icp(hipStream_t st, const long long* rec29, Mailbox* mb, unsigned long long seq);
 void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mailbox* mb, unsigned long long seq);
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones

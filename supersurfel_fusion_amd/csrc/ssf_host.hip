@@ -393,6 +393,13 @@ struct ssf_handle {
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
     ncclComm_t comm = nullptr; int* d_all5 = nullptr;
+    // ... or the peer-to-peer exchange region of ssf_p2p_* (one node; no collective launches): own region, the peers'
+    // regions as mapped into this process, and one sequence number per exchange kind (identical on every rank)
+    struct P2P {
+        unsigned char* region = nullptr; size_t bytes = 0; bool fine = false;
+        P2PView view{}; bool on = false; std::vector<void*> opened;
+        unsigned long long seq_icp = 0, seq_cnt = 0, seq_assoc = 0, seq_migr = 0;
+    } p2p;
     unsigned long long all_seq = 0; bool all_pending = false, all_valid = false;
     long long all_cnt[5 * SSF_MAX_RANKS];
     SurfelSoA model[2]; int mcur = 0;
@@ -946,7 +953,7 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).
         NextFrameIcp next{};
         bool have_next = false;
-        if (h->icp_ahead && !h->comm && h->cfg.nranks == 1 && h->cfg.icp_iter > 0 && !h->pending.empty()) {
+        if (h->icp_ahead && !h->comm && !h->p2p.on && h->cfg.nranks == 1 && h->cfg.icp_iter > 0 && !h->pending.empty()) {
             ExtractCtx& nc = h->ctx[h->pending.front().first];
             const int nslot = h->pending.front().second;
             const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
@@ -1024,11 +1031,15 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {          // no exchan
 
 // ---- multi-GPU exchanges (native RCCL on the track stream) -------------------------------------------------
 // enqueue the all-gather of every rank's Counters::last and its publication to the mailbox
+static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
 static int comm_gather_counts(ssf_handle* h) {
-    RcclApi* api = rccl_api();
-    NCK(api->AllGather(h->d_cnt->last, h->d_all5, 5, ncclInt32, h->comm, h->stream));
     const unsigned long long seq = ++h->all_seq;
-    launch_publish_all_counts(h->stream, h->d_all5, h->cfg.nranks, h->mb_dev, seq);
+    if (h->p2p.on) launch_p2p_counts(h->stream, p2p_view(h, ++h->p2p.seq_cnt), h->d_cnt, h->mb_dev, seq);
+    else {
+        RcclApi* api = rccl_api();
+        NCK(api->AllGather(h->d_cnt->last, h->d_all5, 5, ncclInt32, h->comm, h->stream));
+        launch_publish_all_counts(h->stream, h->d_all5, h->cfg.nranks, h->mb_dev, seq);
+    }
     HCK(hipGetLastError());
     h->all_pending = true;
     return SSF_OK;
@@ -1116,12 +1127,13 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     const bool timing = h->cfg.profile != 0 && h->cc->ctx->timed;     // stage split costs an event synchronise: opt-in
     if (timing) HCK(hipEventRecord(h->ev[1], h->stream));
     RcclApi* api = h->comm ? rccl_api() : nullptr;
-    if (h->comm) { rc = comm_counts(h); if (rc) return rc; }
+    const bool exchanging = h->comm || h->p2p.on;          // a shard of a map that runs its exchanges natively
+    if (exchanging) { rc = comm_counts(h); if (rc) return rc; }
     icp_begin(h, prior);
     int again = h->icp.active ? 1 : 0, valid = 0;
     // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
     // already launched and waits on the device for its transform
-    const bool chain = h->icp_chain && h->go && !h->comm && h->cfg.nranks == 1 && h->cfg.profile != 1;
+    const bool chain = h->icp_chain && h->go && !exchanging && h->cfg.nranks == 1 && h->cfg.profile != 1;
     bool waiting = false; unsigned long long wait_seq_rec = 0, wait_go_seq = 0; IcpGo* wait_slot = nullptr;
     while (again) {
         if (chain) {
@@ -1152,7 +1164,17 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             icp_update(h, (const int64_t*)h->h_icp, &again);
             continue;
         }
-        if (h->comm) {
+        if (h->p2p.on) {
+            // one launch: its last workgroup trades the shard record with the peers through the exchange regions and
+            // publishes the SUM over the ranks (exact: int64)
+            const Rt T = icp_transform(h->icp);
+            const unsigned long long seq = ++h->icp_seq;
+            const P2PView pv = p2p_view(h, ++h->p2p.seq_icp);
+            launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
+                       h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, nullptr, 0, &pv);
+            HCK(hipGetLastError());
+            rc = icp_fetch(h, seq);
+        } else if (h->comm) {
             // shard record -> SUM over the ranks in HBM (exact: int64) -> mailbox -> host solve
             rc = icp_accumulate(h, false);
             if (rc) return rc;
@@ -1177,23 +1199,25 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
     rc = do_match(h);
     if (rc) return rc;
-    if (h->comm) {
+    if (h->p2p.on) launch_p2p_assoc(h->stream, p2p_view(h, ++h->p2p.seq_assoc), h->cc->d_best, h->cc->d_matched);
+    else if (h->comm) {
         // best key over the ranks (keys < 2^63: signed MIN == unsigned MIN), matched = OR over the ranks
         NCK(api->AllReduce(h->cc->d_best, h->cc->d_best, h->S, ncclInt64, ncclMin, h->comm, h->stream));
         NCK(api->AllReduce(h->cc->d_matched, h->cc->d_matched, h->S, ncclUint8, ncclMax, h->comm, h->stream));
     }
     ssf_frame_result r;
-    if (h->comm) {
+    if (exchanging) {
         // rows whose fused position crossed a tile edge move to the rank that owns their new tile: every rank's
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
         rc = fuse_begin(h, 1);
         if (rc) return rc;
-        if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
+        if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 128);
+        else if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
         rc = fuse_end(h, h->d_migrants, &r);
     } else
         rc = do_fuse(h, &r);
     if (rc) return rc;
-    if (h->comm) { rc = comm_gather_counts(h); if (rc) return rc; }     // read at the start of the next frame
+    if (exchanging) { rc = comm_gather_counts(h); if (rc) return rc; }     // read at the start of the next frame
     h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
     if (timing) {
         HCK(hipEventRecord(h->ev[3], h->stream));
@@ -1259,6 +1283,8 @@ void ssf_destroy(ssf_handle* h) {
     for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
+    for (void* q : h->p2p.opened) (void)hipIpcCloseMemHandle(q);
+    if (h->p2p.region) (void)hipFree(h->p2p.region);
     for (auto& c : h->ctx) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
@@ -1635,9 +1661,78 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) {
     h->all_valid = false; h->all_pending = false;
     return SSF_OK;
 }
+// ---- multi-GPU (native, peer to peer: no collective launches) ---------------------------------------------------
+static int p2p_region(ssf_handle* h) {
+    if (h->p2p.region) return SSF_OK;
+    if (h->cfg.nranks > SSF_P2P_MAX_RANKS) { h->err = "the peer-to-peer exchange serves at most 8 ranks (one node)"; return SSF_ERR_INVALID_ARG; }
+    HCK(hipSetDevice(h->cfg.device_id));
+    const size_t bytes = p2p_region_bytes(h->S);
+    void* q = nullptr;
+    // uncached / fine-grained device memory: what a peer stores is visible to a kernel that is already running
+    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) h->p2p.fine = true;
+    else if ((void)hipGetLastError(), hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) == hipSuccess) h->p2p.fine = true;
+    else { (void)hipGetLastError(); HCK(hipMalloc(&q, bytes)); }
+    HCK(hipMemset(q, 0, bytes));
+    HCK(hipDeviceSynchronize());
+    h->p2p.region = (unsigned char*)q; h->p2p.bytes = bytes;
+    return SSF_OK;
+}
+int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes) {
+    if (!h || !region) return SSF_ERR_INVALID_ARG;
+    int rc = p2p_region(h);
+    if (rc) return rc;
+    *region = h->p2p.region; if (bytes) *bytes = h->p2p.bytes;
+    return SSF_OK;
+}
+int ssf_p2p_export(ssf_handle* h, uint8_t* handle64) {
+    if (!h || !handle64) return SSF_ERR_INVALID_ARG;
+    int rc = p2p_region(h);
+    if (rc) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) == SSF_P2P_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t ih;
+    HCK(hipIpcGetMemHandle(&ih, h->p2p.region));
+    std::memcpy(handle64, &ih, sizeof(ih));
+    return SSF_OK;
+}
+static int p2p_finish_attach(ssf_handle* h) {
+    h->p2p.view.me = h->cfg.rank; h->p2p.view.nranks = h->cfg.nranks; h->p2p.view.S = h->S; h->p2p.view.seq = 0;
+    h->p2p.on = true;
+    h->all_valid = false; h->all_pending = false;
+    return SSF_OK;
+}
+static int p2p_attach_check(ssf_handle* h) {
+    if (h->comm || h->p2p.on) { h->err = "an exchange backend is already attached"; return SSF_ERR_STATE; }
+    if (h->stamp != 0 && h->cfg.nranks > 1) { /* joining later is fine as long as every rank does so at the same frame */ }
+    return p2p_region(h);
+}
+int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles) {
+    if (!h || !handles) return SSF_ERR_INVALID_ARG;
+    int rc = p2p_attach_check(h);
+    if (rc) return rc;
+    for (int r = 0; r < h->cfg.nranks; r++) {
+        if (r == h->cfg.rank) { h->p2p.view.peer[r] = h->p2p.region; continue; }
+        hipIpcMemHandle_t ih;
+        std::memcpy(&ih, handles + (size_t)SSF_P2P_HANDLE_BYTES * r, sizeof(ih));
+        void* q = nullptr;
+        HCK(hipIpcOpenMemHandle(&q, ih, hipIpcMemLazyEnablePeerAccess));
+        h->p2p.opened.push_back(q);
+        h->p2p.view.peer[r] = (unsigned char*)q;
+    }
+    return p2p_finish_attach(h);
+}
+int ssf_p2p_attach_local(ssf_handle* h, void* const* regions) {
+    if (!h || !regions) return SSF_ERR_INVALID_ARG;
+    int rc = p2p_attach_check(h);
+    if (rc) return rc;
+    for (int r = 0; r < h->cfg.nranks; r++) {
+        if (r != h->cfg.rank && !regions[r]) { h->err = "a peer region is missing"; return SSF_ERR_INVALID_ARG; }
+        h->p2p.view.peer[r] = r == h->cfg.rank ? h->p2p.region : (unsigned char*)regions[r];
+    }
+    return p2p_finish_attach(h);
+}
 int ssf_get_global_counts(ssf_handle* h, int64_t* out5) {
     if (!h || !out5) return SSF_ERR_INVALID_ARG;
-    if (!h->comm) {
+    if (!h->comm && !h->p2p.on) {
         int rc = hipStreamSynchronize(h->stream) == hipSuccess ? SSF_OK : SSF_ERR_DEVICE;
         Counters c;
         if (rc || hipMemcpy(&c, h->d_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { h->err = "device error"; return SSF_ERR_DEVICE; }

@@ -125,9 +125,61 @@ __device__ __forceinline__ int grid_arrive(unsigned int* ticket) {
     }
     return last;
 }
-// ... and, in the last workgroup, sum the replicas and publish the record
+// ---- peer-to-peer exchange helpers (ssf_device.hpp: P2PView) ----------------------------------------------------------
+__device__ __forceinline__ unsigned char* p2p_peer(const P2PView& pv, int r) {       // uniform select chain (no dynamic kernarg indexing)
+    unsigned char* v = pv.peer[0];
+#pragma unroll
+    for (int i = 1; i < SSF_P2P_MAX_RANKS; i++) v = (r == i) ? pv.peer[i] : v;
+    return v;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)v, src), hi = (unsigned int)__shfl((int)(unsigned int)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define P2P_SPIN_BOUND (1 << 22)      // ~seconds: a peer that never arrives must not hang the device
+// Wave 0 of the last workgroup: this rank's record (tot in lanes 0..28) goes into slot [parity][me] of every peer's region
+// as five self-validating lines (the format of Mailbox::icp_rec); the records of the others are awaited in this rank's
+// own region and added in rank order.  Returns false when a peer's record never arrived.
+__device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, long long& tot, unsigned long long* pay /* LDS, 30 */) {
+    const int l = lane();
+    const unsigned long long seq = pv.seq;
+    const int par = (int)(seq & 1ull);
+    if (l < 29) pay[l] = (unsigned long long)tot;
+    const unsigned long long check = (unsigned long long)wsum64(l < 29 ? tot : 0ll) + seq;
+    if (l == 0) pay[29] = check;
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): one wave, its LDS writes have landed
+    const unsigned long long word = l < 40 ? SSF_ICP_REC_WORD(l, pay, seq) : 0ull;
+#pragma unroll
+    for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
+        if (r >= pv.nranks || r == pv.me) continue;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_icp(par, pv.me));
+        if (l < 40) __hip_atomic_store(&dst[l], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    unsigned char* mine = p2p_peer(pv, pv.me);
+    const bool is_seq_word = l < 40 && (l & 7) == 7, is_payload = l < 40 && (l & 7) != 7 && (7 * (l >> 3) + (l & 7)) < 29;
+    int spins = 0;
+    for (int r = 0; r < pv.nranks; r++) {
+        if (r == pv.me) continue;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(mine + p2p_off_icp(par, r));
+        for (;;) {
+            const unsigned long long w = l < 40 ? __hip_atomic_load(&src[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            const bool lines_ok = __ballot(is_seq_word && w != seq) == 0ull;
+            const unsigned long long sum = (unsigned long long)wsum64(is_payload ? (long long)w : 0ll) + seq;
+            if (lines_ok && sum == shfl_u64(w, 33)) {                   // payload word 29 (the checksum) sits in lane 8 * 4 + 1
+                const unsigned long long v = shfl_u64(w, l < 29 ? 8 * (l / 7) + l % 7 : 0);       // payload word l of the peer
+                if (l < 29) tot += (long long)v;
+                break;
+            }
+            if (++spins > P2P_SPIN_BOUND) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+// ... and, in the last workgroup, sum the replicas and publish the record (P2P: the SUM of the records of all ranks)
+template <bool P2P>
 __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, long long* __restrict__ sums, Mailbox* mb,
-                                            unsigned long long seq) {
+                                            unsigned long long seq, const P2PView& pv) {
     // SSF_ICP_REPLICAS x 32 replica words: thread t sums field t & 31 over every 8th replica (independent
     // loads, one round trip), then 8 partial rows are folded through LDS
     __shared__ long long part[8 * 32];
@@ -146,8 +198,10 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
     if (threadIdx.x < 64) {
         __shared__ unsigned long long pay[30];
         long long tot = 0;
-        if (threadIdx.x < 29) {
+        if (threadIdx.x < 29)
             for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
+        if (P2P) { if (!p2p_icp_exchange(pv, tot, pay)) return; }      // (no record: the host reports the missing peer)
+        if (threadIdx.x < 29) {
             sums[threadIdx.x] = tot;
             pay[threadIdx.x] = (unsigned long long)tot;
         }
@@ -160,11 +214,12 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
             __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+template <bool P2P>
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
-                                             IcpGo* go, unsigned long long go_seq) {
+                                             IcpGo* go, unsigned long long go_seq, P2PView pv) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
@@ -208,7 +263,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     icp_fold(red, replicas);
     if (threadIdx.x == 0) s_last = grid_arrive(ticket);
     __syncthreads();
-    if (s_last) icp_publish(replicas, sums, mb, seq);
+    if (s_last) icp_publish<P2P>(replicas, sums, mb, seq, pv);
 }
 
 // ---- loop-closure registration (DenseRegistration::align) -----------------------------------------------------
@@ -1054,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             s_last = last;
         }
         __syncthreads();
-        if (s_last) icp_publish(nx.replicas, nx.sums, nx.mb, nx.seq);
+        if (s_last) { const P2PView none{}; icp_publish<false>(nx.replicas, nx.sums, nx.mb, nx.seq, none); }
     }
 }
 
@@ -1289,10 +1344,167 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
     st3(M.pos, i, po);
 }
 
+// ---- peer-to-peer exchanges of the fuse stage (ssf_device.hpp: P2PView) ----------------------------------------------------
+// shard sizes: one self-validating line per rank (Counters::last, checksum, sequence number) -> every peer; the lines of
+// all ranks -> the host mailbox (as k_publish_all_counts).  One wave.
+__global__ void k_p2p_counts(P2PView pv, const Counters* __restrict__ cnt, Mailbox* mb, unsigned long long all_seq) {
+    const int l = lane();
+    const unsigned long long seq = pv.seq;
+    const int par = (int)(seq & 1ull);
+    const unsigned int a = (unsigned int)cnt->last[0], b = (unsigned int)cnt->last[1], c = (unsigned int)cnt->last[2],
+                       d = (unsigned int)cnt->last[3], e = (unsigned int)cnt->last[4];
+    const unsigned long long w0 = a | ((unsigned long long)b << 32), w1 = c | ((unsigned long long)d << 32), w2 = e;
+    const unsigned long long mine_word = l == 0 ? w0 : l == 1 ? w1 : l == 2 ? w2 : l == 6 ? w0 + w1 + w2 + seq : l == 7 ? seq : 0ull;
+#pragma unroll
+    for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
+        if (r >= pv.nranks || r == pv.me) continue;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_cnt(par, pv.me));
+        if (l < 8) __hip_atomic_store(&dst[l], mine_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    unsigned char* mine = p2p_peer(pv, pv.me);
+    unsigned long long part = 0;
+    int spins = 0;
+    for (int r = 0; r < pv.nranks; r++) {
+        unsigned long long w = mine_word;
+        if (r != pv.me) {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(mine + p2p_off_cnt(par, r));
+            for (;;) {
+                w = l < 8 ? __hip_atomic_load(&src[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+                const unsigned long long sum = (unsigned long long)wsum64(l < 3 ? (long long)w : 0ll) + seq;
+                if (shfl_u64(w, 7) == seq && shfl_u64(w, 6) == sum) break;
+                if (++spins > P2P_SPIN_BOUND) return;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (l < 3) {
+            const int lo = (int)(unsigned int)w, hi = (int)(unsigned int)(w >> 32);
+            __hip_atomic_store(&mb->all_cnt[5 * r + 2 * l], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            part += (unsigned long long)(unsigned int)lo;
+            if (l < 2) { __hip_atomic_store(&mb->all_cnt[5 * r + 2 * l + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); part += (unsigned long long)(unsigned int)hi; }
+        }
+    }
+    const unsigned long long check = (unsigned long long)wsum64((long long)part) + all_seq;
+    if (l == 0) __hip_atomic_store(&mb->all_check, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (l == 0) __hip_atomic_store(&mb->all_seq, all_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// thread 0: every peer's flag line of `kind` carries pv.seq (its data stores were acknowledged before the flag left)
+__device__ __forceinline__ bool p2p_wait_flags(const P2PView& pv, int kind) {
+    unsigned char* mine = p2p_peer(pv, pv.me);
+    const int par = (int)(pv.seq & 1ull);
+    int spins = 0;
+    for (int r = 0; r < pv.nranks; r++) {
+        if (r == pv.me) continue;
+        const unsigned long long* f = reinterpret_cast<const unsigned long long*>(mine + p2p_off_flag(kind, par, r));
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pv.seq) {
+            if (++spins > P2P_SPIN_BOUND) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ void p2p_raise_flags(const P2PView& pv, int kind) {       // threads 0..nranks-1, after a barrier
+    const int par = (int)(pv.seq & 1ull);
+    const int r = threadIdx.x;
+    if (r < pv.nranks && r != pv.me)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p2p_peer(pv, r) + p2p_off_flag(kind, par, pv.me)), pv.seq,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// association tables: this rank's best[] / matched[] -> every peer, then best := MIN, matched := OR over the ranks.
+// One workgroup (S entries of 9 bytes).
+__global__ __launch_bounds__(1024) void k_p2p_assoc(P2PView pv, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+    const int par = (int)(pv.seq & 1ull), S = pv.S;
+    __shared__ int s_ok;
+#pragma unroll
+    for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
+        if (r >= pv.nranks || r == pv.me) continue;
+        unsigned long long* db = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_best(S, par, pv.me));
+        uint8_t* dm = pv.peer[r] + p2p_off_matched(S, par, pv.me);
+        for (int i = threadIdx.x; i < S; i += blockDim.x) {
+            __hip_atomic_store(&db[i], best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dm[i], matched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store above has been acknowledged by its destination
+    __syncthreads();
+    p2p_raise_flags(pv, P2P_FLAG_ASSOC);
+    if (threadIdx.x == 0) s_ok = p2p_wait_flags(pv, P2P_FLAG_ASSOC) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) return;
+    unsigned char* mine = p2p_peer(pv, pv.me);
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        unsigned long long b = best[i]; uint8_t m = matched[i];
+        for (int r = 0; r < pv.nranks; r++) {
+            if (r == pv.me) continue;
+            const unsigned long long* sb = reinterpret_cast<const unsigned long long*>(mine + p2p_off_best(S, par, r));
+            const uint8_t* sm = mine + p2p_off_matched(S, par, r);
+            const unsigned long long ob = __hip_atomic_load(&sb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint8_t om = __hip_atomic_load(&sm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = ob < b ? ob : b; m = om > m ? om : m;
+        }
+        best[i] = b; matched[i] = m;
+    }
+}
+// migrant table: slot f of this rank's table -> slot f of [parity][me] in every peer (an empty slot sends its first two
+// words only); the last workgroup to finish raises the flags.  One thread per slot.
+__global__ __launch_bounds__(256) void k_p2p_migr_share(P2PView pv, const int32_t* __restrict__ table, unsigned int* ticket) {
+    const int par = (int)(pv.seq & 1ull), S = pv.S;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < S) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(table + (size_t)SSF_MIGRANT_WORDS * f);
+        unsigned long long w[SSF_MIGRANT_WORDS / 2];
+        w[0] = src[0];
+        const bool full = (unsigned int)w[0] != 0u;
+#pragma unroll
+        for (int k = 1; k < SSF_MIGRANT_WORDS / 2; k++) w[k] = full ? src[k] : 0ull;
+#pragma unroll
+        for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
+            if (r >= pv.nranks || r == pv.me) continue;
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_migr(S, par, pv.me)) + (size_t)(SSF_MIGRANT_WORDS / 2) * f;
+            __hip_atomic_store(&dst[0], w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (full) {
+#pragma unroll
+                for (int k = 1; k < SSF_MIGRANT_WORDS / 2; k++) __hip_atomic_store(&dst[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = grid_arrive(ticket);
+    __syncthreads();
+    if (s_last) p2p_raise_flags(pv, P2P_FLAG_MIGR);
+}
+// ... and the peers' slots are added into this rank's table (at most one rank fills a slot: the sum is the union)
+__global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __restrict__ table) {
+    const int par = (int)(pv.seq & 1ull), S = pv.S;
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_ok = p2p_wait_flags(pv, P2P_FLAG_MIGR) ? 1 : 0;
+    __syncthreads();
+    if (!s_ok) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= S) return;
+    unsigned char* mine = p2p_peer(pv, pv.me);
+    int32_t* own = table + (size_t)SSF_MIGRANT_WORDS * f;
+    for (int r = 0; r < pv.nranks; r++) {
+        if (r == pv.me) continue;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(mine + p2p_off_migr(S, par, r)) + (size_t)(SSF_MIGRANT_WORDS / 2) * f;
+        const unsigned long long w0 = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)w0 == 0u) continue;
+        own[0] += (int32_t)(unsigned int)w0; own[1] += (int32_t)(unsigned int)(w0 >> 32);
+#pragma unroll
+        for (int k = 1; k < SSF_MIGRANT_WORDS / 2; k++) {
+            const unsigned long long w = __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            own[2 * k] += (int32_t)(unsigned int)w; own[2 * k + 1] += (int32_t)(unsigned int)(w >> 32);
+        }
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
-                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq) {
+                long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq,
+                const P2PView* pv) {
     ScopedKernel sk("icp_accumulate", st);
     static int per_lane = 0;             // supersurfels per lane before the wave reduction
     if (!per_lane) { const char* e = getenv("SSF_ICP_PER_LANE"); per_lane = e ? atoi(e) : 1; if (per_lane < 1) per_lane = 1; }
@@ -1301,8 +1513,14 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
     if (grid > 4096) grid = 4096;
     const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
-    hipLaunchKernelGGL(k_icp, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
-                       ticket, sums29, mb, seq, dbg, go, go_seq);
+    if (pv)
+        hipLaunchKernelGGL(k_icp<true>, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
+                           ticket, sums29, mb, seq, dbg, go, go_seq, *pv);
+    else {
+        const P2PView none{};
+        hipLaunchKernelGGL(k_icp<false>, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
+                           ticket, sums29, mb, seq, dbg, go, go_seq, none);
+    }
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
@@ -1382,6 +1600,20 @@ void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, i
                        const uint8_t* frgb, const float* fdepth, int n, uint8_t* codes) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_fern_codes, dim3((n + 63) / 64), dim3(64), 0, st, rgb, depth, W, H, fpos, frgb, fdepth, n, codes);
+}
+void launch_p2p_counts(hipStream_t st, const P2PView& pv, const Counters* cnt, Mailbox* mb, unsigned long long all_seq) {
+    ScopedKernel sk("p2p_counts", st);
+    hipLaunchKernelGGL(k_p2p_counts, dim3(1), dim3(64), 0, st, pv, cnt, mb, all_seq);
+}
+void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched) {
+    ScopedKernel sk("p2p_assoc", st);
+    hipLaunchKernelGGL(k_p2p_assoc, dim3(1), dim3(1024), 0, st, pv, best, matched);
+}
+void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket) {
+    ScopedKernel sk("p2p_migrants", st);
+    const int grid = (pv.S + 255) / 256;
+    hipLaunchKernelGGL(k_p2p_migr_share, dim3(grid), dim3(256), 0, st, pv, table, ticket);
+    hipLaunchKernelGGL(k_p2p_migr_gather, dim3(grid), dim3(256), 0, st, pv, table);
 }
 void launch_publish_icp(hipStream_t st, const long long* rec, Mailbox* mb, unsigned long long seq) {
     hipLaunchKernelGGL(k_publish_icp, dim3(1), dim3(64), 0, st, rec, mb, seq);
