@@ -236,6 +236,7 @@ struct NextFrameIcp {
     const uint2* pix2; const float4* fpack;   // packed tables of the next frame
     Rt T;                                     // model -> camera transform of that iteration
     long long* replicas; unsigned int* ticket; long long* sums; unsigned long long seq;
+    const struct P2PView* pv;                 // non-null: the record is traded with the peers (see P2PView below)
 };
 // Model store: the visible rows are a dense array (two of them, ping-pong); the out-of-view
 // rows live in a deque-like store with a live flag per row.  The per-frame stable partition

@@ -736,7 +736,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     return to_host ? icp_fetch(h, seq) : SSF_OK;
 }
 // wait for mailbox record `seq` and copy it to h->h_icp_local
-static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T);
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq = 0);
 // waiter: a launch made ahead that is waiting on the device for the host's word (chained ICP launches).  Before the stream
 // is drained it is told to leave (*waiter_dismissed = true): it would otherwise hold the stream until its own bound expires.
 static int icp_fetch(ssf_handle* h, unsigned long long seq, IcpGo* waiter, unsigned long long waiter_go_seq, bool* waiter_dismissed) {
@@ -903,6 +903,8 @@ static int do_match(ssf_handle* h) {
 // final counters come back through the mailbox (no D2H copy, no stream synchronise).  In two halves: between them a
 // sharded map exchanges the rows that crossed a tile edge (migrate: fuse_begin leaves this shard's migrant table in
 // h->d_migrants; fuse_end takes the rank-reduced table, or nullptr when nothing can arrive).
+static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
+static int comm_gather_counts(ssf_handle* h);
 static int fuse_begin(ssf_handle* h, int migrate) {
     const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis_g = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
@@ -952,8 +954,9 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         // reads, under a transform that is known now (the pose just estimated, when the caller supplies no prior):
         // if that frame's extract has finished, the move kernel accumulates the record on the way (k_move_rows<true>).
         NextFrameIcp next{};
+        P2PView next_pv{};
         bool have_next = false;
-        if (h->icp_ahead && !h->comm && !h->p2p.on && h->cfg.nranks == 1 && h->cfg.icp_iter > 0 && !h->pending.empty()) {
+        if (h->icp_ahead && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.icp_iter > 0 && !h->pending.empty()) {
             ExtractCtx& nc = h->ctx[h->pending.front().first];
             const int nslot = h->pending.front().second;
             const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
@@ -967,6 +970,7 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
                 next.pix2 = nm.pix2; next.fpack = nm.fpack; next.T = icp_transform(first);
                 next.replicas = h->d_icp_replicas; next.ticket = h->d_tickets + 8; next.sums = h->d_icp;
                 next.seq = ++h->icp_seq;
+                if (h->p2p.on) { next_pv = p2p_view(h, ++h->p2p.seq_icp); next.pv = &next_pv; }
                 h->ahead.valid = true; h->ahead.seq = next.seq; h->ahead.ctx = &nc; h->ahead.slot = nslot;
                 h->ahead.stamp = h->stamp + 1; h->ahead.pose = h->pose;
                 have_next = true;
@@ -975,6 +979,9 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         // move: the host continues once the counters arrive (published by the fuse launch), the row moves of this
         // frame overlap the host-side launch work of the next one (stream order keeps every later reader of the
         // model behind them)
+        // (a sharded map: the shard sizes of all ranks are exchanged now -- the counters are final -- so that the next
+        // frame does not have to wait for the row moves to learn them)
+        if (h->comm || h->p2p.on) { int rg = comm_gather_counts(h); if (rg) return rg; }
         launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + (h->fuse_migrate ? 2 : 1) * h->S, h->oov_tail - h->oov_head,
                          h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
         h->mcur ^= 1;
@@ -982,6 +989,7 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
                            h->cfg.shard_tile, h->d_cnt);
         launch_publish_counts(h->stream, h->d_cnt, 0, h->mb_dev, seq);
+        if (h->comm || h->p2p.on) { int rg = comm_gather_counts(h); if (rg) return rg; }
     }
     HCK(hipGetLastError());
     { int rr = retire_active(h); if (rr) return rr; }     // last reader of this frame's buffers is enqueued
@@ -1031,7 +1039,6 @@ static int do_fuse(ssf_handle* h, ssf_frame_result* out) {          // no exchan
 
 // ---- multi-GPU exchanges (native RCCL on the track stream) -------------------------------------------------
 // enqueue the all-gather of every rank's Counters::last and its publication to the mailbox
-static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
 static int comm_gather_counts(ssf_handle* h) {
     const unsigned long long seq = ++h->all_seq;
     if (h->p2p.on) launch_p2p_counts(h->stream, p2p_view(h, ++h->p2p.seq_cnt), h->d_cnt, h->mb_dev, seq);
@@ -1078,8 +1085,9 @@ static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo*
     const unsigned long long go_seq = ++h->go_count;
     IcpGo* slot = h->go + (go_seq % SSF_ICP_GO_SLOTS);
     Rt none; none.R = m3_identity(); none.t = v3(0, 0, 0);
+    const P2PView pv = h->p2p.view;               // (the number of the peer exchange arrives with the go word)
     launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, none,
-               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq);
+               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq, h->p2p.on ? &pv : nullptr);
     HCK(hipGetLastError());
     *seq_out = seq; *slot_out = slot; *go_seq_out = go_seq;
     return SSF_OK;
@@ -1103,9 +1111,10 @@ static void icp_chain_reset(ssf_handle* h) {
     h->icp_chain = false; h->ahead.valid = false;
 }
 // the host's word to a waiting launch: its transform and "go", or "no further iteration"
-static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T) {
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq) {
     volatile IcpGo* s = slot;
     if (T) {
+        s->pad[0] = p2p_seq;
         const float v[12] = {T->R.r0.x, T->R.r0.y, T->R.r0.z, T->R.r1.x, T->R.r1.y, T->R.r1.z, T->R.r2.x, T->R.r2.y, T->R.r2.z,
                              T->t.x, T->t.y, T->t.z};
         for (int i = 0; i < 12; i++) s->T[i] = v[i];
@@ -1133,7 +1142,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     int again = h->icp.active ? 1 : 0, valid = 0;
     // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
     // already launched and waits on the device for its transform
-    const bool chain = h->icp_chain && h->go && !exchanging && h->cfg.nranks == 1 && h->cfg.profile != 1;
+    // (with the peer-to-peer exchange too: there an iteration is one launch as well; every rank takes the same decisions)
+    const bool chain = h->icp_chain && h->go && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.profile != 1;
     bool waiting = false; unsigned long long wait_seq_rec = 0, wait_go_seq = 0; IcpGo* wait_slot = nullptr;
     while (again) {
         if (chain) {
@@ -1141,13 +1151,15 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             if (h->icp.ahead_seq) { seq_rec = h->icp.ahead_seq; h->icp.ahead_seq = 0; }     // iteration 1 came from the move kernel
             else if (waiting) {                                                                 // this iteration is already on the device
                 const Rt T = icp_transform(h->icp);
-                icp_release_waiting(wait_slot, wait_go_seq, &T);
+                icp_release_waiting(wait_slot, wait_go_seq, &T, h->p2p.on ? ++h->p2p.seq_icp : 0);
                 seq_rec = wait_seq_rec; waiting = false;
             } else {
                 const Rt T = icp_transform(h->icp);
                 seq_rec = ++h->icp_seq;
+                P2PView pv{};
+                if (h->p2p.on) pv = p2p_view(h, ++h->p2p.seq_icp);
                 launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
-                           h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec);
+                           h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec, -1, nullptr, 0, h->p2p.on ? &pv : nullptr);
                 HCK(hipGetLastError());
             }
             // the next iteration, should there be one (the loop may run cfg.icp_iter iterations at most)
@@ -1211,13 +1223,12 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
         rc = fuse_begin(h, 1);
         if (rc) return rc;
-        if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 128);
+        if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320);
         else if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
         rc = fuse_end(h, h->d_migrants, &r);
     } else
         rc = do_fuse(h, &r);
     if (rc) return rc;
-    if (exchanging) { rc = comm_gather_counts(h); if (rc) return rc; }     // read at the start of the next frame
     h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
     if (timing) {
         HCK(hipEventRecord(h->ev[3], h->stream));

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
     __shared__ int s_go;
+    __shared__ unsigned long long s_p2p_seq;
     for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
     if (go) {
         // launched ahead of its transform: wait for the host's word (bounded: a lost word must not hang the device)
@@ -240,14 +241,19 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
             // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
             // through the BAR cost the launch behind this one 3 us per frame.)
             if (!told) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (ok)
+            if (ok) {
                 for (int i = 0; i < 12; i++) s_T[i] = __hip_atomic_load(&go->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (a launch made ahead learns the number of its peer exchange with its transform: a dismissed launch must
+                // not use one up, the two slot parities of the exchange regions rely on consecutive numbers)
+                if (P2P) s_p2p_seq = __hip_atomic_load(&go->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             s_go = ok;
         }
         __syncthreads();
         if (!s_go) return;
         T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
         T.t = v3(s_T[9], s_T[10], s_T[11]);
+        if (P2P) pv.seq = s_p2p_seq;
     }
     __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
@@ -952,12 +958,13 @@ struct NextIcp {
 // iteration reads, and its transform (inverse of the pose just estimated) is already known: accumulate that record
 // here, while the rows are in registers, against the next frame's packed tables (the sums are exact integers, so
 // the order of accumulation does not matter), and publish it like k_icp does.
-template <bool ICP>
+// P2P (with ICP): the record is this shard's; the publishing workgroup trades it with the peers as k_icp<true> does.
+template <bool ICP, bool P2P>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
                                                    const uint8_t* __restrict__ state_oov,
                                                    const uint32_t* __restrict__ bc_oov, PartitionWs ws,
                                                    const Counters* __restrict__ cnt, int nb_vis, NextIcp nx, Mailbox* mb,
-                                                   unsigned long long cnt_seq) {
+                                                   unsigned long long cnt_seq, P2PView pv) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     // the frame's counters (finalised by the fuse launch, cnt[1]) go to the host while the rows move
     if (blockIdx.x == 0 && threadIdx.x == 255) {
@@ -1080,6 +1087,10 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         // global row counter.  The few out-of-view blocks with rows that come back into view go there directly.
         // No rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
         const int nkeep = __syncthreads_count(keep);
+        if (P2P && cnt->n_visible == 0) {          // an empty shard still owes its peers a (zero) record
+            if (blockIdx.x == 0) icp_publish<true>(nx.replicas, nx.sums, nx.mb, nx.seq, pv);
+            return;
+        }
         const bool vis = (int)blockIdx.x < nb_vis;
         const int nbr = (cnt->mv_nv + cnt->mv_nc + 255) / 256;
         if (vis ? (int)blockIdx.x >= nbr : nkeep == 0) return;
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             s_last = last;
         }
         __syncthreads();
-        if (s_last) { const P2PView none{}; icp_publish<false>(nx.replicas, nx.sums, nx.mb, nx.seq, none); }
+        if (s_last) icp_publish<P2P>(nx.replicas, nx.sums, nx.mb, nx.seq, pv);
     }
 }
 
@@ -1572,12 +1583,16 @@ void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelS
         nx.cam = cam; nx.pix2 = next->pix2; nx.fpack = next->fpack; nx.T = next->T; nx.replicas = next->replicas;
         nx.ticket = next->ticket; nx.sums = next->sums; nx.mb = mb; nx.seq = next->seq;
         ScopedKernel sk("reorder_move_icp", st);
-        hipLaunchKernelGGL(k_move_rows<true>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq);
+        if (next->pv)
+            hipLaunchKernelGGL((k_move_rows<true, true>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, *next->pv);
+        else
+            hipLaunchKernelGGL((k_move_rows<true, false>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
     } else {
         ScopedKernel sk("reorder_move", st);
-        hipLaunchKernelGGL(k_move_rows<false>, dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq);
+        hipLaunchKernelGGL((k_move_rows<false, false>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
     }
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
