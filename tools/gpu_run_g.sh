@@ -15,6 +15,7 @@ timeout 300 python bench.py --config 3 --extras 0 > $O/bench_config3.json 2> $O/
 timeout 300 python bench.py --config 4 --extras 0 --cpu-frames 0 > $O/bench_config4_1rank.json 2> $O/bench_config4.err
 timeout 300 python bench.py --config 5 --extras 0 --cpu-frames 0 > $O/bench_config5.json 2> $O/bench_config5.err
 timeout 300 python bench.py --force-sharded --extras 0 --cpu-frames 0 > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err
+timeout 300 python bench.py --force-sharded --comm p2p --extras 0 --cpu-frames 0 > $O/bench_one_rank_p2p.json 2> $O/bench_one_rank_p2p.err
 ( cd tools/ab/r01 && timeout 300 python bench.py --cpu-frames 0 ) > $O/r01_1200.json 2>> $O/r01.err
 ( cd tools/ab/r01 && timeout 300 python bench.py --cpu-frames 0 --pipeline-depth 0 --extract-batch 1 --steps 200 ) > $O/r01_latency.json 2>> $O/r01.err
 ( cd tools/ab/r01 && timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-frames 0 ) > $O/r01_s20.json 2>> $O/r01.err
