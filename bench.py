@@ -361,9 +361,11 @@ def main():
     # sequence starts with batches of batch/4 and batch/2 frames, continues with full ones and ends with what is left
     # (ssf_process_sequence): one short untimed sequence with exactly those sizes builds the graphs before the timing
     if batch > 1 and not (depth == 0 and batch == 1):
-        r0, r1 = max(1, batch // 4), max(1, batch // 2)
-        tail = (K - r0 - r1) % batch if K > r0 + r1 else 0
-        extra = r0 + r1 + batch + tail
+        ramp = [max(1, batch // 4), max(1, batch // 2)]
+        if os.environ.get("SSF_SEQ_RAMP"):          # (experiments: the library reads the same variable)
+            ramp = [min(batch, max(1, int(v))) for v in os.environ["SSF_SEQ_RAMP"].split(",") if v]
+        tail = (K - sum(ramp)) % batch if K > sum(ramp) else 0
+        extra = sum(ramp) + batch + tail
         run(Wm, extra)
         Wm += extra                                 # (reported as warmup_extra_frames)
     native_seq = not (depth == 0 and batch == 1) and drv is None

@@ -197,7 +197,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
                 unsigned long long go_seq = 0, const struct P2PView* pv = nullptr);
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const int32_t* label /* FrameMaps::label */, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
@@ -299,8 +299,9 @@ void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mail
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);
 void launch_pack_orient(hipStream_t st, SurfelSoA s, int n, float* out9);
-void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
-                        const float* ntrans, const float* w4, const int32_t* idx4);
+// m nodes; nodes24: scratch of 24 floats per node (the packed node records, see k_pack_nodes)
+void launch_deformation(hipStream_t st, SurfelSoA model, int n, int m, const float* npos, const float* nrot,
+                        const float* ntrans, float* nodes24, const float* w4, const int32_t* idx4);
 
 // profiling hook: every launch_* brackets its kernels through these (ssf_host.hip)
 struct KernelTimer;

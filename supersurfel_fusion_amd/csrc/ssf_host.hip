@@ -290,10 +290,34 @@ static RcclApi* rccl_api() {
 // buffers on a stream of its own; the submitting thread only makes the extract stream wait for the copy's event.
 // A sequence starts with small batches (a quarter, then half of extract_batch, then full ones): the first frame can
 // only be tracked when the whole first batch has been extracted, and a full batch of 8 takes twice as long as one of 2.
-static inline int seq_batch_size(int b, int batch) { return b == 0 ? std::max(1, batch / 4) : (b == 1 ? std::max(1, batch / 2) : batch); }
+// (SSF_SEQ_RAMP="a,b,..": sizes of the leading batches for experiments, each clamped to [1, batch].  Measured over the
+// driver's 20 timed frames, batch 8, three runs each: 2,4 (the default) 5900-5990 frames/s | 2,2 5880-5980 | 2 5760-5820 |
+// 3 5680-5810 | 2,8 5700-5810 | 1 5600-5780 | 4 5530-5560)
+struct SeqRamp { int n = -1; int size[8]; };
+static const SeqRamp& seq_ramp() {
+    static SeqRamp r;
+    if (r.n < 0) {
+        r.n = 0;
+        const char* e = getenv("SSF_SEQ_RAMP");
+        if (e) { for (const char* q = e; *q && r.n < 8;) { r.size[r.n++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
+        else { r.n = 2; r.size[0] = -4; r.size[1] = -2; }          // (negative: batch / |value|)
+    }
+    return r;
+}
+static inline int seq_batch_size(int b, int batch) {
+    const SeqRamp& r = seq_ramp();
+    if (b >= r.n) return batch;
+    const int v = r.size[b] < 0 ? batch / -r.size[b] : r.size[b];
+    return std::min(batch, std::max(1, v));
+}
 static inline int seq_batch_of(int i, int batch) {
-    const int r0 = seq_batch_size(0, batch), r1 = seq_batch_size(1, batch);
-    return i < r0 ? 0 : (i < r0 + r1 ? 1 : 2 + (i - r0 - r1) / batch);
+    int b = 0;
+    for (;; b++) {
+        const int sz = seq_batch_size(b, batch);
+        if (b >= seq_ramp().n) return b + i / batch;
+        if (i < sz) return b;
+        i -= sz;
+    }
 }
 // (a longer ramp -- 2, 4, 4, 6 before the batches of 8 -- was measured in round 2: 6100-6150 against 5960-6260 frames/s over
 // 20 timed frames, i.e. nothing)
@@ -893,7 +917,7 @@ static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.label, h->cc->maps.fpack, h->pose, h->cfg.range_min,
                  h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
     HCK(hipGetLastError());
     return SSF_OK;
@@ -2036,9 +2060,10 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
     const size_t n = h->n_model;
     if (n == 0) return SSF_OK;
-    float *d_np, *d_nr, *d_nt, *d_w; int32_t* d_i;
+    float *d_np, *d_nr, *d_nt, *d_w, *d_nodes; int32_t* d_i;
     DevTemps tmp;
     HCK(tmp.take(&d_np, 12 * (size_t)m)); HCK(tmp.take(&d_nr, 36 * (size_t)m)); HCK(tmp.take(&d_nt, 12 * (size_t)m));
+    HCK(tmp.take(&d_nodes, 96 * (size_t)m));
     HCK(tmp.take(&d_w, 16 * n)); HCK(tmp.take(&d_i, 16 * n));
     hipStream_t st = h->stream;
     HCK(hipMemcpyAsync(d_np, np, 12 * (size_t)m, hipMemcpyHostToDevice, st));
@@ -2048,7 +2073,7 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     HCK(hipMemcpyAsync(d_i, idx4, 16 * n, hipMemcpyHostToDevice, st));
     // applied to the dense logical view (weights are per logical row), then split back into the two stores
     { int rc = materialise(h); if (rc) return rc; }
-    { TimerScope ts(h); launch_deformation(st, h->dense, (int)n, d_np, d_nr, d_nt, d_w, d_i); }
+    { TimerScope ts(h); launch_deformation(st, h->dense, (int)n, m, d_np, d_nr, d_nt, d_nodes, d_w, d_i); }
     { int rc = store_from_dense(h, h->n_model, h->n_visible); if (rc) return rc; }
     HCK(hipStreamSynchronize(st));
     if (h->cfg.profile == 1) timer_collect(&h->timer);

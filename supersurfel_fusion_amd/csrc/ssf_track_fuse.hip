@@ -401,7 +401,7 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 // ---- association ---------------------------------------------------------------------------------
 // one frame supersurfel (or none) per visible model row; cand[id] = the frame supersurfel this row has bid for
 // (-1: none) -- the fuse launch uses it to tell which rows the update is about to rewrite
-__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const uint2* __restrict__ pix2,
+__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const int32_t* __restrict__ label,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
     // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
@@ -417,7 +417,7 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     if (!(pv.z > zmin && pv.z < zmax)) return -1;
     const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
     if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return -1;
-    const int f = (int)pix2[(size_t)py * cam.W + px].x;
+    const int f = label[(size_t)py * cam.W + px];      // (the 4-byte label map, not the 8-byte (label, depth) table of the ICP: half the lines every XCD's L2 pulls in)
     matched[f] = 1;
     float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];           // (conf, lab) (normal) (pos): one line
     asm volatile("" : "+v"(f0.y), "+v"(f1.x), "+v"(f2.x));       // (one gather, not confidence first and the rest later: see icp_row)
@@ -434,14 +434,14 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
     return f;
 }
-__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
+__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const int32_t* __restrict__ label,
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
                                                uint8_t* __restrict__ matched, int32_t* __restrict__ cand) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_visible) return;
-    cand[id] = match_row(cam, model, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
+    cand[id] = match_row(cam, model, id, label, fpack, pose, zmin, zmax, id_offset, best, matched);
 }
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
@@ -1321,23 +1321,45 @@ __global__ void k_lab_refresh(SurfelSoA s, int n) {
 
 // ---- deformation apply ("next" row) -----------------------------------------------------------------
 // rotMatToQuat matrix_math.cuh:529-618; quatToRotMat :512-527 (its wy = q.w*q.z is reproduced)
-__global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const float* __restrict__ npos,
-                                                     const float* __restrict__ nrot, const float* __restrict__ ntrans,
+// the nodes of the deformation graph as one 96-byte record each: (g.xyz, q.x) (t.xyz, q.y) (R row 0, q.z) (R row 1, q.w)
+// (R row 2, 0) (unused) -- the rotation -> quaternion conversion (rotMatToQuat, four branches, IEEE sqrt / divide) is done
+// once per node here instead of four times per supersurfel, and a supersurfel's four nodes are 4 x 5 whole 16-byte loads
+__global__ __launch_bounds__(256) void k_pack_nodes(int m, const float* __restrict__ npos, const float* __restrict__ nrot,
+                                                    const float* __restrict__ ntrans, float4* __restrict__ nodes) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const V3 g = ld3(npos, k), t = ld3(ntrans, k);
+    const M3 R = m3(v3(nrot[9 * k], nrot[9 * k + 1], nrot[9 * k + 2]), v3(nrot[9 * k + 3], nrot[9 * k + 4], nrot[9 * k + 5]),
+                    v3(nrot[9 * k + 6], nrot[9 * k + 7], nrot[9 * k + 8]));
+    float q[4]; rot_to_quat(R, q);
+    float4* o = nodes + 6 * (size_t)k;
+    o[0] = make_float4(g.x, g.y, g.z, q[0]); o[1] = make_float4(t.x, t.y, t.z, q[1]);
+    o[2] = make_float4(R.r0.x, R.r0.y, R.r0.z, q[2]); o[3] = make_float4(R.r1.x, R.r1.y, R.r1.z, q[3]);
+    o[4] = make_float4(R.r2.x, R.r2.y, R.r2.z, 0.f); o[5] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const float4* __restrict__ nodes,
                                                      const float* __restrict__ w4, const int32_t* __restrict__ idx4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const V3 pi = ld3(M.pos, i);
+    const int4 id = reinterpret_cast<const int4*>(idx4)[i];
+    const float4 w = reinterpret_cast<const float4*>(w4)[i];
+    const int node[4] = {id.x, id.y, id.z, id.w};
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+    float4 rec[4][5];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) rec[k][j] = nodes[6 * (size_t)node[k] + j];       // all twenty gathers in one round
     V3 po = v3(0, 0, 0);
     float bq[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int node = idx4[4 * i + k];
-        const float wk = w4[4 * i + k];
-        const V3 gk = ld3(npos, node), tk = ld3(ntrans, node);
-        const M3 Rk = m3(v3(nrot[9 * node], nrot[9 * node + 1], nrot[9 * node + 2]),
-                         v3(nrot[9 * node + 3], nrot[9 * node + 4], nrot[9 * node + 5]),
-                         v3(nrot[9 * node + 6], nrot[9 * node + 7], nrot[9 * node + 8]));
-        float qk[4]; rot_to_quat(Rk, qk);
+        const float wk = wv[k];
+        const V3 gk = v3(rec[k][0].x, rec[k][0].y, rec[k][0].z), tk = v3(rec[k][1].x, rec[k][1].y, rec[k][1].z);
+        const M3 Rk = m3(v3(rec[k][2].x, rec[k][2].y, rec[k][2].z), v3(rec[k][3].x, rec[k][3].y, rec[k][3].z),
+                         v3(rec[k][4].x, rec[k][4].y, rec[k][4].z));
+        const float qk[4] = {rec[k][0].w, rec[k][1].w, rec[k][2].w, rec[k][3].w};
         po = add(po, scale(wk, add(add(m3_mulv(Rk, sub(pi, gk)), gk), tk)));
 #pragma unroll
         for (int a = 0; a < 4; a++) bq[a] += wk * qk[a];
@@ -1533,13 +1555,13 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                            ticket, sums29, mb, seq, dbg, go, go_seq, none);
     }
 }
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const int32_t* label, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand, int S) {
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
-    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
+    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, label, fpack,
                        pose, zmin, zmax, id_offset, best, matched, cand);
 }
 void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
@@ -1643,11 +1665,12 @@ void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lab_refresh, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
-void launch_deformation(hipStream_t st, SurfelSoA model, int n, const float* npos, const float* nrot,
-                        const float* ntrans, const float* w4, const int32_t* idx4) {
+void launch_deformation(hipStream_t st, SurfelSoA model, int n, int m, const float* npos, const float* nrot,
+                        const float* ntrans, float* nodes24, const float* w4, const int32_t* idx4) {
     if (n <= 0) return;
     ScopedKernel sk("apply_deformation", st);
-    hipLaunchKernelGGL(k_deformation, dim3((n + 255) / 256), dim3(256), 0, st, model, n, npos, nrot, ntrans, w4, idx4);
+    hipLaunchKernelGGL(k_pack_nodes, dim3((m + 255) / 256), dim3(256), 0, st, m, npos, nrot, ntrans, reinterpret_cast<float4*>(nodes24));
+    hipLaunchKernelGGL(k_deformation, dim3((n + 255) / 256), dim3(256), 0, st, model, n, reinterpret_cast<const float4*>(nodes24), w4, idx4);
 }
 
 }  // namespace ssf
