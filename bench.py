@@ -56,7 +56,7 @@ ALGO_BYTES = {
     "eval_samples": lambda c: c["batch"] * 8.0 * P,
     "render_moments": lambda c: c["batch"] * 25.0 * P,
     # depth pre-filter (config 5 / depth_prefilter = 1): one frame per launch, 4 B read + 4 B written per pixel; the kernel is
-    # bound by its 177 taps x a specified exp per pixel, not by these bytes
+    # bound by its 149 taps x a specified exp per pixel, not by these bytes
     "bilateral_prefilter": lambda c: 8.0 * P,
 }
 
@@ -125,9 +125,9 @@ def next_kernel_times(lib, dev, model, nvis, cap):
     ms, calls = f.kernel_times().get("bilateral_prefilter", (0.0, 0))
     if calls:
         us = 1000.0 * ms / calls
-        out["bilateral_prefilter"] = dict(width=W, height=H, taps=177, avg_us=us, algo_bytes=8.0 * W * H, achieved_GBs=8.0 * W * H / (us * 1e-6) / 1e9,
+        out["bilateral_prefilter"] = dict(width=W, height=H, taps=149, avg_us=us, algo_bytes=8.0 * W * H, achieved_GBs=8.0 * W * H / (us * 1e-6) / 1e9,
                                           frac_of_hbm_peak=8.0 * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                          note="compute bound: 177 taps x a specified (bit-reproducible) exp per pixel")
+                                          note="compute bound: 149 taps (circle of radius 7) x a specified (bit-reproducible) exp per pixel, two taps per packed fp32 instruction")
     f.process_frame(rgb, depth)
     src = f.get_frame()
     f.reset_kernel_times()

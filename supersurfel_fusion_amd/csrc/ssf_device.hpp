@@ -197,7 +197,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
                 unsigned long long go_seq = 0, const struct P2PView* pv = nullptr);
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const int32_t* label /* FrameMaps::label */, const float4* fpack,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)

@@ -1075,11 +1075,96 @@ __global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ in,
     }
     out[(size_t)y * W + x] = sum1 / sum2;
 }
+// The same filter for the radius the reference's call produces (sigma_space 4.5 -> 7), the kernel is bound by its
+// arithmetic (149 taps x the ~30 operations of the specified exp): rows and extents are compile-time constants (no
+// loop bookkeeping, no extent table), and two taps at a time go through the packed fp32 pipe (v_pk_mul_f32 / v_pk_add_f32:
+// two IEEE operations per lane and instruction, each rounded exactly like the scalar one) -- the same operations on the
+// same operands in the same order per tap, so the bits do not change; (dv, dv) -> dv * dv drops the fabsf.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f exp_neg_spec2(v2f x) {                  // exp_neg_spec (ssf_math.hpp) on two values
+    // (the scalar function also clamps x > 0 to 0: here x = space2 * ss + dv^2 * sc with ss, sc < 0 is never positive)
+    const bool live0 = x.x > -87.0f, live1 = x.y > -87.0f;
+    const v2f t = x * 1.44269502f;
+    v2f kf; kf.x = rintf(t.x); kf.y = rintf(t.y);
+    const v2f r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    v2f p = {1.98412701e-4f, 1.98412701e-4f};
+    p = p * r + 1.38888892e-3f;
+    p = p * r + 8.33333377e-3f;
+    p = p * r + 4.16666679e-2f;
+    p = p * r + 0.166666672f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    v2f two_k;
+    two_k.x = __uint_as_float((uint32_t)(127 + (int)kf.x) << 23); two_k.y = __uint_as_float((uint32_t)(127 + (int)kf.y) << 23);
+    v2f w = p * two_k;
+    w.x = live0 ? w.x : 0.0f; w.y = live1 ? w.y : 0.0f;
+    return w;
+}
+template <int DY>
+__device__ __forceinline__ void bilateral_row7(const float* __restrict__ row, float center, float ss, float sc, float& sum1, float& sum2) {
+    constexpr int R = 7;
+    constexpr int E = DY * DY == 0 ? 7 : (DY * DY <= 9 ? 6 : (DY * DY == 16 ? 5 : (DY * DY == 25 ? 4 : (DY * DY == 36 ? 3 : 0))));
+    static_assert((E + 1) * (E + 1) + DY * DY > R * R && E * E + DY * DY <= R * R, "half-width of the circle in this row");
+    const v2f c2 = {center, center};
+    asm volatile("" ::: "memory");                  // (this row's LDS reads stay in this row: hoisted to the top, the 149 values spill)
+#pragma unroll
+    for (int dx = -E; dx + 1 <= E; dx += 2) {
+        const v2f v = {row[dx], row[dx + 1]};
+        const v2f space2 = {(float)(dx * dx + DY * DY), (float)((dx + 1) * (dx + 1) + DY * DY)};
+        const v2f dv = v - c2;
+        const v2f w = exp_neg_spec2(space2 * ss + (dv * dv) * sc);
+        const v2f wv = w * v;
+        sum1 = sum1 + wv.x; sum2 = sum2 + w.x;      // the first tap, then the second: the definition's order
+        sum1 = sum1 + wv.y; sum2 = sum2 + w.y;
+    }
+    {                                               // 2 E + 1 taps: the last one on its own
+        const float v = row[E];
+        const float dvs = v - center;
+        const float w = exp_neg_spec((float)(E * E + DY * DY) * ss + (dvs * dvs) * sc);
+        sum1 = sum1 + w * v; sum2 = sum2 + w;
+    }
+}
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_bilateral_r7(const float* __restrict__ in, float* __restrict__ out, int W, int H, float ss, float sc) {
+    constexpr int R = 7, BW = BIL_TILE + 2 * R;
+    __shared__ float tile[BW * BW];
+    const int X0 = blockIdx.x * BIL_TILE, Y0 = blockIdx.y * BIL_TILE;
+    for (int i = threadIdx.x; i < BW * BW; i += blockDim.x) {
+        const int gx = reflect101(X0 - R + i % BW, W), gy = reflect101(Y0 - R + i / BW, H);
+        tile[i] = in[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % BIL_TILE, ly = threadIdx.x / BIL_TILE;
+    const int x = X0 + lx, y = Y0 + ly;
+    if (x >= W || y >= H) return;
+    const float* __restrict__ c = &tile[(ly + R) * BW + lx + R];
+    const float center = c[0];
+    float sum1 = 0.f, sum2 = 0.f;
+    bilateral_row7<-7>(c - 7 * BW, center, ss, sc, sum1, sum2); bilateral_row7<-6>(c - 6 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<-5>(c - 5 * BW, center, ss, sc, sum1, sum2); bilateral_row7<-4>(c - 4 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<-3>(c - 3 * BW, center, ss, sc, sum1, sum2); bilateral_row7<-2>(c - 2 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<-1>(c - 1 * BW, center, ss, sc, sum1, sum2); bilateral_row7<0>(c, center, ss, sc, sum1, sum2);
+    bilateral_row7<1>(c + 1 * BW, center, ss, sc, sum1, sum2); bilateral_row7<2>(c + 2 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<3>(c + 3 * BW, center, ss, sc, sum1, sum2); bilateral_row7<4>(c + 4 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<5>(c + 5 * BW, center, ss, sc, sum1, sum2); bilateral_row7<6>(c + 6 * BW, center, ss, sc, sum1, sum2);
+    bilateral_row7<7>(c + 7 * BW, center, ss, sc, sum1, sum2);
+    out[(size_t)y * W + x] = sum1 / sum2;
+}
 void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
     ScopedKernel sk("bilateral_prefilter", st);
     int radius = (int)lrint((double)sigma_space * 1.5);
     if (radius < 1) radius = 1;
     const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
+    static const bool generic_only = getenv("SSF_BILATERAL_GENERIC") != nullptr;
+    if (radius == 7 && !generic_only) {
+        static const int waves = getenv("SSF_BIL_WAVES") ? atoi(getenv("SSF_BIL_WAVES")) : 2;
+        const dim3 grid((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE);
+        if (waves == 3) hipLaunchKernelGGL(k_bilateral_r7<3>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
+        else if (waves == 4) hipLaunchKernelGGL(k_bilateral_r7<4>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
+        else hipLaunchKernelGGL(k_bilateral_r7<2>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
+        return;
+    }
     hipLaunchKernelGGL(k_bilateral, dim3((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE), dim3(256), 0, st, in, out, W, H, radius, ss, sc);
 }
 

@@ -917,7 +917,7 @@ static int do_match(ssf_handle* h) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
     const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.label, h->cc->maps.fpack, h->pose, h->cfg.range_min,
+    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
                  h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
     HCK(hipGetLastError());
     return SSF_OK;

@@ -401,7 +401,7 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 // ---- association ---------------------------------------------------------------------------------
 // one frame supersurfel (or none) per visible model row; cand[id] = the frame supersurfel this row has bid for
 // (-1: none) -- the fuse launch uses it to tell which rows the update is about to rewrite
-__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const int32_t* __restrict__ label,
+__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
     // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
@@ -417,7 +417,10 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     if (!(pv.z > zmin && pv.z < zmax)) return -1;
     const int px = pixel_round(pv.x * cam.fx / pv.z + cam.cx), py = pixel_round(pv.y * cam.fy / pv.z + cam.cy);
     if (!(px >= 0 && px < cam.W && py >= 0 && py < cam.H)) return -1;
-    const int f = label[(size_t)py * cam.W + px];      // (the 4-byte label map, not the 8-byte (label, depth) table of the ICP: half the lines every XCD's L2 pulls in)
+    // (Gathering from the 4-byte label map instead cuts this kernel's fabric traffic from 15.1 to 12.9 MB per launch --
+    // measured, round 2 -- but the launch got 0.3 us SLOWER: the ICP iterations that ran just before have left exactly these
+    // lines of the (label, depth) table in the L2s, the label map's would be cold.)
+    const int f = (int)pix2[(size_t)py * cam.W + px].x;
     matched[f] = 1;
     float4 f0 = fpack[4 * f], f1 = fpack[4 * f + 1], f2 = fpack[4 * f + 2];           // (conf, lab) (normal) (pos): one line
     asm volatile("" : "+v"(f0.y), "+v"(f1.x), "+v"(f2.x));       // (one gather, not confidence first and the rest later: see icp_row)
@@ -434,14 +437,14 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
     return f;
 }
-__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const int32_t* __restrict__ label,
+__global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
                                                uint8_t* __restrict__ matched, int32_t* __restrict__ cand) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_visible) return;
-    cand[id] = match_row(cam, model, id, label, fpack, pose, zmin, zmax, id_offset, best, matched);
+    cand[id] = match_row(cam, model, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
 }
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
@@ -1555,13 +1558,13 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                            ticket, sums29, mb, seq, dbg, go, go_seq, none);
     }
 }
-void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const int32_t* label, const float4* fpack,
+void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand, int S) {
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
-    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, label, fpack,
+    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
                        pose, zmin, zmax, id_offset, best, matched, cand);
 }
 void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
