@@ -64,13 +64,36 @@ ALGO_BYTES = {
 EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
 
 
+def strip_comments(src):
+    """C++ source without comments and with runs of white space collapsed (string and character literals kept)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1]); i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha():
-    """hash of the product's kernel sources: ties a PMC profile under profiles/ to the binary it was taken from"""
+    """hash of the product's kernel sources (comments and white space aside: they do not reach the binary): ties a PMC
+    profile under profiles/ to the code it was taken from"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "supersurfel_fusion_amd", "csrc")
     for f in ("ssf_extract.hip", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
-        h.update(open(os.path.join(d, f), "rb").read())
+        h.update(strip_comments(open(os.path.join(d, f), "r").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
     const int slot = lane() & (ICP_SLOTS - 1);
+    // (Measured and dropped, round 2: a launch made ahead fetching its rows BEFORE it waits for the host's word -- they do not
+    // depend on the transform.  8806-8834 against 8757-8835 frames/s, nothing: the rows are L2 hits left by the previous
+    // iteration, not a trip to HBM.)
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
         icp_row(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), red, slot, dbg);
     __syncthreads();
