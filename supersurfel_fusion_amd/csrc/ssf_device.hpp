@@ -157,6 +157,9 @@ struct Mailbox {
     int all_cnt[5 * SSF_MAX_RANKS];       // Counters::last of every rank (multi-GPU)
     unsigned long long all_check;
     unsigned long long all_seq;
+    // peer-to-peer exchanges: set (never cleared) when a bounded wait for a peer ran out inside a kernel that has no record
+    // of its own to withhold (association, migrant table); the host turns it into SSF_ERR_DEVICE at the end of the frame
+    unsigned int p2p_timeout;
 };
 #define SSF_ICP_REPLICAS 8
 // word w of Mailbox::icp_rec for payload p[0..29] (29 sums + checksum) and sequence number seq
@@ -291,8 +294,8 @@ SSF_HD size_t p2p_region_bytes(int S) { return p2p_off_migr(S, 1, SSF_P2P_MAX_RA
 // launch_icp with pv != nullptr: the launch's last workgroup exchanges the shard record with the peers (pv->seq) and
 // publishes the SUM over the ranks (device record + mailbox), one launch per iteration as on a single GPU
 void launch_p2p_counts(hipStream_t st, const P2PView& pv, const Counters* cnt, Mailbox* mb, unsigned long long all_seq);
-void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched);
-void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket /* 65 zeroed words */);
+void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched, Mailbox* mb);
+void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket /* 65 zeroed words */, Mailbox* mb);
 void launch_publish_icp(hipStream_t st, const long long* rec29, Mailbox* mb, unsigned long long seq);
 void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mailbox* mb, unsigned long long seq);
 // publish the counters to the mailbox (sequence number seq) and reset the per-frame ones

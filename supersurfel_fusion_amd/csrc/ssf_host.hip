@@ -18,6 +18,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -295,14 +296,15 @@ static RcclApi* rccl_api() {
 // 3 5680-5810 | 2,8 5700-5810 | 1 5600-5780 | 4 5530-5560)
 struct SeqRamp { int n = -1; int size[8]; };
 static const SeqRamp& seq_ramp() {
-    static SeqRamp r;
-    if (r.n < 0) {
+    static const SeqRamp ramp = [] {              // (initialised once, also when several handles are driven by several threads)
+        SeqRamp r;
         r.n = 0;
         const char* e = getenv("SSF_SEQ_RAMP");
         if (e) { for (const char* q = e; *q && r.n < 8;) { r.size[r.n++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
         else { r.n = 2; r.size[0] = -4; r.size[1] = -2; }          // (negative: batch / |value|)
-    }
-    return r;
+        return r;
+    }();
+    return ramp;
 }
 static inline int seq_batch_size(int b, int batch) {
     const SeqRamp& r = seq_ramp();
@@ -578,6 +580,11 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
         if (!ex) {
             // captured on a stream of its own, not on the context's: the upload thread (Uploader) may be enqueueing
             // copies on the context's stream at this very moment
+            // (one capture at a time in the process: with several handles driven by several threads -- shards of one map, or
+            // several cameras on one GPU -- captures that ran side by side left, once in ~100 first frames, a graph whose
+            // first replay differed from the eager chain: tools/p2p_probe.py, round 2)
+            static std::mutex capture_mutex;
+            std::lock_guard<std::mutex> capture_lock(capture_mutex);
             bool ok = (h->capture_stream || hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) == hipSuccess) &&
                       hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
@@ -913,10 +920,22 @@ static int store_from_dense(ssf_handle* h, int n, int n_visible) {
     return SSF_OK;
 }
 
-static int do_match(ssf_handle* h) {
+static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
+// exchange != 0 (native multi-rank frame calls with the peer-to-peer backend): the association tables are traded with
+// the peers by the match launch's last workgroup -- or, when no rank has anything to match, by a launch of its own
+static int do_match(ssf_handle* h, int exchange = 0) {
     const long long nmodel = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
     const long long nvis = (h->cfg.nranks > 1 && h->global_n_visible >= 0) ? h->global_n_visible : h->n_visible;
-    const int n = (nmodel > 0 && nvis > 0) ? h->n_visible : 0;
+    const bool any = nmodel > 0 && nvis > 0;               // (global quantities: the same decision on every rank)
+    const int n = any ? h->n_visible : 0;
+    if (exchange && h->p2p.on) {
+        const P2PView pv = p2p_view(h, ++h->p2p.seq_assoc);
+        launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
+                     h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
+        launch_p2p_assoc(h->stream, pv, h->cc->d_best, h->cc->d_matched, h->mb_dev);
+        HCK(hipGetLastError());
+        return SSF_OK;
+    }
     launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
                  h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
     HCK(hipGetLastError());
@@ -927,7 +946,6 @@ static int do_match(ssf_handle* h) {
 // final counters come back through the mailbox (no D2H copy, no stream synchronise).  In two halves: between them a
 // sharded map exchanges the rows that crossed a tile edge (migrate: fuse_begin leaves this shard's migrant table in
 // h->d_migrants; fuse_end takes the rank-reduced table, or nullptr when nothing can arrive).
-static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
 static int comm_gather_counts(ssf_handle* h);
 static int fuse_begin(ssf_handle* h, int migrate) {
     const long long nmodel_g = (h->cfg.nranks > 1 && h->global_n_model >= 0) ? h->global_n_model : h->n_model;
@@ -1039,6 +1057,9 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
     }
     h->n_model = c.n_model; h->n_visible = c.n_visible;
     h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = c.oov_live;
+    if (h->p2p.on && __atomic_load_n(&h->mb_host->p2p_timeout, __ATOMIC_ACQUIRE) != 0u) {
+        h->err = "a peer's association / migrant tables never arrived (peer-to-peer exchange)"; return SSF_ERR_DEVICE;
+    }
     if (out) {
         std::memset(out, 0, sizeof(*out));
         pose_to12(h->pose, out->pose);
@@ -1233,10 +1254,9 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     icp_end(h, &valid);
     const double t_b = now_us();
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
-    rc = do_match(h);
+    rc = do_match(h, 1);
     if (rc) return rc;
-    if (h->p2p.on) launch_p2p_assoc(h->stream, p2p_view(h, ++h->p2p.seq_assoc), h->cc->d_best, h->cc->d_matched);
-    else if (h->comm) {
+    if (h->comm) {
         // best key over the ranks (keys < 2^63: signed MIN == unsigned MIN), matched = OR over the ranks
         NCK(api->AllReduce(h->cc->d_best, h->cc->d_best, h->S, ncclInt64, ncclMin, h->comm, h->stream));
         NCK(api->AllReduce(h->cc->d_matched, h->cc->d_matched, h->S, ncclUint8, ncclMax, h->comm, h->stream));
@@ -1247,7 +1267,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
         rc = fuse_begin(h, 1);
         if (rc) return rc;
-        if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320);
+        if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320, h->mb_dev);
         else if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
         rc = fuse_end(h, h->d_migrants, &r);
     } else

@@ -440,6 +440,10 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
     return f;
 }
+// (Measured and removed, round 2: trading the association tables with the peers in THIS launch's last workgroup instead of
+// in a launch of its own.  The matched flags then have to reach that workgroup through device-scope atomics, and 100 k
+// of them on 300-1200 hot addresses cost 50-100 us: memory-side atomics serialise per address at ~0.1 us -- which is also
+// what bounds this kernel's own atomicMin.  The separate exchange launch costs ~8 us.)
 __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
@@ -965,6 +969,8 @@ struct NextIcp {
 // here, while the rows are in registers, against the next frame's packed tables (the sums are exact integers, so
 // the order of accumulation does not matter), and publish it like k_icp does.
 // P2P (with ICP): the record is this shard's; the publishing workgroup trades it with the peers as k_icp<true> does.
+// (Measured and removed, round 2: one more workgroup of this launch trading the shard sizes with the peers instead of a launch of
+// its own in front of it -- 7030-7180 against 7260-7320 frames/s with every exchange on one rank, nothing at 2 / 4 ranks.)
 template <bool ICP, bool P2P>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
                                                    const uint8_t* __restrict__ state_oov,
@@ -1451,28 +1457,32 @@ __device__ __forceinline__ void p2p_raise_flags(const P2PView& pv, int kind) {  
 }
 // association tables: this rank's best[] / matched[] -> every peer, then best := MIN, matched := OR over the ranks.
 // One workgroup (S entries of 9 bytes).
-__global__ __launch_bounds__(1024) void k_p2p_assoc(P2PView pv, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+__device__ __forceinline__ void p2p_assoc_exchange(const P2PView& pv, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched, int* s_ok, Mailbox* mb) {
     const int par = (int)(pv.seq & 1ull), S = pv.S;
-    __shared__ int s_ok;
+    // (own tables: device-scope atomic loads -- inside k_match they were written by other workgroups of this launch)
 #pragma unroll
     for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
         if (r >= pv.nranks || r == pv.me) continue;
         unsigned long long* db = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_best(S, par, pv.me));
         uint8_t* dm = pv.peer[r] + p2p_off_matched(S, par, pv.me);
         for (int i = threadIdx.x; i < S; i += blockDim.x) {
-            __hip_atomic_store(&db[i], best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&dm[i], matched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&db[i], __hip_atomic_load(&best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dm[i], __hip_atomic_load(&matched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store above has been acknowledged by its destination
     __syncthreads();
     p2p_raise_flags(pv, P2P_FLAG_ASSOC);
-    if (threadIdx.x == 0) s_ok = p2p_wait_flags(pv, P2P_FLAG_ASSOC) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        *s_ok = p2p_wait_flags(pv, P2P_FLAG_ASSOC) ? 1 : 0;
+        if (!*s_ok) __hip_atomic_store(&mb->p2p_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
-    if (!s_ok) return;
+    if (!*s_ok) return;
     unsigned char* mine = p2p_peer(pv, pv.me);
     for (int i = threadIdx.x; i < S; i += blockDim.x) {
-        unsigned long long b = best[i]; uint8_t m = matched[i];
+        unsigned long long b = __hip_atomic_load(&best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint8_t m = __hip_atomic_load(&matched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int r = 0; r < pv.nranks; r++) {
             if (r == pv.me) continue;
             const unsigned long long* sb = reinterpret_cast<const unsigned long long*>(mine + p2p_off_best(S, par, r));
@@ -1483,6 +1493,10 @@ __global__ __launch_bounds__(1024) void k_p2p_assoc(P2PView pv, unsigned long lo
         }
         best[i] = b; matched[i] = m;
     }
+}
+__global__ __launch_bounds__(1024) void k_p2p_assoc(P2PView pv, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched, Mailbox* mb) {
+    __shared__ int s_ok;
+    p2p_assoc_exchange(pv, best, matched, &s_ok, mb);
 }
 // migrant table: slot f of this rank's table -> slot f of [parity][me] in every peer (an empty slot sends its first two
 // words only); the last workgroup to finish raises the flags.  One thread per slot.
@@ -1515,10 +1529,13 @@ __global__ __launch_bounds__(256) void k_p2p_migr_share(P2PView pv, const int32_
     if (s_last) p2p_raise_flags(pv, P2P_FLAG_MIGR);
 }
 // ... and the peers' slots are added into this rank's table (at most one rank fills a slot: the sum is the union)
-__global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __restrict__ table) {
+__global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __restrict__ table, Mailbox* mb) {
     const int par = (int)(pv.seq & 1ull), S = pv.S;
     __shared__ int s_ok;
-    if (threadIdx.x == 0) s_ok = p2p_wait_flags(pv, P2P_FLAG_MIGR) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        s_ok = p2p_wait_flags(pv, P2P_FLAG_MIGR) ? 1 : 0;
+        if (!s_ok) __hip_atomic_store(&mb->p2p_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     if (!s_ok) return;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1607,19 +1624,20 @@ void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelS
                       const Counters* cnt, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
     NextIcp nx{};
+    const dim3 grid(nb_vis + nb_oov);
     if (next) {
         nx.cam = cam; nx.pix2 = next->pix2; nx.fpack = next->fpack; nx.T = next->T; nx.replicas = next->replicas;
         nx.ticket = next->ticket; nx.sums = next->sums; nx.mb = mb; nx.seq = next->seq;
         ScopedKernel sk("reorder_move_icp", st);
         if (next->pv)
-            hipLaunchKernelGGL((k_move_rows<true, true>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+            hipLaunchKernelGGL((k_move_rows<true, true>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
                                bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, *next->pv);
         else
-            hipLaunchKernelGGL((k_move_rows<true, false>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+            hipLaunchKernelGGL((k_move_rows<true, false>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
                                bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
     } else {
         ScopedKernel sk("reorder_move", st);
-        hipLaunchKernelGGL((k_move_rows<false, false>), dim3(nb_vis + nb_oov), dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
+        hipLaunchKernelGGL((k_move_rows<false, false>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
                            bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
     }
 }
@@ -1648,15 +1666,15 @@ void launch_p2p_counts(hipStream_t st, const P2PView& pv, const Counters* cnt, M
     ScopedKernel sk("p2p_counts", st);
     hipLaunchKernelGGL(k_p2p_counts, dim3(1), dim3(64), 0, st, pv, cnt, mb, all_seq);
 }
-void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched) {
+void launch_p2p_assoc(hipStream_t st, const P2PView& pv, unsigned long long* best, uint8_t* matched, Mailbox* mb) {
     ScopedKernel sk("p2p_assoc", st);
-    hipLaunchKernelGGL(k_p2p_assoc, dim3(1), dim3(1024), 0, st, pv, best, matched);
+    hipLaunchKernelGGL(k_p2p_assoc, dim3(1), dim3(1024), 0, st, pv, best, matched, mb);
 }
-void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket) {
+void launch_p2p_migrants(hipStream_t st, const P2PView& pv, int32_t* table, unsigned int* ticket, Mailbox* mb) {
     ScopedKernel sk("p2p_migrants", st);
     const int grid = (pv.S + 255) / 256;
     hipLaunchKernelGGL(k_p2p_migr_share, dim3(grid), dim3(256), 0, st, pv, table, ticket);
-    hipLaunchKernelGGL(k_p2p_migr_gather, dim3(grid), dim3(256), 0, st, pv, table);
+    hipLaunchKernelGGL(k_p2p_migr_gather, dim3(grid), dim3(256), 0, st, pv, table, mb);
 }
 void launch_publish_icp(hipStream_t st, const long long* rec, Mailbox* mb, unsigned long long seq) {
     hipLaunchKernelGGL(k_publish_icp, dim3(1), dim3(64), 0, st, rec, mb, seq);

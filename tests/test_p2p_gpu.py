@@ -42,9 +42,9 @@ def check_against_oracle(world, per_rank, models, oracle_out, oracle_handles):
             util.assert_same_bits(models[r][name], mo[name], "%s of rank %d" % (name, r))
 
 
-@pytest.mark.parametrize("world,pipelined", [(2, False), (3, False), (2, True)])
-def test_ranks_in_one_process_bit_exact(world, pipelined, oracle_lib, product_lib):
-    W, H, nf = 320, 240, 6
+@pytest.mark.parametrize("world,pipelined,nf", [(2, False, 6), (3, False, 6), (2, True, 6), (3, False, 40), (3, True, 40)])
+def test_ranks_in_one_process_bit_exact(world, pipelined, nf, oracle_lib, product_lib):
+    W, H = 320, 240
     kw = dict(pipeline_depth=2, extract_batch=2) if pipelined else {}
     fs = [binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, nb_supersurfels_max=4096, rank=r, nranks=world, shard_tile=0.25, **kw))
           for r in range(world)]

@@ -65,6 +65,11 @@ def worker(rank, world, d, nf, n_model):
                    n_visible=int(res[-1].n_visible), n_model=int(res[-1].n_model)), open(os.path.join(d, "out%d.json" % rank), "w"))
 
 
+REFERENCE_TRACE = None
+KEEP_HANDLES = False
+KEPT = []
+
+
 def threads_mode(world, nf, n_model):
     """the same ranks as handles of ONE process, one host thread each (ssf_p2p_attach_local)"""
     import threading
@@ -92,18 +97,22 @@ def threads_mode(world, nf, n_model):
     dep = [torch.from_numpy(b).to(dev) for _, b in frames]
     order = [0, 1, 2, 3, 4, 5, 6, 7, 6, 5, 4, 3, 2, 1]
     times, iters = [0.0] * world, [0.0] * world
+    trace = [[] for _ in range(world)]                 # (pose bits, icp_iters, global n_visible is implied by the pose) per timed frame
     barrier = threading.Barrier(world)
 
     def drive(r):
         for k in range(20):
             j = order[k % len(order)]
-            fs[r].process_frame_device(rgb[j].data_ptr(), dep[j].data_ptr())
+            res = fs[r].process_frame_device(rgb[j].data_ptr(), dep[j].data_ptr())
+            trace[r].append((bytes(res.pose), res.icp_iters, res.icp_valid, res.n_model, res.n_visible, res.n_removed, res.n_inserted, res.n_updated))
         barrier.wait()
         t0 = time.perf_counter()
         it = 0
         for k in range(20, 20 + nf):
             j = order[k % len(order)]
-            it += fs[r].process_frame_device(rgb[j].data_ptr(), dep[j].data_ptr()).icp_iters
+            res = fs[r].process_frame_device(rgb[j].data_ptr(), dep[j].data_ptr())
+            it += res.icp_iters
+            trace[r].append((bytes(res.pose), res.icp_iters, res.icp_valid, res.n_model, res.n_visible, res.n_removed, res.n_inserted, res.n_updated))
         times[r] = 1e3 * (time.perf_counter() - t0) / nf
         iters[r] = it / nf
 
@@ -112,7 +121,40 @@ def threads_mode(world, nf, n_model):
         t.start()
     for t in ts:
         t.join()
-    print(json.dumps(dict(ranks=world, mode="threads of one process", ms_per_frame=max(times), icp_iters_mean=iters[0])))
+    # the pose does not depend on the number of ranks: every rank of every run must reproduce the one-rank trace bit for bit
+    global REFERENCE_TRACE
+    bad = None
+    if world == 1 and REFERENCE_TRACE is None:
+        REFERENCE_TRACE = trace[0]
+    elif REFERENCE_TRACE is not None:
+        names = ("n_model", "n_visible", "n_removed", "n_inserted", "n_updated")
+        for k, a in enumerate(REFERENCE_TRACE):
+            if bad is not None:
+                break
+            for r in range(world):
+                b = trace[r][k]
+                if a[:3] != b[:3]:
+                    import struct
+                    bad = dict(frame=k, rank=r, what="pose / iterations / validity", want_iters=a[1], got_iters=[trace[q][k][1] for q in range(world)],
+                               ranks_equal_to_reference=[trace[q][k][0] == a[0] for q in range(world)],
+                               ranks_equal_to_rank0=[trace[q][k][0] == trace[0][k][0] for q in range(world)],
+                               want_t=struct.unpack("3f", a[0][36:48]), got_t=[struct.unpack("3f", trace[q][k][0][36:48]) for q in range(world)],
+                               later_frames_differing=sum(1 for kk in range(k, len(REFERENCE_TRACE)) if trace[0][kk][0] != REFERENCE_TRACE[kk][0]))
+                    break
+            if bad is None:
+                for q, nm in enumerate(names):
+                    tot = sum(trace[r][k][3 + q] for r in range(world))
+                    if tot != a[3 + q]:
+                        bad = dict(frame=k, what=nm, want=a[3 + q], got=[trace[r][k][3 + q] for r in range(world)])
+                        break
+    g = [f.global_counts() for f in fs] if world > 1 else []
+    print(json.dumps(dict(ranks=world, mode="threads of one process", ms_per_frame=max(times), icp_iters_mean=iters[0],
+                          first_mismatch_vs_one_rank=bad, global_counts_agree=all(x == g[0] for x in g) if g else None)), flush=True)
+    if not KEEP_HANDLES:
+        for f in fs:
+            f.close()
+    else:
+        KEPT.extend(fs)
 
 
 def main():
@@ -123,8 +165,11 @@ def main():
     ap.add_argument("--worker", type=int, nargs=2, default=None)
     ap.add_argument("--dir", default=None)
     ap.add_argument("--threads", action="store_true", help="the ranks as handles of one process, one host thread each")
+    ap.add_argument("--keep", action="store_true", help="--threads: keep the handles of earlier runs alive (their streams keep their hardware queues)")
     a = ap.parse_args()
     if a.threads:
+        global KEEP_HANDLES
+        KEEP_HANDLES = a.keep
         for world in a.ranks:
             threads_mode(world, a.frames, a.n_model)
         return
