@@ -584,7 +584,9 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
             // several cameras on one GPU -- captures that ran side by side left, once in ~100 first frames, a graph whose
             // first replay differed from the eager chain: tools/p2p_probe.py, round 2)
             static std::mutex capture_mutex;
-            std::lock_guard<std::mutex> capture_lock(capture_mutex);
+            static const bool unlocked = getenv("SSF_CAPTURE_UNLOCKED") != nullptr;          // (control runs of that probe)
+            std::unique_lock<std::mutex> capture_lock(capture_mutex, std::defer_lock);
+            if (!unlocked) capture_lock.lock();
             bool ok = (h->capture_stream || hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) == hipSuccess) &&
                       hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
@@ -593,6 +595,7 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
             }
             if (ok) ok = hipGraphInstantiate(&ex, c.graph[c.count], nullptr, nullptr, 0) == hipSuccess;
             if (!ok) { h->graph_failed = true; ex = nullptr; (void)hipGetLastError(); }
+            if (ex) { HCK(hipGraphLaunch(ex, c.stream)); return SSF_OK; }       // (the first replay still under the lock)
         }
         if (ex) { HCK(hipGraphLaunch(ex, c.stream)); return SSF_OK; }
     }
@@ -1265,7 +1268,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (exchanging) {
         // rows whose fused position crossed a tile edge move to the rank that owns their new tile: every rank's
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
-        rc = fuse_begin(h, 1);
+        static const int migrate = getenv("SSF_NO_MIGRATE") ? 0 : 1;                  // (bisecting switch of tools/p2p_first_frame_stress.py)
+        rc = fuse_begin(h, migrate);
         if (rc) return rc;
         if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320, h->mb_dev);
         else if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
@@ -1376,6 +1380,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
     if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switches (tools/)
     if (const char* e = getenv("SSF_ICP_CHAIN")) h->icp_chain = atoi(e) != 0;
+    if (getenv("SSF_NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
@@ -1467,7 +1472,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          alloc_surfels(h, h->oov[0].rows, OC) && alloc_surfels(h, h->oov[1].rows, OC) && dalloc(h, &h->oov[0].live, OC) &&
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
-         dalloc(h, &h->d_icp, SSF_ICP_RECORD) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
+         dalloc(h, &h->d_icp, 64) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
          dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
@@ -2131,6 +2136,19 @@ int ssf_set_profile(ssf_handle* h, int enable) {
 }
 
 // completion times (us since the call started) of the first 64 frames of the last ssf_process_sequence (tools/startup_probe.py)
+// the record of the last ICP iteration the host fetched (after the exchange of a sharded map: the SUM over the ranks)
+int ssf_dbg_last_icp_record(ssf_handle* h, int64_t* out29) {
+    if (!h || !out29) return SSF_ERR_INVALID_ARG;
+    for (int i = 0; i < 29; i++) out29[i] = h->h_icp_local[i];
+    return SSF_OK;
+}
+// device copy of the last record [0..28] and, with the peer-to-peer exchange, of this shard's own record before it [32..60]
+int ssf_dbg_device_icp_records(ssf_handle* h, int64_t* out64) {
+    if (!h || !out64) return SSF_ERR_INVALID_ARG;
+    HCK(hipStreamSynchronize(h->stream));
+    HCK(hipMemcpy(out64, h->d_icp, 64 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return SSF_OK;
+}
 int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
     if (!h || !out64) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 64; i++) out64[i] = h->seq_done_us[i];

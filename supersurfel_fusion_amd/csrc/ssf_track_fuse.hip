@@ -90,6 +90,7 @@ __device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict_
     atomicAdd(&red[27 * ICP_SLOTS + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
     atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull);
 }
+template <typename T> __device__ __forceinline__ void atomic_add_done(T* p, T v);
 // end of an accumulating kernel, in three steps called by every thread of a workgroup after a barrier:
 // fold the workgroup's table into a replica record ...
 __device__ __forceinline__ void icp_fold(unsigned long long* red, long long* __restrict__ replicas) {
@@ -98,7 +99,7 @@ __device__ __forceinline__ void icp_fold(unsigned long long* red, long long* __r
 #pragma unroll
         for (int sidx = 0; sidx < ICP_SLOTS; sidx++) tot += red[threadIdx.x * ICP_SLOTS + sidx];
         long long* rep = replicas + (size_t)(blockIdx.x % SSF_ICP_REPLICAS) * 32;
-        if (tot != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&rep[threadIdx.x]), tot);
+        if (tot != 0) atomic_add_done(reinterpret_cast<unsigned long long*>(&rep[threadIdx.x]), tot);     // (see atomic_add_done below)
     }
     // The replica updates above are device-scope atomic RMWs; they have completed (vmcnt(0) + barrier) before this
     // workgroup counts its arrival, and the last workgroup reads them back with device-scope atomic loads.
@@ -106,6 +107,22 @@ __device__ __forceinline__ void icp_fold(unsigned long long* red, long long* __r
     // invalidate fence is needed.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+// What a workgroup hands to the LAST workgroup of its launch (the one that sums up and publishes) must have been PERFORMED at
+// the coherence point before the workgroup counts its arrival.  For an atomic without return value the wait counter
+// (s_waitcnt vmcnt(0)) only says that the request has been accepted: with several handles hammering the fabric side by
+// side (tools/p2p_first_frame_stress.py: four ranks of a sharded map on one GPU) the last workgroup was seen reading a
+// replica record / a partition total BEFORE another workgroup's add had landed -- one frame in a few hundred came out a
+// workgroup's worth short.  The value a RETURNING atomic brings back is the proof that it has been performed; these
+// helpers are used for everything the last workgroup of the same launch reads.  (What the NEXT launch reads needs
+// nothing: a kernel boundary completes everything.)
+template <typename T> __device__ __forceinline__ void atomic_add_done(T* p, T v) {
+    const T before = atomicAdd(p, v);
+    asm volatile("" :: "v"(before));
+}
+__device__ __forceinline__ void atomic_store_done(int* p, int v) {
+    const int before = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(before));
 }
 // ... count the arrival (is this the last workgroup?) ...
 // two-level arrival count over all workgroups of the grid (a single counter serialises thousands of same-address
@@ -140,9 +157,8 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
 // Wave 0 of the last workgroup: this rank's record (tot in lanes 0..28) goes into slot [parity][me] of every peer's region
 // as five self-validating lines (the format of Mailbox::icp_rec); the records of the others are awaited in this rank's
 // own region and added in rank order.  Returns false when a peer's record never arrived.
-__device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, long long& tot, unsigned long long* pay /* LDS, 30 */) {
+__device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, unsigned long long seq, long long& tot, unsigned long long* pay /* LDS, 30 */) {
     const int l = lane();
-    const unsigned long long seq = pv.seq;
     const int par = (int)(seq & 1ull);
     if (l < 29) pay[l] = (unsigned long long)tot;
     const unsigned long long check = (unsigned long long)wsum64(l < 29 ? tot : 0ll) + seq;
@@ -177,9 +193,11 @@ __device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, long long& t
     return true;
 }
 // ... and, in the last workgroup, sum the replicas and publish the record (P2P: the SUM of the records of all ranks)
+// (the number of the peer exchange travels beside the view, not in it: a kernel that writes into its P2PView argument gets a
+// private copy of the whole struct in scratch memory)
 template <bool P2P>
 __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, long long* __restrict__ sums, Mailbox* mb,
-                                            unsigned long long seq, const P2PView& pv) {
+                                            unsigned long long seq, const P2PView& pv, unsigned long long p2p_seq) {
     // SSF_ICP_REPLICAS x 32 replica words: thread t sums field t & 31 over every 8th replica (independent
     // loads, one round trip), then 8 partial rows are folded through LDS
     __shared__ long long part[8 * 32];
@@ -200,7 +218,10 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
         long long tot = 0;
         if (threadIdx.x < 29)
             for (int r = 0; r < 8; r++) tot += part[r * 32 + threadIdx.x];
-        if (P2P) { if (!p2p_icp_exchange(pv, tot, pay)) return; }      // (no record: the host reports the missing peer)
+        if (P2P) {
+            if (threadIdx.x < 29) sums[32 + threadIdx.x] = tot;        // (this shard's own record, for tools/p2p_first_frame_stress.py)
+            if (!p2p_icp_exchange(pv, p2p_seq, tot, pay)) return;
+        }      // (no record: the host reports the missing peer)
         if (threadIdx.x < 29) {
             sums[threadIdx.x] = tot;
             pay[threadIdx.x] = (unsigned long long)tot;
@@ -253,8 +274,8 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         if (!s_go) return;
         T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
         T.t = v3(s_T[9], s_T[10], s_T[11]);
-        if (P2P) pv.seq = s_p2p_seq;
     }
+    const unsigned long long p2p_seq = (P2P && go) ? s_p2p_seq : pv.seq;
     __syncthreads();
     const M3 R = T.R; const V3 t = T.t;
     const int slot = lane() & (ICP_SLOTS - 1);
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     icp_fold(red, replicas);
     if (threadIdx.x == 0) s_last = grid_arrive(ticket);
     __syncthreads();
-    if (s_last) icp_publish<P2P>(replicas, sums, mb, seq, pv);
+    if (s_last) icp_publish<P2P>(replicas, sums, mb, seq, pv, p2p_seq);
 }
 
 // ---- loop-closure registration (DenseRegistration::align) -----------------------------------------------------
@@ -560,7 +581,7 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
             const uint32_t other = __shfl_xor(k, 1, 64);
             if (which == 0) bc_oov[ob] = k | (other << 16);
             if (k) {
-                atomicAdd(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + 6 + which], k);
+                atomic_add_done(&ws.tot[(ob & (PART_REPLICAS - 1)) * 8 + 6 + which], k);
                 if (which == 0) atomicAdd(&ws.sup_oov[ob / PART_GROUP], k);
             }
         }
@@ -644,7 +665,7 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
             // the partition drops it (class 2) with its confidence intact; launch_pack_emigrants ships it
             if (sh.migrate && !removed && tile_owner(fused_position, sh.nranks, sh.tile) != sh.rank) {
                 st = 2;
-                atomicAdd(&cnt->n_emigrated, 1);
+                atomic_add_done(&cnt->n_emigrated, 1);
             }
             st3(M.pos, m, fused_position);
             M.conf[m] = removed ? -1.0f : m_conf + f_conf;
@@ -653,10 +674,10 @@ __device__ __forceinline__ void update_group(SurfelSoA M, SurfelSoA F, Rt pose, 
             M.dims[2 * m] = vals.x; M.dims[2 * m + 1] = vals.y;
             M.stamps[2 * m + 1] = stamp;
             state_vis[m] = (uint8_t)st;
-            atomicAdd(&cnt->n_updated, 1);
+            atomic_add_done(&cnt->n_updated, 1);
             const int vb = (int)(m >> 8);
             atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + st], 1u);
-            atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
+            atomic_add_done(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + st], 1u);
         }
     } else {
         const int ch = min(l & 3, 2), l0 = l & ~3;        // (the fourth lane repeats the third channel; its results are unused)
@@ -761,11 +782,11 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
         const uint32_t n = s_cls[seg][st];
         if (n) {
             atomicAdd(&ws.sup_vis[(g_first + seg) * 6 + 3 + st], n);
-            atomicAdd(&ws.tot[(chunk & (PART_REPLICAS - 1)) * 8 + 3 + st], n);
+            atomic_add_done(&ws.tot[(chunk & (PART_REPLICAS - 1)) * 8 + 3 + st], n);
         }
     }
     if (chunk == nchunks - 1 && threadIdx.x == 0)
-        __hip_atomic_store(&cnt->n_inserted, min(base_total + before + total, capacity) - base_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomic_store_done(&cnt->n_inserted, min(base_total + before + total, capacity) - base_total);
 }
 // The fuse launch.  Blocks, in this order:
 //   update     nupd blocks of UPD_PER_WG frame supersurfels (updateModel, update_group); also classifies the rows
@@ -818,7 +839,7 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
             const uint32_t k = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
             if (k) {
                 atomicAdd(&ws.sup_vis[(vb / PART_GROUP) * 6 + threadIdx.x], k);
-                atomicAdd(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
+                atomic_add_done(&ws.tot[(vb & (PART_REPLICAS - 1)) * 8 + threadIdx.x], k);
             }
         }
     } else if (b >= nupd)
@@ -1100,7 +1121,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         // No rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
         const int nkeep = __syncthreads_count(keep);
         if (P2P && cnt->n_visible == 0) {          // an empty shard still owes its peers a (zero) record
-            if (blockIdx.x == 0) icp_publish<true>(nx.replicas, nx.sums, nx.mb, nx.seq, pv);
+            if (blockIdx.x == 0) icp_publish<true>(nx.replicas, nx.sums, nx.mb, nx.seq, pv, pv.seq);
             return;
         }
         const bool vis = (int)blockIdx.x < nb_vis;
@@ -1132,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             s_last = last;
         }
         __syncthreads();
-        if (s_last) icp_publish<P2P>(nx.replicas, nx.sums, nx.mb, nx.seq, pv);
+        if (s_last) icp_publish<P2P>(nx.replicas, nx.sums, nx.mb, nx.seq, pv, pv.seq);
     }
 }
 
@@ -1465,12 +1486,18 @@ __device__ __forceinline__ void p2p_assoc_exchange(const P2PView& pv, unsigned l
         if (r >= pv.nranks || r == pv.me) continue;
         unsigned long long* db = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_best(S, par, pv.me));
         uint8_t* dm = pv.peer[r] + p2p_off_matched(S, par, pv.me);
-        for (int i = threadIdx.x; i < S; i += blockDim.x) {
-            __hip_atomic_store(&db[i], __hip_atomic_load(&best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&dm[i], __hip_atomic_load(&matched[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // (returning exchanges, not stores: what comes back is the proof that the word has landed in the peer's memory
+        // before this rank raises its flag -- see atomic_add_done)
+        unsigned int* dm32 = reinterpret_cast<unsigned int*>(dm);
+        const unsigned int* m32 = reinterpret_cast<const unsigned int*>(matched);
+        unsigned long long sink = 0;
+        for (int i = threadIdx.x; i < S; i += blockDim.x)
+            sink ^= __hip_atomic_exchange(&db[i], __hip_atomic_load(&best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = threadIdx.x; i < (S + 3) / 4; i += blockDim.x)
+            sink ^= __hip_atomic_exchange(&dm32[i], __hip_atomic_load(&m32[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("" :: "v"(sink));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every store above has been acknowledged by its destination
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     p2p_raise_flags(pv, P2P_FLAG_ASSOC);
     if (threadIdx.x == 0) {
@@ -1514,11 +1541,12 @@ __global__ __launch_bounds__(256) void k_p2p_migr_share(P2PView pv, const int32_
         for (int r = 0; r < SSF_P2P_MAX_RANKS; r++) {
             if (r >= pv.nranks || r == pv.me) continue;
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(pv.peer[r] + p2p_off_migr(S, par, pv.me)) + (size_t)(SSF_MIGRANT_WORDS / 2) * f;
-            __hip_atomic_store(&dst[0], w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned long long sink = __hip_atomic_exchange(&dst[0], w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (returning: see p2p_assoc_exchange)
             if (full) {
 #pragma unroll
-                for (int k = 1; k < SSF_MIGRANT_WORDS / 2; k++) __hip_atomic_store(&dst[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int k = 1; k < SSF_MIGRANT_WORDS / 2; k++) sink ^= __hip_atomic_exchange(&dst[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            asm volatile("" :: "v"(sink));
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
