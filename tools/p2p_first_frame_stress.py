@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=3)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--n-model", type=int, default=200000)
+    ap.add_argument("--spread-priorities", action="store_true", help="ranks 2, 3 get a normal-priority track stream (hardware queues are per priority level)")
     ap.add_argument("--check-maps", action="store_true", help="after the last frame compare every handle's frame maps and frame supersurfels with the one-rank run's")
     ap.add_argument("--independent", action="store_true", help="the handles are NOT shards: each holds the whole map (no exchange), "
                                                                "all run side by side -- is it the exchange, or handles running concurrently?")
@@ -54,6 +55,11 @@ def main():
         fs = []
         for r in range(world):
             sel = own == r
+            if a.spread_priorities:                  # two track streams per priority level instead of four at the highest
+                if r >= 2:
+                    os.environ["SSF_TRACK_PRIORITY"] = "0"
+                else:
+                    os.environ.pop("SSF_TRACK_PRIORITY", None)
             f = binding.Fusion(lib, bench.make_cfg(lib, int(sel.sum()) + 65536, r, world, None, False, 0, 1))
             f.set_model({k: v[sel] for k, v in model.items()}, int((sel & vis).sum()), 30)
             fs.append(f)
