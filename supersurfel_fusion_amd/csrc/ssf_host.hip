@@ -430,6 +430,8 @@ struct ssf_handle {
     long long all_cnt[5 * SSF_MAX_RANKS];
     SurfelSoA model[2]; int mcur = 0;
     std::vector<void*> allocs;
+    struct Guarded { void* base; size_t bytes, guard; };
+    std::vector<Guarded> guarded;         // SSF_ALLOC_GUARD (debug): see dalloc
     float* d_bf_in = nullptr; float* d_bf_out = nullptr; float* d_orient9 = nullptr;
     long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
@@ -515,10 +517,39 @@ static int wait_seq(ssf_handle* h, const volatile unsigned long long* word, unsi
 template <typename T>
 static bool dalloc(ssf_handle* h, T** p, size_t count) {
     void* q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
+    // (SSF_ALLOC_GUARD=bytes: that much unused memory on both sides of every buffer -- a probe for out-of-bounds accesses
+    // between the small buffers of handles that live side by side, tools/p2p_first_frame_stress.py)
+    static const size_t guard = getenv("SSF_ALLOC_GUARD") ? (size_t)atoll(getenv("SSF_ALLOC_GUARD")) & ~(size_t)255 : 0;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (hipMalloc(&q, bytes + 2 * guard) != hipSuccess) return false;
     h->allocs.push_back(q);
-    *p = (T*)q;
+    if (guard) {                                   // poisoned guard zones, checked by ssf_destroy
+        static const int poison_all = getenv("SSF_GUARD_BYTE") ? atoi(getenv("SSF_GUARD_BYTE")) & 255 : 0xA5;
+        static const int only = getenv("SSF_GUARD_ONLY") ? atoi(getenv("SSF_GUARD_ONLY")) : -1;      // poison this allocation's zones, zero the others'
+        const int poison = (only < 0 || (int)h->guarded.size() == only) ? poison_all : 0;
+        (void)hipMemset(q, poison, guard);
+        (void)hipMemset((char*)q + guard + bytes, poison, guard);
+        h->guarded.push_back({q, bytes, guard});
+    }
+    *p = (T*)((char*)q + guard);
     return true;
+}
+static void check_guards(ssf_handle* h) {
+    int idx = 0;
+    for (auto& g : h->guarded) {
+        std::vector<unsigned char> host(g.guard);
+        for (int side = 0; side < 2; side++) {
+            const char* zone = (const char*)g.base + (side ? g.guard + g.bytes : 0);
+            if (hipMemcpy(host.data(), zone, g.guard, hipMemcpyDeviceToHost) != hipSuccess) continue;
+            size_t first = g.guard, last = 0, n = 0;
+            static const int poison = getenv("SSF_GUARD_BYTE") ? atoi(getenv("SSF_GUARD_BYTE")) & 255 : 0xA5;
+            for (size_t i = 0; i < g.guard; i++) if (host[i] != (unsigned char)poison) { if (first == g.guard) first = i; last = i; n++; }
+            if (n) std::fprintf(stderr, "[ssf guard] allocation #%d (%zu bytes): %zu bytes modified %s it, offsets %zu..%zu relative to the %s (rank %d)\n",
+                                idx, g.bytes, n, side ? "BEHIND" : "IN FRONT OF", side ? first : g.guard - 1 - last, side ? last : g.guard - 1 - first,
+                                side ? "end" : "start", h->cfg.rank);
+        }
+        idx++;
+    }
 }
 static bool alloc_surfels(ssf_handle* h, SurfelSoA& s, size_t n) {
     return dalloc(h, &s.pos, 3 * n) && dalloc(h, &s.col, 3 * n) && dalloc(h, &s.lab, 3 * n) && dalloc(h, &s.stamps, 2 * n) &&
@@ -1351,6 +1382,7 @@ void ssf_destroy(ssf_handle* h) {
         if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    if (!h->guarded.empty() && !getenv("SSF_GUARD_ONLY")) check_guards(h);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

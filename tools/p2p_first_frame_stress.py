@@ -103,6 +103,8 @@ def main():
     ref_model = ref_fs[0].get_model() if a.check_maps else None
     for f in ref_fs:
         f.close()
+    import hashlib
+    print("reference digest (poses, counters of the one-rank run):", hashlib.sha256(b"".join(x[0] + str(x[1:6]).encode() for x in ref)).hexdigest()[:16], flush=True)
     bad, t0 = [], time.time()
     GOOD = {}
     GOOD_OWN = {}
