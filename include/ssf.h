@@ -349,9 +349,9 @@ int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
  *   ssf_p2p_region / ssf_p2p_attach_local   the same for handles that live in ONE process (several shards on one
  *                         GPU, or several GPUs driven by one process with peer access enabled): regions[r] = the
  *                         pointer ssf_p2p_region returned for rank r.  Each rank must then be driven by its own
- *                         host thread: a frame call returns only when every peer has made the same call.  Shards
- *                         that SHARE one GPU this way: at most three (every rank needs a hardware queue of its own
- *                         while it waits for its peers).
+ *                         host thread: a frame call returns only when every peer has made the same call (and every
+ *                         rank's stream needs a hardware queue of its own while it waits: the runtime provides four
+ *                         per priority level; with more, the ranks time-slice).
  * All ranks must process the same frames in the same order.  A peer that never arrives makes the waiting call fail
  * with SSF_ERR_DEVICE after a bounded wait (seconds); it does not hang the device.  The CPU checker exports these
  * symbols and returns SSF_ERR_DEVICE. */

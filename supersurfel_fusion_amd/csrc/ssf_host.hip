@@ -1760,9 +1760,13 @@ static int p2p_region(ssf_handle* h) {
     HCK(hipSetDevice(h->cfg.device_id));
     const size_t bytes = p2p_region_bytes(h->S);
     void* q = nullptr;
-    // uncached / fine-grained device memory: what a peer stores is visible to a kernel that is already running
-    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) h->p2p.fine = true;
-    else if ((void)hipGetLastError(), hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) == hipSuccess) h->p2p.fine = true;
+    // Plain device memory.  Everything a peer reads or writes in a region is a system-scope atomic (cache-bypassing), so the
+    // mapping need not be uncached -- and an UNCACHED region (hipExtMallocWithFlags, what this code used first) is what made
+    // four ranks sharing one GPU differ from the one-rank run in the first frames of a freshly created group: 162 bad cycles
+    // in 1800 against 0 in 1800 with plain memory, same box, processes interleaved (tools/p2p_first_frame_stress.py,
+    // profiles/p2p_campaigns_r02.txt).  The uncached mapping stays available for experiments on a real multi-GPU node.
+    static const bool uncached = getenv("SSF_P2P_REGION_UNCACHED") != nullptr;
+    if (uncached && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) h->p2p.fine = true;
     else { (void)hipGetLastError(); HCK(hipMalloc(&q, bytes)); }
     HCK(hipMemset(q, 0, bytes));
     HCK(hipDeviceSynchronize());

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--n-model", type=int, default=200000)
     ap.add_argument("--spread-priorities", action="store_true", help="ranks 2, 3 get a normal-priority track stream (hardware queues are per priority level)")
+    ap.add_argument("--records", action="store_true", help="also fetch every rank's own and reduced ICP record after every frame (a legacy-stream copy per frame)")
     ap.add_argument("--check-maps", action="store_true", help="after the last frame compare every handle's frame maps and frame supersurfels with the one-rank run's")
     ap.add_argument("--independent", action="store_true", help="the handles are NOT shards: each holds the whole map (no exchange), "
                                                                "all run side by side -- is it the exchange, or handles running concurrently?")
@@ -80,7 +81,10 @@ def main():
                     rec = np.zeros(29, np.int64)
                     lib.lib.ssf_dbg_last_icp_record(fs[r].h, rec.ctypes.data_as(C.c_void_p))
                     dev_rec = np.zeros(64, np.int64)
-                    lib.lib.ssf_dbg_device_icp_records(fs[r].h, dev_rec.ctypes.data_as(C.c_void_p))
+                    # (a blocking copy on the legacy stream: while another thread captures its extract graph the runtime
+                    # refuses it -- "would make the legacy stream depend on a capturing stream" -- so only where asked for)
+                    if a.records:
+                        lib.lib.ssf_dbg_device_icp_records(fs[r].h, dev_rec.ctypes.data_as(C.c_void_p))
                     out[r].append((bytes(res.pose), res.icp_iters, res.n_model, res.n_updated, res.n_inserted, res.n_removed, rec, dev_rec))
             except Exception as e:
                 errs.append(str(e))
