@@ -79,7 +79,7 @@ def test_ranks_in_one_process_bit_exact(world, pipelined, nf, oracle_lib, produc
     assert sum(x["icp_iters"] for x in out[0]) >= nf - 1                   # the ICP exchange did run
 
 
-@pytest.mark.parametrize("world,pipelined", [(2, False), (2, True)])
+@pytest.mark.parametrize("world,pipelined", [(2, False), (2, True), (3, False), (4, True)])
 def test_ranks_in_separate_processes_bit_exact(world, pipelined, oracle_lib, tmp_path):
     W, H, nf = 320, 240, 6
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
