@@ -264,7 +264,7 @@ void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, i
                        const uint8_t* frgb, const float* fdepth, int n, uint8_t* codes);
 // ---- peer-to-peer exchanges (ssf_p2p_* in ssf.h) ----------------------------------------------
 // The ranks of one node exchange their small per-frame records through memory instead of through collective launches:
-// every rank owns an exchange REGION in its HBM (fine-grained, exported to the other processes through an IPC handle)
+// every rank owns an exchange REGION in its HBM (plain device memory, exported to the other processes through an IPC handle)
 // with one slot per (exchange kind, parity of the exchange's sequence number, source rank).  A producer stores its
 // record straight into slot [.][.][me] of every peer's region (xGMI stores) and then waits in its OWN region for the
 // slots of the others -- an all-gather by remote stores followed by a local, fixed-order reduction.  Two parities are
