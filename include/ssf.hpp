@@ -44,17 +44,26 @@ public:
     SupersurfelFusion& operator=(const SupersurfelFusion&) = delete;
     ~SupersurfelFusion() { if (h_) ssf_destroy(h_); }
 
-    /* initialize(): supersurfel_fusion.hpp:46-74 -- the 21 path-relevant arguments map 1:1 onto ssf_config.
-     * pipeline_depth / extract_batch: see ssf_config (0 / 1 = the reference's one-frame-in-flight behaviour).
-     * depth_prefilter: true (default) = processFrame filters the depth image first, as the reference's does
-     * (supersurfel_fusion.cu:180); false = the caller hands over the depth it wants segmented. */
+    /* initialize(): supersurfel_fusion.hpp:46-74 -- the reference's complete parameter list, in its order and with its
+     * defaults, so that the nodes' calls (node/supersurfel_fusion_node.cpp:256-284,
+     * node/supersurfel_fusion_rgbd_benchmark_node.cpp: same 29 positional arguments) compile unchanged.  The 21
+     * path-relevant arguments map 1:1 onto ssf_config; the last eight configure the reference's sparse VO (ORB
+     * features), loop closure and MOD, which are outside this library (their outputs enter processFrame as `vo_pose`
+     * and `dynamic`): accepted and ignored.  What this library adds -- pipelining, batching, the pre-filter switch --
+     * is set by name BEFORE initialize (setPipeline / setDepthPrefilter below) or through initialize(const ssf_config&);
+     * the defaults are the reference's behaviour: one frame in flight, processFrame filters the depth image first
+     * (supersurfel_fusion.cu:180). */
     void initialize(const CamParam& cam, int cell_size = 16, float lambda_pos = 50.f, float lambda_bound = 1000.f,
                     float lambda_size = 10000.f, float lambda_disp = 1e6f, float thresh_disp = 1e-4f,
                     int seg_iter = 10, bool seg_use_ransac = true, int nb_samples = 16, int filter_iter = 4,
                     float filter_alpha = 0.1f, float filter_beta = 1.0f, float filter_threshold = 0.05f,
                     float range_min = 0.2f, float range_max = 5.0f, int delta_t = 20, float conf_thresh = 2500.f,
                     int nb_supersurfels_max = 50000, int icp_iter = 10, double icp_cov_thresh = 0.04,
-                    int pipeline_depth = 0, int extract_batch = 1, bool depth_prefilter = true) {
+                    int nb_features = 2000, float features_scale_factor = 1.2f, int features_nb_levels = 8,
+                    int ini_th_fast = 20, int min_th_fast = 7, int untracked_threshold = 10,
+                    bool enable_loop_closure = true, bool enable_mod = true) {
+        (void)nb_features; (void)features_scale_factor; (void)features_nb_levels; (void)ini_th_fast; (void)min_th_fast;
+        (void)untracked_threshold; (void)enable_loop_closure; (void)enable_mod;
         ssf_config c; ssf_default_config(&c);
         c.width = cam.width; c.height = cam.height; c.fx = cam.fx; c.fy = cam.fy; c.cx = cam.cx; c.cy = cam.cy;
         c.cell_size = cell_size; c.lambda_pos = lambda_pos; c.lambda_bound = lambda_bound; c.lambda_size = lambda_size;
@@ -62,10 +71,15 @@ public:
         c.nb_samples = nb_samples; c.filter_iter = filter_iter; c.filter_alpha = filter_alpha; c.filter_beta = filter_beta;
         c.filter_threshold = filter_threshold; c.range_min = range_min; c.range_max = range_max; c.delta_t = delta_t;
         c.conf_thresh = conf_thresh; c.nb_supersurfels_max = nb_supersurfels_max; c.icp_iter = icp_iter;
-        c.icp_cov_thresh = icp_cov_thresh; c.pipeline_depth = pipeline_depth; c.extract_batch = extract_batch;
-        c.depth_prefilter = depth_prefilter ? 1 : 0;
+        c.icp_cov_thresh = icp_cov_thresh; c.pipeline_depth = pipeline_depth_; c.extract_batch = extract_batch_;
+        c.depth_prefilter = depth_prefilter_ ? 1 : 0;
         initialize(c);
     }
+    /* library-specific knobs, by name; they take effect at the next initialize().  pipeline_depth / extract_batch: see
+     * ssf_config (0 / 1 = the reference's one-frame-in-flight behaviour; 2 / 8 for replay through processSequence).
+     * depth_prefilter false = the caller hands over the depth it wants segmented. */
+    void setPipeline(int pipeline_depth, int extract_batch) { pipeline_depth_ = pipeline_depth; extract_batch_ = extract_batch; }
+    void setDepthPrefilter(bool on) { depth_prefilter_ = on; }
     void initialize(const ssf_config& c) {
         if (h_) { ssf_destroy(h_); h_ = nullptr; }
         if (ssf_create(&c, &h_) != SSF_OK) { h_ = nullptr; throw std::runtime_error(ssf_last_error(nullptr)); }
@@ -168,6 +182,7 @@ private:
     ssf_handle* h_ = nullptr;
     ssf_frame_result last_{};
     int width_ = 0, height_ = 0;
+    int pipeline_depth_ = 0, extract_batch_ = 1; bool depth_prefilter_ = true;
 };
 
 }  /* namespace supersurfel_fusion */

@@ -25,6 +25,8 @@ BENCHMARK_LAUNCH = dict(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=
                         filter_iter=3, filter_alpha=0.1, filter_beta=1.0, filter_threshold=0.05, range_min=0.2, range_max=5.0,
                         delta_t=20, conf_thresh=2560.0, nb_supersurfels_max=100000, icp_iter=10, icp_cov_thresh=0.05,
                         depth_prefilter=1, prefilter_sigma_color=0.03, prefilter_sigma_space=4.5)
+# rgbd_benchmark/fr3_cam.yaml: the intrinsics the launch file loads for rgbd_dataset_freiburg3_walking_halfsphere
+FR3_INTRINSICS = dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6)
 
 
 def read_associations(path, max_frames=None):
@@ -131,6 +133,54 @@ def replay(fusion, frames, out_path=None, export_model=None, pipelined=False):
     if export_model:
         fusion.export_model_txt(export_model)
     return lines, results
+
+
+def stage_figures(fusion, raw_depth):
+    """Per-stage figures of the frame just processed against the RAW sensor depth it came from (a real-data sanity check
+    of the extract stage that does not go through the trajectory): the plane-rendered depth of a3-a5 against the raw
+    depth on the inlier pixels, the inlier share of the valid-depth pixels, the share of superpixels that became
+    valid frame supersurfels (a6)."""
+    plane = fusion.plane_depth().astype(np.float64)
+    inl = fusion.inlier_map() != 0
+    raw = np.asarray(raw_depth, np.float64)
+    ok = inl & (raw > 0) & np.isfinite(plane)
+    rel = np.abs(plane[ok] - raw[ok]) / raw[ok]
+    fr = fusion.get_frame()
+    return dict(plane_vs_raw_median=float(np.median(rel)) if rel.size else float("nan"),
+                plane_vs_raw_p90=float(np.percentile(rel, 90)) if rel.size else float("nan"),
+                inlier_share_of_valid_depth=float(ok.sum() / max(1, (raw > 0).sum())),
+                valid_supersurfel_share=float((fr["confidences"] > 0).mean()))
+
+
+def quat_xyzw_to_rot(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def prior_consistency(fusion, frames, prior_xyz, prior_quat):
+    """Every frame (rgb, depth) is processed with prior_xyz[i] / prior_quat[i] (camera-to-map, TUM order) as its pose
+    prior -- processFrame's `pose = vo->getPose()` -- and the size of the ICP correction is recorded where the ICP
+    result was accepted.  Frame 0 builds the map at its prior."""
+    dt, da, valid, n = [], [], 0, 0
+    for i, (rgb, depth) in enumerate(frames):
+        R = quat_xyzw_to_rot(prior_quat[i])
+        prior = np.concatenate([R.reshape(-1), np.asarray(prior_xyz[i], np.float64)]).astype(np.float32)
+        r = fusion.process_frame(rgb, depth, prior_pose=prior)
+        n += 1
+        if i == 0 or not r["icp_valid"]:
+            continue
+        valid += 1
+        P = np.asarray(r["pose"], np.float64)
+        dR = R.T @ P[:9].reshape(3, 3)
+        dt.append(float(np.linalg.norm(P[9:] - prior_xyz[i])))
+        da.append(float(np.degrees(np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0)))))
+    return dict(frames=n, icp_valid_frames=valid,
+                correction_translation_median_m=float(np.median(dt)) if dt else None,
+                correction_translation_p90_m=float(np.percentile(dt, 90)) if dt else None,
+                correction_rotation_median_deg=float(np.median(da)) if da else None,
+                correction_rotation_p90_deg=float(np.percentile(da, 90)) if da else None)
 
 
 def frames_from_dataset(dataset_dir, depth_scale=0.0002, max_frames=None):

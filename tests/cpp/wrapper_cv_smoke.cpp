@@ -1,6 +1,6 @@
 // The cv::Mat surface of include/ssf.hpp (processFrame(cv::Mat, cv::Mat), computeSuperpixelSegIm, computeSlantedPlaneIm:
 // the reference's signatures, supersurfel_fusion.hpp:75-80) against the cv::Mat test double, plus getModelDevice and the
-// depth_prefilter switch of initialize().  Prints checksums that tests/test_cpp_wrapper.py compares with the Python mirror.
+// setDepthPrefilter switch.  Prints checksums that tests/test_cpp_wrapper.py compares with the Python mirror.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,8 +18,10 @@ int main(int argc, char** argv) {
     cam.fx = (float)std::atof(argv[5]); cam.fy = (float)std::atof(argv[6]); cam.cx = (float)std::atof(argv[7]); cam.cy = (float)std::atof(argv[8]);
     try {
         SupersurfelFusion a;
-        // prefilter explicitly OFF (the trailing switch), everything else as wrapper_smoke.cpp
-        a.initialize(cam, 16, 10.f, 1000.f, 1000.f, 1e8f, 1e-4f, 10, true, 16, 4, 0.1f, 1.0f, 0.05f, 0.2f, 5.0f, 20, 2500.f, 50000, 10, 0.04, 0, 1, false);
+        // prefilter explicitly OFF (a named setter: initialize() carries the reference's parameter list only), everything
+        // else as wrapper_smoke.cpp
+        a.setDepthPrefilter(false);
+        a.initialize(cam, 16, 10.f, 1000.f, 1000.f, 1e8f);
         for (int k = 0; k < n; k++) {
             cv::Mat rgb(H, W, CV_8UC3), depth(H, W, CV_32FC1);
             if (std::fread(rgb.ptr<uint8_t>(), 1, (size_t)3 * W * H, f) != (size_t)3 * W * H) return 4;

@@ -112,6 +112,40 @@ def test_cv_mat_surface_on_the_hip_library(oracle_lib, product_lib, tmp_path):
     _run_cv(oracle_lib, os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
 
 
+def _run_node_call(lib_path, lib_name, tmp_path):
+    """tests/cpp/node_initialize_call.cpp: the reference nodes' literal 29-argument initialize() call
+    (node/supersurfel_fusion_node.cpp:256-284) compiles against include/ssf.hpp, and the eight sparse-VO / loop-closure /
+    MOD arguments do not reach any library knob: same frames as the POD configuration with the same 21 path values."""
+    W, H, n = 160, 128, 3
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            rgb, depth = util.frame(k, W, H)
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes()); f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+    exe = tmp_path / "node_initialize_call"
+    libdir = os.path.dirname(lib_path)
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "node_initialize_call.cpp"), "-o", str(exe), "-L", libdir, "-l" + lib_name, "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    K = synthetic.intrinsics(W, H)
+    r = subprocess.run([str(exe), str(W), str(H), str(n), str(raw)] + [repr(float(K[k])) for k in ("fx", "fy", "cx", "cy")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "defaults_are_the_references 1", r.stdout
+    assert lines[1].startswith("node_call_equals_pod_config 1 n="), r.stdout
+    assert int(lines[1].split("n=")[1]) > 0
+
+
+def test_the_reference_nodes_initialize_call_compiles_and_means_the_same(oracle_lib, tmp_path):
+    _run_node_call(ORACLE_LIB, "ssf_oracle", tmp_path)
+
+
+@pytest.mark.gpu
+def test_the_reference_nodes_initialize_call_on_the_hip_library(product_lib, tmp_path):
+    _run_node_call(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
+
+
 def test_model_device_view_has_the_reference_layout(oracle_lib):
     """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
     import ctypes as C
