@@ -320,6 +320,8 @@ def main():
             return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
         if exchange:
             if a.comm == "p2p":
+                # every rank on its own GPU (LOCAL_RANK): fine-grained regions; a forced one-rank run shares its GPU with itself
+                fus.p2p_configure(all_ranks_on_this_device=(world == 1))
                 fus.p2p_attach()                   # IPC handles of the exchange regions, all-gathered over torch.distributed
             else:
                 fus.comm_attach()

@@ -335,6 +335,8 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
 int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
 
 /* ---- multi-GPU, native: peer to peer over xGMI, no collective launches ---------------------------
+ * EXPERIMENTAL until a run on two GPUs has passed tests/test_p2p_gpu.py bit for bit: every test so far had all ranks on
+ * ONE GPU (threads of one process, and separate processes through IPC handles); no store has crossed xGMI yet.
  * The latency-tuned exchange SURVEY.md section 5 / 8e proposes for the ranks of ONE node (cfg.nranks <= 8): every
  * handle owns an exchange region in its HBM; a rank stores its small records (29 x int64 ICP record per iteration,
  * association tables, migrant table, shard sizes) straight into the other ranks' regions and sums what arrives in
@@ -353,9 +355,17 @@ int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
  *                         rank's stream needs a hardware queue of its own while it waits: the runtime provides four
  *                         per priority level; with more, the ranks time-slice).
  * All ranks must process the same frames in the same order.  A peer that never arrives makes the waiting call fail
- * with SSF_ERR_DEVICE after a bounded wait (seconds); it does not hang the device.  The CPU checker exports these
+ * with SSF_ERR_DEVICE after a bounded wait (ssf_p2p_configure's timeout, wall clock); it does not hang the device.  The CPU checker exports these
  * symbols and returns SSF_ERR_DEVICE. */
 #define SSF_P2P_HANDLE_BYTES 64
+/* Optional, BEFORE ssf_p2p_export / ssf_p2p_region (the region is allocated there):
+ *   all_ranks_on_this_device  0 (default): peers live on other GPUs -- the region is FINE-GRAINED device memory
+ *                             (hipDeviceMallocFinegrained), the only kind HIP keeps coherent while a kernel that polls it is
+ *                             running and another device stores into it; 1: every rank of the map is a handle on THIS
+ *                             handle's GPU (several shards on one GPU): plain device memory.
+ *   timeout_s                 wall-clock bound (default 30 s) of every wait for a peer inside a kernel; also settable after
+ *                             the attach.  Ranks may reach their first exchange this far apart. */
+int ssf_p2p_configure(ssf_handle* h, int all_ranks_on_this_device, double timeout_s);
 int ssf_p2p_export(ssf_handle* h, uint8_t* handle64);
 int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles);
 int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes);

@@ -155,6 +155,7 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) { (void)id128; if (h) h
 int ssf_p2p_export(ssf_handle* h, uint8_t* handle64) { (void)handle64; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles) { (void)handles; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes) { (void)region; (void)bytes; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
+int ssf_p2p_configure(ssf_handle* h, int same_device, double timeout_s) { (void)same_device; (void)timeout_s; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_attach_local(ssf_handle* h, void* const* regions) { (void)regions; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_get_global_counts(ssf_handle* h, int64_t* out5) {
     if (!h || !out5) return SSF_ERR_INVALID_ARG;

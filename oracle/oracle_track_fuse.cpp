@@ -534,7 +534,7 @@ void fuse_begin(State& s, const uint64_t* best, const uint8_t* matched, int migr
 // and the stable 3-way reorder; emigrants are dropped without counting as removed.
 void fuse_end(State& s, const int32_t* table, ssf_frame_result* out) {
     const ssf_config& c = s.cfg;
-    int n_removed = 0;
+    int n_removed = 0, n_lost = 0;              // n_lost: arrivals from other shards that found this one full
     Surfels& M = s.model;
     if (!s.f_first) {                                                           // supersurfel_fusion.cu:351
         const Mat33 R = s.pose.R; const f3 t = s.pose.t;
@@ -542,7 +542,9 @@ void fuse_end(State& s, const int32_t* table, ssf_frame_result* out) {
             for (int f = 0; f < s.S; f++) {
                 const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * f];
                 if (w[0] - 1 != c.rank) continue;
-                if (s.n_model >= c.nb_supersurfels_max) continue;               // no room: dropped, like an insertion
+                // no room: the row is lost to the whole map (its old shard has let it go) -- counted as removed HERE, so that
+                // the sums of the per-shard counters stay the unsharded bookkeeping (n_model before = after + removed - inserted)
+                if (s.n_model >= c.nb_supersurfels_max) { n_lost++; continue; }
                 const int k = s.n_model++;
                 slot_to_row(M, k, w);
                 s.model_lab[k] = rgbToLab(M.col[k]);
@@ -602,7 +604,7 @@ void fuse_end(State& s, const int32_t* table, ssf_frame_result* out) {
         for (int i = 0; i < 3; i++) { out->pose[3 * i] = s.pose.R.r[i].x; out->pose[3 * i + 1] = s.pose.R.r[i].y; out->pose[3 * i + 2] = s.pose.R.r[i].z; }
         out->pose[9] = s.pose.t.x; out->pose[10] = s.pose.t.y; out->pose[11] = s.pose.t.z;
         out->icp_valid = s.last_icp_valid; out->icp_iters = s.last_icp_iters;
-        out->n_model = s.n_model; out->n_visible = s.n_visible; out->n_removed = n_removed;
+        out->n_model = s.n_model; out->n_visible = s.n_visible; out->n_removed = n_removed + n_lost;
         out->n_inserted = s.f_inserted; out->n_updated = s.f_updated; out->stamp = s.stamp;
     }
     s.stamp++;                                                                  // :522

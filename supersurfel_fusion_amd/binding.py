@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -139,6 +139,7 @@ class Library:
         L.ssf_p2p_attach.argtypes = [vp, vp]
         L.ssf_p2p_region.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ssf_p2p_attach_local.argtypes = [vp, C.POINTER(C.c_void_p)]
+        L.ssf_p2p_configure.argtypes = [vp, C.c_int, C.c_double]
         L.ssf_get_global_counts.argtypes = [vp, vp]
         L.ssf_stage_begin_submitted.argtypes = [vp]
         L.ssf_stage_icp_accumulate_device.argtypes = [vp, vp]
@@ -408,6 +409,11 @@ class Fusion:
 
     # peer-to-peer exchange (ssf_p2p_* in ssf.h): the ranks of one node trade their records through each other's HBM
     P2P_HANDLE_BYTES = 64
+
+    def p2p_configure(self, all_ranks_on_this_device=False, timeout_s=30.0):
+        """before p2p_export / p2p_region: plain device memory when every rank is a handle on this GPU (fine-grained
+        otherwise), and the wall-clock bound of every in-kernel wait for a peer"""
+        self._ck(self.L.lib.ssf_p2p_configure(self.h, 1 if all_ranks_on_this_device else 0, float(timeout_s)), "ssf_p2p_configure")
 
     def p2p_export(self):
         """64-byte IPC handle of this handle's exchange region (to be shipped to the other ranks)"""

@@ -277,7 +277,8 @@ void launch_fern_codes(hipStream_t st, const uint8_t* rgb, const float* depth, i
 // Everything a peer reads or writes in a region goes through system-scope atomic loads / stores (write-through,
 // cache-bypassing), so no cache write-back / invalidate is part of the protocol.
 #define SSF_P2P_MAX_RANKS 8
-struct P2PView { unsigned char* peer[SSF_P2P_MAX_RANKS]; int me, nranks, S; unsigned long long seq; };
+// timeout_ticks: bound of every in-kernel wait for a peer, in ticks of wall_clock64() (ssf_p2p_configure)
+struct P2PView { unsigned char* peer[SSF_P2P_MAX_RANKS]; int me, nranks, S; unsigned long long seq, timeout_ticks; };
 enum { P2P_FLAG_ASSOC = 0, P2P_FLAG_MIGR = 1 };
 #define SSF_P2P_HEADER 8192
 SSF_HD size_t p2p_slot(int par, int src) { return (size_t)(par * SSF_P2P_MAX_RANKS + src); }

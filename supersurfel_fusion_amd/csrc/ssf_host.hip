@@ -423,6 +423,7 @@ struct ssf_handle {
     // regions as mapped into this process, and one sequence number per exchange kind (identical on every rank)
     struct P2P {
         unsigned char* region = nullptr; size_t bytes = 0; bool fine = false;
+        bool same_device = false; double timeout_s = 30.0;       // ssf_p2p_configure
         P2PView view{}; bool on = false; std::vector<void*> opened;
         unsigned long long seq_icp = 0, seq_cnt = 0, seq_assoc = 0, seq_migr = 0;
     } p2p;
@@ -1019,7 +1020,7 @@ static int fuse_begin(ssf_handle* h, int migrate) {
 static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out) {
     SurfelSoA& M = h->model[h->mcur];
     const unsigned long long seq = ++h->cnt_seq;
-    h->fusing = false;
+    h->fusing = false;                           // (also on every error path below: the frame is over either way)
     if (!h->fuse_first) {
         const PartitionWs& ws = h->fuse_ws;
         if (h->fuse_migrate && d_table)
@@ -1092,6 +1093,7 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
     h->n_model = c.n_model; h->n_visible = c.n_visible;
     h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = c.oov_live;
     if (h->p2p.on && __atomic_load_n(&h->mb_host->p2p_timeout, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(&h->mb_host->p2p_timeout, 0u, __ATOMIC_RELEASE);       // reported once; a later frame starts clean
         h->err = "a peer's association / migrant tables never arrived (peer-to-peer exchange)"; return SSF_ERR_DEVICE;
     }
     if (out) {
@@ -1301,9 +1303,16 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
         static const int migrate = getenv("SSF_NO_MIGRATE") ? 0 : 1;                  // (bisecting switch of tools/p2p_first_frame_stress.py)
         rc = fuse_begin(h, migrate);
-        if (rc) return rc;
+        if (rc) { h->fusing = false; return rc; }
         if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320, h->mb_dev);
-        else if (h->fuse_migrate) NCK(api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream));
+        else if (h->fuse_migrate) {
+            const ncclResult_t nr = api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream);
+            if (nr != ncclSuccess) {          // the frame cannot be completed: the handle must not stay "between the two halves"
+                h->fusing = false;
+                h->err = std::string("ncclAllReduce (migrant table): ") + (api->GetErrorString ? api->GetErrorString(nr) : "RCCL error");
+                return SSF_ERR_DEVICE;
+            }
+        }
         rc = fuse_end(h, h->d_migrants, &r);
     } else
         rc = do_fuse(h, &r);
@@ -1754,23 +1763,48 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) {
     return SSF_OK;
 }
 // ---- multi-GPU (native, peer to peer: no collective launches) ---------------------------------------------------
+// the bound of every in-kernel wait for a peer, in ticks of the device's constant-rate wall clock (wall_clock64)
+static int p2p_set_timeout(ssf_handle* h) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    h->p2p.view.timeout_ticks = (unsigned long long)(h->p2p.timeout_s * 1000.0 * (double)khz);
+    return SSF_OK;
+}
 static int p2p_region(ssf_handle* h) {
     if (h->p2p.region) return SSF_OK;
     if (h->cfg.nranks > SSF_P2P_MAX_RANKS) { h->err = "the peer-to-peer exchange serves at most 8 ranks (one node)"; return SSF_ERR_INVALID_ARG; }
     HCK(hipSetDevice(h->cfg.device_id));
     const size_t bytes = p2p_region_bytes(h->S);
     void* q = nullptr;
-    // Plain device memory.  Everything a peer reads or writes in a region is a system-scope atomic (cache-bypassing), so the
-    // mapping need not be uncached -- and an UNCACHED region (hipExtMallocWithFlags, what this code used first) is what made
-    // four ranks sharing one GPU differ from the one-rank run in the first frames of a freshly created group: 162 bad cycles
-    // in 1800 against 0 in 1800 with plain memory, same box, processes interleaved (tools/p2p_first_frame_stress.py,
-    // profiles/p2p_campaigns_r02.txt).  The uncached mapping stays available for experiments on a real multi-GPU node.
+    // Which memory: peers store into this region and this rank's kernels poll it WHILE THEY RUN.  HIP guarantees coherence
+    // of ordinary (coarse-grained) device memory across devices only at kernel boundaries -- the owner's L2 may serve its
+    // polling loads stale lines while another GPU writes over xGMI -- so the region is FINE-GRAINED device memory
+    // (hipDeviceMallocFinegrained) unless the caller has declared, through ssf_p2p_configure, that every rank of the map
+    // lives on this handle's device (several shards on one GPU: the one arrangement this build could be run in).  There
+    // plain memory is used: all accesses to a region are system-scope atomics that meet in the same memory, and round 2's
+    // campaigns (profiles/p2p_campaigns_r02.txt) ran 2600 create-attach-run cycles clean with it against 211 bad ones with
+    // an UNCACHED region (hipDeviceMallocUncached; SSF_P2P_REGION_UNCACHED=1 brings that mapping back for experiments).
     static const bool uncached = getenv("SSF_P2P_REGION_UNCACHED") != nullptr;
     if (uncached && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) h->p2p.fine = true;
-    else { (void)hipGetLastError(); HCK(hipMalloc(&q, bytes)); }
+    else if (!uncached && !h->p2p.same_device && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) == hipSuccess) h->p2p.fine = true;
+    else {
+        (void)hipGetLastError();
+        if (!h->p2p.same_device && !uncached) { h->err = "fine-grained device memory for the exchange region is not available"; return SSF_ERR_DEVICE; }
+        HCK(hipMalloc(&q, bytes));
+    }
     HCK(hipMemset(q, 0, bytes));
     HCK(hipDeviceSynchronize());
     h->p2p.region = (unsigned char*)q; h->p2p.bytes = bytes;
+    return SSF_OK;
+}
+int ssf_p2p_configure(ssf_handle* h, int all_ranks_on_this_device, double timeout_s) {
+    if (!h || !(timeout_s > 0.0)) return SSF_ERR_INVALID_ARG;
+    if (h->p2p.region && (all_ranks_on_this_device != 0) != h->p2p.same_device) {
+        h->err = "ssf_p2p_configure: the exchange region is already allocated (call before ssf_p2p_export / ssf_p2p_region)"; return SSF_ERR_STATE;
+    }
+    h->p2p.same_device = all_ranks_on_this_device != 0;
+    h->p2p.timeout_s = timeout_s;
+    if (h->p2p.on) { int rc = p2p_set_timeout(h); if (rc) return rc; }
     return SSF_OK;
 }
 int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes) {
@@ -1791,6 +1825,7 @@ int ssf_p2p_export(ssf_handle* h, uint8_t* handle64) {
     return SSF_OK;
 }
 static int p2p_finish_attach(ssf_handle* h) {
+    { int rc = p2p_set_timeout(h); if (rc) return rc; }
     h->p2p.view.me = h->cfg.rank; h->p2p.view.nranks = h->cfg.nranks; h->p2p.view.S = h->S; h->p2p.view.seq = 0;
     h->p2p.on = true;
     h->all_valid = false; h->all_pending = false;
@@ -1921,7 +1956,7 @@ int ssf_stage_match_device(ssf_handle* h, uint64_t* d_best, uint8_t* d_matched) 
 }
 int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* d_matched, ssf_frame_result* out) {
     if (!h || !d_best || !d_matched) return SSF_ERR_INVALID_ARG;
-    if (!h->have_frame) return SSF_ERR_STATE;
+    if (!h->have_frame || h->fusing) return SSF_ERR_STATE;
     TimerScope ts(h);
     HCK(hipMemcpyAsync(h->cc->d_best, d_best, (size_t)h->S * 8, hipMemcpyDeviceToDevice, h->stream));
     HCK(hipMemcpyAsync(h->cc->d_matched, d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
@@ -1935,8 +1970,9 @@ int ssf_stage_fuse_begin_device(ssf_handle* h, const uint64_t* d_best, const uin
     HCK(hipMemcpyAsync(h->cc->d_matched, d_matched, (size_t)h->S, hipMemcpyDeviceToDevice, h->stream));
     int rc = fuse_begin(h, 1);
     if (rc) return rc;
-    if (h->fuse_migrate) HCK(hipMemcpyAsync(d_table, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S * 4, hipMemcpyDeviceToDevice, h->stream));
-    else HCK(hipMemsetAsync(d_table, 0, (size_t)SSF_MIGRANT_WORDS * h->S * 4, h->stream));
+    const hipError_t e = h->fuse_migrate ? hipMemcpyAsync(d_table, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S * 4, hipMemcpyDeviceToDevice, h->stream)
+                                         : hipMemsetAsync(d_table, 0, (size_t)SSF_MIGRANT_WORDS * h->S * 4, h->stream);
+    if (e != hipSuccess) { h->fusing = false; h->err = std::string("migrant table copy: ") + hipGetErrorString(e); return SSF_ERR_DEVICE; }
     return SSF_OK;
 }
 int ssf_stage_fuse_end_device(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out) {
@@ -1954,8 +1990,11 @@ int ssf_stage_fuse_begin(ssf_handle* h, const uint64_t* best, const uint8_t* mat
     int rc = fuse_begin(h, 1);
     if (rc) return rc;
     const size_t bytes = (size_t)SSF_MIGRANT_WORDS * h->S * 4;
-    if (h->fuse_migrate) { HCK(hipMemcpyAsync(table, h->d_migrants, bytes, hipMemcpyDeviceToHost, h->stream)); HCK(hipStreamSynchronize(h->stream)); }
-    else std::memset(table, 0, bytes);
+    if (h->fuse_migrate) {
+        hipError_t e = hipMemcpyAsync(table, h->d_migrants, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->fusing = false; h->err = std::string("migrant table copy: ") + hipGetErrorString(e); return SSF_ERR_DEVICE; }
+    } else std::memset(table, 0, bytes);
     return SSF_OK;
 }
 int ssf_stage_fuse_end(ssf_handle* h, const int32_t* table, ssf_frame_result* out) {
@@ -1967,7 +2006,7 @@ int ssf_stage_fuse_end(ssf_handle* h, const int32_t* table, ssf_frame_result* ou
 }
 int ssf_stage_fuse(ssf_handle* h, const uint64_t* best, const uint8_t* matched, ssf_frame_result* out) {
     if (!h || !best || !matched) return SSF_ERR_INVALID_ARG;
-    if (!h->have_frame) return SSF_ERR_STATE;
+    if (!h->have_frame || h->fusing) return SSF_ERR_STATE;
     TimerScope ts(h);
     HCK(hipMemcpyAsync(h->cc->d_best, best, (size_t)h->S * 8, hipMemcpyHostToDevice, h->stream));
     HCK(hipMemcpyAsync(h->cc->d_matched, matched, (size_t)h->S, hipMemcpyHostToDevice, h->stream));

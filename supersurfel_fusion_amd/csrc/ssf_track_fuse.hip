@@ -153,7 +153,19 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
     const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)v, src), hi = (unsigned int)__shfl((int)(unsigned int)(v >> 32), src);
     return ((unsigned long long)hi << 32) | lo;
 }
-#define P2P_SPIN_BOUND (1 << 22)      // ~seconds: a peer that never arrives must not hang the device
+// A peer that never arrives must not hang the device: every wait for a peer is bounded by WALL-CLOCK time (the constant-rate
+// counter behind wall_clock64(), P2PView::timeout_ticks = ssf_p2p_configure's timeout), not by a spin count -- ranks in
+// separate processes reach their first exchange seconds apart (set_model of a large map, graph captures, a cold box).
+struct P2PDeadline {
+    unsigned long long t0, ticks; unsigned int spins;
+    __device__ __forceinline__ explicit P2PDeadline(const P2PView& pv) : t0(wall_clock64()), ticks(pv.timeout_ticks), spins(0u) {}
+    // call once per unsuccessful poll; true = give up
+    __device__ __forceinline__ bool expired() {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) != 0u) return false;
+        return wall_clock64() - t0 > ticks;
+    }
+};
 // Wave 0 of the last workgroup: this rank's record (tot in lanes 0..28) goes into slot [parity][me] of every peer's region
 // as five self-validating lines (the format of Mailbox::icp_rec); the records of the others are awaited in this rank's
 // own region and added in rank order.  Returns false when a peer's record never arrived.
@@ -173,7 +185,7 @@ __device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, unsigned lon
     }
     unsigned char* mine = p2p_peer(pv, pv.me);
     const bool is_seq_word = l < 40 && (l & 7) == 7, is_payload = l < 40 && (l & 7) != 7 && (7 * (l >> 3) + (l & 7)) < 29;
-    int spins = 0;
+    P2PDeadline deadline(pv);
     for (int r = 0; r < pv.nranks; r++) {
         if (r == pv.me) continue;
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(mine + p2p_off_icp(par, r));
@@ -186,8 +198,7 @@ __device__ __forceinline__ bool p2p_icp_exchange(const P2PView& pv, unsigned lon
                 if (l < 29) tot += (long long)v;
                 break;
             }
-            if (++spins > P2P_SPIN_BOUND) return false;
-            __builtin_amdgcn_s_sleep(1);
+            if (deadline.expired()) return false;
         }
     }
     return true;
@@ -1196,8 +1207,8 @@ __global__ __launch_bounds__(1024) void k_migrate_in(SurfelSoA M, const int32_t*
                                                      Counters* cnt, ClassifyArgs ca, Rt pose, int stamp,
                                                      uint8_t* __restrict__ state_vis, PartitionWs ws) {
     __shared__ int wave_tot[16];
-    __shared__ int s_in[3];
-    if (threadIdx.x < 3) s_in[threadIdx.x] = 0;
+    __shared__ int s_in[4];                 // arrivals by state; [3] = arrivals turned away (shard at capacity)
+    if (threadIdx.x < 4) s_in[threadIdx.x] = 0;
     const Counters c1 = cnt[1];
     const int base_row = c1.mv_nv + c1.mv_nc;                  // first free row behind the insertions
     const int total_before = c1.n_model + c1.n_state2;         // rows in the store before this frame's removals
@@ -1226,20 +1237,21 @@ __global__ __launch_bounds__(1024) void k_migrate_in(SurfelSoA M, const int32_t*
             state_vis[k] = (uint8_t)st;
             atomicAdd(&ws.sup_vis[((k >> 8) / PART_GROUP) * 6 + 3 + st], 1u);
             atomicAdd(&s_in[st], 1);
-        }
+        } else if (flag)
+            atomicAdd(&s_in[3], 1);             // no room: lost to the whole map (the source shard has let it go) -> counted as removed here
         running += min(total, max(0, capacity - total_before - running));
         __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int in0 = s_in[0], in1 = s_in[1], in2 = s_in[2], n_in = in0 + in1 + in2;
-        if (n_in) {
+        const int in0 = s_in[0], in1 = s_in[1], in2 = s_in[2], n_in = in0 + in1 + in2, lost = s_in[3];
+        if (n_in || lost) {
             for (int q = 0; q < 2; q++) {
                 Counters c = cnt[q];
                 c.n_model += in0 + in1; c.n_visible += in0;
                 c.oov_tail += in1; c.oov_live += in1; c.mv_nc += n_in;
-                if (q == 1) { c.n_state0 += in0; c.n_state1 += in1; c.n_state2 += in2; c.n_removed += in2; }
-                c.last[0] = c.n_model; c.last[1] = c.n_visible; if (q == 1) c.last[2] = c.n_removed; else c.last[2] += in2;
+                if (q == 1) { c.n_state0 += in0; c.n_state1 += in1; c.n_state2 += in2; c.n_removed += in2 + lost; }
+                c.last[0] = c.n_model; c.last[1] = c.n_visible; if (q == 1) c.last[2] = c.n_removed; else c.last[2] += in2 + lost;
                 cnt[q] = c;
             }
         }
@@ -1429,7 +1441,7 @@ __global__ void k_p2p_counts(P2PView pv, const Counters* __restrict__ cnt, Mailb
     }
     unsigned char* mine = p2p_peer(pv, pv.me);
     unsigned long long part = 0;
-    int spins = 0;
+    P2PDeadline deadline(pv);
     for (int r = 0; r < pv.nranks; r++) {
         unsigned long long w = mine_word;
         if (r != pv.me) {
@@ -1438,8 +1450,7 @@ __global__ void k_p2p_counts(P2PView pv, const Counters* __restrict__ cnt, Mailb
                 w = l < 8 ? __hip_atomic_load(&src[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
                 const unsigned long long sum = (unsigned long long)wsum64(l < 3 ? (long long)w : 0ll) + seq;
                 if (shfl_u64(w, 7) == seq && shfl_u64(w, 6) == sum) break;
-                if (++spins > P2P_SPIN_BOUND) return;
-                __builtin_amdgcn_s_sleep(1);
+                if (deadline.expired()) return;
             }
         }
         if (l < 3) {
@@ -1458,14 +1469,12 @@ __global__ void k_p2p_counts(P2PView pv, const Counters* __restrict__ cnt, Mailb
 __device__ __forceinline__ bool p2p_wait_flags(const P2PView& pv, int kind) {
     unsigned char* mine = p2p_peer(pv, pv.me);
     const int par = (int)(pv.seq & 1ull);
-    int spins = 0;
+    P2PDeadline deadline(pv);
     for (int r = 0; r < pv.nranks; r++) {
         if (r == pv.me) continue;
         const unsigned long long* f = reinterpret_cast<const unsigned long long*>(mine + p2p_off_flag(kind, par, r));
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pv.seq) {
-            if (++spins > P2P_SPIN_BOUND) return false;
-            __builtin_amdgcn_s_sleep(1);
-        }
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != pv.seq)
+            if (deadline.expired()) return false;
     }
     return true;
 }

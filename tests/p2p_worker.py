@@ -22,6 +22,7 @@ def main():
     lib = binding.load_product()
     kw = dict(pipeline_depth=2, extract_batch=2) if pipelined else {}
     f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=rank, nranks=world, shard_tile=0.25, **kw))
+    f.p2p_configure(all_ranks_on_this_device=True)             # (the ranks are processes that share the box's one GPU)
     mine = f.p2p_export()
     tmp = os.path.join(d, "h%d.tmp" % rank)
     mine.tofile(tmp)

@@ -235,3 +235,7 @@ def test_openmp_build_equals_single_thread(oracle_lib):
         g.fuse_end(tables[-1] * 0)
     assert np.array_equal(tables[0], tables[1]) and (tables[0][:, 0] != 0).sum() > 0     # some rows do leave the shard
     util.compare_state(ga, gb, maps=False, frame_surfels=False)
+
+
+def test_an_arrival_at_a_full_shard_is_counted_as_removed(oracle_lib):
+    util.arrival_at_a_full_shard(oracle_lib)

@@ -48,6 +48,8 @@ def test_ranks_in_one_process_bit_exact(world, pipelined, nf, oracle_lib, produc
     kw = dict(pipeline_depth=2, extract_batch=2) if pipelined else {}
     fs = [binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, nb_supersurfels_max=4096, rank=r, nranks=world, shard_tile=0.25, **kw))
           for r in range(world)]
+    for f in fs:
+        f.p2p_configure(all_ranks_on_this_device=True)         # (one GPU per box: every rank is a handle on it)
     regions = [f.p2p_region()[0] for f in fs]
     for f in fs:
         f.p2p_attach_local(regions)
@@ -107,6 +109,8 @@ def test_a_missing_peer_is_an_error_not_a_hang(product_lib):
     """rank 0 of a two-rank map whose peer never calls: the frame call fails after the bounded wait"""
     W, H = 160, 128
     fs = [binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, nb_supersurfels_max=2048, rank=r, nranks=2, shard_tile=0.25)) for r in range(2)]
+    for f in fs:
+        f.p2p_configure(all_ranks_on_this_device=True, timeout_s=3.0)
     regions = [f.p2p_region()[0] for f in fs]
     fs[0].p2p_attach_local(regions)
     rgb, depth = util.frame(0, W, H)

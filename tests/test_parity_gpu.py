@@ -552,3 +552,12 @@ def test_tracking_survives_a_starved_host(oracle_lib, product_lib):
         util.same_result(a, c)
     util.compare_state(fo, fh, maps=False, frame_surfels=False)
     util.compare_state(fo, fl, maps=False, frame_surfels=False)
+
+
+def test_an_arrival_at_a_full_shard_is_counted_as_removed(oracle_lib, product_lib):
+    """k_migrate_in turns a row away when its shard is at capacity: the row is counted in n_removed there (the source shard
+    has already let it go), same as the oracle; everything else of the frame is untouched"""
+    fh, r0h, r1h = util.arrival_at_a_full_shard(product_lib)
+    fo, r0o, r1o = util.arrival_at_a_full_shard(oracle_lib)
+    util.same_result(r0h, r0o); util.same_result(r1h, r1o)
+    util.compare_state(fh, fo)

@@ -95,3 +95,40 @@ def exchange_and_fuse(ranks, best, matched):
     assert (filled <= 1).all(), "two ranks filled the same slot of the migrant table"
     total = np.sum(np.stack(tables).astype(np.int64), axis=0).astype(np.int32)
     return [f.fuse_end(total) for f in ranks]
+
+
+def arrival_at_a_full_shard(lib, W=160, H=128):
+    """A shard (rank 0 of 2) filled to its capacity receives one more row through the migrant table: the row cannot be
+    stored, so it is lost to the whole map (its source shard has already let it go) and must show up in n_removed of the
+    frame -- otherwise the sums of the per-shard counters stop being the unsharded bookkeeping.  Returns (handle,
+    result without the arrival, result with it)."""
+    out = []
+    for crafted in (False, True):
+        S = ((W + 15) // 16) * ((H + 15) // 16)
+        cap = S + 16
+        f = binding.Fusion(lib, make_cfg(lib, W, H, nb_supersurfels_max=cap, rank=0, nranks=2, shard_tile=0.25))
+        f.process_frame(*frame(0, W, H))
+        m = f.get_model()
+        valid = np.flatnonzero(m["confidences"] > 0)
+        pick = valid[np.arange(cap) % len(valid)]                        # capacity rows, all valid, all in view
+        full = {name: m[name][pick].copy() for name in m}
+        full["confidences"][:] = 5000.0                                  # nothing is culled as unstable
+        f.set_model(full, cap, 1)
+        f.stage_extract(*frame(1, W, H))
+        f.icp_begin()
+        while f.icp_update(f.icp_accumulate()):
+            pass
+        f.icp_end()
+        best, matched = f.match()
+        table = f.fuse_begin(best, matched)
+        if crafted:
+            slot = int(np.flatnonzero(table[:, 0] == 0)[0])
+            row = np.concatenate([full["positions"][0], full["colors"][0], full["stamps"][0].view(np.float32), full["orientations"][0],
+                                  full["shapes"][0], full["dims"][0], full["confidences"][:1]]).astype(np.float32)
+            table[slot, 0] = 1                                           # destination rank 0 (+ 1)
+            table[slot, 2:28] = row.view(np.int32)
+        out.append((f, f.fuse_end(table)))
+    (f0, r0), (f1, r1) = out
+    assert r1["n_removed"] == r0["n_removed"] + 1, (r0, r1)
+    assert r1["n_model"] == r0["n_model"] and r1["n_visible"] == r0["n_visible"]
+    return f1, r0, r1

@@ -65,6 +65,8 @@ def main():
             f.set_model({k: v[sel] for k, v in model.items()}, int((sel & vis).sum()), 30)
             fs.append(f)
         if world > 1:
+            for f in fs:
+                f.p2p_configure(all_ranks_on_this_device=True)
             regions = [f.p2p_region()[0] for f in fs]
             for f in fs:
                 f.p2p_attach_local(regions)

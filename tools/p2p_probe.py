@@ -36,6 +36,7 @@ def worker(rank, world, d, nf, n_model):
     f = binding.Fusion(lib, bench.make_cfg(lib, len(model["confidences"]) + 65536, rank, world, None, False, 0, 1))
     f.set_model(model, nvis, 30)
     if world > 1:
+        f.p2p_configure(all_ranks_on_this_device=True)
         mine = f.p2p_export()
         mine.tofile(os.path.join(d, "h%d.tmp" % rank)); os.replace(os.path.join(d, "h%d.tmp" % rank), os.path.join(d, "h%d.bin" % rank))
         hs = []
@@ -89,6 +90,8 @@ def threads_mode(world, nf, n_model):
         f.set_model({k: v[sel] for k, v in model.items()}, int((sel & vis).sum()), 30)
         fs.append(f)
     if world > 1:
+        for f in fs:
+            f.p2p_configure(all_ranks_on_this_device=True)
         regions = [f.p2p_region()[0] for f in fs]
         for f in fs:
             f.p2p_attach_local(regions)
