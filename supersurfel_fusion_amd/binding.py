@@ -170,7 +170,10 @@ def load_product():
     CPU fallback.  torch is imported first so that exactly one HIP runtime (the one torch
     ships, SONAME libamdhip64.so.7) lives in the process."""
     import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
-    return Library(PRODUCT_LIB)
+    # SSF_PRODUCT_VARIANT=<tag>: a differently compiled build of the SAME sources next to the product (csrc/variants/<tag>/,
+    # e.g. with in-kernel cycle counters: tools/build_variant.sh) -- for A/B probes on the GPU box, never for tests
+    tag = os.environ.get("SSF_PRODUCT_VARIANT")
+    return Library(os.path.join(_HERE, "csrc", "variants", tag, "libssf_hip.so") if tag else PRODUCT_LIB)
 
 
 def _ptr(a):

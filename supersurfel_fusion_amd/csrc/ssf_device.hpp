@@ -92,6 +92,10 @@ struct FrameMaps {
     // (pos.xyz, 0) (unused)
     uint2* pix2; float4* fpack;
     uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
+    // resident relabelling (k_passes, launch_update_passes): second label map -- only the border pixels of the resident
+    // regions are ever valid in it -- and the frame's barrier words (one 64-bit word per phase: arrivals | abort << 32),
+    // zeroed by ingest
+    int32_t* label_alt; unsigned long long* pbar;
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
     const float* srgb_lut; // srgb_expand(c/255) for c = 0..255, built on the host with the same function
@@ -120,6 +124,7 @@ SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     }
     m.sp = slab_shift(m.sp, o); m.samples = slab_shift(m.samples, o); m.sample_score = slab_shift(m.sample_score, o);
     m.moments = slab_shift(m.moments, o); m.filt = slab_shift(m.filt, o); m.epoch = slab_shift(m.epoch, o);
+    m.label_alt = slab_shift(m.label_alt, o); m.pbar = slab_shift(m.pbar, o);
     m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
     return m;
 }
@@ -160,6 +165,9 @@ struct Mailbox {
     // peer-to-peer exchanges: set (never cleared) when a bounded wait for a peer ran out inside a kernel that has no record
     // of its own to withhold (association, migrant table); the host turns it into SSF_ERR_DEVICE at the end of the frame
     unsigned int p2p_timeout;
+    // resident relabelling: set (never cleared by the device) when a launch's workgroups could not all become resident
+    // within its bound and gave up (the frames of that batch are invalid; the host reports SSF_ERR_DEVICE)
+    unsigned int extract_abort;
 };
 #define SSF_ICP_REPLICAS 8
 // word w of Mailbox::icp_rec for payload p[0..29] (29 sums + checksum) and sequence number seq
@@ -172,6 +180,12 @@ void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameM
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
 int pass_tile_npx(int nb);     // 1: 32-wide relabelling tiles, 2: 64-wide (log regions of 512 entries per tile)
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0);
+// Passes [k0, k1) of one phase (all RGB or all RGB-D) in ONE launch whose workgroups keep their region of the label map
+// in LDS from pass to pass (k_passes in ssf_extract.hip); returns false -- nothing launched -- when the geometry does
+// not qualify (the caller then launches the passes one by one).  Both sums buffers are complete afterwards.
+// abort_flag: host-visible word set (never cleared) when the launch's workgroups could not all become resident and gave up.
+bool launch_update_passes(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k0, int k1, bool rgbd, unsigned int* abort_flag);
+bool update_passes_resident(const SegParams& p, int nb);       // would launch_update_passes take this geometry?
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb);
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac);

@@ -459,6 +459,7 @@ struct ssf_handle {
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
     bool graph_failed = false; hipStream_t capture_stream = nullptr;
+    hipEvent_t ev_resident = nullptr; bool ev_resident_valid = false;     // resident relabelling launches take turns (resident_turn_begin)
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
     int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
@@ -585,13 +586,34 @@ struct TimerScope {
 // Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
 // kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
 // only materialised where a later stage wants it: before the plane filter.
-static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st) {
+// Resident relabelling launches (k_passes) need all their workgroups on the chip at once; two of them from different
+// extract contexts could each hold half of the slots and wait for the other half forever (bounded: they would give up and
+// the batch would be lost).  So they are serialised across the contexts of a handle: each one waits for the event recorded
+// behind the previous one.  (One host thread makes all these calls, in order: a single event suffices -- a wait refers to
+// the record that preceded it.)
+static void resident_turn_begin(ssf_handle* h, hipStream_t st) {
+    if (h->ev_resident_valid) (void)hipStreamWaitEvent(st, h->ev_resident, 0);
+}
+static void resident_turn_end(ssf_handle* h, hipStream_t st) {
+    if (!h->ev_resident && hipEventCreateWithFlags(&h->ev_resident, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->ev_resident = nullptr; return; }
+    if (hipEventRecord(h->ev_resident, st) == hipSuccess) h->ev_resident_valid = true;
+}
+static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, bool resident = false) {
     const SegParams& p = h->seg;
     const int nb = c.count;
     const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
     const int k1 = std::min(4 * (h->cfg.seg_iter / 2), limit), k2 = std::min(4 * h->cfg.seg_iter, std::max(limit, k1));
-    for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false);
+    // (resident form: all passes of a phase in one launch whose workgroups keep their region of the label map in LDS,
+    // k_passes in ssf_extract.hip; per-pass launches when the geometry does not qualify or SSF_RESIDENT_PASSES=0)
+    unsigned int* abort_flag = &h->mb_dev->extract_abort;
+    const bool multi = h->ctx.size() > 1;
+    if (resident) {
+        if (multi) resident_turn_begin(h, st);
+        (void)launch_update_passes(st, p, c.maps, nb, 0, k1, false, abort_flag);
+        if (multi) resident_turn_end(h, st);
+    } else
+        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false);
     // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
     if (h->cfg.seg_use_ransac) {
         launch_init_samples(st, p, c.maps, nb, k1 & 1);
@@ -599,13 +621,21 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st) {
         launch_init_disp(st, p, c.maps, nb, true);
     } else launch_init_disp(st, p, c.maps, nb, false);
     int k = k1;
-    for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true);
+    if (resident) {
+        if (multi) resident_turn_begin(h, st);
+        (void)launch_update_passes(st, p, c.maps, nb, k1, k2, true, abort_flag);
+        if (multi) resident_turn_end(h, st);
+        k = std::max(k1, k2);
+    } else
+        for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true);
     launch_plane_filter(st, p, c.maps, nb, k & 1);             // final merge (table + planes) + smoothing sweeps
     launch_render_moments(st, p, h->cam, c.maps, nb);
 }
 // ~45 short dependent kernels: replayed as one captured hipGraph (launch-bound inner loop), one graph per
 // batch size; eager when kernels are individually timed or the pass count is being bisected
 static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
+    // the resident form is 8 launches instead of 45 and carries event waits between contexts: launched eagerly, no graph
+    if (update_passes_resident(h->seg, c.count)) { enqueue_segmentation(h, c, c.stream, true); return SSF_OK; }
     const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
     if (use_graph) {
         hipGraphExec_t& ex = c.exec[c.count];
@@ -1092,6 +1122,12 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
     }
     h->n_model = c.n_model; h->n_visible = c.n_visible;
     h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = c.oov_live;
+    if (__atomic_load_n(&h->mb_host->extract_abort, __ATOMIC_ACQUIRE) != 0u) {
+        __atomic_store_n(&h->mb_host->extract_abort, 0u, __ATOMIC_RELEASE);
+        h->err = "a resident relabelling launch could not get all its workgroups onto the GPU and gave up (the GPU is oversubscribed: "
+                 "several processes? SSF_RESIDENT_PASSES=0 selects per-pass launches); the frames of that batch are invalid";
+        return SSF_ERR_DEVICE;
+    }
     if (h->p2p.on && __atomic_load_n(&h->mb_host->p2p_timeout, __ATOMIC_ACQUIRE) != 0u) {
         __atomic_store_n(&h->mb_host->p2p_timeout, 0u, __ATOMIC_RELEASE);       // reported once; a later frame starts clean
         h->err = "a peer's association / migrant tables never arrived (peer-to-peer exchange)"; return SSF_ERR_DEVICE;
@@ -1395,6 +1431,7 @@ void ssf_destroy(ssf_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->ev_resident) (void)hipEventDestroy(h->ev_resident);
     for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1461,6 +1498,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         FrameMaps& m = c.maps;
         take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
         take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1); take(m.pix2, P); take(m.fpack, 4 * S);
+        take(m.label_alt, P); take(m.pbar, 16);
         for (int b = 0; b < 2; b++) take(m.sums[b].r, S);
         for (int b = 0; b < 3; b++) { take(m.log.ent[b], NT * 256); take(m.log.disp[b], NT * 256); take(m.log.count[b], NT); }
         SurfelSoA& f = c.frame;
