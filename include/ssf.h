@@ -229,6 +229,10 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth_m, int o
                       const uint8_t* dynamic_mask);
 /* Stop the segmentation after max_passes relabelling passes (0 = all); test/bisect aid. */
 int ssf_debug_set_max_passes(ssf_handle* h, int max_passes);
+/* Test / measurement hook: from how many visible rows on a frame's tracking streams a TILE-SORTED copy of their ICP /
+ * association fields (product: never by default -- measured slower at BASELINE config 3 --; 0 = always, < 0 = never; results are the same
+ * bit for bit either way: DESIGN.md section 4.  The checker accepts and ignores it). */
+int ssf_debug_set_bin_min_rows(ssf_handle* h, int min_rows);
 /* Product-internal upkeep made callable for tests: compact the out-of-view row store now (DESIGN.md
  * section 3; a no-op for the results).  The CPU checker has no such store and returns SSF_OK. */
 int ssf_debug_recentre(ssf_handle* h);
@@ -415,6 +419,24 @@ int ssf_bilateral_filter(ssf_handle* h, const void* depth_in, void* depth_out, i
 int ssf_apply_deformation(ssf_handle* h, const float* node_positions, const float* node_rotations,
                           const float* node_translations, int n_nodes, const float* weights4,
                           const int32_t* idx4);
+
+/* ---- sharded maps: re-homing after positions changed outside a frame -------------------------------------------
+ * ssf_apply_deformation moves EVERY row (applyDeformation, deformation_graph_kernels.cu:27-73); the per-frame migration
+ * (ssf_stage_fuse_begin / _end, or inside ssf_process_frame with an exchange backend attached) only moves rows a frame has
+ * updated.  After a loop closure on a sharded map, one sweep of these two calls puts every row back on the rank that owns
+ * the world tile of its position (a rare, bulk operation; the transport between the ranks is the caller's --
+ * supersurfel_fusion_amd/sharded.py does it over torch.distributed):
+ *   ssf_rehome_begin   the valid rows whose position belongs to another rank's tile leave this shard, in logical order, as
+ *                      records of SSF_MIGRANT_WORDS int32 words in the caller's `table` (room for table_rows records): word 0
+ *                      = destination rank + 1, word 1 = 1 when the row sat in the shard's visible block, words 2..27 = the
+ *                      row (layout of the migrant table above).  *n_out = their number.  SSF_ERR_CAPACITY (nothing changed)
+ *                      when table_rows records do not suffice.
+ *   ssf_rehome_end     `table` holds n records -- the tables of all ranks one after the other in rank order, or any selection
+ *                      in that order that contains every record addressed to this rank: those are appended, the ones
+ *                      flagged visible behind the visible block, the others behind the out-of-view rows.
+ * No frame may be pending in the extract pipeline.  Both calls are no-ops for an unsharded handle. */
+int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out);
+int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* With cfg.profile = 1: per-kernel accumulated hipEvent time since the last reset.

@@ -91,6 +91,7 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_
 int ssf_debug_recentre(ssf_handle* h) { return h ? SSF_OK : SSF_ERR_INVALID_ARG; }
 long long ssf_debug_recentre_count(const ssf_handle* h) { return h ? 0 : -1; }
 int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->s.max_passes = n; return SSF_OK; }
+int ssf_debug_set_bin_min_rows(ssf_handle* h, int n) { (void)n; return h ? SSF_OK : SSF_ERR_INVALID_ARG; }     // (a layout choice of the product; nothing to do here)
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;
     h->s.id_offset = off; h->s.global_n_model = gm; h->s.global_n_visible = gv; return SSF_OK;
@@ -380,6 +381,19 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
                           const float* w4, const int32_t* idx4) {
     if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
     apply_deformation(h->s, np, nr, nt, m, w4, idx4); return SSF_OK;
+}
+int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out) {
+    if (!h || !n_out || table_rows < 0 || (!table && table_rows > 0)) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) { h->s.err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    const int n = rehome_begin(h->s, table, table_rows);
+    if (n < 0) { h->s.err = "ssf_rehome_begin: the table is too small for the rows that leave"; return SSF_ERR_CAPACITY; }
+    *n_out = n; return SSF_OK;
+}
+int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n) {
+    if (!h || n < 0 || (!table && n > 0)) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty()) { h->s.err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    if (!rehome_end(h->s, table, n)) { h->s.err = "ssf_rehome_end: no room for the arriving rows"; return SSF_ERR_CAPACITY; }
+    return SSF_OK;
 }
 int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device) {
     (void)on_device;

@@ -654,6 +654,61 @@ Mat33 quat_to_rot(const float* q) {
     return m;
 }
 
+// ---- re-homing of a sharded map (multi-GPU; no reference counterpart) --------------------------------------------
+// applyDeformation moves EVERY row (deformation_graph_kernels.cu:27-73), the per-frame migration only rows a frame has
+// updated: after a loop closure a shard holds rows whose tile belongs to another rank until this sweep has run.
+// rehome_begin: the valid rows that now belong elsewhere leave, in logical order, as migrant-table records (word 1 = 1
+// when the row sat in the visible block); the others close ranks, visible block first.  Returns the number of records,
+// or -1 (nothing changed) when `cap` records do not suffice.
+int rehome_begin(State& s, int32_t* table, int cap) {
+    const ssf_config& c = s.cfg;
+    if (c.nranks <= 1) return 0;
+    Surfels& M = s.model;
+    int n_leave = 0;
+    for (int i = 0; i < s.n_model; i++) if (M.conf[i] > 0.0f && owner_of(s, M.pos[i]) != c.rank) n_leave++;
+    if (n_leave > cap) return -1;
+    int w = 0, k = 0, nv = 0;
+    for (int i = 0; i < s.n_model; i++) {
+        const int dest = M.conf[i] > 0.0f ? owner_of(s, M.pos[i]) : c.rank;
+        if (dest != c.rank) {
+            int32_t* rec = &table[(size_t)SSF_MIGRANT_WORDS * w++];
+            row_to_slot(M, i, dest, rec);
+            rec[1] = i < s.n_visible ? 1 : 0;
+        } else {
+            if (k != i) { M.copy_row(k, M, i); s.model_lab[k] = s.model_lab[i]; }
+            if (i < s.n_visible) nv++;
+            k++;
+        }
+    }
+    s.n_model = k; s.n_visible = nv;
+    return w;
+}
+// rehome_end: the records addressed to this rank arrive, in table order: those flagged visible behind the visible
+// block, the others behind the out-of-view rows.  false (nothing changed) when the shard has no room for them.
+bool rehome_end(State& s, const int32_t* table, int n) {
+    const ssf_config& c = s.cfg;
+    int av = 0, ao = 0;
+    for (int j = 0; j < n; j++) {
+        const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * j];
+        if (w[0] - 1 == c.rank) { if (w[1]) av++; else ao++; }
+    }
+    if (av + ao == 0) return true;
+    if (s.n_model + av + ao > c.nb_supersurfels_max) return false;
+    Surfels& M = s.model;
+    // make room for the visible arrivals between the two blocks: the out-of-view rows move up by av (from the back)
+    for (int i = s.n_model - 1; i >= s.n_visible; i--) { M.copy_row(i + av, M, i); s.model_lab[i + av] = s.model_lab[i]; }
+    int kv = s.n_visible, ko = s.n_model + av;
+    for (int j = 0; j < n; j++) {
+        const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * j];
+        if (w[0] - 1 != c.rank) continue;
+        const int k = w[1] ? kv++ : ko++;
+        slot_to_row(M, k, w);
+        s.model_lab[k] = rgbToLab(M.col[k]);
+    }
+    s.n_visible += av; s.n_model += av + ao;
+    return true;
+}
+
 // applyDeformation, deformation_graph_kernels.cu:27-73
 void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
                        const float* w4, const int32_t* idx4) {

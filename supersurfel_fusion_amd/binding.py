@@ -57,7 +57,7 @@ class SsfFrameResult(C.Structure):
 ABI_SYMBOLS = [
     "ssf_abi_version", "ssf_backend_name", "ssf_default_config", "ssf_create", "ssf_destroy",
     "ssf_last_error", "ssf_process_frame", "ssf_process_frame_device", "ssf_stage_extract",
-    "ssf_debug_set_max_passes", "ssf_stage_set_shard", "ssf_stage_icp_begin",
+    "ssf_debug_set_max_passes", "ssf_debug_set_bin_min_rows", "ssf_stage_set_shard", "ssf_stage_icp_begin",
     "ssf_stage_icp_accumulate", "ssf_stage_icp_update", "ssf_stage_icp_end", "ssf_stage_match",
     "ssf_stage_fuse", "ssf_get_pose", "ssf_set_pose", "ssf_get_counts", "ssf_get_model",
     "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_rehome_begin", "ssf_rehome_end", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -99,6 +99,7 @@ class Library:
         L.ssf_process_frame_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(SsfFrameResult)]
         L.ssf_stage_extract.argtypes = [vp, vp, vp, C.c_int, vp]
         L.ssf_debug_set_max_passes.argtypes = [vp, C.c_int]
+        L.ssf_debug_set_bin_min_rows.argtypes = [vp, C.c_int]
         L.ssf_debug_recentre.argtypes = [vp]
         L.ssf_debug_recentre_count.argtypes = [vp]
         L.ssf_debug_recentre_count.restype = C.c_longlong
@@ -140,6 +141,8 @@ class Library:
         L.ssf_p2p_region.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.ssf_p2p_attach_local.argtypes = [vp, C.POINTER(C.c_void_p)]
         L.ssf_p2p_configure.argtypes = [vp, C.c_int, C.c_double]
+        L.ssf_rehome_begin.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.ssf_rehome_end.argtypes = [vp, vp, C.c_int]
         L.ssf_get_global_counts.argtypes = [vp, vp]
         L.ssf_stage_begin_submitted.argtypes = [vp]
         L.ssf_stage_icp_accumulate_device.argtypes = [vp, vp]
@@ -303,6 +306,10 @@ class Fusion:
 
     def set_max_passes(self, n):
         self._ck(self.L.lib.ssf_debug_set_max_passes(self.h, n), "ssf_debug_set_max_passes")
+
+    def set_bin_min_rows(self, n):
+        """visible rows from which a frame's tracking streams a tile-sorted copy of them (product default: never; 0 = always)"""
+        self._ck(self.L.lib.ssf_debug_set_bin_min_rows(self.h, int(n)), "ssf_debug_set_bin_min_rows")
 
     def set_shard(self, id_offset, global_n_model, global_n_visible):
         self._ck(self.L.lib.ssf_stage_set_shard(self.h, id_offset, global_n_model, global_n_visible), "ssf_stage_set_shard")
@@ -550,6 +557,19 @@ class Fusion:
              np.ascontiguousarray(idx4, np.int32)]
         self._ck(self.L.lib.ssf_apply_deformation(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), len(a[0]),
                                                   _ptr(a[3]), _ptr(a[4])), "ssf_apply_deformation")
+
+    def rehome_begin(self, capacity=None):
+        """rows that now belong to another rank's tile leave this shard -> (n, MIGRANT_WORDS) int32 records"""
+        cap = self.counts()["n_model"] if capacity is None else int(capacity)
+        table = np.zeros((max(cap, 1), MIGRANT_WORDS), np.int32)
+        n = C.c_int(0)
+        self._ck(self.L.lib.ssf_rehome_begin(self.h, _ptr(table), cap, C.byref(n)), "ssf_rehome_begin")
+        return table[:n.value].copy()
+
+    def rehome_end(self, table):
+        """table: the records of all ranks in rank order (those addressed to this rank are appended)"""
+        table = np.ascontiguousarray(table, np.int32).reshape(-1, MIGRANT_WORDS)
+        self._ck(self.L.lib.ssf_rehome_end(self.h, _ptr(table), len(table)), "ssf_rehome_end")
 
     def bilateral_filter(self, depth):
         depth = np.ascontiguousarray(depth, np.float32)

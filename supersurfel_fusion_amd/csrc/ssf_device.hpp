@@ -213,10 +213,17 @@ struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; 
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
-                unsigned long long go_seq = 0, const struct P2PView* pv = nullptr);
+                unsigned long long go_seq = 0, const struct P2PView* pv = nullptr, int by_tile = 0);
+// Tile-sorted copy of the ICP / association fields of the n visible rows of `model` (pos, lab, r2, conf -> the same
+// streams of `out`; out_idx[j] = the row's index in the visible array) under transform T (model -> camera): see k_bin_* in
+// ssf_track_fuse.hip.  count / cursor: bin_count_words(cam) words each, count zero at rest.  launch_icp(by_tile = 1) /
+// launch_match(orig = out_idx) then take `out` as their rows.
+void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out, int32_t* out_idx);
+int bin_count_words(const Cam& cam);
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
-                  unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S);
+                  unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S,
+                  const int32_t* orig = nullptr /* model = tile-sorted copy: index of each row in the visible array */);
 struct OovStore { SurfelSoA rows; uint8_t* live; int cap; };      // out-of-view rows of the model store (see below)
 // Sums the per-frame stable partition works from (k_update_insert / k_move_rows in ssf_track_fuse.hip): per group of PART_GROUP blocks
 // the class counts (sup_vis: 6 per group, sup_oov: rows that come back into view), and the frame totals
@@ -246,6 +253,12 @@ void launch_pack_emigrants(hipStream_t st, SurfelSoA model, const unsigned long 
 void launch_migrate_in(hipStream_t st, SurfelSoA model, const int32_t* table, int S, int rank, int capacity, Counters* cnt,
                        const Cam& cam, Rt pose, int stamp, const float* plane_depth, int delta_t, float conf_thresh, float zmin,
                        float zmax, uint8_t* state_vis, const PartitionWs& ws);
+// re-homing of a sharded map (ssf_rehome_begin / _end): split the dense view into the rows that stay (-> stay, ranks closed,
+// visible block first) and the rows that leave (-> migrant-table records); bc: 3 words per block of 256 rows, tot3: totals
+// (staying, leaving, staying rows of the visible block); unpack: records -> rows [base, base + n) of dst
+void launch_rehome_split(hipStream_t st, SurfelSoA dense, int n, int n_visible, int rank, int nranks, float tile, uint32_t* bc, int* tot3,
+                         SurfelSoA stay, int32_t* table, int table_rows);
+void launch_rehome_unpack(hipStream_t st, const int32_t* table, int n, SurfelSoA dst, int base);
 void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int S, int capacity, int rank,
                         int nranks, float tile, Counters* cnt);
 // first ICP iteration of the next frame, accumulated by the row-move kernel of this one (launch_classify_reorder)

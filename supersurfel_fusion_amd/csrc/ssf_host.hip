@@ -459,6 +459,10 @@ struct ssf_handle {
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
     bool graph_failed = false; hipStream_t capture_stream = nullptr;
+    // tile-sorted copy of the visible rows' ICP / association fields (launch_bin_rows), made at the start of a frame's
+    // tracking when the visible set is large (bin_min_rows); valid for that frame only
+    SurfelSoA bins{}; int32_t* d_bin_idx = nullptr; uint32_t* d_bin_count = nullptr; uint32_t* d_bin_cursor = nullptr;
+    bool bins_valid = false; int bin_min_rows = -1;      // OFF: measured a loss at BASELINE config 3 (k_icp is bound by its LDS atomics, not by the gathers; sorted rows pile k_match's atomicMin onto the same words)
     hipEvent_t ev_resident = nullptr; bool ev_resident_valid = false;     // resident relabelling launches take turns (resident_turn_begin)
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
@@ -791,6 +795,7 @@ static void icp_start_from(IcpLoop& I, const Rt& pose) {
     for (int i = 0; i < 16; i++) I.tf_inc[i] = (i % 5 == 0) ? 1.0 : 0.0;
 }
 static void icp_begin(ssf_handle* h, const float* prior) {
+    h->bins_valid = false;                        // (process_oldest makes this frame's tile-sorted copy after this call)
     if (prior) h->pose = pose_from12(prior);
     IcpLoop& I = h->icp;
     // a record accumulated ahead is this frame's first iteration only if nothing it was computed from has changed
@@ -822,12 +827,14 @@ static Rt icp_transform(IcpLoop& I) {
     Rt T; T.R = m3_mul(R_inc, I.R_init); T.t = add(m3_mulv(R_inc, I.t_init), t_inc);
     return T;
 }
+// the rows an ICP / association launch streams: the visible array, or its tile-sorted copy when this frame has one
+static inline const SurfelSoA& icp_rows(const ssf_handle* h) { return h->bins_valid ? h->bins : h->model[h->mcur]; }
 static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullptr) {
     IcpLoop& I = h->icp;
     const Rt T = icp_transform(I);
     const unsigned long long seq = ++h->icp_seq;
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
-               h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq);
+    launch_icp(h->stream, h->cam, icp_rows(h), h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
+               h->d_icp_replicas, h->d_tickets + 8, d_out ? d_out : h->d_icp, h->mb_dev, seq, -1, nullptr, 0, nullptr, h->bins_valid ? 1 : 0);
     HCK(hipGetLastError());
     return to_host ? icp_fetch(h, seq) : SSF_OK;
 }
@@ -858,7 +865,12 @@ static int icp_fetch(ssf_handle* h, unsigned long long seq, IcpGo* waiter, unsig
             // Nothing for 5 s.  The device may simply be slow or stalled (a cold box, a debugger, another tenant): drain the
             // stream -- however long that takes -- and look again before calling it an error; only a record that is
             // still missing once everything enqueued has run is one.
-            if (drained) { h->err = "ICP mailbox record never arrived"; return SSF_ERR_DEVICE; }
+            if (drained) {
+                char where[160];
+                std::snprintf(where, sizeof(where), " (rank %d of %d, frame stamp %d, iteration %d, record %llu, peer exchange %llu, %d visible rows)", h->cfg.rank,
+                              h->cfg.nranks, h->stamp, h->icp.iter, seq, h->p2p.seq_icp, h->n_visible);
+                h->err = std::string("ICP mailbox record never arrived") + where; return SSF_ERR_DEVICE;
+            }
             if (waiter) { icp_release_waiting(waiter, waiter_go_seq, nullptr); if (waiter_dismissed) *waiter_dismissed = true; waiter = nullptr; }
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) { h->err = std::string("device error while waiting for the ICP record: ") + hipGetErrorString(e); return SSF_ERR_DEVICE; }
@@ -981,7 +993,10 @@ static int store_from_dense(ssf_handle* h, int n, int n_visible) {
     HCK(hipStreamSynchronize(h->stream));
     HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
     h->n_model = n; h->n_visible = n_visible; h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = n_oov;
-    h->all_valid = false;
+    // the shard sizes the ranks exchanged at the end of the last frame (read lazily at the start of the next) describe the
+    // map that has just been replaced: dropped, the next frame exchanges them afresh (every rank replaces its shard in the
+    // same call sequence -- ssf_set_model, ssf_apply_deformation, ssf_rehome_* -- so the exchange numbers stay in step)
+    h->all_valid = false; h->all_pending = false;
     return SSF_OK;
 }
 
@@ -995,15 +1010,17 @@ static int do_match(ssf_handle* h, int exchange = 0) {
     const int n = any ? h->n_visible : 0;
     if (exchange && h->p2p.on) {
         const P2PView pv = p2p_view(h, ++h->p2p.seq_assoc);
-        launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
-                     h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
+        launch_match(h->stream, h->cam, icp_rows(h), n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
+                     h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S, h->bins_valid ? h->d_bin_idx : nullptr);
         launch_p2p_assoc(h->stream, pv, h->cc->d_best, h->cc->d_matched, h->mb_dev);
         HCK(hipGetLastError());
+        h->bins_valid = false;
         return SSF_OK;
     }
-    launch_match(h->stream, h->cam, h->model[h->mcur], n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
-                 h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S);
+    launch_match(h->stream, h->cam, icp_rows(h), n, h->cc->maps.pix2, h->cc->maps.fpack, h->pose, h->cfg.range_min,
+                 h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand, h->S, h->bins_valid ? h->d_bin_idx : nullptr);
     HCK(hipGetLastError());
+    h->bins_valid = false;                        // (the fuse launch that follows rewrites the rows the copy was made from)
     return SSF_OK;
 }
 
@@ -1203,8 +1220,8 @@ static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo*
     IcpGo* slot = h->go + (go_seq % SSF_ICP_GO_SLOTS);
     Rt none; none.R = m3_identity(); none.t = v3(0, 0, 0);
     const P2PView pv = h->p2p.view;               // (the number of the peer exchange arrives with the go word)
-    launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, none,
-               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq, h->p2p.on ? &pv : nullptr);
+    launch_icp(h->stream, h->cam, icp_rows(h), h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, none,
+               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq, h->p2p.on ? &pv : nullptr, h->bins_valid ? 1 : 0);
     HCK(hipGetLastError());
     *seq_out = seq; *slot_out = slot; *go_seq_out = go_seq;
     return SSF_OK;
@@ -1256,6 +1273,15 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     const bool exchanging = h->comm || h->p2p.on;          // a shard of a map that runs its exchanges natively
     if (exchanging) { rc = comm_counts(h); if (rc) return rc; }
     icp_begin(h, prior);
+    // a large visible set: its ICP / association fields once more, sorted by the image tile they project to under the
+    // frame's initial transform (ssf_track_fuse.hip, k_bin_*): the iterations and the association stream that copy
+    h->bins_valid = false;
+    if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0) {
+        Rt T0; T0.R = h->icp.R_init; T0.t = h->icp.t_init;
+        launch_bin_rows(h->stream, h->cam, h->model[h->mcur], h->n_visible, T0, h->d_bin_count, h->d_bin_cursor, h->bins, h->d_bin_idx);
+        HCK(hipGetLastError());
+        h->bins_valid = true;
+    }
     int again = h->icp.active ? 1 : 0, valid = 0;
     // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
     // already launched and waits on the device for its transform
@@ -1275,8 +1301,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
                 seq_rec = ++h->icp_seq;
                 P2PView pv{};
                 if (h->p2p.on) pv = p2p_view(h, ++h->p2p.seq_icp);
-                launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
-                           h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec, -1, nullptr, 0, h->p2p.on ? &pv : nullptr);
+                launch_icp(h->stream, h->cam, icp_rows(h), h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
+                           h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec, -1, nullptr, 0, h->p2p.on ? &pv : nullptr, h->bins_valid ? 1 : 0);
                 HCK(hipGetLastError());
             }
             // the next iteration, should there be one (the loop may run cfg.icp_iter iterations at most)
@@ -1299,8 +1325,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             const Rt T = icp_transform(h->icp);
             const unsigned long long seq = ++h->icp_seq;
             const P2PView pv = p2p_view(h, ++h->p2p.seq_icp);
-            launch_icp(h->stream, h->cam, h->model[h->mcur], h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
-                       h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, nullptr, 0, &pv);
+            launch_icp(h->stream, h->cam, icp_rows(h), h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, T,
+                       h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, nullptr, 0, &pv, h->bins_valid ? 1 : 0);
             HCK(hipGetLastError());
             rc = icp_fetch(h, seq);
         } else if (h->comm) {
@@ -1553,6 +1579,14 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, 64) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
          dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
+    {
+        const int bw = bin_count_words(h->cam);
+        if (const char* e = getenv("SSF_BIN_MIN_ROWS")) h->bin_min_rows = atoi(e);          // (measurement switch; < 0: never)
+        if (bw > 16384) h->bin_min_rows = -1;                                              // (the histogram lives in LDS)
+        ok = ok && dalloc(h, &h->bins.pos, 3 * N) && dalloc(h, &h->bins.lab, 3 * N) && dalloc(h, &h->bins.r2, 3 * N) && dalloc(h, &h->bins.conf, N) &&
+             dalloc(h, &h->d_bin_idx, N) && dalloc(h, &h->d_bin_count, (size_t)bw) && dalloc(h, &h->d_bin_cursor, (size_t)bw);
+        if (ok) (void)hipMemsetAsync(h->d_bin_count, 0, (size_t)bw * 4, h->stream);
+    }
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
              hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;
@@ -1927,6 +1961,12 @@ int ssf_debug_recentre(ssf_handle* h) {
 }
 long long ssf_debug_recentre_count(const ssf_handle* h) { return h ? h->n_recentres : -1; }
 int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVALID_ARG; h->max_passes = n; return SSF_OK; }
+// visible rows from which a frame's tracking streams a tile-sorted copy of them (default: never; 0: always)
+int ssf_debug_set_bin_min_rows(ssf_handle* h, int n) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    h->bin_min_rows = bin_count_words(h->cam) > 16384 ? -1 : n;
+    return SSF_OK;
+}
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;
     h->id_offset = off; h->global_n_model = gm; h->global_n_visible = gv; return SSF_OK;
@@ -2215,6 +2255,70 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     { int rc = store_from_dense(h, h->n_model, h->n_visible); if (rc) return rc; }
     HCK(hipStreamSynchronize(st));
     if (h->cfg.profile == 1) timer_collect(&h->timer);
+    return SSF_OK;
+}
+
+// ---- re-homing of a sharded map (see ssf.h): rows moved by ssf_apply_deformation go to the rank that owns their tile ----
+// A rare, bulk operation (a loop closure): worked on the dense logical view with full-model copies; the transport between
+// the ranks is the caller's (supersurfel_fusion_amd/sharded.py: torch.distributed; the tests: files / memory).
+int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out) {
+    if (!h || !n_out || table_rows < 0 || (!table && table_rows > 0)) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty() || h->fusing) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    *n_out = 0;
+    const int n = h->n_model;
+    if (h->cfg.nranks <= 1 || n == 0) return SSF_OK;
+    hipStream_t st = h->stream;
+    { int rc = materialise(h); if (rc) return rc; }
+    int32_t* d_table = nullptr; int* d_tot = nullptr;
+    DevTemps tmp;
+    HCK(tmp.take(&d_table, (size_t)std::max(table_rows, 1) * SSF_MIGRANT_WORDS * 4)); HCK(tmp.take(&d_tot, 16));
+    SurfelSoA scratch = h->oov[h->ocur ^ 1].rows;          // (the other out-of-view store is scratch between recentres)
+    launch_rehome_split(st, h->dense, n, h->n_visible, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_bc_oov, d_tot, scratch, d_table, table_rows);
+    HCK(hipGetLastError());
+    int tot[3] = {0, 0, 0};
+    HCK(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, st));
+    HCK(hipStreamSynchronize(st));
+    if (tot[1] > table_rows) { h->err = "ssf_rehome_begin: the table is too small for the rows that leave"; return SSF_ERR_CAPACITY; }   // (stores untouched)
+    if (tot[1] == 0) return SSF_OK;
+    HCK(hipMemcpyAsync(table, d_table, (size_t)tot[1] * SSF_MIGRANT_WORDS * 4, hipMemcpyDeviceToHost, st));
+    { int rc = copy_soa(h, h->dense, scratch, (size_t)tot[0]); if (rc) return rc; }
+    { int rc = store_from_dense(h, tot[0], tot[2]); if (rc) return rc; }
+    HCK(hipStreamSynchronize(st));
+    *n_out = tot[1];
+    return SSF_OK;
+}
+int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n_rec) {
+    if (!h || n_rec < 0 || (!table && n_rec > 0)) return SSF_ERR_INVALID_ARG;
+    if (!h->pending.empty() || h->fusing) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    // the records addressed to this rank, split by the block they arrive in (table order kept)
+    std::vector<int32_t> vis, oov;
+    for (int j = 0; j < n_rec; j++) {
+        const int32_t* w = table + (size_t)SSF_MIGRANT_WORDS * j;
+        if (w[0] - 1 != h->cfg.rank) continue;
+        std::vector<int32_t>& dst = w[1] ? vis : oov;
+        dst.insert(dst.end(), w, w + SSF_MIGRANT_WORDS);
+    }
+    const int av = (int)(vis.size() / SSF_MIGRANT_WORDS), ao = (int)(oov.size() / SSF_MIGRANT_WORDS);
+    if (av + ao == 0) return SSF_OK;
+    const int n = h->n_model, nv = h->n_visible;
+    if ((long long)n + av + ao > h->cfg.nb_supersurfels_max) { h->err = "ssf_rehome_end: no room for the arriving rows"; return SSF_ERR_CAPACITY; }
+    hipStream_t st = h->stream;
+    { int rc = materialise(h); if (rc) return rc; }
+    int32_t* d_rec = nullptr;
+    DevTemps tmp;
+    HCK(tmp.take(&d_rec, (size_t)(av + ao) * SSF_MIGRANT_WORDS * 4));
+    if (av) HCK(hipMemcpyAsync(d_rec, vis.data(), vis.size() * 4, hipMemcpyHostToDevice, st));
+    if (ao) HCK(hipMemcpyAsync(d_rec + vis.size(), oov.data(), oov.size() * 4, hipMemcpyHostToDevice, st));
+    // [visible | arrivals flagged visible | out of view | the other arrivals], assembled in the scratch store
+    SurfelSoA scratch = h->oov[h->ocur ^ 1].rows;
+    { int rc = copy_soa(h, scratch, h->dense, (size_t)nv); if (rc) return rc; }
+    launch_rehome_unpack(st, d_rec, av, scratch, nv);
+    { int rc = copy_soa(h, soa_rows(scratch, (size_t)nv + av), soa_rows(h->dense, (size_t)nv), (size_t)(n - nv)); if (rc) return rc; }
+    launch_rehome_unpack(st, d_rec + vis.size(), ao, scratch, n + av);
+    HCK(hipGetLastError());
+    { int rc = copy_soa(h, h->dense, scratch, (size_t)n + av + ao); if (rc) return rc; }
+    { int rc = store_from_dense(h, n + av + ao, nv + av); if (rc) return rc; }
+    HCK(hipStreamSynchronize(st));
     return SSF_OK;
 }
 

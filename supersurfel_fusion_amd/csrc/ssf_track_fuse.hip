@@ -50,12 +50,14 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 #ifndef ICP_SLOTS
 #define ICP_SLOTS 16      // lane & 15 spreads the same-address traffic (64 columns measured no faster)
 #endif
-// the 29 terms of one visible supersurfel (position, cached Lab, normal row) under transform (R, t)
-__device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
-                                        const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm,
-                                        unsigned long long* red, int slot, int dbg) {
+// the 29 terms of one visible supersurfel (position, cached Lab, normal row) under transform (R, t), each handed to
+// emit(k, value) as soon as it is computed (k is a compile-time constant after unrolling): JtJ k = 0..20 (fixed point 2^20),
+// Jtr 21..26 (2^24), squared residual 27 (2^44), inlier count 28
+template <typename Emit>
+__device__ __forceinline__ void icp_row_terms(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                              const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm, int dbg, Emit emit) {
     const V3 ps = add(m3_mulv(R, mpos), t);
-    if (dbg & 1) { if (ps.z > 1e30f) atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull); return; }
+    if (dbg & 1) { if (ps.z > 1e30f) emit(28, 1ll); return; }
     const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
     const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
     if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return;
@@ -77,18 +79,22 @@ __device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict_
     const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
     const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
     const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
-    if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) atomicAdd(&red[slot], 1ull); return; }
+    if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) emit(0, 1ll); return; }
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 6; j++, k++)
-            atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
+        for (int j = i; j < 6; j++, k++) emit(k, (long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-        atomicAdd(&red[(21 + i) * ICP_SLOTS + slot], (unsigned long long)(long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
-    atomicAdd(&red[27 * ICP_SLOTS + slot], (unsigned long long)fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
-    atomicAdd(&red[28 * ICP_SLOTS + slot], 1ull);
+    for (int i = 0; i < 6; i++) emit(21 + i, (long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
+    emit(27, fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+    emit(28, 1ll);
+}
+// one row per thread: every term straight into the workgroup's LDS table (lane & 15 spreads the same-address traffic)
+__device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                        const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm,
+                                        unsigned long long* red, int slot, int dbg) {
+    icp_row_terms(cam, pix2, fpack, R, t, mpos, mlab, mnrm, dbg, [&](int k, long long v) { atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)v); });
 }
 template <typename T> __device__ __forceinline__ void atomic_add_done(T* p, T v);
 // end of an accumulating kernel, in three steps called by every thread of a workgroup after a barrier:
@@ -130,7 +136,18 @@ __device__ __forceinline__ void atomic_store_done(int* p, int v) {
 #ifndef ARRIVE_GROUPS
 #define ARRIVE_GROUPS 64u
 #endif
+// SSF_ARRIVE_FENCED (an experiment build, tools/build_variant.sh fenced -DSSF_ARRIVE_FENCED): real
+// agent-scope release / acquire ordering around the arrival ticket -- one fence per workgroup, not per atomic -- to tell
+// whether the first-frame divergence seen with UNCACHED exchange regions (round 2) was the relaxed arrival protocol's.
+#ifdef SSF_ARRIVE_FENCED
+#define SSF_ARRIVE_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define SSF_ARRIVE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define SSF_ARRIVE_RELEASE() do { } while (0)
+#define SSF_ARRIVE_ACQUIRE() do { } while (0)
+#endif
 __device__ __forceinline__ int grid_arrive(unsigned int* ticket) {
+    SSF_ARRIVE_RELEASE();
     const unsigned int g = blockIdx.x & (ARRIVE_GROUPS - 1u);
     const unsigned int in_group = (gridDim.x - g + ARRIVE_GROUPS - 1u) / ARRIVE_GROUPS, groups = min(gridDim.x, ARRIVE_GROUPS);
     int last = 0;
@@ -140,6 +157,7 @@ __device__ __forceinline__ int grid_arrive(unsigned int* ticket) {
         const unsigned int tg = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tg == groups - 1) { last = 1; __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
+    if (last) SSF_ARRIVE_ACQUIRE();
     return last;
 }
 // ---- peer-to-peer exchange helpers (ssf_device.hpp: P2PView) ----------------------------------------------------------
@@ -246,12 +264,20 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
             __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-template <bool P2P>
+// Rows sorted by image tile (k_bin_* below) are handed to the launch's workgroups so that ONE XCD works on one contiguous
+// eighth of them -- an eighth of the image: its L2 then holds an eighth of the frame's (label, depth) table instead of
+// all of it.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): logical block =
+// the (b / 8)-th block of that XCD's share.  Bijective for any grid size.
+__device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int nb) {
+    const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+template <bool P2P, bool ACC>
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
-                                             IcpGo* go, unsigned long long go_seq, P2PView pv) {
+                                             IcpGo* go, unsigned long long go_seq, P2PView pv, int by_tile) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
@@ -293,8 +319,24 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     // (Measured and dropped, round 2: a launch made ahead fetching its rows BEFORE it waits for the host's word -- they do not
     // depend on the transform.  8806-8834 against 8757-8835 frames/s, nothing: the rows are L2 hits left by the previous
     // iteration, not a trip to HBM.)
-    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
-        icp_row(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), red, slot, dbg);
+    // (by_tile: `model` is the tile-sorted copy of the visible rows -- pos / lab / r2 streams only -- and the blocks are dealt
+    // to the XCDs in contiguous shares; the sums are exact integers, so the order of the rows does not matter)
+    const unsigned int blk = by_tile ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (ACC) {
+        // several rows per thread (SSF_ICP_PER_LANE, measurement only): the rows' terms are summed in registers and go to the
+        // workgroup's LDS table once per thread
+        long long acc[29];
+#pragma unroll
+        for (int k = 0; k < 29; k++) acc[k] = 0;
+        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
+            icp_row_terms(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), 0, [&](int k, long long v) { acc[k] += v; });
+        if (acc[28] != 0) {
+#pragma unroll
+            for (int k = 0; k < 29; k++) atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)acc[k]);
+        }
+    } else
+        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
+            icp_row(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), red, slot, dbg);
     __syncthreads();
     __shared__ int s_last;
     if (dbg & 4) {                              // probe: fold only
@@ -436,13 +478,15 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 // ---- association ---------------------------------------------------------------------------------
 // one frame supersurfel (or none) per visible model row; cand[id] = the frame supersurfel this row has bid for
 // (-1: none) -- the fuse launch uses it to tell which rows the update is about to rewrite
-__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int id, const uint2* __restrict__ pix2,
+// (j: row of the view the kernel streams -- the visible array itself, or its tile-sorted copy --; id: the row's index in
+// the visible array, which is what the association key carries)
+__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
     // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
     // row -> pixel -> frame supersurfel -> atomic, three dependent round trips instead of five
-    float m_conf = model.conf[id];
-    V3 mp = ld3(model.pos, id), m_r2 = ld3(model.r2, id), m_lab = ld3(model.lab, id);
+    float m_conf = model.conf[j];
+    V3 mp = ld3(model.pos, j), m_r2 = ld3(model.r2, j), m_lab = ld3(model.lab, j);
     asm volatile("" : "+v"(m_conf), "+v"(mp.x), "+v"(m_r2.x), "+v"(m_lab.x));
     if (!(m_conf > 0.0f)) return -1;
     const M3 R = pose.R; const V3 t = pose.t;
@@ -479,12 +523,106 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
 __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
-                                               uint8_t* __restrict__ matched, int32_t* __restrict__ cand) {
+                                               uint8_t* __restrict__ matched, int32_t* __restrict__ cand, const int32_t* __restrict__ orig) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_visible) return;
-    cand[id] = match_row(cam, model, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
+    // (orig != nullptr: `model` is the tile-sorted copy, orig[j] the row's index in the visible array; blocks dealt to the XCDs
+    // in contiguous shares -- see xcd_block)
+    const int j = (orig ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= n_visible) return;
+    const int id = orig ? orig[j] : j;
+    cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
 }
+
+// ---- image-space order for the model side of ICP / association ------------------------------------------------------------
+// The visible rows sit in arrival order (the reference's: supersurfel_fusion.cu:469-472), so consecutive rows project to
+// unrelated pixels: every gather of the frame's (label, depth) table is a line of its own, and each of the eight L2s
+// ends up pulling the whole table (PMC, round 2: k_match moved 2.8x, k_icp 1.5x their algorithmic bytes).  For large
+// visible sets (BASELINE config 3: 1 M rows, ten iterations per frame) the rows' ICP / association fields are therefore
+// copied once per frame into a TILE-SORTED array: key = the 32 x 32 pixel tile the row projects to under the frame's
+// initial transform (rows that project nowhere: one more bin at the end).  Counting sort in three launches -- per-tile
+// counts (LDS histogram per 4096 rows, one global atomic per non-empty bin), exclusive scan (one workgroup), scatter
+// (the histogram again, one returning atomic per non-empty bin for the segment's base) -- 88 B per row of traffic, against
+// 36-44 B per row and ITERATION saved from going to memory.  The order inside a bin is arrival order of the atomics, i.e.
+// arbitrary: every consumer is order-free (exact integer sums, atomicMin with the row's own index in the key), so the
+// results stay bit-identical; the stored model keeps the reference's order.
+#define BIN_TILE 32
+#define BIN_ROWS_PER_WG 4096
+__device__ __forceinline__ int bin_of(const Cam& cam, const M3& R, const V3& t, const V3& pos, int nbx, int nbins) {
+    const V3 ps = add(m3_mulv(R, pos), t);
+    const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx), v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
+    if (!(ps.z > 0.0f && u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return nbins - 1;
+    return (v / BIN_TILE) * nbx + u / BIN_TILE;
+}
+extern __shared__ __attribute__((aligned(16))) unsigned int bin_lds[];
+__global__ __launch_bounds__(256) void k_bin_count(Cam cam, const float* __restrict__ pos, int n, Rt T, int nbx, int nbins, uint32_t* __restrict__ count) {
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bin_lds[i] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_ROWS_PER_WG;
+    for (int k = threadIdx.x; k < BIN_ROWS_PER_WG; k += blockDim.x) {
+        const int i = base + k;
+        if (i < n) atomicAdd(&bin_lds[bin_of(cam, T.R, T.t, ld3(pos, i), nbx, nbins)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) { const unsigned int c = bin_lds[i]; if (c) atomicAdd(&count[i], c); }
+}
+// exclusive scan of the bin counts -> cursor (the scatter's running position per bin); the counts are left zeroed for the next frame
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ count, uint32_t* __restrict__ cursor, int nbins) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (int b0 = 0; b0 < nbins; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const uint32_t c = i < nbins ? count[i] : 0u;
+        if (i < nbins) count[i] = 0u;
+        uint32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
+        if (lane() == 63) wsum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wsum[w];
+        if (i < nbins) cursor[i] = before + v - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + v;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(Cam cam, SurfelSoA M, int n, Rt T, int nbx, int nbins, uint32_t* __restrict__ cursor,
+                                                     SurfelSoA out /* pos, lab, r2, conf */, int32_t* __restrict__ out_idx) {
+    unsigned int* hist = bin_lds;                     // rows of this segment per bin, then: next free position of the bin's run
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_ROWS_PER_WG;
+    constexpr int PER = BIN_ROWS_PER_WG / 256;
+    int bin[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = base + threadIdx.x + 256 * k;
+        bin[k] = -1;
+        if (i < n) { bin[k] = bin_of(cam, T.R, T.t, ld3(M.pos, i), nbx, nbins); atomicAdd(&hist[bin[k]], 1u); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) { const unsigned int c = hist[i]; hist[i] = c ? atomicAdd(&cursor[i], c) : 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = base + threadIdx.x + 256 * k;
+        if (bin[k] < 0) continue;
+        const size_t j = atomicAdd(&hist[bin[k]], 1u);
+        st3(out.pos, j, ld3(M.pos, i)); st3(out.lab, j, ld3(M.lab, i)); st3(out.r2, j, ld3(M.r2, i));
+        out.conf[j] = M.conf[i]; out_idx[j] = i;
+    }
+}
+void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out, int32_t* out_idx) {
+    const int nbx = (cam.W + BIN_TILE - 1) / BIN_TILE, nbins = nbx * ((cam.H + BIN_TILE - 1) / BIN_TILE) + 1;
+    ScopedKernel sk("bin_rows", st);
+    const int nwg = (n + BIN_ROWS_PER_WG - 1) / BIN_ROWS_PER_WG;
+    hipLaunchKernelGGL(k_bin_count, dim3(nwg), dim3(256), (size_t)nbins * 4, st, cam, model.pos, n, T, nbx, nbins, count);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, count, cursor, nbins);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nwg), dim3(256), (size_t)nbins * 4, st, cam, model, n, T, nbx, nbins, cursor, out, out_idx);
+}
+int bin_count_words(const Cam& cam) { return ((cam.W + BIN_TILE - 1) / BIN_TILE) * ((cam.H + BIN_TILE - 1) / BIN_TILE) + 1; }
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
 // filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
@@ -1141,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         __shared__ int s_last;
         icp_fold(red, nx.replicas);
         if (threadIdx.x == 0) {
+            SSF_ARRIVE_RELEASE();
             unsigned int rows = (unsigned int)nkeep;
             bool report = true;
             if (vis) {
@@ -1161,6 +1300,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
                 last = rows != 0u && before + rows == total;
                 if (last) __hip_atomic_store(&nx.ticket[65], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (last) SSF_ARRIVE_ACQUIRE();
             s_last = last;
         }
         __syncthreads();
@@ -1256,6 +1396,80 @@ __global__ __launch_bounds__(1024) void k_migrate_in(SurfelSoA M, const int32_t*
             }
         }
     }
+}
+
+// ---- re-homing of a sharded map after positions changed outside a frame (ssf_rehome_begin / _end in ssf.h) ---------------
+// over the dense logical view [visible | out of view]: a row leaves when it is valid and its position belongs to another
+// rank's tile.  Three launches: per-block counts (staying rows, leaving rows, staying rows of the visible block), their
+// exclusive scan by one workgroup (totals -> tot3), and the ordered scatter: staying rows close ranks in `stay`, leaving
+// rows become migrant-table records (word 1 = 1: the row sat in the visible block) in logical order.
+__device__ __forceinline__ int rehome_class(const SurfelSoA& D, int i, int n, int rank, int nranks, float tile) {
+    if (i >= n) return 2;                                          // 0 stays, 1 leaves
+    return (D.conf[i] > 0.0f && tile_owner(ld3(D.pos, i), nranks, tile) != rank) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_rehome_count(SurfelSoA D, int n, int n_visible, int rank, int nranks, float tile, uint32_t* __restrict__ bc) {
+    __shared__ int part[4][3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = rehome_class(D, i, n, rank, nranks, tile);
+    const int k0 = __popcll(__ballot(c == 0)), k1 = __popcll(__ballot(c == 1)), k2 = __popcll(__ballot(c == 0 && i < n_visible));
+    if (lane() == 0) { part[threadIdx.x >> 6][0] = k0; part[threadIdx.x >> 6][1] = k1; part[threadIdx.x >> 6][2] = k2; }
+    __syncthreads();
+    if (threadIdx.x < 3) bc[3 * blockIdx.x + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_rehome_scan(uint32_t* __restrict__ bc, int nblocks, int* __restrict__ tot3) {
+    __shared__ uint32_t wtot[16][6];
+    __shared__ uint32_t tot[3];
+    block_scan_counts<3>(bc, nblocks, tot, wtot);
+    if (threadIdx.x < 3) tot3[threadIdx.x] = (int)tot[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_rehome_scatter(SurfelSoA D, int n, int n_visible, int rank, int nranks, float tile,
+                                                        const uint32_t* __restrict__ bc, SurfelSoA stay, int32_t* __restrict__ table, int table_rows) {
+    __shared__ int part[4][2];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, wv = threadIdx.x >> 6;
+    const int c = rehome_class(D, i, n, rank, nranks, tile);
+    const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1);
+    if (lane() == 0) { part[wv][0] = __popcll(m0); part[wv][1] = __popcll(m1); }
+    __syncthreads();
+    if (c > 1) return;
+    int before = 0;
+    for (int w = 0; w < wv; w++) before += part[w][c];
+    const size_t j = (size_t)bc[3 * blockIdx.x + c] + before + __popcll((c == 0 ? m0 : m1) & ((1ull << lane()) - 1ull));
+    if (c == 0) { copy_row(D, (size_t)i, stay, j); return; }
+    if (j >= (size_t)table_rows) return;                               // (the host sees the total and reports SSF_ERR_CAPACITY)
+    const RowRegs r = load_row(D, (size_t)i);
+    int32_t* o = table + (size_t)SSF_MIGRANT_WORDS * j;
+    o[0] = tile_owner(r.pos, nranks, tile) + 1; o[1] = i < n_visible ? 1 : 0;
+    const float v[26] = {r.pos.x, r.pos.y, r.pos.z, r.col.x, r.col.y, r.col.z, __int_as_float(r.s0), __int_as_float(r.s1),
+                         r.r0.x, r.r0.y, r.r0.z, r.r1.x, r.r1.y, r.r1.z, r.r2.x, r.r2.y, r.r2.z,
+                         r.shape.xx, r.shape.xy, r.shape.xz, r.shape.yy, r.shape.yz, r.shape.zz, r.d0, r.d1, r.conf};
+#pragma unroll
+    for (int q = 0; q < 26; q++) o[2 + q] = __float_as_int(v[q]);
+}
+// records [0, n) of a packed table -> rows [base, base + n) of D (the Lab cache is rebuilt from the colour)
+__global__ __launch_bounds__(256) void k_rehome_unpack(const int32_t* __restrict__ table, int n, SurfelSoA D, int base) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t* w = table + (size_t)SSF_MIGRANT_WORDS * j;
+    float v[26];
+#pragma unroll
+    for (int q = 0; q < 26; q++) v[q] = __int_as_float(w[2 + q]);
+    RowRegs row;
+    row.pos = v3(v[0], v[1], v[2]); row.col = v3(v[3], v[4], v[5]); row.lab = rgb_to_lab(row.col);
+    row.s0 = __float_as_int(v[6]); row.s1 = __float_as_int(v[7]);
+    row.r0 = v3(v[8], v[9], v[10]); row.r1 = v3(v[11], v[12], v[13]); row.r2 = v3(v[14], v[15], v[16]);
+    row.shape = sym3(v[17], v[18], v[19], v[20], v[21], v[22]); row.d0 = v[23]; row.d1 = v[24]; row.conf = v[25];
+    store_row(D, (size_t)base + j, row);
+}
+void launch_rehome_split(hipStream_t st, SurfelSoA dense, int n, int n_visible, int rank, int nranks, float tile, uint32_t* bc, int* tot3,
+                         SurfelSoA stay, int32_t* table, int table_rows) {
+    const int nb = (n + 255) / 256;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_rehome_count, dim3(nb), dim3(256), 0, st, dense, n, n_visible, rank, nranks, tile, bc);
+    hipLaunchKernelGGL(k_rehome_scan, dim3(1), dim3(1024), 0, st, bc, nb, tot3);
+    hipLaunchKernelGGL(k_rehome_scatter, dim3(nb), dim3(256), 0, st, dense, n, n_visible, rank, nranks, tile, bc, stay, table, table_rows);
+}
+void launch_rehome_unpack(hipStream_t st, const int32_t* table, int n, SurfelSoA dst, int base) {
+    if (n > 0) hipLaunchKernelGGL(k_rehome_unpack, dim3((n + 255) / 256), dim3(256), 0, st, table, n, dst, base);
 }
 
 // ---- out-of-view store maintenance: stable compaction of the live rows into the other store -------------------
@@ -1597,32 +1811,36 @@ __global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq,
-                const P2PView* pv) {
+                const P2PView* pv, int by_tile) {
     ScopedKernel sk("icp_accumulate", st);
-    static int per_lane = 0;             // supersurfels per lane before the wave reduction
-    if (!per_lane) { const char* e = getenv("SSF_ICP_PER_LANE"); per_lane = e ? atoi(e) : 1; if (per_lane < 1) per_lane = 1; }
+    // rows per thread: 1.  SSF_ICP_PER_LANE=n (measurement): n rows per thread with their terms summed in REGISTERS and one
+    // LDS atomic per term and thread (k_icp<., true>) -- measured at BASELINE config 3 (1 M rows in view): 35-38 us per
+    // iteration for n = 2, 4, 8 against 29-30 us: the kernel is bound by its chain of dependent gathers (row -> pixel ->
+    // frame supersurfel), which eight waves per SIMD hide better than three
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SSF_ICP_PER_LANE"); forced = e ? std::max(1, atoi(e)) : 0; }
+    const int per_lane = forced ? forced : 1;
     const int per_block = 256 * per_lane;
     int grid = (n_visible + per_block - 1) / per_block;
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
     if (grid > 4096) grid = 4096;
     const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
-    if (pv)
-        hipLaunchKernelGGL(k_icp<true>, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
-                           ticket, sums29, mb, seq, dbg, go, go_seq, *pv);
-    else {
-        const P2PView none{};
-        hipLaunchKernelGGL(k_icp<false>, dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas,
-                           ticket, sums29, mb, seq, dbg, go, go_seq, none);
-    }
+    const bool acc = per_lane > 1 && dbg == 0;       // (the probe switches live in the one-row-per-thread form)
+    const P2PView none{};
+    const P2PView& v = pv ? *pv : none;
+    if (pv && acc) hipLaunchKernelGGL((k_icp<true, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
+    else if (pv) hipLaunchKernelGGL((k_icp<true, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
+    else if (acc) hipLaunchKernelGGL((k_icp<false, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
+    else hipLaunchKernelGGL((k_icp<false, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
-                  unsigned long long* best, uint8_t* matched, int32_t* cand, int S) {
+                  unsigned long long* best, uint8_t* matched, int32_t* cand, int S, const int32_t* orig) {
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
     hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
-                       pose, zmin, zmax, id_offset, best, matched, cand);
+                       pose, zmin, zmax, id_offset, best, matched, cand, orig);
 }
 void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,

@@ -39,6 +39,29 @@ import torch.distributed as dist
 COUNT_KEYS = ("n_model", "n_visible", "n_removed", "n_inserted", "n_updated")
 
 
+def rehome_over(fusion, world, group=None, device=None):
+    """the re-homing sweep of ONE rank's handle over torch.distributed (any backend): also for handles that run their
+    frames through the native exchanges (ssf_comm_attach / ssf_p2p_attach)"""
+    if world <= 1:
+        return 0
+    mine = fusion.rehome_begin()
+    dev = device if device is not None else torch.device("cpu")
+    n_all = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(n_all, torch.tensor([len(mine)], dtype=torch.int64, device=dev), group=group)
+    n_all = [int(v) for v in n_all.cpu()]
+    cap = max(n_all)
+    if cap == 0:
+        return 0
+    pad = torch.zeros((cap, mine.shape[1]), dtype=torch.int32, device=dev)
+    if len(mine):
+        pad[:len(mine)] = torch.from_numpy(mine).to(dev)
+    got = torch.zeros((world * cap, mine.shape[1]), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(got, pad, group=group)
+    got = got.cpu().numpy().reshape(world, cap, -1)
+    fusion.rehome_end(np.concatenate([got[r, :n_all[r]] for r in range(world)]))
+    return sum(n_all)
+
+
 class ShardedFusion:
     def __init__(self, fusion, device=None, group=None, stream=None, always_reduce=False):
         self.f = fusion
@@ -132,6 +155,13 @@ class ShardedFusion:
         assert self.f.pending_frames() == 0, "frames are pending: use process_submitted"
         self.f.submit_frame(rgb, depth, dynamic_mask, on_device=on_device)
         return self.process_submitted(prior_pose)
+
+    def rehome(self):
+        """After Fusion.apply_deformation on a sharded map (a loop closure moves every row): one sweep that puts every row
+        back on the rank that owns the world tile of its position (ssf_rehome_begin / _end).  The leaving rows of all ranks
+        are all-gathered (padded to the largest table) and every rank keeps the records addressed to it."""
+        rehome_over(self.f, self.world, group=self.group, device=self.device)
+        self._counts = None
 
     def invalidate_counts(self):
         """Call after Fusion.set_model / apply_deformation changed the shard outside process_frame."""

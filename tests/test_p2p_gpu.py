@@ -81,28 +81,155 @@ def test_ranks_in_one_process_bit_exact(world, pipelined, nf, oracle_lib, produc
     assert sum(x["icp_iters"] for x in out[0]) >= nf - 1                   # the ICP exchange did run
 
 
-@pytest.mark.parametrize("world,pipelined", [(2, False), (2, True), (3, False), (4, True)])
-def test_ranks_in_separate_processes_bit_exact(world, pipelined, oracle_lib, tmp_path):
-    W, H, nf = 320, 240, 6
+def run_workers(cfg, tmp_path, timeout=600):
+    """one process per rank (tests/p2p_worker.py) -> their output archives"""
+    import json
+    cfg = dict(cfg, dir=str(tmp_path))
+    cpath = os.path.join(str(tmp_path), "config.json")
+    json.dump(cfg, open(cpath, "w"))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H),
-                               str(nf), "1" if pipelined else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), cpath, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(cfg["world"])]
     logs = []
     for p in procs:
         try:
-            logs.append(p.communicate(timeout=300)[0])
+            logs.append(p.communicate(timeout=timeout)[0])
         except subprocess.TimeoutExpired:
             p.kill()
             logs.append(p.communicate()[0])
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-    outs = [np.load(os.path.join(str(tmp_path), "out%d.npz" % r)) for r in range(world)]
+    return [np.load(os.path.join(str(tmp_path), "out%d.npz" % r)) for r in range(cfg["world"])]
+
+
+@pytest.mark.parametrize("world,pipelined", [(2, False), (2, True), (3, False), (4, True)])
+def test_ranks_in_separate_processes_bit_exact(world, pipelined, oracle_lib, tmp_path):
+    W, H, nf = 320, 240, 6
+    outs = run_workers(dict(world=world, W=W, H=H, frames=nf, pipelined=pipelined), tmp_path, 300)
     fo, oo = _emulated_ranks(oracle_lib, world, W, H, nf)
     per_rank = [(o["poses"], o["counts"]) for o in outs]
     models = [{k[len("model_"):]: o[k] for k in o.files if k.startswith("model_")} for o in outs]
     check_against_oracle(world, per_rank, models, oo, fo)
     for o in outs:
         assert [int(v) for v in o["global_counts"][:2]] == [int(oo[-1][1][:, 0].sum()), int(oo[-1][1][:, 1].sum())]
+
+
+# ---- the native exchange at BASELINE size: every rank against the UNSHARDED oracle --------------------------------------------
+@pytest.fixture(scope="module")
+def fast_oracle():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return binding.Library(os.path.join(ROOT, "oracle", "_build", "libssf_oracle_omp.so"))
+
+
+def check_against_unsharded(world, tile, want, outs, single_model, rank_models):
+    """want: the unsharded oracle's frame results; outs[r]: (poses, counts) of rank r; the maps as get_model() dicts"""
+    from supersurfel_fusion_amd import synthetic
+    for k, w in enumerate(want):
+        for r in range(world):
+            util.assert_same_bits(outs[r][0][k], w["pose"], "pose of frame %d on rank %d" % (k, r))
+        for j, key in enumerate(KEYS):
+            assert sum(int(outs[r][1][k][j]) for r in range(world)) == w[key], (k, key, [int(outs[r][1][k][j]) for r in range(world)], w[key])
+    for r, m in enumerate(rank_models):
+        ok = m["confidences"] > 0
+        assert (synthetic.tile_owner(m["positions"][ok], world, tile) == r).all(), "a row lives on a rank that does not own its tile"
+    merged = {name: np.concatenate([m[name] for m in rank_models]) for name, _, _ in binding.SURFEL_FIELDS}
+    assert len(merged["confidences"]) == len(single_model["confidences"])
+    assert np.array_equal(util.rows_multiset(merged), util.rows_multiset(single_model)), "union of the shards != the unsharded map"
+
+
+def test_config4_two_million_rows_over_four_processes_native_exchange(fast_oracle, tmp_path):
+    """BASELINE config 4 on the NATIVE exchange path: a 2 M-supersurfel map sharded by world tile over 4 ranks = 4 processes
+    whose exchange regions are opened through IPC handles (ssf_p2p_export / ssf_p2p_attach), 640x480, 6 frames pipelined:
+    every rank holds the UNSHARDED oracle's pose bit for bit, the per-shard counters sum to the oracle's, the union of the
+    shards is the oracle's map, every row lives on the owner of its tile.  (All four on the box's one GPU: what crosses
+    xGMI on a real node lands in the same HBM here.)"""
+    import p2p_worker
+    cfg = dict(world=4, W=640, H=480, frames=6, pipelined=True, depth=2, batch=2, seed_n=2000000, tile=0.5)
+    fo = binding.Fusion(fast_oracle, p2p_worker.make_config(fast_oracle, dict(cfg, pipelined=False), 0, 1, cfg["seed_n"] + 65536))
+    model, nvis, _ = p2p_worker.seed_shard(cfg, 0, 1)
+    fo.set_model(model, nvis, 30)
+    want = [fo.process_frame(r, d) for r, d in p2p_worker.frames_of(cfg)]
+    outs = run_workers(cfg, tmp_path, 900)
+    assert want[-1]["icp_valid"] == 1 and sum(w["icp_iters"] for w in want) >= 6
+    models = [{k[len("model_"):]: o[k] for k in o.files if k.startswith("model_")} for o in outs]
+    check_against_unsharded(4, 0.5, want, [(o["poses"], o["counts"]) for o in outs], fo.get_model(), models)
+    assert min(len(m["confidences"]) for m in models) > 300000
+
+
+def test_config5_tum_shaped_three_threads_deformation_and_rehoming(fast_oracle, product_lib):
+    """BASELINE config 5 on the native exchange path, ranks as threads of one process (ssf_p2p_attach_local): TUM-shaped frames
+    (u16 depth at 5000 / m, 25 % holes, benchmark launch parameters, pre-filter on), a 1 M-row map over 3 ranks, 3 frames,
+    one loop-closure deformation (applyDeformation: every row moves) followed by the re-homing sweep (ssf_rehome_begin /
+    _end) -- the owner invariant holds at once --, then 3 more frames: all against the unsharded oracle."""
+    import p2p_worker
+    from supersurfel_fusion_amd import synthetic
+    world, tile = 3, 0.5
+    cfg = dict(world=world, W=640, H=480, frames=6, pipelined=True, depth=2, batch=2, seed_n=1000000, tile=tile, tum=True)
+    frames = p2p_worker.frames_of(cfg)
+    fo = binding.Fusion(fast_oracle, p2p_worker.make_config(fast_oracle, dict(cfg, pipelined=False), 0, 1, cfg["seed_n"] + 65536))
+    model, nvis, _ = p2p_worker.seed_shard(cfg, 0, 1)
+    fo.set_model(model, nvis, 30)
+    fs = []
+    for r in range(world):
+        m, nv, cap = p2p_worker.seed_shard(cfg, r, world)
+        f = binding.Fusion(product_lib, p2p_worker.make_config(product_lib, cfg, r, world, cap))
+        f.set_model(m, nv, 30)
+        f.p2p_configure(all_ranks_on_this_device=True, timeout_s=20.0)
+        fs.append(f)
+    regions = [f.p2p_region()[0] for f in fs]
+    for f in fs:
+        f.p2p_attach_local(regions)
+
+    def drive_all(part):
+        out, errors = [None] * world, []
+
+        def drive(r):
+            try:
+                out[r] = p2p_worker.run_frames(fs[r], part, True)
+            except Exception as e:
+                errors.append((r, e))
+        threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+        assert not errors, errors
+        return out
+
+    want = [fo.process_frame(r, d) for r, d in frames[:3]]
+    got = drive_all(frames[:3])
+    for f in [fo] + fs:
+        f.apply_deformation(*util.deformation_for(f.get_model(), 200, angle=0.01, shift=0.02))
+    strays = sum(int((synthetic.tile_owner(f.get_model()["positions"][f.get_model()["confidences"] > 0], world, tile) != r).sum()) for r, f in enumerate(fs))
+    moved = util.rehome_in_process(fs)
+    assert strays > 100 and sum(moved) == strays
+    for r, f in enumerate(fs):
+        m = f.get_model()
+        assert (synthetic.tile_owner(m["positions"][m["confidences"] > 0], world, tile) == r).all(), "not at home right after the sweep"
+    want += [fo.process_frame(r, d) for r, d in frames[3:]]
+    got2 = drive_all(frames[3:])
+    outs = [(np.stack([x["pose"] for x in got[r] + got2[r]]), np.array([[x[k] for k in KEYS] for x in got[r] + got2[r]], np.int64)) for r in range(world)]
+    check_against_unsharded(world, tile, want, outs, fo.get_model(), [f.get_model() for f in fs])
+    assert want[-1]["icp_valid"] == 1
+
+
+def test_rehoming_across_processes(fast_oracle, tmp_path):
+    """the deformation + re-homing sweep with the ranks as separate processes (tables traded through files, as the IPC handles
+    are), frames on the native exchange before and after it"""
+    import p2p_worker
+    cfg = dict(world=3, W=320, H=240, frames=6, pipelined=True, depth=1, batch=2, seed_n=60000, tile=0.25, deform_after=3, nodes=24, angle=0.02, shift=0.05)
+    fo = binding.Fusion(fast_oracle, p2p_worker.make_config(fast_oracle, dict(cfg, pipelined=False), 0, 1, cfg["seed_n"] + 65536))
+    model, nvis, _ = p2p_worker.seed_shard(cfg, 0, 1)
+    fo.set_model(model, nvis, 30)
+    frames = p2p_worker.frames_of(cfg)
+    want = [fo.process_frame(r, d) for r, d in frames[:3]]
+    fo.apply_deformation(*util.deformation_for(fo.get_model(), 24, angle=0.02, shift=0.05))
+    want += [fo.process_frame(r, d) for r, d in frames[3:]]
+    outs = run_workers(cfg, tmp_path, 600)
+    homes = [np.load(os.path.join(str(tmp_path), "home%d.npy" % r)) for r in range(3)]
+    assert all(int(h[0]) == 1 for h in homes) and sum(int(h[1]) for h in homes) > 0
+    models = [{k[len("model_"):]: o[k] for k in o.files if k.startswith("model_")} for o in outs]
+    check_against_unsharded(3, 0.25, want, [(o["poses"], o["counts"]) for o in outs], fo.get_model(), models)
 
 
 def test_a_missing_peer_is_an_error_not_a_hang(product_lib):

@@ -561,3 +561,29 @@ def test_an_arrival_at_a_full_shard_is_counted_as_removed(oracle_lib, product_li
     fo, r0o, r1o = util.arrival_at_a_full_shard(oracle_lib)
     util.same_result(r0h, r0o); util.same_result(r1h, r1o)
     util.compare_state(fh, fo)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_tile_sorted_rows_bit_exact(pipelined, oracle_lib, product_lib):
+    """ICP and association streaming the TILE-SORTED copy of the visible rows (k_bin_*, launch_icp(by_tile) / launch_match(orig):
+    forced for every frame here; off by default -- measured slower): exact integer sums and
+    atomicMin keys that carry the row's own index make every result independent of the order of the rows."""
+    fo, nv = seeded(oracle_lib, 50000, 640, 480)
+    kw = dict(pipeline_depth=2, extract_batch=2) if pipelined else {}
+    fh, _ = seeded(product_lib, 50000, 640, 480, **kw)
+    fh.set_bin_min_rows(0)
+    frames = [util.frame(k, 640, 480, noise=True, holes=0.02) for k in range(5)]
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False) if pipelined \
+        else [fh.process_frame(r, d) for r, d in frames]
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    assert want[-1]["icp_valid"] == 1 and want[-1]["n_updated"] > 100
+    util.compare_state(fo, fh)
+    # an empty map and a first frame take the same path
+    fo2, fh2 = pair(oracle_lib, product_lib, 320, 240, nb_supersurfels_max=8192)
+    fh2.set_bin_min_rows(0)
+    for k in range(4):
+        util.same_result(fo2.process_frame(*util.frame(k, 320, 240)), fh2.process_frame(*util.frame(k, 320, 240)))
+    util.compare_state(fo2, fh2)

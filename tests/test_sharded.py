@@ -84,3 +84,93 @@ def test_sharded_driver_equals_process_frame(oracle_lib):
         ra = fa.process_frame(rgb, depth); rb = drv.process_frame(rgb, depth)
         util.same_result(ra, rb)
     util.compare_state(fa, fb)
+
+
+def _drive_emulated(fs, k):
+    """one frame of a sharded map whose ranks are handles of this process (exchanges on the host between the stage calls)"""
+    world = len(fs)
+    rgb, depth = util.frame(k, W, H)
+    counts = np.array([[f.counts()["n_model"], f.counts()["n_visible"]] for f in fs], np.int64)
+    for f in fs:
+        f.stage_extract(rgb, depth)
+    g_model, g_vis = int(counts[:, 0].sum()), int(counts[:, 1].sum())
+    for r, f in enumerate(fs):
+        f.set_shard(int(counts[:r, 1].sum()), g_model, g_vis)
+        f.icp_begin()
+    again = g_vis > 0
+    while again:
+        total = sum(f.icp_accumulate() for f in fs)
+        again = [f.icp_update(total) for f in fs][0]
+    for f in fs:
+        f.icp_end()
+    bm = [f.match() for f in fs]
+    return util.exchange_and_fuse(fs, np.minimum.reduce([b for b, _ in bm]), np.maximum.reduce([m for _, m in bm]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rehoming_after_a_deformation(world, oracle_lib):
+    """applyDeformation moves every row: after it a shard holds rows of other ranks' tiles until ssf_rehome_begin / _end have
+    run; then the owner invariant holds at once, the union of the shards is the deformed unsharded map row for row, and the
+    frames that follow give every rank the unsharded pose"""
+    from supersurfel_fusion_amd import synthetic
+    tile = 0.25
+    single = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
+    fs = [binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096, rank=r, nranks=world, shard_tile=tile)) for r in range(world)]
+    for k in range(3):
+        single.process_frame(*util.frame(k, W, H))
+        _drive_emulated(fs, k)
+    for f in [single] + fs:
+        m = f.get_model()
+        f.apply_deformation(*util.deformation_for(m, 12, angle=0.05, shift=0.08))
+    strays = sum(int((synthetic.tile_owner(f.get_model()["positions"][f.get_model()["confidences"] > 0], world, tile) != r).sum()) for r, f in enumerate(fs))
+    assert strays > 0, "the deformation was meant to push rows over tile edges"
+    moved = util.rehome_in_process(fs)
+    assert sum(moved) == strays
+    for r, f in enumerate(fs):
+        m = f.get_model()
+        ok = m["confidences"] > 0
+        assert (synthetic.tile_owner(m["positions"][ok], world, tile) == r).all(), "a row is not on its tile's owner right after the sweep"
+    merged = {name: np.concatenate([f.get_model()[name] for f in fs]) for name, _, _ in binding.SURFEL_FIELDS}
+    assert np.array_equal(util.rows_multiset(merged), util.rows_multiset(single.get_model()))
+    assert sum(f.counts()["n_visible"] for f in fs) == single.counts()["n_visible"]
+    for k in range(3, 6):
+        want = single.process_frame(*util.frame(k, W, H))
+        res = _drive_emulated(fs, k)
+        for r_ in res:
+            util.assert_same_bits(r_["pose"], want["pose"], "pose after the sweep, frame %d" % k)
+        assert sum(r_["n_model"] for r_ in res) == want["n_model"]
+    assert util.rehome_in_process(fs) == [0] * world                 # nothing left to move
+
+
+def _rehome_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = binding.Library(ORACLE_LIB)
+    f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=rank, nranks=world, shard_tile=0.25))
+    drv = sharded.ShardedFusion(f)
+    for k in range(3):
+        drv.process_frame(*util.frame(k, W, H))
+    f.apply_deformation(*util.deformation_for(f.get_model(), 12, angle=0.05, shift=0.08))
+    drv.rehome()
+    poses = [drv.process_frame(*util.frame(k, W, H))["pose"] for k in range(3, 5)]
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), poses=np.array(poses), **f.get_model())
+    dist.destroy_process_group()
+
+
+def test_rehoming_over_torch_distributed(oracle_lib, tmp_path):
+    """the same sweep through sharded.ShardedFusion.rehome (gloo, world 2): all-gather of the padded tables"""
+    from supersurfel_fusion_amd import synthetic
+    world = 2
+    mp.spawn(_rehome_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    single = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
+    for k in range(3):
+        single.process_frame(*util.frame(k, W, H))
+    single.apply_deformation(*util.deformation_for(single.get_model(), 12, angle=0.05, shift=0.08))
+    poses = [single.process_frame(*util.frame(k, W, H))["pose"] for k in range(3, 5)]
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r, d in enumerate(ranks):
+        assert np.array_equal(d["poses"].view(np.uint32), np.array(poses).view(np.uint32))
+        ok = d["confidences"] > 0
+        assert (synthetic.tile_owner(d["positions"][ok], world, 0.25) == r).all()
+    merged = {name: np.concatenate([d[name] for d in ranks]) for name, _, _ in binding.SURFEL_FIELDS}
+    assert np.array_equal(util.rows_multiset(merged), util.rows_multiset(single.get_model()))

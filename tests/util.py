@@ -132,3 +132,46 @@ def arrival_at_a_full_shard(lib, W=160, H=128):
     assert r1["n_removed"] == r0["n_removed"] + 1, (r0, r1)
     assert r1["n_model"] == r0["n_model"] and r1["n_visible"] == r0["n_visible"]
     return f1, r0, r1
+
+
+def row_hash(model):
+    """a 32-bit key per model row that depends only on the row's content (so that a shard and the unsharded map derive
+    the same per-row quantities, whatever the order of their rows)"""
+    n = len(model["confidences"])
+    w = np.concatenate([np.ascontiguousarray(model[name]).reshape(n, -1).view(np.uint32) for name in ("positions", "stamps", "dims")], axis=1).astype(np.uint64)
+    h = np.zeros(n, np.uint64)
+    for j in range(w.shape[1]):
+        h = (h * np.uint64(1099511628211) + w[:, j] + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFFFFFF)
+    return (h ^ (h >> np.uint64(17))).astype(np.uint64)
+
+
+def deformation_for(model, n_nodes, seed=5, angle=0.01, shift=0.004):
+    """a synthetic loop-closure deformation (applyDeformation's inputs): the node set depends only on (n_nodes, seed), a
+    row's four node indices and weights only on the row itself -- the same deformation for every sharding of one map"""
+    rng = np.random.default_rng(seed)
+    npos = rng.uniform(-3, 3, (n_nodes, 3)).astype(np.float32)
+    ang = rng.uniform(-angle, angle, (n_nodes, 3))
+    nrot = np.stack([(synthetic.rot_y(a[1]) @ synthetic.rot_x(a[0])).reshape(9) for a in ang]).astype(np.float32)
+    ntr = rng.uniform(-shift, shift, (n_nodes, 3)).astype(np.float32)
+    h = row_hash(model)
+    idx = np.stack([(h >> np.uint64(8 * j)) % np.uint64(n_nodes) for j in range(4)], axis=1).astype(np.int32)
+    raw = np.stack([((h >> np.uint64(5 * j + 3)) & np.uint64(31)).astype(np.float32) + 1.0 for j in range(4)], axis=1)
+    w = (raw / raw.sum(axis=1, keepdims=True)).astype(np.float32)
+    return npos, nrot, ntr, w, idx
+
+
+def rehome_in_process(ranks):
+    """the re-homing sweep of ssf_rehome_begin / _end for ranks that live in one process: every rank's leaving rows, in
+    rank order, offered to every rank"""
+    tables = [f.rehome_begin() for f in ranks]
+    allt = np.concatenate(tables) if sum(len(t) for t in tables) else np.zeros((0, binding.MIGRANT_WORDS), np.int32)
+    for f in ranks:
+        f.rehome_end(allt)
+    return [len(t) for t in tables]
+
+
+def rows_multiset(m):
+    n = len(m["confidences"])
+    cols = [np.ascontiguousarray(m[name]).reshape(n, -1).view(np.uint32) for name, _, _ in binding.SURFEL_FIELDS]
+    rows = np.concatenate(cols, axis=1)
+    return rows[np.lexsort(rows.T[::-1])]
