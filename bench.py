@@ -36,7 +36,7 @@ W, H = 640, 480
 N_MODEL = 1000000
 PARAMS = dict(lambda_pos=10.0, lambda_bound=1000.0, lambda_size=1000.0, lambda_disp=1e8, thresh_disp=1e-4,
               seg_iter=10, filter_iter=3, delta_t=20, conf_thresh=2560.0, icp_iter=10, icp_cov_thresh=0.05)
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the copy ceiling of the box is measured live: measured_hbm_peak()
 
 # algorithmic bytes per unit of each kernel (DESIGN.md "Kernels")
 P = W * H
@@ -55,9 +55,9 @@ ALGO_BYTES = {
     "init_disp": lambda c: c["batch"] * 9.0 * P,
     "eval_samples": lambda c: c["batch"] * 8.0 * P,
     "render_moments": lambda c: c["batch"] * 25.0 * P,
-    # depth pre-filter (config 5 / depth_prefilter = 1): one frame per launch, 4 B read + 4 B written per pixel; the kernel is
+    # depth pre-filter (config 5 / depth_prefilter = 1): the frames of a batch per launch, 4 B read + 4 B written per pixel; the kernel is
     # bound by its 149 taps x a specified exp per pixel, not by these bytes
-    "bilateral_prefilter": lambda c: 8.0 * P,
+    "bilateral_prefilter": lambda c: c["batch"] * 8.0 * P,
 }
 
 
@@ -95,6 +95,24 @@ def kernel_source_sha():
     for f in ("ssf_extract.hip", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
         h.update(strip_comments(open(os.path.join(d, f), "r").read()).encode())
     return h.hexdigest()[:16]
+
+
+def measured_hbm_peak(dev, mib=1024, reps=12):
+    """What a plain device-to-device stream copy sustains on THIS box ("report both nominal and
+    measured-achievable"): bytes read + bytes written per second of torch's copy kernel over two 1 GiB buffers, best of
+    `reps` (MI355X_MICROARCH.md: ~6.3 TB/s of the 8 TB/s spec)."""
+    n = mib * (1 << 20) // 4
+    a_, b_ = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    a_.fill_(1.0); b_.copy_(a_)
+    torch.cuda.synchronize(dev)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b_.copy_(a_); e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a_, b_
+    return best
 
 
 def make_cfg(lib, cap, rank=0, nranks=1, stream=None, force_icp=False, pipeline_depth=0, extract_batch=1, prefilter=0):
@@ -464,20 +482,26 @@ def main():
         # --pmc passes of this same command, recorded in profiles/pmc_r02.json by tools/pmc_summary.py together with
         # a hash of the kernel sources it was taken at -- bench.py cannot run the profiler on itself).  A file taken
         # at other sources, or at another extract batch, does not describe this binary: traffic = null then.
-        traffic, traffic_note = None, "profiles/pmc_r02.json absent"
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_r02.json")
-        if os.path.exists(pmc_path):
+        import glob
+        traffic, traffic_note = None, "no profiles/pmc_r*.json"
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9].json")))
+        if pmcs:
+            pmc_path = pmcs[-1]; pmc_name = "profiles/" + os.path.basename(pmc_path)
             pmc = json.load(open(pmc_path))
             if pmc.get("source_sha") != kernel_source_sha():
-                traffic_note = "profiles/pmc_r02.json was recorded at other kernel sources (%s)" % pmc.get("source_sha")
+                traffic_note = "%s was recorded at other kernel sources (%s)" % (pmc_name, pmc.get("source_sha"))
             elif pmc.get("extract_batch", 1) != batch and dom in EXTRACT_KERNELS:     # per-launch traffic depends on the batch
-                traffic_note = "profiles/pmc_r02.json was recorded at extract_batch %s" % pmc.get("extract_batch")
+                traffic_note = "%s was recorded at extract_batch %s" % (pmc_name, pmc.get("extract_batch"))
             else:
                 traffic = pmc["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_r02.json @ %s" % pmc.get("source_sha")
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, %s @ %s" % (pmc_name, pmc.get("source_sha"))
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_note=traffic_note, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
+    # nominal AND measured-achievable peak: a stream copy on this box, outside every timed region
+    hbm_measured = measured_hbm_peak(dev) if rank == 0 else None
+    if roofline is not None and hbm_measured:
+        roofline["peak_measured"] = hbm_measured; roofline["frac_of_measured"] = roofline["achieved"] / hbm_measured
 
     # ---- CPU baseline: the reference has no CPU implementation of this path, so the baseline
     # is the oracle restatement built -O3 -march=native ON THIS BOX, timed (i) single-threaded and (ii) with OpenMP over
@@ -528,13 +552,30 @@ def main():
     # ---- the same workload handed over differently (N = 1): host-resident frames (what the reference's caller has: cv::Mat,
     # PCIe-inclusive) and with the library's depth pre-filter inside the frame (what the reference's processFrame does with
     # OpenCV's bilateralFilter).  Never `value`: extra keys. -------------------------------------------------------------------
+    # ---- the steady-state rate: the same call over >= 600 frames, outside the timed region.  A short timed region (the
+    # driver's --steps 20) is mostly pipeline fill -- the first frame can only be tracked once its batch has been extracted --;
+    # this number says what the pipeline sustains (with the default --steps 1200, `value` is already that) -------------------
+    steady = None
+    if native_seq and world == 1 and a.extras:
+        ks = 720
+        prep_s = f.prepare_sequence([d_rgb[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)],
+                                    [d_depth[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        f.process_prepared(prep_s, on_device=True)
+        torch.cuda.synchronize(dev)
+        steady = dict(frames_per_sec=ks / (time.perf_counter() - t1), frames=ks,
+                      note="ssf_process_sequence over %d further frames of the same stream, same handle, outside the timed region" % ks)
     extras = None
     if rank == 0 and world == 1 and a.extras and not exchange and native_seq:
         extras = {}
         nx = 240                                     # (outside the timed region: independent of --steps)
         host_frames = [(np.ascontiguousarray(h_frames[i][0]), np.ascontiguousarray(h_frames[i][1])) for i in range(nr)]
         hsweep = Sweep(host_frames)
-        for key, kw, on_dev in (("host_frames_pageable", dict(), False), ("with_depth_prefilter", dict(prefilter=1), True)):
+        # the last one is what a node that swaps the library in gets from processFrame (supersurfel_fusion.cu:173-181): host images
+        # (cv::Mat) in, depth pre-filter inside the frame -- both together
+        for key, kw, on_dev in (("host_frames_pageable", dict(), False), ("with_depth_prefilter", dict(prefilter=1), True),
+                                ("host_frames_and_depth_prefilter", dict(prefilter=1), False)):
             fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, depth, batch, **kw))
             fx.set_model(model_local, nvis_local, 30)
             def seq(first, count):
@@ -578,6 +619,11 @@ def main():
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
+            "steady_state_frames_per_sec": steady["frames_per_sec"] if steady else None, "steady_state": steady,
+            "hbm_peak_measured_GBs": hbm_measured,
+            # the reference node's real call (host images in, depth pre-filter inside the frame), beside the headline
+            # whose frames are HBM-resident and already filtered
+            "as_the_reference_node_calls_it_frames_per_sec": (extras or {}).get("host_frames_and_depth_prefilter", {}).get("frames_per_sec"),
             "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "extras": extras, "kernel_source_sha": kernel_source_sha(), "host_affinity": affinity,
             "per_kernel": per_kernel,
         }

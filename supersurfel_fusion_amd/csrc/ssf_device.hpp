@@ -196,6 +196,8 @@ void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, i
                              float zmax, int stamp0, const uint8_t* dynamic_mask, unsigned mask_bits,
                              unsigned long long* best, uint8_t* matched);
 void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space);
+// the nb frames of a batch in ONE launch: frame b from in.depth[b] to out0 + b * slab bytes
+void launch_bilateral_batch(hipStream_t st, const BatchIn& in, float* out0, size_t slab, int nb, int W, int H, float sigma_color, float sigma_space);
 void launch_boundary_map(hipStream_t st, const SegParams& p, const int32_t* label, int32_t* out);
 void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const uint32_t* rgba, uint8_t* out /* 3P */);
 

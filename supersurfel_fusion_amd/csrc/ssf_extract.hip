@@ -1485,8 +1485,12 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
     return i;
 }
-__global__ __launch_bounds__(256) void k_bilateral(const float* __restrict__ in, float* __restrict__ out, int W, int H,
+// (every frame of an extract batch in one launch: frame = blockIdx.z, input = the caller's / the upload ring's buffer of that
+// frame, output = out0 + frame * slab bytes)
+__global__ __launch_bounds__(256) void k_bilateral(BatchIn bin, float* __restrict__ out0, size_t slab, int W, int H,
                                                    int radius, float ss, float sc) {
+    const float* __restrict__ in = batch_pick(bin.depth, (int)blockIdx.z);
+    float* __restrict__ out = slab_shift(out0, (size_t)blockIdx.z * slab);
     __shared__ float tile[(BIL_TILE + 2 * BIL_RMAX) * (BIL_TILE + 2 * BIL_RMAX)];
     __shared__ int s_ext[2 * BIL_RMAX + 1];            // half-width of the circular support in row dy
     const int X0 = blockIdx.x * BIL_TILE, Y0 = blockIdx.y * BIL_TILE;
@@ -1592,7 +1596,9 @@ __device__ __forceinline__ void bilateral_row7(const float* __restrict__ row, fl
     }
 }
 template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_bilateral_r7(const float* __restrict__ in, float* __restrict__ out, int W, int H, float ss, float sc) {
+__global__ __launch_bounds__(256, WAVES) void k_bilateral_r7(BatchIn bin, float* __restrict__ out0, size_t slab, int W, int H, float ss, float sc) {
+    const float* __restrict__ in = batch_pick(bin.depth, (int)blockIdx.z);
+    float* __restrict__ out = slab_shift(out0, (size_t)blockIdx.z * slab);
     constexpr int R = 7, BW = BIL_TILE + 2 * R;
     __shared__ float tile[BW * BW];
     const int X0 = blockIdx.x * BIL_TILE, Y0 = blockIdx.y * BIL_TILE;
@@ -1617,21 +1623,25 @@ __global__ __launch_bounds__(256, WAVES) void k_bilateral_r7(const float* __rest
     bilateral_row7<7>(c + 7 * BW, center, ss, sc, sum1, sum2);
     out[(size_t)y * W + x] = sum1 / sum2;
 }
-void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
+void launch_bilateral_batch(hipStream_t st, const BatchIn& in, float* out0, size_t slab, int nb, int W, int H, float sigma_color, float sigma_space) {
     ScopedKernel sk("bilateral_prefilter", st);
     int radius = (int)lrint((double)sigma_space * 1.5);
     if (radius < 1) radius = 1;
     const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
     static const bool generic_only = getenv("SSF_BILATERAL_GENERIC") != nullptr;
+    const dim3 grid((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE, nb);
     if (radius == 7 && !generic_only) {
         static const int waves = getenv("SSF_BIL_WAVES") ? atoi(getenv("SSF_BIL_WAVES")) : 2;
-        const dim3 grid((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE);
-        if (waves == 3) hipLaunchKernelGGL(k_bilateral_r7<3>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
-        else if (waves == 4) hipLaunchKernelGGL(k_bilateral_r7<4>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
-        else hipLaunchKernelGGL(k_bilateral_r7<2>, grid, dim3(256), 0, st, in, out, W, H, ss, sc);
+        if (waves == 3) hipLaunchKernelGGL(k_bilateral_r7<3>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
+        else if (waves == 4) hipLaunchKernelGGL(k_bilateral_r7<4>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
+        else hipLaunchKernelGGL(k_bilateral_r7<2>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
         return;
     }
-    hipLaunchKernelGGL(k_bilateral, dim3((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE), dim3(256), 0, st, in, out, W, H, radius, ss, sc);
+    hipLaunchKernelGGL(k_bilateral, grid, dim3(256), 0, st, in, out0, slab, W, H, radius, ss, sc);
+}
+void launch_bilateral(hipStream_t st, const float* in, float* out, int W, int H, float sigma_color, float sigma_space) {
+    BatchIn b{}; b.depth[0] = in;
+    launch_bilateral_batch(st, b, out, 0, 1, W, H, sigma_color, sigma_space);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

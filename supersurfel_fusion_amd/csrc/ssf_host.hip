@@ -678,12 +678,9 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
     c.timed = h->cfg.profile != 0;
     if (c.timed) HCK(hipEventRecord(c.ev_t0, st));
-    if (h->cfg.depth_prefilter) {                                          // supersurfel_fusion.cu:180
-        for (int b = 0; b < nb; b++) {
-            float* out = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
-            launch_bilateral(st, c.in.depth[b], out, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
-            c.in.depth[b] = out;
-        }
+    if (h->cfg.depth_prefilter) {                                          // supersurfel_fusion.cu:180 -- the batch's frames in one launch
+        launch_bilateral_batch(st, c.in, c.d_depth_filt, c.maps.slab, nb, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
+        for (int b = 0; b < nb; b++) c.in.depth[b] = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
     }
     launch_ingest(st, h->seg, c.in, c.maps, nb, c.epoch0);
     int rc = run_segmentation(h, c);
