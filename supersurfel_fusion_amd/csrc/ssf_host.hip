@@ -1547,9 +1547,14 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             // low priority: the track chain (ICP -> fuse, on h->stream) is the critical path, and the
             // runtime keeps a separate pool of hardware queues per priority, so every context gets a
             // queue of its own instead of sharing one with the track stream (head-of-line blocking)
+            // (context 0 one level above the others: a sequence that starts on an empty pipeline puts its first, small batch
+            // there -- ssf_process_sequence -- and that batch is what the track chain waits for while the larger batches of the
+            // other contexts, launched microseconds later, compete for the part.  SSF_CTX0_PRIORITY=0 switches it off.)
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) == hipSuccess; c.own_stream = ok;
+            static const bool ctx0_up = !(getenv("SSF_CTX0_PRIORITY") && atoi(getenv("SSF_CTX0_PRIORITY")) == 0);
+            const int prio = (ci == 0 && ctx0_up && least - greatest >= 2) ? least - 1 : least;
+            ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio) == hipSuccess; c.own_stream = ok;
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
@@ -1648,6 +1653,13 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
     for (int i = 0; i < n; i++) if (!rgb[i] || !depth[i]) return SSF_ERR_INVALID_ARG;
     int rc = SSF_OK;
+    // an empty pipeline: the sequence's first (small) batch goes to context 0, whose stream outranks the other contexts'
+    // (ssf_create): the batch the track chain is waiting for is not slowed down by the larger ones launched right behind it
+    if (h->ctx.size() > 1 && !h->ctx[h->open_ctx].launched && h->ctx[h->open_ctx].count == 0) {
+        bool idle = true;
+        for (auto& c : h->ctx) idle = idle && !c.launched && c.count == 0;
+        if (idle) h->open_ctx = 0;
+    }
     const bool ahead = !on_device && h->ctx.size() > 1 && n > 1;       // host frames, pipelined: copy them ahead
     if (ahead) {
         const size_t P = (size_t)h->cfg.width * h->cfg.height;
