@@ -334,6 +334,8 @@ def main():
             nrot = np.stack([(synthetic.rot_y(a_[1]) @ synthetic.rot_x(a_[0])).reshape(9) for a_ in ang]).astype(np.float32)
             fus.apply_deformation(rng.uniform(-3, 3, (m_, 3)).astype(np.float32), nrot, rng.uniform(-1e-3, 1e-3, (m_, 3)).astype(np.float32),
                                   rng.dirichlet(np.ones(4), n_).astype(np.float32), rng.integers(0, m_, (n_, 4)).astype(np.int32))
+            if world > 1:                              # a sharded map: the rows the deformation pushed over a tile edge go to their new owners
+                sharded.rehome_over(fus, world, device=dev)
         if py_driver:
             return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
         if exchange:
