@@ -501,7 +501,7 @@ def main():
                         traffic=traffic, traffic_note=traffic_note, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"])
     # nominal AND measured-achievable peak: a stream copy on this box, outside every timed region
-    hbm_measured = measured_hbm_peak(dev) if rank == 0 else None
+    hbm_measured = measured_hbm_peak(dev) if (rank == 0 and a.extras) else None          # (--extras 0: profiling runs stay free of the copy kernels)
     if roofline is not None and hbm_measured:
         roofline["peak_measured"] = hbm_measured; roofline["frac_of_measured"] = roofline["achieved"] / hbm_measured
 
