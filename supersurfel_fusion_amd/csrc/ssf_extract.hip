@@ -502,511 +502,6 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     }
 }
 
-// ---- the same pass, ONE WAVE per tile (round 3) ----------------------------------------------------------------------------
-// With several extract contexts in flight the part is full of relabelling workgroups, and what a pass costs is WAVE-SLOT TIME:
-// waves x the latency chain of a wave (one trip to memory, the window rows, the decisions, the flush: ~7 us), in 1.6 rounds
-// for an 8-frame launch of 256-thread workgroups (10 080 waves against 6 144 slots).  Only a quarter of a tile's pass pixels can
-// change at all (boundary pixels that pass the connectivity guard), so three of the four waves of k_update_pass spend the
-// long stretch -- the energy evaluation -- with a few live lanes.  Here a tile is ONE wave: every lane takes four pass pixels
-// through the cheap part (neighbourhood, guard, the own plane's inlier test), the pixels that can change are COMPACTED
-// (ballot + prefix, no atomics) into an LDS list, and the wave works that list off 64 at a time (one or two rounds).  Same
-// arithmetic, same log / double-buffer protocol, same tile grid as k_update_pass -- a launch of 8 frames is 2520 waves instead
-// of 10 080.  MEASURED (round 3, profiles/resident_passes_r03.txt): bit-exact, but 1.5x SLOWER per launch (22 / 31 us against
-// 15 / 20 for eight frames): the chain of the single wave is twice as long -- four times the cheap part per lane, and the
-// instruction stream of ONE wave is itself a latency chain (~16 cycles per instruction at this occupancy).  Kept as a
-// measurement switch (SSF_PASS_ONE_WAVE=1); the 256-thread form stays the default.
-template <bool RGBD>
-__global__ __launch_bounds__(64) void k_update_pass_w1(SegParams p, FrameMaps m, int pass, int OX, int OY) {
-    constexpr int TWW = TILE + 2, LOGN = 256, NPXL = 4, NT = (TWW * TW + 63) / 64;
-    __shared__ int tile[TWW * TW];
-    __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];
-    __shared__ uint32_t l_px[256]; __shared__ float l_disp[256]; __shared__ unsigned short l_pos[256];   // the compacted list: colour, disparity, (lx | ly << 6 | prev_inlier << 12)
-    m = batch_slot(m, blockIdx.z);
-    const int l = threadIdx.x;
-    const bool odd = (pass & 1) != 0;
-    const SpSums sr = odd ? m.sums[1] : m.sums[0], sw = odd ? m.sums[0] : m.sums[1];
-    const int X0 = blockIdx.x * TILE - (OX ? 0 : TILE - 2), Y0 = blockIdx.y * TILE;
-    int32_t* __restrict__ lab = m.label;
-    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int lp = (pass + 2) % 3, lc = pass % 3;
-    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
-    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
-    // this lane's pass pixels: element e = l + 64 s of the tile's 256 (local columns 4j+1, 4j+2 of the pass rows)
-    int lxh[NPXL], lyh[NPXL]; bool in_image[NPXL]; size_t q[NPXL];
-    uint32_t px[NPXL]; float disp[NPXL]; unsigned char prev_inlier[NPXL];
-#pragma unroll
-    for (int s = 0; s < NPXL; s++) {
-        const int e = l + 64 * s;
-        const int tx = e & 15, ty = e >> 4;
-        const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;
-        const int x = X0 + lx0, y = Y0 + ly0;
-        lxh[s] = lx0 + 1; lyh[s] = ly0 + 1;
-        in_image[s] = x >= 0 && x < p.W && y < p.H;
-        q[s] = in_image[s] ? (size_t)y * p.W + x : 0;
-        px[s] = m.rgba[q[s]];
-        disp[s] = 0.f; prev_inlier[s] = 0;
-        if (RGBD) { disp[s] = m.disp[q[s]]; prev_inlier[s] = m.inlier[q[s]]; }
-    }
-    int tile_reg[NT];
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-        const int i = l + 64 * k;
-        const int lx = i % TWW, ly = i / TWW;
-        const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
-        tile_reg[k] = -1;
-        if (i < TWW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
-    }
-    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
-    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    int4 prev_ent[NPXL]; float prev_disp[NPXL];
-#pragma unroll
-    for (int s = 0; s < NPXL; s++) {
-        prev_ent[s] = make_int4(0, 0, 0, 0); prev_disp[s] = 0.f;
-        const unsigned int e = l + 64u * s;
-        if (e < n_prev) {
-            prev_ent[s] = pent[(size_t)tile_id * LOGN + e];
-            if (RGBD) prev_disp[s] = pdis[(size_t)tile_id * LOGN + e];
-        }
-    }
-    // window of grid cells around the tile (as k_update_pass)
-    int margin = 2;
-    const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
-    const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
-    while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
-    const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
-    const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
-    const bool window_ok = nwx * nwy <= WIN_MAX;
-    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (window_ok && l < nwx * nwy) {                         // (WIN_MAX = 64 = one cell per lane)
-        const int cx = wcx0 + l % nwx, cy = wcy0 + l / nwx;
-        if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) w_row[l] = row_from_sums(sr, cy * p.gx + cx, RGBD, zero_row);
-    }
-    if (window_ok) for (int i = l; i < nwx * nwy * F_COUNT; i += 64) w_acc[i] = 0ull;
-#pragma unroll
-    for (int k = 0; k < NT; k++) { const int i = l + 64 * k; if (i < TWW * TW) tile[i] = tile_reg[k]; }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): one wave -- its LDS writes have landed, in order
-    __builtin_amdgcn_wave_barrier();
-    const float inv_gx = 1.0f / (float)p.gx;
-    auto slot_of = [&](int lbl) -> int {
-        const int cyl = (int)(((float)lbl + 0.5f) * inv_gx);
-        const int wx = (lbl - cyl * p.gx) - wcx0, wy = cyl - wcy0;
-        return (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
-    };
-    auto row_of = [&](int lbl) -> SpRow {
-        const int ws = slot_of(lbl);
-        if (ws >= 0) return w_row[ws];
-        return row_from_sums(sr, lbl, RGBD, zero_row);
-    };
-    auto add_delta = [&](int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {
-        const unsigned fl = rgbf >> 24;
-        const int wf = slot_of(from), wt = slot_of(to);
-        if (fl & 1u) {
-            if (wf >= 0) lds_rgb(&w_acc[wf * F_COUNT], -1, px_x, px_y, rgbf);
-            if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
-            if (wf < 0 || wt < 0) {
-                const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
-                if (wf < 0) { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
-                              atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
-                if (wt < 0) { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
-                              atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
-            }
-        }
-        if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
-        if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
-    };
-    int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
-    float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
-    unsigned int n_log = 0;                                   // (uniform: log entries of this tile so far)
-    // one relabelled / re-flagged pixel: sums delta + log entry; the log slot comes from a ballot over the lanes that have one
-    auto commit = [&](bool have, int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {
-        const unsigned long long mask = __ballot(have);
-        if (have) {
-            add_delta(from, to, px_x, px_y, rgbf, d);
-            const unsigned int slot = n_log + (unsigned int)__popcll(mask & ((1ull << l) - 1ull));
-            cent[(size_t)tile_id * LOGN + slot] = make_int4(from, to, px_x | (px_y << 16), (int)rgbf);
-            if (RGBD) cdis[(size_t)tile_id * LOGN + slot] = d;
-        }
-        n_log += (unsigned int)__popcll(mask);
-    };
-    // ---- part A: every pass pixel through the cheap tests; the ones that can change are compacted into the list
-    unsigned int n_el = 0;
-#pragma unroll
-    for (int s = 0; s < NPXL; s++) {
-        const int lx = lxh[s], ly = lyh[s];
-        const int index = in_image[s] ? tile[ly * TWW + lx] : 0;
-        const int n0 = tile[(ly - 1) * TWW + lx], n1 = tile[ly * TWW + lx - 1], n2 = tile[ly * TWW + lx + 1], n3 = tile[(ly + 1) * TWW + lx];
-        const int bounds = (n0 != index) + (n1 != index) + (n2 != index) + (n3 != index);
-        bool eligible = in_image[s] && bounds != 0;
-        if (eligible) {
-            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-            bool prev = tile[(ly + oy[0]) * TWW + lx + ox[0]] == index;
-            int jump = 0;
-#pragma unroll
-            for (int k = 1; k < 8; k++) {
-                const bool cur = tile[(ly + oy[k]) * TWW + lx + ox[k]] == index;
-                if (prev != cur) { jump++; prev = cur; }
-            }
-            eligible = !(jump > 2);
-        }
-        // a pixel that cannot change its label can still change its inlier flag (RGB-D): settled here
-        if (RGBD) {
-            unsigned flags = 0u; unsigned char inlier = 0xff;
-            const bool settle = in_image[s] && !eligible;
-            if (settle) {
-                const SpRow own = row_of(index);
-                const int x = X0 + lx - 1, y = Y0 + ly - 1;
-                const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-                const float de = (dp - disp[s]) * (dp - disp[s]);
-                if (!isfinite(de) || de > p.thresh_disp || dp < 0.f) inlier = 0;
-                if (inlier && !prev_inlier[s]) flags |= 2u;
-                if (prev_inlier[s] && !inlier) flags |= 4u;
-                if (inlier != prev_inlier[s]) m.inlier[q[s]] = inlier;
-            }
-            commit(settle && flags != 0u, index, index, X0 + lx - 1, Y0 + ly - 1, (px[s] & 0x00FFFFFFu) | (flags << 24), disp[s]);
-        }
-        const unsigned long long em = __ballot(eligible);
-        if (eligible) {
-            const unsigned int j = n_el + (unsigned int)__popcll(em & ((1ull << l) - 1ull));
-            l_px[j] = px[s]; l_disp[j] = disp[s];
-            l_pos[j] = (unsigned short)(lx | (ly << 6) | ((prev_inlier[s] ? 1 : 0) << 12));
-        }
-        n_el += (unsigned int)__popcll(em);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // ---- part B: the pixels that can change, 64 at a time: the energy evaluation of k_update_pass, line by line
-    for (unsigned int base = 0; base < n_el; base += 64) {
-        const unsigned int j = base + l;
-        const bool have = j < n_el;
-        int index = 0, new_index = 0, lx = 1, ly = 1; unsigned flags = 0u; uint32_t pxv = 0u; float dv = 0.f;
-        if (have) {
-            pxv = l_px[j]; dv = l_disp[j];
-            const unsigned int pos = l_pos[j];
-            lx = (int)(pos & 63u); ly = (int)((pos >> 6) & 63u);
-            const unsigned char pinl = (unsigned char)(((pos >> 12) & 1u) ? 0xff : 0);
-            const int x = X0 + lx - 1, y = Y0 + ly - 1;
-            index = tile[ly * TWW + lx]; new_index = index;
-            const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-            int nl[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TWW + lx + nx[k]];
-            const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
-            const SpRow own = row_of(index);
-            float disp_energy = 0.f;
-            unsigned char inlier = 0xff;
-            if (RGBD) {
-                const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-                disp_energy = (dp - dv) * (dp - dv);
-                if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
-            }
-            const float cr = (float)(pxv & 255u), cg = (float)((pxv >> 8) & 255u), cb = (float)((pxv >> 16) & 255u);
-            const float posx = (float)x, posy = (float)y;
-            const float size = own.size;
-            const float sc = size / (size - 1.f);
-            const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
-            const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
-            const float dsize = size - (float)p.min_size;
-            float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
-            if (RGBD) best = best + p.lambda_disp * disp_energy;
-            best = best - p.lambda_size * fminf(dsize, 0.f);
-            best = best + p.lambda_bound * (float)bounds;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i_n = nl[k];
-                if (i_n == -1 || i_n == index) continue;
-                const SpRow nb = row_of(i_n);
-                const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-                const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-                const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-                float n_de = 0.f; unsigned char n_inlier = 0xff;
-                if (RGBD) {
-                    const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
-                    n_de = (dp - dv) * (dp - dv);
-                    if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
-                }
-                const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-                float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-                if (RGBD) e = e + p.lambda_disp * n_de;
-                e = e - p.lambda_size * fminf(ndsize, 0.f);
-                e = e + p.lambda_bound * (float)b;
-                if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
-            }
-            const size_t qq = (size_t)y * p.W + x;
-            if (new_index != index) lab[qq] = new_index;
-            flags = (new_index != index) ? 1u : 0u;
-            if (RGBD) {
-                if (inlier && (!pinl || index != new_index)) flags |= 2u;
-                if (pinl && (!inlier || (inlier && index != new_index))) flags |= 4u;
-                if (inlier != pinl) m.inlier[qq] = inlier;
-            }
-        }
-        commit(have && flags != 0u, index, new_index, X0 + lx - 1, Y0 + ly - 1, (pxv & 0x00FFFFFFu) | (flags << 24), dv);
-    }
-    // ---- replay of this tile's log of the previous pass into the buffer this pass writes, then the flush
-#pragma unroll
-    for (int s = 0; s < NPXL; s++)
-        if (l + 64u * s < n_prev)
-            add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (window_ok)
-        for (int i = l; i < nwx * nwy * F_COUNT; i += 64) {
-            const long long v = (long long)w_acc[i];
-            if (v == 0) continue;
-            const int wi = i / F_COUNT;
-            flush_field(sw, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i % F_COUNT, v);
-        }
-    if (l == 0) {
-        unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
-        ccnt[tile_id] = n_log;
-    }
-}
-
-// ---- the same pass with the changeable pixels compacted and the idle waves RELEASED (round 3) -----------------------------
-// What a relabelling launch costs when several extract contexts keep the part full is wave-slot time: waves x the life of a
-// wave.  In k_update_pass all four waves of a tile live until the flush, although after the cheap tests only about a quarter
-// of the tile's 256 pass pixels -- one wave's worth -- can change at all.  Here the four waves do the cheap part (one pass pixel
-// per lane, as before), push the pixels that can change into an LDS list, replay the previous pass' log, and then every wave
-// the list does not need EXITS (its slot is free for the next workgroup); the remaining one or two waves evaluate the
-// energies (one list entry per lane), apply, flush and write the log count.  Arithmetic, log / double-buffer protocol and
-// tile grid are k_update_pass's.  (Round 2 tried the compaction alone -- all waves staying for the flush -- and saw no gain:
-// the slots were not released.)
-template <bool RGBD, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass_c(SegParams p, FrameMaps m, int pass, int OX, int OY) {
-    constexpr int TWW = TILE + 2, LOGN = 256;
-    __shared__ int tile[TWW * TW];
-    __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];
-    __shared__ uint32_t l_px[256]; __shared__ float l_disp[256]; __shared__ unsigned short l_pos[256];   // the list: colour, disparity, (lx | ly << 6 | prev_inlier << 12)
-    __shared__ unsigned int s_nlog, s_nel;
-    m = batch_slot(m, blockIdx.z);
-    const bool odd = (pass & 1) != 0;
-    const SpSums sr = odd ? m.sums[1] : m.sums[0], sw = odd ? m.sums[0] : m.sums[1];
-    const int X0 = blockIdx.x * TILE - (OX ? 0 : TILE - 2), Y0 = blockIdx.y * TILE;
-    int32_t* __restrict__ lab = m.label;
-    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-    const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;
-    const int x = X0 + lx0, y = Y0 + ly0, lx = lx0 + 1, ly = ly0 + 1;
-    const bool in_image = x >= 0 && x < p.W && y < p.H;
-    const size_t q = in_image ? (size_t)y * p.W + x : 0;
-    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int lp = (pass + 2) % 3, lc = pass % 3;
-    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
-    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
-    const uint32_t px = m.rgba[q];
-    float disp = 0.f; unsigned char prev_inlier = 0;
-    if (RGBD) { disp = m.disp[q]; prev_inlier = m.inlier[q]; }
-    constexpr int TILE_LOADS = (TWW * TW + 255) / 256;
-    int tile_reg[TILE_LOADS];
-#pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) {
-        const int i = threadIdx.x + 256 * k;
-        const int tlx = i % TWW, tly = i / TWW;
-        const int gx_ = X0 - 1 + tlx, gy_ = Y0 - 1 + tly;
-        tile_reg[k] = -1;
-        if (i < TWW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
-    }
-    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
-    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    int4 prev_ent = make_int4(0, 0, 0, 0); float prev_disp = 0.f;
-    if (threadIdx.x < n_prev) {
-        prev_ent = pent[(size_t)tile_id * LOGN + threadIdx.x];
-        if (RGBD) prev_disp = pdis[(size_t)tile_id * LOGN + threadIdx.x];
-    }
-    int margin = 2;
-    const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
-    const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
-    while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
-    const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
-    const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
-    const bool window_ok = nwx * nwy <= WIN_MAX;
-    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (window_ok && threadIdx.x < (RGBD ? 128 : 64)) {
-        const int i = threadIdx.x & 63;
-        const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
-        if (i < nwx * nwy && cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) {
-            const int k = cy * p.gx + cx;
-            if (threadIdx.x < 64) {
-                SpRow row = zero_row;
-                row_means_from_sums(sr, k, row);
-                w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
-                if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
-            } else {
-                float ta, tb, tc;
-                row_plane_from_sums(sr, k, ta, tb, tc);
-                w_row[i].ta = ta; w_row[i].tb = tb; w_row[i].tc = tc;
-            }
-        }
-    }
-    if (threadIdx.x == 0) { s_nlog = 0; s_nel = 0; }
-    if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
-#pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) { const int i = threadIdx.x + 256 * k; if (i < TWW * TW) tile[i] = tile_reg[k]; }
-    __syncthreads();
-    const float inv_gx = 1.0f / (float)p.gx;
-    auto slot_of = [&](int l) -> int {
-        const int cyl = (int)(((float)l + 0.5f) * inv_gx);
-        const int wx = (l - cyl * p.gx) - wcx0, wy = cyl - wcy0;
-        return (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
-    };
-    auto row_of = [&](int l) -> SpRow {
-        const int ws = slot_of(l);
-        if (ws >= 0) return w_row[ws];
-        return row_from_sums(sr, l, RGBD, zero_row);
-    };
-    auto add_delta = [&](int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {
-        const unsigned fl = rgbf >> 24;
-        const int wf = slot_of(from), wt = slot_of(to);
-        if (fl & 1u) {
-            if (wf >= 0) lds_rgb(&w_acc[wf * F_COUNT], -1, px_x, px_y, rgbf);
-            if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
-            if (wf < 0 || wt < 0) {
-                const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
-                if (wf < 0) { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
-                              atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
-                if (wt < 0) { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
-                              atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
-            }
-        }
-        if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
-        if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
-    };
-    int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
-    float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
-    auto commit = [&](int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {      // sums delta + log entry of one pixel
-        add_delta(from, to, px_x, px_y, rgbf, d);
-        const unsigned int slot = atomicAdd(&s_nlog, 1u);
-        cent[(size_t)tile_id * LOGN + slot] = make_int4(from, to, px_x | (px_y << 16), (int)rgbf);
-        if (RGBD) cdis[(size_t)tile_id * LOGN + slot] = d;
-    };
-    // ---- part A (all four waves): the cheap tests of this thread's pass pixel
-    {
-        const int index = in_image ? tile[ly * TWW + lx] : 0;
-        const int n0 = tile[(ly - 1) * TWW + lx], n1 = tile[ly * TWW + lx - 1], n2 = tile[ly * TWW + lx + 1], n3 = tile[(ly + 1) * TWW + lx];
-        const int bounds = (n0 != index) + (n1 != index) + (n2 != index) + (n3 != index);
-        bool eligible = in_image && bounds != 0;
-        if (eligible) {
-            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-            bool prev = tile[(ly + oy[0]) * TWW + lx + ox[0]] == index;
-            int jump = 0;
-#pragma unroll
-            for (int k = 1; k < 8; k++) {
-                const bool cur = tile[(ly + oy[k]) * TWW + lx + ox[k]] == index;
-                if (prev != cur) { jump++; prev = cur; }
-            }
-            eligible = !(jump > 2);
-        }
-        if (RGBD && in_image && !eligible) {          // cannot change its label, may change its inlier flag: settled here
-            const SpRow own = row_of(index);
-            const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-            const float de = (dp - disp) * (dp - disp);
-            unsigned char inlier = 0xff;
-            if (!isfinite(de) || de > p.thresh_disp || dp < 0.f) inlier = 0;
-            unsigned flags = 0u;
-            if (inlier && !prev_inlier) flags |= 2u;
-            if (prev_inlier && !inlier) flags |= 4u;
-            if (inlier != prev_inlier) m.inlier[q] = inlier;
-            if (flags) commit(index, index, x, y, (px & 0x00FFFFFFu) | (flags << 24), disp);
-        }
-        const unsigned long long em = __ballot(eligible);
-        unsigned int wbase = 0;
-        if ((threadIdx.x & 63) == 0 && em) wbase = atomicAdd(&s_nel, (unsigned int)__popcll(em));
-        wbase = (unsigned int)__shfl((int)wbase, 0, 64);
-        if (eligible) {
-            const unsigned int j = wbase + (unsigned int)__popcll(em & ((1ull << (threadIdx.x & 63)) - 1ull));
-            l_px[j] = px; l_disp[j] = disp;
-            l_pos[j] = (unsigned short)(lx | (ly << 6) | ((prev_inlier ? 1 : 0) << 12));
-        }
-        // the replay of this tile's log of the previous pass also belongs to the part every wave takes
-        if (threadIdx.x < n_prev)
-            add_delta(prev_ent.x, prev_ent.y, prev_ent.z & 0xFFFF, (prev_ent.z >> 16) & 0xFFFF, (uint32_t)prev_ent.w, prev_disp);
-    }
-    __syncthreads();
-    // ---- the waves the list does not need leave now (wave 0 always stays: it flushes)
-    const unsigned int n_el = s_nel;
-    const unsigned int alive = max(1u, (n_el + 63u) >> 6);            // waves that stay
-    if ((threadIdx.x >> 6) >= alive) return;
-    // ---- part B: one list entry per lane -- the energy evaluation of k_update_pass, line by line
-    if (threadIdx.x < n_el) {
-        const unsigned int j = threadIdx.x;
-        const uint32_t pxv = l_px[j]; const float dv = l_disp[j];
-        const unsigned int pos = l_pos[j];
-        const int elx = (int)(pos & 63u), ely = (int)((pos >> 6) & 63u);
-        const unsigned char pinl = (unsigned char)(((pos >> 12) & 1u) ? 0xff : 0);
-        const int ex = X0 + elx - 1, ey = Y0 + ely - 1;
-        const int index = tile[ely * TWW + elx];
-        int new_index = index;
-        const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-        int nl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) nl[k] = tile[(ely + ny[k]) * TWW + elx + nx[k]];
-        const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
-        const SpRow own = row_of(index);
-        float disp_energy = 0.f;
-        unsigned char inlier = 0xff;
-        if (RGBD) {
-            const float dp = (own.ta * (float)ex + own.tb * (float)ey) + own.tc;
-            disp_energy = (dp - dv) * (dp - dv);
-            if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
-        }
-        const float cr = (float)(pxv & 255u), cg = (float)((pxv >> 8) & 255u), cb = (float)((pxv >> 16) & 255u);
-        const float posx = (float)ex, posy = (float)ey;
-        const float size = own.size;
-        const float sc = size / (size - 1.f);
-        const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
-        const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
-        const float dsize = size - (float)p.min_size;
-        float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
-        if (RGBD) best = best + p.lambda_disp * disp_energy;
-        best = best - p.lambda_size * fminf(dsize, 0.f);
-        best = best + p.lambda_bound * (float)bounds;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i_n = nl[k];
-            if (i_n == -1 || i_n == index) continue;
-            const SpRow nb = row_of(i_n);
-            const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-            const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-            const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-            float n_de = 0.f; unsigned char n_inlier = 0xff;
-            if (RGBD) {
-                const float dp = (nb.ta * (float)ex + nb.tb * (float)ey) + nb.tc;
-                n_de = (dp - dv) * (dp - dv);
-                if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
-            }
-            const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-            float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-            if (RGBD) e = e + p.lambda_disp * n_de;
-            e = e - p.lambda_size * fminf(ndsize, 0.f);
-            e = e + p.lambda_bound * (float)b;
-            if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
-        }
-        const size_t qq = (size_t)ey * p.W + ex;
-        if (new_index != index) lab[qq] = new_index;
-        unsigned flags = (new_index != index) ? 1u : 0u;
-        if (RGBD) {
-            if (inlier && (!pinl || index != new_index)) flags |= 2u;
-            if (pinl && (!inlier || (inlier && index != new_index))) flags |= 4u;
-            if (inlier != pinl) m.inlier[qq] = inlier;
-        }
-        if (flags) commit(index, new_index, ex, ey, (pxv & 0x00FFFFFFu) | (flags << 24), dv);
-    }
-    // ---- the flush, by the waves that stayed (one wave: its LDS operations are in order; more: a barrier among them)
-    if (alive > 1) __syncthreads(); else { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
-    if (window_ok)
-        for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += 64 * (int)alive) {
-            const long long v = (long long)w_acc[i];
-            if (v == 0) continue;
-            const int wi = i / F_COUNT;
-            flush_field(sw, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i % F_COUNT, v);
-        }
-    if (threadIdx.x == 0) {
-        unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
-        ccnt[tile_id] = s_nlog;
-    }
-}
-
 // ---- resident relabelling: all passes of a phase in one launch -----------------------------------------------------
 // k_update_pass above pays, forty times per frame, a launch, a trip to memory for the label tile and the pixel operands,
 // and the window rows' arithmetic in every one of its 2520 workgroups (8 frames) -- a latency chain per wave that left the
@@ -2186,25 +1681,10 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
     static int waves = 0;
     if (!waves) { const char* e = getenv("SSF_PASS_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 6; }
-    // SSF_PASS_ONE_WAVE=1 (measurement): one wave per tile with the changeable pixels compacted (k_update_pass_w1).  Measured,
-    // round 3: 22 / 31 us per 8-frame launch (RGB / RGB-D) against 15 / 20, one frame 11 / 16 against 6 / 8 -- a quarter of
-    // the waves, but each wave's chain twice as long: the pass is bound by the instruction chain of a wave as much as by
-    // its trip to memory
-    static int one_wave = -1;
-    if (one_wave < 0) { const char* e = getenv("SSF_PASS_ONE_WAVE"); one_wave = e ? atoi(e) : 0; }
-    if (one_wave && npx == 1 && dbg == 0) {
-        if (rgbd) hipLaunchKernelGGL(k_update_pass_w1<true>, grid, dim3(64), 0, st, p, m, k, ox, oy);
-        else hipLaunchKernelGGL(k_update_pass_w1<false>, grid, dim3(64), 0, st, p, m, k, ox, oy);
-        return;
-    }
-    // the changeable pixels compacted, the waves the list does not need released (k_update_pass_c): SSF_PASS_COMPACT=0 for the plain form
-    static int compact = -1;
-    if (compact < 0) { const char* e = getenv("SSF_PASS_COMPACT"); compact = e ? atoi(e) : 1; }
-    if (compact && npx == 1 && dbg == 0) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass_c<true, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy);
-        else hipLaunchKernelGGL((k_update_pass_c<false, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy);
-        return;
-    }
+    // (Round 3 measured two more forms of this pass against the 256-thread kernel -- one wave per tile with the changeable
+    // pixels compacted: 22 / 31 us per 8-frame launch against 15 / 20; four waves that compact the changeable pixels into an
+    // LDS list and RELEASE the waves the list does not need: 17 / 22 us, same frame rate -- both bit-exact, both slower; they
+    // live in the history, not in the source.)
     if (npx == 2) {
         if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
         else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
