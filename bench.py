@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0) with the contract keys plus "roofline" (dominant k
 live with hipEvents on the library's stream) and "cpu_baseline" (the CPU oracle = a single-threaded
 port of the reference algorithm, timed on this box's host cores on a bounded sample)."""
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -421,10 +422,27 @@ def main():
     barrier()
     t0 = time.perf_counter()
     results = f.process_prepared(prepared, on_device=True) if native_seq else run(Wm, K)
+    t_ret = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    fill = None
     if native_seq:
         results = [r.as_dict() for r in results]
+        if K <= 64:
+            # where a short timed region goes: completion time of every frame inside ssf_process_sequence (the library's
+            # own clock, from its entry), the call's return and the end of the closing barrier, all in microseconds
+            tt_ = np.zeros(64)
+            lib.lib.ssf_dbg_sequence_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            lib.lib.ssf_dbg_sequence_times(f.h, tt_.ctypes.data_as(ctypes.c_void_p))
+            fill = dict(frame_done_us=[round(float(v), 1) for v in tt_[:K]], call_returned_us=round(1e6 * (t_ret - t0), 1),
+                        region_us=round(1e6 * dt, 1), icp_iters=[int(r["icp_iters"]) for r in results])
+            if hasattr(lib.lib, "ssf_dbg_sequence_marks"):
+                mk = np.zeros(320)
+                lib.lib.ssf_dbg_sequence_marks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+                lib.lib.ssf_dbg_sequence_marks(f.h, mk.ctypes.data_as(ctypes.c_void_p))
+                for j, name in enumerate(("track_entered_us", "first_icp_record_us", "icp_done_us")):
+                    fill[name] = [round(float(v), 1) for v in mk[64 * j:64 * j + K]]
+                fill["extract_batches_launched"] = [dict(at_us=round(float(mk[256 + 2 * i]), 1), frames=int(mk[257 + 2 * i]), host_us=round(1e4 * (mk[257 + 2 * i] % 1.0), 1)) for i in range(32) if mk[256 + 2 * i] >= 0]
     iters = [r["icp_iters"] for r in results]
     last = results[-1]
     # strictly sequential latency (one frame in flight, pipeline_depth 0 / extract_batch 1): a second handle at
@@ -622,6 +640,7 @@ def main():
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,
             "stage_ms": {"extract": stage[0], "icp": stage[1], "fuse": stage[2]},
             "steady_state_frames_per_sec": steady["frames_per_sec"] if steady else None, "steady_state": steady,
+            "pipeline_fill": fill,
             "hbm_peak_measured_GBs": hbm_measured,
             # the reference node's real call (host images in, depth pre-filter inside the frame), beside the headline
             # whose frames are HBM-resident and already filtered
@@ -633,7 +652,6 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)             # C-level buffers of the runtime libraries (to stderr)
         os.dup2(saved_stdout, 1)

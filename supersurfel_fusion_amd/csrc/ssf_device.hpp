@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include "ssf_math.hpp"
 #include "../../include/ssf.h"
 
@@ -36,6 +37,8 @@ struct alignas(64) SumRec {
     int32_t sx, sy, sr, sg, sb, n, dx, dy, dn; int32_t pad0[7];
     long long dxx, dyy, dxy, dxd, dyd, dd; long long pad1[2];
 };
+static_assert(offsetof(SumRec, dn) == 32 && offsetof(SumRec, dxx) == 64 && offsetof(SumRec, dd) == 104 && sizeof(SumRec) == 128,
+              "k_update_pass flushes its accumulators by field offset");
 struct SpSums { SumRec* r; };
 
 // device-side counters shared by the fuse kernels (no host round trip between them)
@@ -70,6 +73,7 @@ struct SegParams {
     float filter_alpha, filter_beta, filter_threshold;
     int filter_iter;
     uint64_t seed;
+    float inv_gx;         // 1.0f / (float)gx (one IEEE division, made on the host)
 };
 
 // One relabelled pixel of a pass, replayed by the next pass into the lagging sums buffer.

@@ -265,12 +265,24 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 // launch: with 8 frames per launch the 32-wide grid is 2520 workgroups = 10080 waves, more than the 8192 the part
 // holds at once (a second, mostly empty round of workgroups); the 64-wide grid fits in one round and amortises the
 // window's row computation and the flush over twice the pixels.  NPX = 1 stays for single-frame launches (latency).
+// Instruction diet (round 3).  Counters + an experiment (150 extra vector instructions per wave: +2.3 us on a 20 us launch) show the
+// pass is bound by instruction ISSUE as much as by latency: 6.3 M wave-level VALU instructions per 8-frame RGB-D launch are
+// 10 us of the part's vector issue capacity.  Hence: the candidate labels of a pixel de-duplicated and compacted (the wave walks
+// 1-2 candidates instead of 4 directions), interior tiles staged without bounds tests and through one scalar base, the
+// connectivity guard as a bit mask + popcount, window slots by unsigned compares, the nine 32-bit sums in 32-bit LDS
+// accumulators, the disparity terms of a pixel converted once for both signs, the flush addressed by field offset
+// instead of a 15-way switch, the previous pass' log entry fetched without a branch (behind one, the compiler waited for
+// it -- a second dependent trip to memory -- before it requested the window's sums).
+#define PASS_F32 9                  // F_SX .. F_DN: 32-bit accumulators; F_DXX .. F_DD: 64-bit
+#define PASS_F64 (F_COUNT - PASS_F32)
 template <bool RGBD, int NPX, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     constexpr int TWX = TILE * NPX, TWW = TWX + 2, LOGN = 256 * NPX;
     __shared__ int tile[TWW * TW];
     __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * F_COUNT];   // this tile's sum deltas (own + replayed), flushed once
+    __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
+    __shared__ unsigned int w_acc32[WIN_MAX * PASS_F32];      // this tile's sum deltas (own + replayed), flushed once
+    __shared__ unsigned long long w_acc64[WIN_MAX * PASS_F64];
     __shared__ unsigned int s_nlog;
     m = batch_slot(m, blockIdx.z);
     const bool odd = (pass & 1) != 0;
@@ -289,13 +301,10 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         in_image[s] = x[s] >= 0 && x[s] < p.W && y[s] < p.H;
         q[s] = in_image[s] ? (size_t)y[s] * p.W + x[s] : 0;
     }
-    // this tile's log of the previous pass is replayed at the very end; its entry count (uniform, a scalar load)
-    // is requested first so that only the valid entries are fetched (an unconditional fetch of the whole region costs
-    // 5 B per pixel of HBM)
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int lp = (pass + 2) % 3, lc = pass % 3;
     const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
-    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;
+    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;          // (uniform: a scalar load, needed only further down)
     // operands that do not depend on the label tile: in flight while the tile is staged
     uint32_t px[NPX]; float disp[NPX]; unsigned char prev_inlier[NPX];
 #pragma unroll
@@ -305,67 +314,99 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (RGBD) { disp[s] = m.disp[q[s]]; prev_inlier[s] = m.inlier[q[s]]; }
     }
     // the label tile + halo: requested into registers NOW (independent loads), stored to LDS after the superpixel rows
-    // have been computed -- one memory round trip for tile, pixel operands, sums and log instead of two
+    // have been computed -- one memory round trip for tile, pixel operands, sums and log
     constexpr int TILE_LOADS = (TWW * TW + 255) / 256;
     int tile_reg[TILE_LOADS];
+    // Element offsets first -- without bounds tests when the halo lies inside the image (uniform), clamped into the image
+    // otherwise, `outside` = the rounds whose element is not in the image -- then ONE unconditional round of loads for both
+    // kinds of tile.  (Loads behind a branch, or in two alternative blocks, made the compiler wait for the pixel operands
+    // before it issued them: a second dependent trip to memory.)  The last, partial round re-reads the tile's last element
+    // in its idle lanes.
+    unsigned int tile_off[TILE_LOADS]; unsigned int outside = 0u;
+    const bool interior = X0 >= 1 && X0 + TWX < p.W && Y0 >= 1 && Y0 + TILE < p.H;
+    if (interior) {
+        const unsigned int base_off = (unsigned int)((Y0 - 1) * p.W + (X0 - 1));
 #pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) {
-        const int i = threadIdx.x + 256 * k;
-        const int lx = i % TWW, ly = i / TWW;
-        const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
-        tile_reg[k] = -1;
-        if (!(dbg & 32) && i < TWW * TW && gx_ >= 0 && gx_ < p.W && gy_ >= 0 && gy_ < p.H) tile_reg[k] = lab[(size_t)gy_ * p.W + gx_];
-    }
-    // the valid entries of the previous pass' log (replayed at the very end)
-    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
-    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
-    int4 prev_ent[NPX]; float prev_disp[NPX];
+        for (int k = 0; k < TILE_LOADS; k++) {
+            const int i = 256 * (k + 1) <= TWW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TWW * TW - 1);
+            const int ly = i / TWW, lx = i - ly * TWW;
+            tile_off[k] = base_off + (unsigned int)(ly * p.W + lx);
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < NPX; s++) {
-        prev_ent[s] = make_int4(0, 0, 0, 0); prev_disp[s] = 0.f;
-        const unsigned int e = threadIdx.x + 256u * s;
-        if (e < n_prev) {
-            prev_ent[s] = pent[(size_t)tile_id * LOGN + e];
-            if (RGBD) prev_disp[s] = pdis[(size_t)tile_id * LOGN + e];
+        for (int k = 0; k < TILE_LOADS; k++) {
+            const int i = 256 * (k + 1) <= TWW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TWW * TW - 1);
+            const int ly = i / TWW, lx = i - ly * TWW;
+            const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
+            const int cx_ = min(max(gx_, 0), p.W - 1), cy_ = min(max(gy_, 0), p.H - 1);
+            if (cx_ != gx_ || cy_ != gy_) outside |= 1u << k;
+            tile_off[k] = (unsigned int)(cy_ * p.W + cx_);
         }
     }
+    if (dbg & 32) outside = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; k++) tile_reg[k] = lab[tile_off[k]];
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
     const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
     const int tcx1 = min(X0 + TWX - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
     while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
     const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
-    const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
-    const bool window_ok = nwx * nwy <= WIN_MAX;
+    const int nwx_ = tcx1 - tcx0 + 1 + 2 * margin, nwy_ = tcy1 - tcy0 + 1 + 2 * margin;
+    const bool window_ok = nwx_ * nwy_ <= WIN_MAX;
+    const int nwx = window_ok ? nwx_ : 0, nwy = window_ok ? nwy_ : 0, nslots = nwx * nwy;   // no window: every label takes the exact path
     const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (window <= 64 cells: wave 0 builds the means of cell `lane`, wave 1 -- RGB-D passes -- its plane, side by side)
-    if (window_ok && !(dbg & 1) && threadIdx.x < (RGBD ? 128 : 64)) {
+    if (threadIdx.x < (RGBD ? 128 : 64)) {
         const int i = threadIdx.x & 63;
-        const int cx = wcx0 + i % nwx, cy = wcy0 + i / nwx;
-        if (i < nwx * nwy && cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) {
+        if (i < nslots) {
+            const int wy = i / nwx, wx = i - wy * nwx;
+            const int cx = wcx0 + wx, cy = wcy0 + wy;
+            const bool inside = cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy;
             const int k = cy * p.gx + cx;
-            if (threadIdx.x < 64) {
-                SpRow row = zero_row;
-                row_means_from_sums(sr, k, row);
-                w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
-                if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
-            } else {
-                float ta, tb, tc;
-                row_plane_from_sums(sr, k, ta, tb, tc);
-                w_row[i].ta = ta; w_row[i].tb = tb; w_row[i].tc = tc;
+            if (threadIdx.x < 64) w_label[i] = inside ? k : -1;
+            if (inside && !(dbg & 1)) {
+                if (threadIdx.x < 64) {
+                    SpRow row = zero_row;
+                    row_means_from_sums(sr, k, row);
+                    w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
+                    if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
+                } else {
+                    float ta, tb, tc;
+                    row_plane_from_sums(sr, k, ta, tb, tc);
+                    w_row[i].ta = ta; w_row[i].tb = tb; w_row[i].tc = tc;
+                }
             }
         }
     }
-    if (threadIdx.x == 0) s_nlog = 0;
-    if (window_ok) for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) w_acc[i] = 0ull;
+    // this tile's log of the previous pass is replayed at the very end.  Only the valid entries are fetched (an unconditional
+    // fetch of the whole region cost 5 B per pixel of HBM): the other lanes read entry 0 again -- one address, and no branch
+    // around the load (behind a branch the compiler waits for the entry at once)
+    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
+    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
+    int4 prev_ent[NPX]; float prev_disp[NPX];
 #pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) { const int i = threadIdx.x + 256 * k; if (i < TWW * TW) tile[i] = tile_reg[k]; }
+    for (int s = 0; s < NPX; s++) {
+        const unsigned int e = threadIdx.x + 256u * s;
+        const size_t le = (size_t)tile_id * LOGN + (e < n_prev ? e : 0u);
+        prev_ent[s] = pent[le];
+        prev_disp[s] = 0.f;
+        if (RGBD) prev_disp[s] = pdis[le];
+    }
+    if (threadIdx.x == 0) s_nlog = 0;
+    for (int i = threadIdx.x; i < nslots * PASS_F32; i += blockDim.x) w_acc32[i] = 0u;
+    for (int i = threadIdx.x; i < nslots * PASS_F64; i += blockDim.x) w_acc64[i] = 0ull;
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; k++) {
+        const int i = threadIdx.x + 256 * k;
+        if (256 * (k + 1) <= TWW * TW || i < TWW * TW) tile[i] = (outside >> k) & 1u ? -1 : tile_reg[k];
+    }
     __syncthreads();
-    const float inv_gx = 1.0f / (float)p.gx;
+    const float inv_gx = p.inv_gx;
     auto slot_of = [&](int l) -> int {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
-        const int wx = (l - cyl * p.gx) - wcx0, wy = cyl - wcy0;
-        return (window_ok && wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
+        const unsigned int wx = (unsigned int)((l - cyl * p.gx) - wcx0), wy = (unsigned int)(cyl - wcy0);
+        return (wx < (unsigned int)nwx && wy < (unsigned int)nwy) ? (int)(wy * nwx + wx) : -1;
     };
     auto row_of = [&](int l) -> SpRow {
         const int ws = slot_of(l);
@@ -377,48 +418,72 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         const unsigned fl = rgbf >> 24;
         const int wf = slot_of(from), wt = slot_of(to);
         if (fl & 1u) {
-            if (wf >= 0) lds_rgb(&w_acc[wf * F_COUNT], -1, px_x, px_y, rgbf);
-            if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
-            if (wf < 0 || wt < 0) {
-                const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
-                if (wf < 0) { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
-                              atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
-                if (wt < 0) { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
-                              atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
+            const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
+            if (wf >= 0) {
+                unsigned int* a = &w_acc32[wf * PASS_F32];
+                atomicAdd(&a[F_SX], (unsigned int)-px_x); atomicAdd(&a[F_SY], (unsigned int)-px_y); atomicAdd(&a[F_SR], (unsigned int)-ir);
+                atomicAdd(&a[F_SG], (unsigned int)-ig); atomicAdd(&a[F_SB], (unsigned int)-ib); atomicAdd(&a[F_N], 0xFFFFFFFFu);
+            } else { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
+                     atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
+            if (wt >= 0) {
+                unsigned int* a = &w_acc32[wt * PASS_F32];
+                atomicAdd(&a[F_SX], (unsigned int)px_x); atomicAdd(&a[F_SY], (unsigned int)px_y); atomicAdd(&a[F_SR], (unsigned int)ir);
+                atomicAdd(&a[F_SG], (unsigned int)ig); atomicAdd(&a[F_SB], (unsigned int)ib); atomicAdd(&a[F_N], 1u);
+            } else { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
+                     atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
+        }
+        if (RGBD && (fl & 6u)) {
+            // the nine disparity terms of the pixel, converted once: added to `to` (flag 2), taken from `from` (flag 4)
+            const long long xx = (long long)px_x * px_x, yy = (long long)px_y * px_y, xy = (long long)px_x * px_y;
+            const long long xd = fx64((double)((float)px_x * d), SSF_DISP_SCALE, SSF_DISP_LIM);
+            const long long yd = fx64((double)((float)px_y * d), SSF_DISP_SCALE, SSF_DISP_LIM);
+            const long long dd = fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM);
+            if (fl & 2u) {
+                if (wt >= 0) {
+                    unsigned int* a = &w_acc32[wt * PASS_F32]; unsigned long long* b = &w_acc64[wt * PASS_F64];
+                    atomicAdd(&a[F_DX], (unsigned int)px_x); atomicAdd(&a[F_DY], (unsigned int)px_y); atomicAdd(&a[F_DN], 1u);
+                    lds_add_i64(&b[F_DXX - PASS_F32], xx); lds_add_i64(&b[F_DYY - PASS_F32], yy); lds_add_i64(&b[F_DXY - PASS_F32], xy);
+                    lds_add_i64(&b[F_DXD - PASS_F32], xd); lds_add_i64(&b[F_DYD - PASS_F32], yd); lds_add_i64(&b[F_DD - PASS_F32], dd);
+                } else disp_sums_add(sw, to, px_x, px_y, d, +1);
+            }
+            if (fl & 4u) {
+                if (wf >= 0) {
+                    unsigned int* a = &w_acc32[wf * PASS_F32]; unsigned long long* b = &w_acc64[wf * PASS_F64];
+                    atomicAdd(&a[F_DX], (unsigned int)-px_x); atomicAdd(&a[F_DY], (unsigned int)-px_y); atomicAdd(&a[F_DN], 0xFFFFFFFFu);
+                    lds_add_i64(&b[F_DXX - PASS_F32], -xx); lds_add_i64(&b[F_DYY - PASS_F32], -yy); lds_add_i64(&b[F_DXY - PASS_F32], -xy);
+                    lds_add_i64(&b[F_DXD - PASS_F32], -xd); lds_add_i64(&b[F_DYD - PASS_F32], -yd); lds_add_i64(&b[F_DD - PASS_F32], -dd);
+                } else disp_sums_add(sw, from, px_x, px_y, d, -1);
             }
         }
-        if (fl & 2u) { if (wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, d); else disp_sums_add(sw, to, px_x, px_y, d, +1); }
-        if (fl & 4u) { if (wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, d); else disp_sums_add(sw, from, px_x, px_y, d, -1); }
     };
-    // (Measured and dropped, round 2: routing the boundary pixels that may change -- a quarter of the pass pixels, whose energy
-    // evaluation is the longest stretch of the kernel -- through a dense LDS list worked off by one or two full waves instead
-    // of four sparse ones.  Bit-exact, fewer VALU lanes wasted, but 1 us SLOWER per 8-frame launch: the kernel is bound by
-    // the latency chain of a wave, not by instruction issue -- profiles/pmc_r02_occupancy.txt.)
     if (dbg & 2) return;
+#ifdef SSF_PASS_JUNK
+    // measurement only: SSF_PASS_JUNK extra vector instructions per wave (is the pass bound by instruction issue?)
+    {
+        float junk = __uint_as_float(threadIdx.x | 0x3f800000u);
+#pragma unroll
+        for (int i = 0; i < SSF_PASS_JUNK; i++) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(junk));
+        if (junk == 12345.678f) s_nlog = 1;
+    }
+#endif
     int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
     float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const int lx = lxh[s], ly = lyh[s];
-        const int index = in_image[s] ? tile[ly * TWW + lx] : 0;
+        const int* __restrict__ t = &tile[ly * TWW + lx];
+        const int index = in_image[s] ? t[0] : 0;
         int new_index = index;
-        const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-        int nl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) nl[k] = tile[(ly + ny[k]) * TWW + lx + nx[k]];
+        const int nl[4] = {t[-TWW], t[-1], t[1], t[TWW]};                           // N, W, E, S
         const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
         bool eligible = in_image[s] && bounds != 0 && !(dbg & 4);
         if (eligible) {
-            // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
-            const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-            bool prev = tile[(ly + oy[0]) * TWW + lx + ox[0]] == index;
-            int jump = 0;
-#pragma unroll
-            for (int k = 1; k < 8; k++) {
-                const bool cur = tile[(ly + oy[k]) * TWW + lx + ox[k]] == index;
-                if (prev != cur) { jump++; prev = cur; }
-            }
-            eligible = !(jump > 2);
+            // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W; the label changes
+            // more than twice along the ring = the pixel is a bridge.  Bit k of `ring`: ring pixel k carries the pixel's label
+            const unsigned int ring = (t[-TWW - 1] == index ? 1u : 0u) | (nl[0] == index ? 2u : 0u) | (t[-TWW + 1] == index ? 4u : 0u) |
+                                      (nl[2] == index ? 8u : 0u) | (t[TWW + 1] == index ? 16u : 0u) | (nl[3] == index ? 32u : 0u) |
+                                      (t[TWW - 1] == index ? 64u : 0u) | (nl[1] == index ? 128u : 0u);
+            eligible = __popc((ring ^ (ring >> 1)) & 0x7Fu) <= 2;
         }
         SpRow own = zero_row;
         if (in_image[s] && (RGBD || eligible)) own = row_of(index);
@@ -429,38 +494,55 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             disp_energy = (dp - disp[s]) * (dp - disp[s]);
             if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
         }
+        const float cr = (float)(px[s] & 255u), cg = (float)((px[s] >> 8) & 255u), cb = (float)((px[s] >> 16) & 255u);
+        const float posx = (float)x[s], posy = (float)y[s];
+        float best = 0.f;
         if (eligible) {
-            const float cr = (float)(px[s] & 255u), cg = (float)((px[s] >> 8) & 255u), cb = (float)((px[s] >> 16) & 255u);
-            const float posx = (float)x[s], posy = (float)y[s];
             const float size = own.size;
             const float sc = size / (size - 1.f);
             const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
             const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
             const float dsize = size - (float)p.min_size;
-            float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
+            best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
             if (RGBD) best = best + p.lambda_disp * disp_energy;
             best = best - p.lambda_size * fminf(dsize, 0.f);
             best = best + p.lambda_bound * (float)bounds;
+        }
+        // the DISTINCT neighbour labels other than the pixel's own, in the order N, W, E, S (a label met a second time has the
+        // same energy and cannot win against itself under the strict comparison: skipping it changes nothing).  Compacted per
+        // lane, so that the wave walks max-over-lanes(count) candidates -- one or two on a boundary -- instead of four directions
+        {
+            const bool ok0 = eligible && nl[0] != -1 && nl[0] != index;
+            const bool ok1 = eligible && nl[1] != -1 && nl[1] != index && nl[1] != nl[0];
+            const bool ok2 = eligible && nl[2] != -1 && nl[2] != index && nl[2] != nl[0] && nl[2] != nl[1];
+            const bool ok3 = eligible && nl[3] != -1 && nl[3] != index && nl[3] != nl[0] && nl[3] != nl[1] && nl[3] != nl[2];
+            const int p1 = ok0 ? 1 : 0, p2 = p1 + (ok1 ? 1 : 0), p3 = p2 + (ok2 ? 1 : 0), ncand = p3 + (ok3 ? 1 : 0);
+            const int c0 = ok0 ? nl[0] : (ok1 ? nl[1] : (ok2 ? nl[2] : nl[3]));
+            const int c1 = (ok1 && p1 == 1) ? nl[1] : ((ok2 && p2 == 1) ? nl[2] : nl[3]);
+            const int c2 = (ok2 && p2 == 2) ? nl[2] : nl[3];
+            const int c3 = nl[3];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i_n = nl[k];
-                if (i_n == -1 || i_n == index) continue;
-                const SpRow nb = row_of(i_n);
-                const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-                const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-                const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-                float n_de = 0.f; unsigned char n_inlier = 0xff;
-                if (RGBD) {
-                    const float dp = (nb.ta * (float)x[s] + nb.tb * (float)y[s]) + nb.tc;
-                    n_de = (dp - disp[s]) * (dp - disp[s]);
-                    if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+            for (int j = 0; j < 4; j++) {
+                if (__ballot(j < ncand) == 0ull) break;               // (wave-uniform)
+                if (j < ncand) {
+                    const int i_n = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+                    const SpRow nb = row_of(i_n);
+                    const float ndx = posx - nb.cx, ndy = posy - nb.cy;
+                    const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
+                    const float ndsize = (nb.size + 1.f) - (float)p.min_size;
+                    float n_de = 0.f; unsigned char n_inlier = 0xff;
+                    if (RGBD) {
+                        const float dp = (nb.ta * (float)x[s] + nb.tb * (float)y[s]) + nb.tc;
+                        n_de = (dp - disp[s]) * (dp - disp[s]);
+                        if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
+                    }
+                    const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
+                    float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
+                    if (RGBD) e = e + p.lambda_disp * n_de;
+                    e = e - p.lambda_size * fminf(ndsize, 0.f);
+                    e = e + p.lambda_bound * (float)b;
+                    if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
                 }
-                const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-                float e = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-                if (RGBD) e = e + p.lambda_disp * n_de;
-                e = e - p.lambda_size * fminf(ndsize, 0.f);
-                e = e + p.lambda_bound * (float)b;
-                if (e < best) { best = e; new_index = i_n; if (RGBD) inlier = n_inlier; }
             }
         }
         unsigned flags = 0u;
@@ -489,13 +571,17 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                 add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
     __syncthreads();
-    if (window_ok)
-        for (int i = threadIdx.x; i < nwx * nwy * F_COUNT; i += blockDim.x) {
-            const long long v = (long long)w_acc[i];
-            if (v == 0) continue;
-            const int wi = i / F_COUNT;
-            flush_field(sw, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i % F_COUNT, v);
-        }
+    // flush: one global atomic per accumulator that is not zero; the record's nine int32 sums and six int64 sums are
+    // addressed by field number (SumRec: int32 fields from byte 0, int64 fields from byte 64)
+    for (int i = threadIdx.x; i < nslots * F_COUNT; i += blockDim.x) {
+        const int wi = i / F_COUNT, f = i - wi * F_COUNT;
+        const bool narrow = f < PASS_F32;
+        const long long v = narrow ? (long long)(int)w_acc32[wi * PASS_F32 + (narrow ? f : 0)] : (long long)w_acc64[wi * PASS_F64 + (narrow ? 0 : f - PASS_F32)];
+        if (v == 0) continue;
+        SumRec* rec = &sw.r[w_label[wi]];
+        if (narrow) atomicAdd(&rec->sx + f, (int)v);
+        else atomic_add_i64(&rec->dxx + (f - PASS_F32), v);
+    }
     if (threadIdx.x == 0) {
         unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
         ccnt[tile_id] = s_nlog;

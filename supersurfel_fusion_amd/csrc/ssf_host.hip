@@ -414,6 +414,7 @@ struct ssf_handle {
     // ssf_process_sequence: frames still to be submitted; do_fuse submits them between its launches and its wait for
     // the counters (the ~40 us of host work of a batch launch hide behind the ~55 us fuse chain on the GPU)
     const void* const* seq_rgb = nullptr; const void* const* seq_depth = nullptr; int seq_next = 0, seq_n = 0, seq_on_device = 0, stamp_bias = 0;
+    int seq_k = 0;                            // frame of the sequence the track loop is working on (debug marks)
     int seq_batches = 0;                      // batches launched by the running ssf_process_sequence (see seq_batch_size)
     Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
@@ -475,6 +476,7 @@ struct ssf_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     KernelTimer timer;
     std::vector<std::string> timer_names;
+    double seq_mark_us[4][64] = {{0}}, seq_launch_us[32] = {0}, seq_launch_host_us[32] = {0}; int seq_launch_n[32] = {0}, seq_launches = 0;   // debug: entry / first ICP record / ICP done / counters back per frame, batch launches
     double seq_t0_us = 0, seq_done_us[64] = {0};      // debug: completion time of the first frames of the last ssf_process_sequence
     double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // debug: submit | icp loop | match+fuse | frames | extract ready at activation | first icp iteration
 };
@@ -670,7 +672,9 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
 }
 
 // Launch the extract stage of the open batch of context c (asynchronous; nothing is waited for).
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int launch_batch(ssf_handle* h, ExtractCtx& c) {
+    const double t_launch0 = now_us();
     hipStream_t st = c.stream;
     const bool multi = h->ctx.size() > 1;
     const int nb = c.count;
@@ -692,7 +696,10 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     if (multi) HCK(hipEventRecord(c.ev_done, st));
     c.launched = true; c.waited = false; c.inflight = nb; c.nb_launched = nb;
     h->open_ctx = (int)((&c - h->ctx.data() + 1) % (ptrdiff_t)h->ctx.size());
-    if (h->seq_n > 0) h->seq_batches++;
+    if (h->seq_n > 0) {
+        if (h->seq_launches < 32) { h->seq_launch_us[h->seq_launches] = t_launch0 - h->seq_t0_us; h->seq_launch_host_us[h->seq_launches] = now_us() - t_launch0; h->seq_launch_n[h->seq_launches++] = nb; }
+        h->seq_batches++;
+    }
     return SSF_OK;
 }
 // Add one frame to the open batch; the batch is launched when it is full (or when its first frame is needed).
@@ -1256,12 +1263,13 @@ static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt
 }
 
 // ICP + association + fusion of the oldest submitted frame, on the track stream
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* out) {
     TimerScope ts(h);
     int rc = activate_oldest(h);
     if (rc) return rc;
     const double t_a = now_us();
+    const int kf = h->seq_n > 0 ? h->seq_k : -1;          // frame number inside a sequence (debug marks)
+    if (kf >= 0 && kf < 64) { h->seq_mark_us[0][kf] = t_a - h->seq_t0_us; h->seq_mark_us[1][kf] = 0; }
     if (h->ctx.size() > 1 && hipEventQuery(h->cc->ctx->ev_done) == hipSuccess) h->host_us[4] += 1;
     bool first_it = true;
     const bool timing = h->cfg.profile != 0 && h->cc->ctx->timed;     // stage split costs an event synchronise: opt-in
@@ -1312,7 +1320,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             rc = icp_fetch(h, seq_rec, waiting ? wait_slot : nullptr, wait_go_seq, &dismissed);
             if (dismissed) waiting = false;           // (the next iteration, if any, is launched afresh)
             if (rc) { if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr); icp_chain_reset(h); return rc; }
-            if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
+            if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; if (kf >= 0 && kf < 64) h->seq_mark_us[1][kf] = now_us() - h->seq_t0_us; }
             icp_update(h, (const int64_t*)h->h_icp, &again);
             continue;
         }
@@ -1348,6 +1356,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr);     // no further iteration: the launch made ahead leaves
     icp_end(h, &valid);
     const double t_b = now_us();
+    if (kf >= 0 && kf < 64) h->seq_mark_us[2][kf] = t_b - h->seq_t0_us;
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
     rc = do_match(h, 1);
     if (rc) return rc;
@@ -1499,6 +1508,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.lambda_disp = cfg->lambda_disp; p.thresh_disp = cfg->thresh_disp;
     p.filter_alpha = cfg->filter_alpha; p.filter_beta = cfg->filter_beta; p.filter_threshold = cfg->filter_threshold;
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
+    p.inv_gx = 1.0f / (float)h->gx;
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
     // relabelling tiles (the shifted grid has one more column): 32-wide tiles with 256 log entries each, or 64-wide
@@ -1691,15 +1701,16 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
         u.start();
     }
     h->seq_rgb = rgb; h->seq_depth = depth; h->seq_next = 0; h->seq_n = n; h->seq_on_device = on_device; h->seq_upload = ahead;
-    h->seq_batches = 0;
+    h->seq_batches = 0; h->seq_launches = 0;
     h->seq_t0_us = now_us();
     for (int k = 0; k < n && !rc; k++) {
         while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
             TimerScope ts(h);
             rc = seq_submit(h);
         }
+        h->seq_k = k;
         if (!rc) rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
-        if (k < 64) h->seq_done_us[k] = now_us() - h->seq_t0_us;
+        if (k < 64) h->seq_done_us[k] = h->seq_mark_us[3][k] = now_us() - h->seq_t0_us;
         if (ahead) h->up->processed.store(k + 1, std::memory_order_release);
     }
     if (ahead) {
@@ -2373,6 +2384,14 @@ int ssf_dbg_device_icp_records(ssf_handle* h, int64_t* out64) {
     if (!h || !out64) return SSF_ERR_INVALID_ARG;
     HCK(hipStreamSynchronize(h->stream));
     HCK(hipMemcpy(out64, h->d_icp, 64 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return SSF_OK;
+}
+// per frame of the last sequence (first 64): entry of the track loop, first ICP record back, ICP loop done, counters
+// back [us from the call's entry]; then 32 x (time, frames) of the extract batches launched
+int ssf_dbg_sequence_marks(ssf_handle* h, double* out320) {
+    if (!h || !out320) return SSF_ERR_INVALID_ARG;
+    for (int m = 0; m < 4; m++) for (int i = 0; i < 64; i++) out320[m * 64 + i] = h->seq_mark_us[m][i];
+    for (int i = 0; i < 32; i++) { out320[256 + 2 * i] = i < h->seq_launches ? h->seq_launch_us[i] : -1.0; out320[257 + 2 * i] = i < h->seq_launches ? h->seq_launch_n[i] + h->seq_launch_host_us[i] / 1e4 : 0; }
     return SSF_OK;
 }
 int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
