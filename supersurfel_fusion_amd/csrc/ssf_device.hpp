@@ -74,6 +74,7 @@ struct SegParams {
     int filter_iter;
     uint64_t seed;
     float inv_gx;         // 1.0f / (float)gx (one IEEE division, made on the host)
+    uint32_t cell_magic;  // ceil(2^32 / cell) (0 when cell == 1): x / cell == mulhi(x, cell_magic) for 0 <= x < 65536
 };
 
 // One relabelled pixel of a pass, replayed by the next pass into the lagging sums buffer.

@@ -172,12 +172,14 @@ __device__ __forceinline__ int tile_boundary(const int* tile, int lx, int ly) { 
 // Window of grid cells around a 32x32 tile.  Superpixels stay close to their seed cell, so per-tile
 // LDS tables indexed by window cell serve (almost) every label of the tile; a label that drifted out
 // of the window takes an exact global-memory slow path.
+// x / p.cell for a pixel coordinate (0 <= x < 65536) without the 20-instruction integer division
+__device__ __forceinline__ int div_cell(const SegParams& p, int x) { return p.cell_magic ? (int)__umulhi((unsigned int)x, p.cell_magic) : x; }
 struct CellWindow {
     int cx0, cy0, nwx, nwy, gx; float inv_gx; bool ok;
     __device__ __forceinline__ void init(const SegParams& p, int X0, int Y0, int max_entries) {
         int margin = 2;
-        const int tcx0 = X0 / p.cell, tcy0 = Y0 / p.cell;
-        const int tcx1 = min(X0 + TILE - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
+        const int tcx0 = div_cell(p, X0), tcy0 = div_cell(p, Y0);
+        const int tcx1 = div_cell(p, min(X0 + TILE - 1, p.W - 1)), tcy1 = div_cell(p, min(Y0 + TILE - 1, p.H - 1));
         while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > max_entries) margin--;
         cx0 = tcx0 - margin; cy0 = tcy0 - margin;
         nwx = tcx1 - tcx0 + 1 + 2 * margin; nwy = tcy1 - tcy0 + 1 + 2 * margin;
@@ -329,8 +331,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
             const int i = 256 * (k + 1) <= TWW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TWW * TW - 1);
-            const int ly = i / TWW, lx = i - ly * TWW;
-            tile_off[k] = base_off + (unsigned int)(ly * p.W + lx);
+            const int ly = i / TWW;                                  // element (ly, i - ly * TWW): offset ly * W + i - ly * TWW
+            tile_off[k] = base_off + (unsigned int)i + __umul24((unsigned int)ly, (unsigned int)(p.W - TWW));   // (24-bit multiplies are full rate)
         }
     } else {
 #pragma unroll
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
             const int cx_ = min(max(gx_, 0), p.W - 1), cy_ = min(max(gy_, 0), p.H - 1);
             if (cx_ != gx_ || cy_ != gy_) outside |= 1u << k;
-            tile_off[k] = (unsigned int)(cy_ * p.W + cx_);
+            tile_off[k] = __umul24((unsigned int)cy_, (unsigned int)p.W) + (unsigned int)cx_;
         }
     }
     if (dbg & 32) outside = 0xFFFFFFFFu;
@@ -348,8 +350,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     for (int k = 0; k < TILE_LOADS; k++) tile_reg[k] = lab[tile_off[k]];
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
-    const int tcx0 = max(X0, 0) / p.cell, tcy0 = Y0 / p.cell;
-    const int tcx1 = min(X0 + TWX - 1, p.W - 1) / p.cell, tcy1 = min(Y0 + TILE - 1, p.H - 1) / p.cell;
+    const int tcx0 = div_cell(p, max(X0, 0)), tcy0 = div_cell(p, Y0);
+    const int tcx1 = div_cell(p, min(X0 + TWX - 1, p.W - 1)), tcy1 = div_cell(p, min(Y0 + TILE - 1, p.H - 1));
     while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
     const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
     const int nwx_ = tcx1 - tcx0 + 1 + 2 * margin, nwy_ = tcy1 - tcy0 + 1 + 2 * margin;
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     if (threadIdx.x < (RGBD ? 128 : 64)) {
         const int i = threadIdx.x & 63;
         if (i < nslots) {
-            const int wy = i / nwx, wx = i - wy * nwx;
+            // (i / nwx for i < 64, nwx <= 8: (i + 0.5) / nwx is at least 1/16 away from an integer -- an approximate reciprocal will do)
+            const int wy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)nwx)), wx = i - __mul24(wy, nwx);
             const int cx = wcx0 + wx, cy = wcy0 + wy;
             const bool inside = cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy;
             const int k = cy * p.gx + cx;
@@ -405,12 +408,12 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     const float inv_gx = p.inv_gx;
     auto slot_of = [&](int l) -> int {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
-        const unsigned int wx = (unsigned int)((l - cyl * p.gx) - wcx0), wy = (unsigned int)(cyl - wcy0);
-        return (wx < (unsigned int)nwx && wy < (unsigned int)nwy) ? (int)(wy * nwx + wx) : -1;
+        const unsigned int wx = (unsigned int)((l - __mul24(cyl, p.gx)) - wcx0), wy = (unsigned int)(cyl - wcy0);
+        return (wx < (unsigned int)nwx && wy < (unsigned int)nwy) ? (int)(__umul24(wy, (unsigned int)nwx) + wx) : -1;
     };
     auto row_of = [&](int l) -> SpRow {
         const int ws = slot_of(l);
-        if (ws >= 0) return w_row[ws];
+        if (ws >= 0) return *reinterpret_cast<const SpRow*>(reinterpret_cast<const char*>(w_row) + __umul24((unsigned int)ws, (unsigned int)sizeof(SpRow)));
         return row_from_sums(sr, l, RGBD, zero_row);          // drifted out of the window: exact slow path
     };
     // sum deltas of one relabelled pixel: LDS accumulators of the window, global atomics outside it
@@ -420,13 +423,13 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (fl & 1u) {
             const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
             if (wf >= 0) {
-                unsigned int* a = &w_acc32[wf * PASS_F32];
+                unsigned int* a = &w_acc32[__umul24((unsigned int)wf, PASS_F32)];
                 atomicAdd(&a[F_SX], (unsigned int)-px_x); atomicAdd(&a[F_SY], (unsigned int)-px_y); atomicAdd(&a[F_SR], (unsigned int)-ir);
                 atomicAdd(&a[F_SG], (unsigned int)-ig); atomicAdd(&a[F_SB], (unsigned int)-ib); atomicAdd(&a[F_N], 0xFFFFFFFFu);
             } else { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
                      atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
             if (wt >= 0) {
-                unsigned int* a = &w_acc32[wt * PASS_F32];
+                unsigned int* a = &w_acc32[__umul24((unsigned int)wt, PASS_F32)];
                 atomicAdd(&a[F_SX], (unsigned int)px_x); atomicAdd(&a[F_SY], (unsigned int)px_y); atomicAdd(&a[F_SR], (unsigned int)ir);
                 atomicAdd(&a[F_SG], (unsigned int)ig); atomicAdd(&a[F_SB], (unsigned int)ib); atomicAdd(&a[F_N], 1u);
             } else { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
@@ -434,13 +437,15 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
         if (RGBD && (fl & 6u)) {
             // the nine disparity terms of the pixel, converted once: added to `to` (flag 2), taken from `from` (flag 4)
-            const long long xx = (long long)px_x * px_x, yy = (long long)px_y * px_y, xy = (long long)px_x * px_y;
+            // (coordinates < 2^16: the products fit 32 bits unsigned, and a 24-bit multiply returns the low 32 bits of a 48-bit product)
+            const long long xx = (long long)__umul24((unsigned int)px_x, (unsigned int)px_x), yy = (long long)__umul24((unsigned int)px_y, (unsigned int)px_y),
+                            xy = (long long)__umul24((unsigned int)px_x, (unsigned int)px_y);
             const long long xd = fx64((double)((float)px_x * d), SSF_DISP_SCALE, SSF_DISP_LIM);
             const long long yd = fx64((double)((float)px_y * d), SSF_DISP_SCALE, SSF_DISP_LIM);
             const long long dd = fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM);
             if (fl & 2u) {
                 if (wt >= 0) {
-                    unsigned int* a = &w_acc32[wt * PASS_F32]; unsigned long long* b = &w_acc64[wt * PASS_F64];
+                    unsigned int* a = &w_acc32[__umul24((unsigned int)wt, PASS_F32)]; unsigned long long* b = &w_acc64[__umul24((unsigned int)wt, PASS_F64)];
                     atomicAdd(&a[F_DX], (unsigned int)px_x); atomicAdd(&a[F_DY], (unsigned int)px_y); atomicAdd(&a[F_DN], 1u);
                     lds_add_i64(&b[F_DXX - PASS_F32], xx); lds_add_i64(&b[F_DYY - PASS_F32], yy); lds_add_i64(&b[F_DXY - PASS_F32], xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], xd); lds_add_i64(&b[F_DYD - PASS_F32], yd); lds_add_i64(&b[F_DD - PASS_F32], dd);
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             }
             if (fl & 4u) {
                 if (wf >= 0) {
-                    unsigned int* a = &w_acc32[wf * PASS_F32]; unsigned long long* b = &w_acc64[wf * PASS_F64];
+                    unsigned int* a = &w_acc32[__umul24((unsigned int)wf, PASS_F32)]; unsigned long long* b = &w_acc64[__umul24((unsigned int)wf, PASS_F64)];
                     atomicAdd(&a[F_DX], (unsigned int)-px_x); atomicAdd(&a[F_DY], (unsigned int)-px_y); atomicAdd(&a[F_DN], 0xFFFFFFFFu);
                     lds_add_i64(&b[F_DXX - PASS_F32], -xx); lds_add_i64(&b[F_DYY - PASS_F32], -yy); lds_add_i64(&b[F_DXY - PASS_F32], -xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], -xd); lds_add_i64(&b[F_DYD - PASS_F32], -yd); lds_add_i64(&b[F_DD - PASS_F32], -dd);
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const int lx = lxh[s], ly = lyh[s];
-        const int* __restrict__ t = &tile[ly * TWW + lx];
+        const int* __restrict__ t = &tile[__mul24(ly, TWW) + lx];
         const int index = in_image[s] ? t[0] : 0;
         int new_index = index;
         const int nl[4] = {t[-TWW], t[-1], t[1], t[TWW]};                           // N, W, E, S
@@ -573,10 +578,11 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     __syncthreads();
     // flush: one global atomic per accumulator that is not zero; the record's nine int32 sums and six int64 sums are
     // addressed by field number (SumRec: int32 fields from byte 0, int64 fields from byte 64)
-    for (int i = threadIdx.x; i < nslots * F_COUNT; i += blockDim.x) {
-        const int wi = i / F_COUNT, f = i - wi * F_COUNT;
+    static_assert(F_COUNT == 15 && WIN_MAX * F_COUNT < 4681, "i / 15 by multiplication");
+    for (unsigned int i = threadIdx.x; i < (unsigned int)(nslots * F_COUNT); i += 256u) {
+        const int wi = (int)(__umul24(i, 4370u) >> 16), f = (int)i - __mul24(wi, F_COUNT);          // i / 15, i % 15
         const bool narrow = f < PASS_F32;
-        const long long v = narrow ? (long long)(int)w_acc32[wi * PASS_F32 + (narrow ? f : 0)] : (long long)w_acc64[wi * PASS_F64 + (narrow ? 0 : f - PASS_F32)];
+        const long long v = narrow ? (long long)(int)w_acc32[__mul24(wi, PASS_F32) + (narrow ? f : 0)] : (long long)w_acc64[__mul24(wi, PASS_F64) + (narrow ? 0 : f - PASS_F32)];
         if (v == 0) continue;
         SumRec* rec = &sw.r[w_label[wi]];
         if (narrow) atomicAdd(&rec->sx + f, (int)v);

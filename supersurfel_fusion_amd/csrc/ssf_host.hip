@@ -1509,6 +1509,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.filter_alpha = cfg->filter_alpha; p.filter_beta = cfg->filter_beta; p.filter_threshold = cfg->filter_threshold;
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
     p.inv_gx = 1.0f / (float)h->gx;
+    p.cell_magic = c > 1 ? (uint32_t)((0x100000000ull + (uint64_t)c - 1) / (uint64_t)c) : 0u;
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
     // relabelling tiles (the shifted grid has one more column): 32-wide tiles with 256 log entries each, or 64-wide
