@@ -214,13 +214,18 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // the transform is in go->T) or go_seq | SSF_ICP_GO_ABORT (no further iteration: leave at once).  IcpGo lives in
 // fine-grained DEVICE memory that the host writes directly (large BAR): ~1 us from the host's store to the kernel's
 // eyes (tools/probe/bar_write.hip), against ~5 us for a launch to start.
+// go_seq | SSF_ICP_GO_MATCH (a launch made with `match`): the loop has ended and go->T holds the frame's final POSE -- the
+// waiting launch does the association (k_match's work) instead of an iteration: the association then starts ~1 us after
+// the host's decision instead of a launch latency later.
 struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; };       // one 128-byte slot
 #define SSF_ICP_GO_ABORT (1ull << 63)
+#define SSF_ICP_GO_MATCH (1ull << 62)
 #define SSF_ICP_GO_SLOTS 4
+struct MatchArgs { float zmin, zmax; long long id_offset; unsigned long long* best; uint8_t* matched; int32_t* cand; };    // launch_match's arguments
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
-                unsigned long long go_seq = 0, const struct P2PView* pv = nullptr, int by_tile = 0);
+                unsigned long long go_seq = 0, const struct P2PView* pv = nullptr, int by_tile = 0, const MatchArgs* match = nullptr);
 // Tile-sorted copy of the ICP / association fields of the n visible rows of `model` (pos, lab, r2, conf -> the same
 // streams of `out`; out_idx[j] = the row's index in the visible array) under transform T (model -> camera): see k_bin_* in
 // ssf_track_fuse.hip.  count / cursor: bin_count_words(cam) words each, count zero at rest.  launch_icp(by_tile = 1) /

@@ -414,6 +414,7 @@ struct ssf_handle {
     // ssf_process_sequence: frames still to be submitted; do_fuse submits them between its launches and its wait for
     // the counters (the ~40 us of host work of a batch launch hide behind the ~55 us fuse chain on the GPU)
     const void* const* seq_rgb = nullptr; const void* const* seq_depth = nullptr; int seq_next = 0, seq_n = 0, seq_on_device = 0, stamp_bias = 0;
+    long long n_waiter_matches = 0;           // frames whose association ran in a waiting ICP launch (debug)
     int seq_k = 0;                            // frame of the sequence the track loop is working on (debug marks)
     int seq_batches = 0;                      // batches launched by the running ssf_process_sequence (see seq_batch_size)
     Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
@@ -843,7 +844,7 @@ static int icp_accumulate(ssf_handle* h, bool to_host, long long* d_out = nullpt
     return to_host ? icp_fetch(h, seq) : SSF_OK;
 }
 // wait for mailbox record `seq` and copy it to h->h_icp_local
-static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq = 0);
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq = 0, bool match = false);
 // waiter: a launch made ahead that is waiting on the device for the host's word (chained ICP launches).  Before the stream
 // is drained it is told to leave (*waiter_dismissed = true): it would otherwise hold the stream until its own bound expires.
 static int icp_fetch(ssf_handle* h, unsigned long long seq, IcpGo* waiter, unsigned long long waiter_go_seq, bool* waiter_dismissed) {
@@ -1218,14 +1219,21 @@ static int comm_counts(ssf_handle* h) {
 
 // ---- chained ICP launches --------------------------------------------------------------------------------
 // launch the NEXT iteration now, to wait on the device for its transform; returns the sequence number of its record
+// (match_capable: the launch can be told to do the frame's association instead of an iteration -- SSF_ICP_GO_MATCH)
+static bool icp_waiter_can_match(const ssf_handle* h) {
+    static const bool off = getenv("SSF_NO_MATCH_IN_WAITER") != nullptr;          // (measurement switch)
+    return !off && !h->p2p.on && !h->comm && h->cfg.nranks == 1 && !h->bins_valid && h->cfg.profile == 0;
+}
 static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo** slot_out, unsigned long long* go_seq_out) {
     const unsigned long long seq = ++h->icp_seq;
     const unsigned long long go_seq = ++h->go_count;
     IcpGo* slot = h->go + (go_seq % SSF_ICP_GO_SLOTS);
     Rt none; none.R = m3_identity(); none.t = v3(0, 0, 0);
     const P2PView pv = h->p2p.view;               // (the number of the peer exchange arrives with the go word)
+    const MatchArgs ma{h->cfg.range_min, h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand};
     launch_icp(h->stream, h->cam, icp_rows(h), h->n_visible, h->cc->maps.pix2, h->cc->maps.fpack, none,
-               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq, h->p2p.on ? &pv : nullptr, h->bins_valid ? 1 : 0);
+               h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq, -1, slot, go_seq, h->p2p.on ? &pv : nullptr, h->bins_valid ? 1 : 0,
+               icp_waiter_can_match(h) ? &ma : nullptr);
     HCK(hipGetLastError());
     *seq_out = seq; *slot_out = slot; *go_seq_out = go_seq;
     return SSF_OK;
@@ -1249,7 +1257,7 @@ static void icp_chain_reset(ssf_handle* h) {
     h->icp_chain = false; h->ahead.valid = false;
 }
 // the host's word to a waiting launch: its transform and "go", or "no further iteration"
-static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq) {
+static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq, bool match) {
     volatile IcpGo* s = slot;
     if (T) {
         s->pad[0] = p2p_seq;
@@ -1257,7 +1265,7 @@ static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt
                              T->t.x, T->t.y, T->t.z};
         for (int i = 0; i < 12; i++) s->T[i] = v[i];
         store_fence();                            // (the mapping is write-combining: transform before flag, flag out now)
-        s->flag = go_seq;
+        s->flag = match ? (go_seq | SSF_ICP_GO_MATCH) : go_seq;
     } else s->flag = go_seq | SSF_ICP_GO_ABORT;
     store_fence();
 }
@@ -1353,13 +1361,22 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         if (first_it) { h->host_us[5] += now_us() - t_a; first_it = false; }
         icp_update(h, (const int64_t*)h->h_icp, &again);
     }
-    if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr);     // no further iteration: the launch made ahead leaves
-    icp_end(h, &valid);
+    // no further iteration: the launch made ahead leaves -- or, told the frame's final pose, does the association on its way
+    // out (the rows, tables and frame it was launched with are the ones the association reads)
+    bool matched_by_waiter = false;
+    if (waiting && !timing && icp_waiter_can_match(h)) {
+        icp_end(h, &valid);
+        icp_release_waiting(wait_slot, wait_go_seq, &h->pose, 0, true);
+        matched_by_waiter = true;
+    } else {
+        if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr);
+        icp_end(h, &valid);
+    }
     const double t_b = now_us();
     if (kf >= 0 && kf < 64) h->seq_mark_us[2][kf] = t_b - h->seq_t0_us;
     if (timing) HCK(hipEventRecord(h->ev[2], h->stream));
-    rc = do_match(h, 1);
-    if (rc) return rc;
+    if (matched_by_waiter) h->n_waiter_matches++;
+    else { rc = do_match(h, 1); if (rc) return rc; }
     if (h->comm) {
         // best key over the ranks (keys < 2^63: signed MIN == unsigned MIN), matched = OR over the ranks
         NCK(api->AllReduce(h->cc->d_best, h->cc->d_best, h->S, ncclInt64, ncclMin, h->comm, h->stream));
@@ -2395,6 +2412,8 @@ int ssf_dbg_sequence_marks(ssf_handle* h, double* out320) {
     for (int i = 0; i < 32; i++) { out320[256 + 2 * i] = i < h->seq_launches ? h->seq_launch_us[i] : -1.0; out320[257 + 2 * i] = i < h->seq_launches ? h->seq_launch_n[i] + h->seq_launch_host_us[i] / 1e4 : 0; }
     return SSF_OK;
 }
+// frames whose association ran inside a waiting ICP launch (SSF_ICP_GO_MATCH) since the handle was created
+long long ssf_dbg_waiter_matches(ssf_handle* h) { return h ? h->n_waiter_matches : -1; }
 int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
     if (!h || !out64) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 64; i++) out64[i] = h->seq_done_us[i];

@@ -272,12 +272,15 @@ __device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int n
     const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
 }
+__device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
+                                         const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
+                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched);
 template <bool P2P, bool ACC>
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
-                                             IcpGo* go, unsigned long long go_seq, P2PView pv, int by_tile) {
+                                             IcpGo* go, unsigned long long go_seq, P2PView pv, int by_tile, MatchArgs ma) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                 const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (v == go_seq) { ok = 1; told = 1; break; }
                 if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
+                if (v == (go_seq | SSF_ICP_GO_MATCH)) { ok = 2; told = 1; break; }       // the loop is over: associate under the pose in go->T
                 __builtin_amdgcn_s_sleep(1);
             }
             // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
@@ -311,6 +315,15 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         if (!s_go) return;
         T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
         T.t = v3(s_T[9], s_T[10], s_T[11]);
+        if constexpr (!P2P && !ACC) {
+            if (s_go == 2) {
+                // findBestMatches in the launch that was waiting for the next iteration (k_match's rows, k_match's arithmetic)
+                if (ma.best && !by_tile)
+                    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
+                        ma.cand[id] = match_row(cam, model, id, id, pix2, fpack, T, ma.zmin, ma.zmax, ma.id_offset, ma.best, ma.matched);
+                return;
+            }
+        }
     }
     const unsigned long long p2p_seq = (P2P && go) ? s_p2p_seq : pv.seq;
     __syncthreads();
@@ -1811,8 +1824,9 @@ __global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq,
-                const P2PView* pv, int by_tile) {
+                const P2PView* pv, int by_tile, const MatchArgs* match) {
     ScopedKernel sk("icp_accumulate", st);
+    const MatchArgs ma = match ? *match : MatchArgs{0.f, 0.f, 0, nullptr, nullptr, nullptr};
     // rows per thread: 1.  SSF_ICP_PER_LANE=n (measurement): n rows per thread with their terms summed in REGISTERS and one
     // LDS atomic per term and thread (k_icp<., true>) -- measured at BASELINE config 3 (1 M rows in view): 35-38 us per
     // iteration for n = 2, 4, 8 against 29-30 us: the kernel is bound by its chain of dependent gathers (row -> pixel ->
@@ -1828,10 +1842,10 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     const bool acc = per_lane > 1 && dbg == 0;       // (the probe switches live in the one-row-per-thread form)
     const P2PView none{};
     const P2PView& v = pv ? *pv : none;
-    if (pv && acc) hipLaunchKernelGGL((k_icp<true, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
-    else if (pv) hipLaunchKernelGGL((k_icp<true, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
-    else if (acc) hipLaunchKernelGGL((k_icp<false, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
-    else hipLaunchKernelGGL((k_icp<false, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile);
+    if (pv && acc) hipLaunchKernelGGL((k_icp<true, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
+    else if (pv) hipLaunchKernelGGL((k_icp<true, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
+    else if (acc) hipLaunchKernelGGL((k_icp<false, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
+    else hipLaunchKernelGGL((k_icp<false, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,

@@ -587,3 +587,25 @@ def test_tile_sorted_rows_bit_exact(pipelined, oracle_lib, product_lib):
     for k in range(4):
         util.same_result(fo2.process_frame(*util.frame(k, 320, 240)), fh2.process_frame(*util.frame(k, 320, 240)))
     util.compare_state(fo2, fh2)
+
+
+def test_association_inside_the_waiting_icp_launch(oracle_lib, product_lib):
+    """When the ICP loop ends by convergence, the launch that was made ahead for the next iteration is told the frame's final
+    pose and does the association on its way out (SSF_ICP_GO_MATCH, k_icp) instead of being dismissed in front of a k_match
+    launch.  Same rows, same tables, same arithmetic: every result is the oracle's, and the path is really taken."""
+    import ctypes as C
+    fo, nv = seeded(oracle_lib, 50000, 640, 480)
+    fh, _ = seeded(product_lib, 50000, 640, 480, pipeline_depth=2, extract_batch=2)
+    frames = [util.frame(k, 640, 480, noise=True, holes=0.02) for k in range(8)]
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
+    product_lib.lib.ssf_dbg_waiter_matches.restype = C.c_longlong
+    product_lib.lib.ssf_dbg_waiter_matches.argtypes = [C.c_void_p]
+    n = product_lib.lib.ssf_dbg_waiter_matches(fh.h)
+    iters = [r["icp_iters"] for r in got]
+    assert n >= 1, ("no frame's association ran in a waiting launch", iters)
+    assert n == sum(1 for r in got if 0 < r["icp_iters"] < 10), (n, iters)
