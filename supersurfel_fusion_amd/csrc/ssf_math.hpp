@@ -262,13 +262,25 @@ SSF_HD int pixel_round(float v) {
 
 // exact fixed-point terms (order-independent sums)
 SSF_HD long long fx64(double v, double scale, double lim) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The same value as the host branch below, in fewer instructions (twelve of these per pixel in k_render_moments):
+    // clamp by min / max (a NaN is replaced at the end), and the round-to-nearest-even conversion of |t| < 2^51 by the
+    // magic-number addition -- t + 1.5 * 2^52 is rounded to an integer by the addition itself (default rounding mode) and lies
+    // in the binade whose unit is 1, so the integer is the difference of the bit patterns; there is no hardware
+    // double -> int64 conversion, the general sequence is ~8 double-precision instructions.  With a compile-time `lim`
+    // below 2^50 the general sequence is not even emitted.
+    const double t0 = v * scale;
+    const double t = __builtin_fmin(__builtin_fmax(t0, -lim), lim);
+    long long r;
+    if (lim <= 1125899906842624.0 || __builtin_fabs(t) < 2251799813685248.0)
+        r = __double_as_longlong(t + 6755399441055744.0) - 0x4338000000000000LL;
+    else r = __double2ll_rn(t);
+    return t0 == t0 ? r : 0;
+#else
     double t = v * scale;
     if (!(t == t)) return 0;
     if (t > lim) t = lim;
     if (t < -lim) t = -lim;
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __double2ll_rn(t);
-#else
     return llrint(t);
 #endif
 }
