@@ -277,14 +277,17 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 // it -- a second dependent trip to memory -- before it requested the window's sums).
 #define PASS_F32 9                  // F_SX .. F_DN: 32-bit accumulators; F_DXX .. F_DD: 64-bit
 #define PASS_F64 (F_COUNT - PASS_F32)
+// accumulators of one window slot: 24 dwords = six 16-byte chunks -- the nine 32-bit sums (chunks 0-2, three dwords of padding),
+// then the six 64-bit sums (chunks 3-5; RGB passes never touch them).  Zeroed and scanned a chunk at a time.
+#define PASS_ACC_DW 24
+#define PASS_ACC_WIDE_DW 12
 template <bool RGBD, int NPX, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
     constexpr int TWX = TILE * NPX, TWW = TWX + 2, LOGN = 256 * NPX;
     __shared__ int tile[TWW * TW];
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
-    __shared__ unsigned int w_acc32[WIN_MAX * PASS_F32];      // this tile's sum deltas (own + replayed), flushed once
-    __shared__ unsigned long long w_acc64[WIN_MAX * PASS_F64];
+    __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
     m = batch_slot(m, blockIdx.z);
     const bool odd = (pass & 1) != 0;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             tile_off[k] = __umul24((unsigned int)cy_, (unsigned int)p.W) + (unsigned int)cx_;
         }
     }
-    if (dbg & 32) outside = 0xFFFFFFFFu;
+    const bool no_tile = (dbg & 32) != 0;                      // (probe: every element reads as outside the image)
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) tile_reg[k] = lab[tile_off[k]];
     // window of grid cells around the tile whose superpixel rows are cached in LDS
@@ -397,12 +400,15 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (RGBD) prev_disp[s] = pdis[le];
     }
     if (threadIdx.x == 0) s_nlog = 0;
-    for (int i = threadIdx.x; i < nslots * PASS_F32; i += blockDim.x) w_acc32[i] = 0u;
-    for (int i = threadIdx.x; i < nslots * PASS_F64; i += blockDim.x) w_acc64[i] = 0ull;
+    constexpr int ACC_CHUNKS = RGBD ? 6 : 2;                  // 16-byte chunks of a slot that a pass of this kind can touch (RGB: sx .. n)
+    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += blockDim.x) {
+        const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);      // i / 6, i / 2
+        reinterpret_cast<uint4*>(w_acc)[__mul24(wi, 6) + (i - __mul24(wi, ACC_CHUNKS))] = make_uint4(0u, 0u, 0u, 0u);
+    }
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) {
         const int i = threadIdx.x + 256 * k;
-        if (256 * (k + 1) <= TWW * TW || i < TWW * TW) tile[i] = (outside >> k) & 1u ? -1 : tile_reg[k];
+        if (256 * (k + 1) <= TWW * TW || i < TWW * TW) tile[i] = (no_tile || (!interior && ((outside >> k) & 1u))) ? -1 : tile_reg[k];
     }
     __syncthreads();
     const float inv_gx = p.inv_gx;
@@ -423,13 +429,13 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (fl & 1u) {
             const int ir = (int)(rgbf & 255u), ig = (int)((rgbf >> 8) & 255u), ib = (int)((rgbf >> 16) & 255u);
             if (wf >= 0) {
-                unsigned int* a = &w_acc32[__umul24((unsigned int)wf, PASS_F32)];
+                unsigned int* a = &w_acc[__umul24((unsigned int)wf, PASS_ACC_DW)];
                 atomicAdd(&a[F_SX], (unsigned int)-px_x); atomicAdd(&a[F_SY], (unsigned int)-px_y); atomicAdd(&a[F_SR], (unsigned int)-ir);
                 atomicAdd(&a[F_SG], (unsigned int)-ig); atomicAdd(&a[F_SB], (unsigned int)-ib); atomicAdd(&a[F_N], 0xFFFFFFFFu);
             } else { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
                      atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
             if (wt >= 0) {
-                unsigned int* a = &w_acc32[__umul24((unsigned int)wt, PASS_F32)];
+                unsigned int* a = &w_acc[__umul24((unsigned int)wt, PASS_ACC_DW)];
                 atomicAdd(&a[F_SX], (unsigned int)px_x); atomicAdd(&a[F_SY], (unsigned int)px_y); atomicAdd(&a[F_SR], (unsigned int)ir);
                 atomicAdd(&a[F_SG], (unsigned int)ig); atomicAdd(&a[F_SB], (unsigned int)ib); atomicAdd(&a[F_N], 1u);
             } else { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             const long long dd = fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM);
             if (fl & 2u) {
                 if (wt >= 0) {
-                    unsigned int* a = &w_acc32[__umul24((unsigned int)wt, PASS_F32)]; unsigned long long* b = &w_acc64[__umul24((unsigned int)wt, PASS_F64)];
+                    unsigned int* a = &w_acc[__umul24((unsigned int)wt, PASS_ACC_DW)]; unsigned long long* b = reinterpret_cast<unsigned long long*>(a + PASS_ACC_WIDE_DW);
                     atomicAdd(&a[F_DX], (unsigned int)px_x); atomicAdd(&a[F_DY], (unsigned int)px_y); atomicAdd(&a[F_DN], 1u);
                     lds_add_i64(&b[F_DXX - PASS_F32], xx); lds_add_i64(&b[F_DYY - PASS_F32], yy); lds_add_i64(&b[F_DXY - PASS_F32], xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], xd); lds_add_i64(&b[F_DYD - PASS_F32], yd); lds_add_i64(&b[F_DD - PASS_F32], dd);
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             }
             if (fl & 4u) {
                 if (wf >= 0) {
-                    unsigned int* a = &w_acc32[__umul24((unsigned int)wf, PASS_F32)]; unsigned long long* b = &w_acc64[__umul24((unsigned int)wf, PASS_F64)];
+                    unsigned int* a = &w_acc[__umul24((unsigned int)wf, PASS_ACC_DW)]; unsigned long long* b = reinterpret_cast<unsigned long long*>(a + PASS_ACC_WIDE_DW);
                     atomicAdd(&a[F_DX], (unsigned int)-px_x); atomicAdd(&a[F_DY], (unsigned int)-px_y); atomicAdd(&a[F_DN], 0xFFFFFFFFu);
                     lds_add_i64(&b[F_DXX - PASS_F32], -xx); lds_add_i64(&b[F_DYY - PASS_F32], -yy); lds_add_i64(&b[F_DXY - PASS_F32], -xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], -xd); lds_add_i64(&b[F_DYD - PASS_F32], -yd); lds_add_i64(&b[F_DD - PASS_F32], -dd);
@@ -576,17 +582,28 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                 add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
     __syncthreads();
-    // flush: one global atomic per accumulator that is not zero; the record's nine int32 sums and six int64 sums are
-    // addressed by field number (SumRec: int32 fields from byte 0, int64 fields from byte 64)
-    static_assert(F_COUNT == 15 && WIN_MAX * F_COUNT < 4681, "i / 15 by multiplication");
-    for (unsigned int i = threadIdx.x; i < (unsigned int)(nslots * F_COUNT); i += 256u) {
-        const int wi = (int)(__umul24(i, 4370u) >> 16), f = (int)i - __mul24(wi, F_COUNT);          // i / 15, i % 15
-        const bool narrow = f < PASS_F32;
-        const long long v = narrow ? (long long)(int)w_acc32[__mul24(wi, PASS_F32) + (narrow ? f : 0)] : (long long)w_acc64[__mul24(wi, PASS_F64) + (narrow ? 0 : f - PASS_F32)];
-        if (v == 0) continue;
+    // flush: the accumulators are scanned a 16-byte chunk at a time (most are zero); one global atomic per sum that is not.
+    // The record's nine int32 sums and six int64 sums are addressed by field number (SumRec: int32 fields from byte 0, int64
+    // fields from byte 64)
+    static_assert(WIN_MAX * 6 <= 32768, "i / 6 by multiplication");
+    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += blockDim.x) {
+        const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);
+        const int c = i - __mul24(wi, ACC_CHUNKS);
+        const uint4 v = reinterpret_cast<const uint4*>(w_acc)[__mul24(wi, 6) + c];
+        if ((v.x | v.y | v.z | v.w) == 0u) continue;
         SumRec* rec = &sw.r[w_label[wi]];
-        if (narrow) atomicAdd(&rec->sx + f, (int)v);
-        else atomic_add_i64(&rec->dxx + (f - PASS_F32), v);
+        if (c < 3) {
+            int* f = &rec->sx + 4 * c;                             // (chunk 2: dn and three dwords of padding, always zero)
+            if (v.x) atomicAdd(f, (int)v.x);
+            if (v.y) atomicAdd(f + 1, (int)v.y);
+            if (v.z) atomicAdd(f + 2, (int)v.z);
+            if (v.w) atomicAdd(f + 3, (int)v.w);
+        } else {
+            long long* f = &rec->dxx + 2 * (c - 3);
+            const long long lo = (long long)(((unsigned long long)v.y << 32) | v.x), hi = (long long)(((unsigned long long)v.w << 32) | v.z);
+            if (lo) atomic_add_i64(f, lo);
+            if (hi) atomic_add_i64(f + 1, hi);
+        }
     }
     if (threadIdx.x == 0) {
         unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
