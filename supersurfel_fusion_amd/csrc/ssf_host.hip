@@ -1725,6 +1725,9 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
         while (!rc && h->seq_next < n && !h->ctx[h->open_ctx].launched) {       // fill the pipeline (later refills happen inside do_fuse)
             TimerScope ts(h);
             rc = seq_submit(h);
+            // (Measured and removed, round 3: a head start of 150-450 us for the first, small batch before the larger ones join it
+            // on the GPU.  Its frame is through at 0.6-0.7 ms instead of 0.83, but the 20-frame sequence takes 3.2-3.5 ms
+            // instead of 3.07: the fill is bound by the extract work of the first 14 frames, not by its order -- profiles/fill_r03.txt.)
         }
         h->seq_k = k;
         if (!rc) rc = process_oldest(h, nullptr, out ? &out[k] : nullptr);
