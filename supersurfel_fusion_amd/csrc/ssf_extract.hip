@@ -613,8 +613,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 
 // ---- resident relabelling: all passes of a phase in one launch -----------------------------------------------------
 // k_update_pass above pays, forty times per frame, a launch, a trip to memory for the label tile and the pixel operands,
-// and the window rows' arithmetic in every one of its 2520 workgroups (8 frames) -- a latency chain per wave that left the
-// kernel at 0.22 of the HBM roofline for two rounds.  k_passes keeps the STATE ON THE CHIP instead: the frame is cut into
+// and the window rows' arithmetic in every one of its 2520 workgroups (8 frames) -- read, when this kernel was written, as a
+// latency chain per wave (it turned out to be instruction issue: see the diet above k_update_pass).  k_passes keeps the STATE ON THE CHIP instead: the frame is cut into
 // regions (80 x 60 pixels, say), one workgroup per region stays resident for all passes of a phase (20 at the reference's
 // seg_iter) with its region of the label map (+ a one-pixel halo) and of the inlier mask in LDS.  Per pass a workgroup
 //   1. replays its previous pass' sum deltas into the lagging sums buffer, reads the (quiescent) sums of the grid cells
