@@ -289,27 +289,33 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
     if (go) {
         // launched ahead of its transform: wait for the host's word (bounded: a lost word must not hang the device)
-        if (threadIdx.x == 0) {
+        // (wave 0: its first lane polls; the transform is then fetched by twelve lanes in ONE instruction -- read word by word by
+        // the polling lane it was twelve dependent trips to fine-grained memory at the head of every chained iteration)
+        if (threadIdx.x < 64) {
             int ok = 0, told = 0;
-            for (int spin = 0; spin < (1 << 22); spin++) {
-                const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v == go_seq) { ok = 1; told = 1; break; }
-                if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
-                if (v == (go_seq | SSF_ICP_GO_MATCH)) { ok = 2; told = 1; break; }       // the loop is over: associate under the pose in go->T
-                __builtin_amdgcn_s_sleep(1);
+            if (threadIdx.x == 0) {
+                for (int spin = 0; spin < (1 << 22); spin++) {
+                    const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (v == go_seq) { ok = 1; told = 1; break; }
+                    if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
+                    if (v == (go_seq | SSF_ICP_GO_MATCH)) { ok = 2; told = 1; break; }       // the loop is over: associate under the pose in go->T
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
+                // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
+                // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
+                // through the BAR cost the launch behind this one 3 us per frame.)
+                if (!told) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_go = ok;
             }
-            // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
-            // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
-            // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
-            // through the BAR cost the launch behind this one 3 us per frame.)
-            if (!told) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = __builtin_amdgcn_readfirstlane(ok);
             if (ok) {
-                for (int i = 0; i < 12; i++) s_T[i] = __hip_atomic_load(&go->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (the host stored the transform, fenced, then stored the word the first lane has just seen)
+                if (threadIdx.x < 12) s_T[threadIdx.x] = __hip_atomic_load(&go->T[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 // (a launch made ahead learns the number of its peer exchange with its transform: a dismissed launch must
                 // not use one up, the two slot parities of the exchange regions rely on consecutive numbers)
-                if (P2P) s_p2p_seq = __hip_atomic_load(&go->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (P2P && threadIdx.x == 12) s_p2p_seq = __hip_atomic_load(&go->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            s_go = ok;
         }
         __syncthreads();
         if (!s_go) return;
