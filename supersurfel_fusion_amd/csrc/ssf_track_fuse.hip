@@ -354,8 +354,13 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
             for (int k = 0; k < 29; k++) atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)acc[k]);
         }
     } else
-        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
-            icp_row(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), red, slot, dbg);
+        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
+            // the row's three fields in ONE round trip (left alone, the compiler fetches colour and normal only behind the
+            // test of the projected position: a second dependent trip in every iteration)
+            V3 mpos = ld3(model.pos, id), mlab = ld3(model.lab, id), mnrm = ld3(model.r2, id);
+            asm volatile("" : "+v"(mpos.x), "+v"(mlab.x), "+v"(mnrm.x));
+            icp_row(cam, pix2, fpack, R, t, mpos, mlab, mnrm, red, slot, dbg);
+        }
     __syncthreads();
     __shared__ int s_last;
     if (dbg & 4) {                              // probe: fold only
@@ -1191,10 +1196,16 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
     if ((int)blockIdx.x < nb_vis) {
         const int nv = cnt->mv_nv, n_rows = nv + cnt->mv_nc;              // mv_nc = rows appended in this frame (insertions + arrivals)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < n_rows) cls = (i < nv ? 0 : 3) + (int)state_vis[i];
-        // the row itself is requested now: its loads travel while the prefix below is worked out
+        // the row itself is requested now, together with its state byte (not behind it: a row that turns out to be removed is
+        // fetched for nothing, every other row saves a dependent trip to memory): the loads travel while the prefix below
+        // is worked out
         RowRegs row;
-        if (cls == 0 || cls == 1 || cls == 3 || cls == 4) row = load_row(V, i);
+        if (i < n_rows) {
+            int st = (int)state_vis[i];
+            row = load_row(V, i);
+            asm volatile("" : "+v"(st), "+v"(row.pos.x));
+            cls = (i < nv ? 0 : 3) + st;
+        }
         // prefix: the sums of the groups before this block's group (6 counters wide: word w belongs to class w % 6),
         // then the states of the rows of the earlier blocks of its own group, 16 per load
         const int g0 = (int)(blockIdx.x / PART_GROUP), ng = 6 * g0;
@@ -1257,7 +1268,11 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
     } else {
         const int ob = blockIdx.x - nb_vis;
         const long long phys = (long long)cnt->mv_head_old + (long long)ob * blockDim.x + threadIdx.x;
-        if (phys < cnt->mv_tail_old && O.live[phys]) cls = (int)state_oov[phys];
+        if (phys < cnt->mv_tail_old) {             // (both bytes in one round trip)
+            int lv = (int)O.live[phys], st = (int)state_oov[phys];
+            asm volatile("" : "+v"(lv), "+v"(st));
+            if (lv) cls = st;
+        }
         const unsigned long long mask = __ballot(cls == 0);
         if (cls == 0) in_wave = __popcll(mask & ((1ull << lane()) - 1ull));
         if (lane() == 0) hist[wv][0] = __popcll(mask);
