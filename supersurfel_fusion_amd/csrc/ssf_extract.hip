@@ -163,6 +163,35 @@ __device__ __forceinline__ void load_label_tile(int* tile, const int32_t* __rest
         tile[i] = (x >= 0 && x < W && y >= 0 && y < H) ? src[(size_t)y * W + x] : -1;
     }
 }
+// The same tile in two steps, so that its five loads per thread travel together with everything else a kernel requests
+// up front: tile_request issues them unconditionally (offsets clamped into the image, `outside` = the rounds whose
+// element is not in it; loads behind bounds tests are separate blocks for the compiler, which then waits for each),
+// tile_commit stores the tile to LDS.
+#define TILE_ROUNDS ((TW * TW + 255) / 256)
+struct TileRegs { int v[TILE_ROUNDS]; unsigned int outside; };
+__device__ __forceinline__ TileRegs tile_request(const int32_t* __restrict__ src, int X0, int Y0, int W, int H) {
+    TileRegs t; t.outside = 0u;
+    unsigned int off[TILE_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < TILE_ROUNDS; k++) {
+        const int i = 256 * (k + 1) <= TW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TW * TW - 1);
+        const int ly = i / TW, lx = i - ly * TW;
+        const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
+        const int cx_ = min(max(gx_, 0), W - 1), cy_ = min(max(gy_, 0), H - 1);
+        if (cx_ != gx_ || cy_ != gy_) t.outside |= 1u << k;
+        off[k] = __umul24((unsigned int)cy_, (unsigned int)W) + (unsigned int)cx_;
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_ROUNDS; k++) t.v[k] = src[off[k]];
+    return t;
+}
+__device__ __forceinline__ void tile_commit(int* tile, const TileRegs& t) {
+#pragma unroll
+    for (int k = 0; k < TILE_ROUNDS; k++) {
+        const int i = threadIdx.x + 256 * k;
+        if (256 * (k + 1) <= TW * TW || i < TW * TW) tile[i] = (t.outside >> k) & 1u ? -1 : t.v[k];
+    }
+}
 __device__ __forceinline__ int tile_boundary(const int* tile, int lx, int ly) {   // lx,ly in halo coordinates
     const int own = tile[ly * TW + lx];
     return (tile[(ly - 1) * TW + lx] != own) + (tile[ly * TW + lx - 1] != own) + (tile[ly * TW + lx + 1] != own) +
@@ -1170,19 +1199,34 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
     const int32_t* __restrict__ label = m.label;
     // this thread's pixels: requested up front, in flight while the window's planes are staged
     constexpr int PX = TILE * TILE / 256;
+    // (clamped addresses, no branch around the loads: pixels outside the image are skipped below; and the window's planes
+    // requested in the same round, stored to LDS afterwards -- one trip to memory in front of the evaluation instead of
+    // one per piece)
     int pl[PX]; float pd[PX];
 #pragma unroll
     for (int k = 0; k < PX; k++) {
         const int i = threadIdx.x + 256 * k;
-        const int x = X0 + i % TILE, y = Y0 + i / TILE;
-        pl[k] = -1; pd[k] = 0.f;
-        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pl[k] = label[q]; pd[k] = m.disp[q]; }
+        const int x = min(X0 + i % TILE, p.W - 1), y = min(Y0 + i / TILE, p.H - 1);
+        const unsigned int q = __umul24((unsigned int)y, (unsigned int)p.W) + (unsigned int)x;
+        pl[k] = label[q]; pd[k] = m.disp[q];
     }
-    for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
-        const int l = win.label_of(i / ns, p.gy);
-        w_plane[i] = l >= 0 ? m.samples[(size_t)l * ns + i % ns] : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int PLANE_ROUNDS = EVAL_WIN * EVAL_NS / 256;
+    float4 wp[PLANE_ROUNDS]; bool wp_ok[PLANE_ROUNDS];
+    const int n_planes = win.size() * ns;
+#pragma unroll
+    for (int k = 0; k < PLANE_ROUNDS; k++) {
+        const int i = threadIdx.x + 256 * k;
+        int l = -1, sk = 0;
+        if (i < n_planes) { const int wi = i / ns; sk = i - wi * ns; l = win.label_of(wi, p.gy); }
+        wp_ok[k] = l >= 0;
+        wp[k] = m.samples[(size_t)(l >= 0 ? l : 0) * ns + sk];
     }
-    for (int i = threadIdx.x; i < win.size() * ns * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
+    for (int i = threadIdx.x; i < n_planes * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
+#pragma unroll
+    for (int k = 0; k < PLANE_ROUNDS; k++) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < n_planes) w_plane[i] = wp_ok[k] ? wp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PX; k++) {
@@ -1243,11 +1287,11 @@ __global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int
     constexpr int PX = TILE * TILE / 256;
     int pl[PX]; float pd[PX];
 #pragma unroll
-    for (int k = 0; k < PX; k++) {
+    for (int k = 0; k < PX; k++) {                 // (clamped addresses, no branch around the loads: see k_eval_samples)
         const int i = threadIdx.x + 256 * k;
-        const int x = X0 + i % TILE, y = Y0 + i / TILE;
-        pl[k] = -1; pd[k] = 0.f;
-        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pl[k] = label[q]; pd[k] = m.disp[q]; }
+        const int x = min(X0 + i % TILE, p.W - 1), y = min(Y0 + i / TILE, p.H - 1);
+        const unsigned int q = __umul24((unsigned int)y, (unsigned int)p.W) + (unsigned int)x;
+        pl[k] = label[q]; pd[k] = m.disp[q];
     }
     for (int i = threadIdx.x; i < win.size() * 9 * ACC_REP; i += blockDim.x) w_acc[i] = 0ull;
     if (ransac)
@@ -1394,33 +1438,45 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m,
 // (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
 // boundary test and the 13 moment sums (fixed point 2^24, exact), which are accumulated with LDS
 // integer atomics per window superpixel and flushed once per tile.
+#ifndef MOM_REP
+#define MOM_REP 4        // replicas of the 13 moment accumulators of a window cell (8: 53 KB of LDS, two waves per SIMD; measured 8 / 4 / 2: 69.6 / 60.9 / 67.0 us per 8-frame launch)
+#endif
 __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m) {
     __shared__ int tile[TW * TW];
-    __shared__ SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * 13 * ACC_REP];    // ACC_REP replicas (lane id) against same-address serialisation
+    __shared__ __attribute__((aligned(16))) SpRow w_row[WIN_MAX];
+    __shared__ unsigned long long w_acc[WIN_MAX * 13 * MOM_REP];    // MOM_REP replicas (lane id) against same-address serialisation
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     CellWindow win; win.init(p, X0, Y0, WIN_MAX);
-    for (int i = threadIdx.x; i < win.size(); i += blockDim.x) {
-        const int l = win.label_of(i, p.gy);
-        if (l >= 0) w_row[i] = m.sp[l];
+    // Everything the workgroup needs from memory is requested first -- the window's rows, the gamma table, this thread's
+    // pixels, the label tile -- and stored to LDS afterwards: ONE round trip.  (Staged piece by piece, each piece was a
+    // trip of its own: four of them in front of the first useful instruction.)
+    static_assert(WIN_MAX <= 256, "one window row per thread");
+    const int wl = (int)threadIdx.x < win.size() ? win.label_of(threadIdx.x, p.gy) : -1;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    {
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(&m.sp[wl >= 0 ? wl : 0]);
+        r0 = q[0]; r1 = q[1]; r2 = q[2];                      // (unconditional: row 0 for the lanes without a window cell)
     }
-    for (int i = threadIdx.x; i < win.size() * 13 * ACC_REP; i += blockDim.x) w_acc[i] = 0ull;
-    // the gamma table in LDS: three lookups per pixel would otherwise be global loads queued behind this thread's
-    // stores (the maps may alias as far as the compiler knows)
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = m.srgb_lut[threadIdx.x];
-    // this thread's pixels: inlier flag and colour requested up front (in flight while the tile is staged)
+    const float lut = m.srgb_lut[threadIdx.x];
+    // this thread's pixels: inlier flag and colour (clamped addresses, used only for pixels inside the image)
     constexpr int PX = TILE * TILE / 256;
     unsigned char pin[PX]; uint32_t prgba[PX];
 #pragma unroll
     for (int k = 0; k < PX; k++) {
         const int i = threadIdx.x + 256 * k;
-        const int x = X0 + i % TILE, y = Y0 + i / TILE;
-        pin[k] = 0; prgba[k] = 0;
-        if (x < p.W && y < p.H) { const size_t q = (size_t)y * p.W + x; pin[k] = m.inlier[q]; prgba[k] = m.rgba[q]; }
+        const int x = min(X0 + i % TILE, p.W - 1), y = min(Y0 + i / TILE, p.H - 1);
+        const unsigned int q = __umul24((unsigned int)y, (unsigned int)p.W) + (unsigned int)x;
+        pin[k] = m.inlier[q]; prgba[k] = m.rgba[q];
     }
-    load_label_tile(tile, m.label, X0, Y0, p.W, p.H);
+    const TileRegs treg = tile_request(m.label, X0, Y0, p.W, p.H);
+    for (int i = threadIdx.x; i < win.size() * 13 * MOM_REP; i += blockDim.x) w_acc[i] = 0ull;
+    // the gamma table in LDS: three lookups per pixel would otherwise be global loads queued behind this thread's
+    // stores (the maps may alias as far as the compiler knows)
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut;
+    if (wl >= 0) { float4* w = reinterpret_cast<float4*>(&w_row[threadIdx.x]); w[0] = r0; w[1] = r1; w[2] = r2; }
+    tile_commit(tile, treg);
     __syncthreads();
     float out_depth[PX]; int out_label[PX];
 #pragma unroll
@@ -1445,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const Sym3 c = sym_outer(pos);
         const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
         if (ws >= 0) {
-            unsigned long long* a = &w_acc[(ws * ACC_REP + (lane_id() & (ACC_REP - 1))) * 13];
+            unsigned long long* a = &w_acc[(ws * MOM_REP + (lane_id() & (MOM_REP - 1))) * 13];
 #pragma unroll
             for (int j = 0; j < 12; j++) lds_add_i64(&a[j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
             lds_add_i64(&a[12], 1);
@@ -1468,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
     for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) {
         long long v = 0;
 #pragma unroll
-        for (int r = 0; r < ACC_REP; r++) v += (long long)w_acc[((i / 13) * ACC_REP + r) * 13 + i % 13];
+        for (int r = 0; r < MOM_REP; r++) v += (long long)w_acc[((i / 13) * MOM_REP + r) * 13 + i % 13];
         if (v != 0) atomic_add_i64(&m.moments[(size_t)win.label_of(i / 13, p.gy) * 13 + i % 13], v);
     }
 }
