@@ -304,6 +304,22 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 // accumulators, the disparity terms of a pixel converted once for both signs, the flush addressed by field offset
 // instead of a 15-way switch, the previous pass' log entry fetched without a branch (behind one, the compiler waited for
 // it -- a second dependent trip to memory -- before it requested the window's sums).
+// Global accesses of the pass as (uniform 64-bit base) + (32-bit BYTE offset in a vector register): the form the hardware
+// takes directly (`global_load_dword v, v_off, s[base]`).  Indexing a typed pointer with an integer makes the compiler
+// widen, shift and add in 64 bits per access (v_mad_i64_i32 / v_lshl_add_u64 and a zeroed high half): two or three
+// vector instructions and a register pair each, a dozen times per thread.  Every map of a frame is far below 4 GB.
+template <typename T> __device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned int byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ void st_off(void* __restrict__ base, unsigned int byte_off, const T& v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+#ifndef SSF_PASS_NPREV_RGBD
+#define SSF_PASS_NPREV_RGBD 1
+#endif
+#ifndef SSF_PASS_NPREV_RGB
+#define SSF_PASS_NPREV_RGB 0
+#endif
 #define PASS_F32 9                  // F_SX .. F_DN: 32-bit accumulators; F_DXX .. F_DD: 64-bit
 #define PASS_F64 (F_COUNT - PASS_F32)
 // accumulators of one window slot: 24 dwords = six 16-byte chunks -- the nine 32-bit sums (chunks 0-2, three dwords of padding),
@@ -312,8 +328,8 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 #define PASS_ACC_WIDE_DW 12
 template <bool RGBD, int NPX, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
-    constexpr int TWX = TILE * NPX, TWW = TWX + 2, LOGN = 256 * NPX;
-    __shared__ int tile[TWW * TW];
+    constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
+    __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
     __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
@@ -322,10 +338,10 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
-    const int X0 = blockIdx.x * TWX - (OX ? 0 : TWX - 2), Y0 = blockIdx.y * TILE;  // OX = 0: tiles start at 2 (mod 4)
+    const int X0 = __builtin_amdgcn_readfirstlane(blockIdx.x * TWX - (OX ? 0 : TWX - 2)), Y0 = __builtin_amdgcn_readfirstlane(blockIdx.y * TILE);  // OX = 0: tiles start at 2 (mod 4)
     int32_t* __restrict__ lab = m.label;
     // this thread's pass pixels: local columns 4j+1, 4j+2 of pass rows; pixel s of the thread is element threadIdx.x + 256 s
-    int x[NPX], y[NPX], lxh[NPX], lyh[NPX]; bool in_image[NPX]; size_t q[NPX];
+    int x[NPX], y[NPX], lxh[NPX], lyh[NPX]; bool in_image[NPX]; unsigned int q[NPX];
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const int e = threadIdx.x + 256 * s;
@@ -333,62 +349,93 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         const int lx0 = 4 * (tx >> 1) + 1 + (tx & 1), ly0 = 2 * ty + OY;
         x[s] = X0 + lx0; y[s] = Y0 + ly0; lxh[s] = lx0 + 1; lyh[s] = ly0 + 1;      // lxh / lyh: halo coordinates
         in_image[s] = x[s] >= 0 && x[s] < p.W && y[s] < p.H;
-        q[s] = in_image[s] ? (size_t)y[s] * p.W + x[s] : 0;
+        q[s] = in_image[s] ? __umul24((unsigned int)y[s], (unsigned int)p.W) + (unsigned int)x[s] : 0u;      // (W, H < 2^16)
     }
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int lp = (pass + 2) % 3, lc = pass % 3;
     const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
-    const unsigned int n_prev = pass > 0 ? pcnt[tile_id] : 0u;          // (uniform: a scalar load, needed only further down)
+    // The previous pass' entry count of this tile (uniform, needed only further down).  Behind `pass > 0` the compiler waits
+    // for the word inside the branch -- a dependent trip to memory before the first vector load is issued.  Form 1 requests it
+    // unconditionally (at pass 0 the word is a stale count of an earlier frame and is ignored), form 2 as a VECTOR load of
+    // one address (an opaque zero in a vector register makes the address look per-lane), which travels with the pixel
+    // operands and costs no scalar register.  The RGB variant lives at 8 waves per SIMD with no register to spare: which form
+    // pays is measured per variant (SSF_PASS_NPREV_RGBD / SSF_PASS_NPREV_RGB).
+    constexpr int NPREV_FORM = RGBD ? SSF_PASS_NPREV_RGBD : SSF_PASS_NPREV_RGB;
+    unsigned int n_prev_word = 0u;
+    if (NPREV_FORM == 0) { if (pass > 0) n_prev_word = pcnt[tile_id]; }
+    else if (NPREV_FORM == 1) n_prev_word = pcnt[tile_id];
+    else { int lane_zero = 0; asm volatile("" : "+v"(lane_zero)); n_prev_word = pcnt[tile_id + lane_zero]; }
     // operands that do not depend on the label tile: in flight while the tile is staged
     uint32_t px[NPX]; float disp[NPX]; unsigned char prev_inlier[NPX];
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
-        px[s] = m.rgba[q[s]];
+        px[s] = ld_off<uint32_t>(m.rgba, 4u * q[s]);
         disp[s] = 0.f; prev_inlier[s] = 0;
-        if (RGBD) { disp[s] = m.disp[q[s]]; prev_inlier[s] = m.inlier[q[s]]; }
+        if (RGBD) { disp[s] = ld_off<float>(m.disp, 4u * q[s]); prev_inlier[s] = ld_off<unsigned char>(m.inlier, q[s]); }
     }
     // the label tile + halo: requested into registers NOW (independent loads), stored to LDS after the superpixel rows
-    // have been computed -- one memory round trip for tile, pixel operands, sums and log
-    constexpr int TILE_LOADS = (TWW * TW + 255) / 256;
-    int tile_reg[TILE_LOADS];
-    // Element offsets first -- without bounds tests when the halo lies inside the image (uniform), clamped into the image
-    // otherwise, `outside` = the rounds whose element is not in the image -- then ONE unconditional round of loads for both
-    // kinds of tile.  (Loads behind a branch, or in two alternative blocks, made the compiler wait for the pixel operands
-    // before it issued them: a second dependent trip to memory.)  The last, partial round re-reads the tile's last element
-    // in its idle lanes.
-    unsigned int tile_off[TILE_LOADS]; unsigned int outside = 0u;
-    const bool interior = X0 >= 1 && X0 + TWX < p.W && Y0 >= 1 && Y0 + TILE < p.H;
+    // have been computed -- one memory round trip for tile, pixel operands, sums and log.
+    // The tile travels in QUADS: a row of the LDS tile is TWP = TWX + 4 labels (the 2 + TWX halo columns and two columns of
+    // padding that nothing reads), i.e. TWP / 4 16-byte quads, and quad e of the tile lies at LDS dword 4 e.  When the
+    // halo (and the padding) lies inside the image -- a uniform test -- a lane fetches a quad with ONE 16-byte load (the
+    // address is only 4-byte aligned: X0 - 1 is odd; global loads take that) and stores it with one ds_write_b128: two
+    // rounds per thread instead of five rounds of single labels, a third of the address arithmetic.  Edge tiles fetch the
+    // four labels of a quad one by one from offsets clamped into the image; `outside` = the labels that are not in it.
+    // Either way the loads are unconditional (loads behind a branch made the compiler wait for the pixel operands before it
+    // issued them: a second dependent trip to memory); the idle lanes of the last round re-read the tile's last quad.
+    constexpr int TWP = TWX + 4, QPR = TWP / 4, NQ = QPR * TW, TILE_LOADS = (NQ + 255) / 256;
+    constexpr unsigned int QPR_MAGIC = 65536u / QPR + 1u;          // e / QPR == (e * QPR_MAGIC) >> 16 for e < 1024
+    static_assert(NQ <= 1024 && TILE_LOADS * 4 <= 32, "quad index / outside mask");
+    uint4 tile_reg[TILE_LOADS]; unsigned int outside = 0u;
+    const bool no_tile = (dbg & 32) != 0;                      // (probe: every element reads as outside the image)
+    const bool interior = X0 >= 1 && X0 - 1 + TWP <= p.W && Y0 >= 1 && Y0 + TILE < p.H;
     if (interior) {
+        typedef uint32_t Quad __attribute__((ext_vector_type(4), aligned(4)));     // ONE load of four labels, 4-byte aligned
         const unsigned int base_off = (unsigned int)((Y0 - 1) * p.W + (X0 - 1));
+        unsigned int tile_off[TILE_LOADS];
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
-            const int i = 256 * (k + 1) <= TWW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TWW * TW - 1);
-            const int ly = i / TWW;                                  // element (ly, i - ly * TWW): offset ly * W + i - ly * TWW
-            tile_off[k] = base_off + (unsigned int)i + __umul24((unsigned int)ly, (unsigned int)(p.W - TWW));   // (24-bit multiplies are full rate)
+            const unsigned int e = 256 * (k + 1) <= NQ ? threadIdx.x + 256u * k : min(threadIdx.x + 256u * k, (unsigned int)(NQ - 1));
+            const unsigned int ly = __umul24(e, QPR_MAGIC) >> 16;      // quad (ly, e - ly * QPR): label offset ly * W + 4 (e - ly * QPR)
+            tile_off[k] = 4u * (base_off + 4u * e + __umul24(ly, (unsigned int)(p.W - TWP)));   // bytes (24-bit multiplies are full rate)
+        }
+#pragma unroll
+        for (int k = 0; k < TILE_LOADS; k++) {
+            const Quad v = ld_off<Quad>(lab, tile_off[k]);
+            tile_reg[k] = make_uint4(v.x, v.y, v.z, v.w);
         }
     } else {
+        unsigned int tile_off[TILE_LOADS][4];
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
-            const int i = 256 * (k + 1) <= TWW * TW ? threadIdx.x + 256 * k : min((int)threadIdx.x + 256 * k, TWW * TW - 1);
-            const int ly = i / TWW, lx = i - ly * TWW;
-            const int gx_ = X0 - 1 + lx, gy_ = Y0 - 1 + ly;
-            const int cx_ = min(max(gx_, 0), p.W - 1), cy_ = min(max(gy_, 0), p.H - 1);
-            if (cx_ != gx_ || cy_ != gy_) outside |= 1u << k;
-            tile_off[k] = __umul24((unsigned int)cy_, (unsigned int)p.W) + (unsigned int)cx_;
-        }
-    }
-    const bool no_tile = (dbg & 32) != 0;                      // (probe: every element reads as outside the image)
+            const unsigned int e = 256 * (k + 1) <= NQ ? threadIdx.x + 256u * k : min(threadIdx.x + 256u * k, (unsigned int)(NQ - 1));
+            const int ly = (int)(__umul24(e, QPR_MAGIC) >> 16), lx = 4 * ((int)e - ly * QPR);
+            const int gy_ = Y0 - 1 + ly, cy_ = min(max(gy_, 0), p.H - 1);
+            const unsigned int row_off = __umul24((unsigned int)cy_, (unsigned int)p.W);
 #pragma unroll
-    for (int k = 0; k < TILE_LOADS; k++) tile_reg[k] = lab[tile_off[k]];
+            for (int j = 0; j < 4; j++) {
+                const int gx_ = X0 - 1 + lx + j, cx_ = min(max(gx_, 0), p.W - 1);
+                if (cx_ != gx_ || cy_ != gy_) outside |= 1u << (4 * k + j);
+                tile_off[k][j] = 4u * (row_off + (unsigned int)cx_);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TILE_LOADS; k++)
+            tile_reg[k] = make_uint4(ld_off<uint32_t>(lab, tile_off[k][0]), ld_off<uint32_t>(lab, tile_off[k][1]), ld_off<uint32_t>(lab, tile_off[k][2]), ld_off<uint32_t>(lab, tile_off[k][3]));
+    }
+    if (no_tile) outside = 0xFFFFFFFFu;
     // window of grid cells around the tile whose superpixel rows are cached in LDS
     int margin = 2;
     const int tcx0 = div_cell(p, max(X0, 0)), tcy0 = div_cell(p, Y0);
     const int tcx1 = div_cell(p, min(X0 + TWX - 1, p.W - 1)), tcy1 = div_cell(p, min(Y0 + TILE - 1, p.H - 1));
     while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
-    const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
+    // (uniform values, said so: without the readfirstlane the RGB-D variant computed the whole window geometry -- two
+    // mul_hi, four quarter-rate mul_lo, the margin loop -- in vector registers, ~45 issue slots per wave)
+    margin = __builtin_amdgcn_readfirstlane(margin);
+    const int wcx0 = __builtin_amdgcn_readfirstlane(tcx0 - margin), wcy0 = __builtin_amdgcn_readfirstlane(tcy0 - margin);
     const int nwx_ = tcx1 - tcx0 + 1 + 2 * margin, nwy_ = tcy1 - tcy0 + 1 + 2 * margin;
     const bool window_ok = nwx_ * nwy_ <= WIN_MAX;
-    const int nwx = window_ok ? nwx_ : 0, nwy = window_ok ? nwy_ : 0, nslots = nwx * nwy;   // no window: every label takes the exact path
+    const int nwx = __builtin_amdgcn_readfirstlane(window_ok ? nwx_ : 0), nwy = __builtin_amdgcn_readfirstlane(window_ok ? nwy_ : 0), nslots = nwx * nwy;   // no window: every label takes the exact path
     const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (window <= 64 cells: wave 0 builds the means of cell `lane`, wave 1 -- RGB-D passes -- its plane, side by side)
     if (threadIdx.x < (RGBD ? 128 : 64)) {
@@ -420,24 +467,34 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
     const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
     int4 prev_ent[NPX]; float prev_disp[NPX];
+    const unsigned int n_prev = pass > 0 ? n_prev_word : 0u;
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const unsigned int e = threadIdx.x + 256u * s;
-        const size_t le = (size_t)tile_id * LOGN + (e < n_prev ? e : 0u);
-        prev_ent[s] = pent[le];
+        const unsigned int le = (unsigned int)tile_id * LOGN + (e < n_prev ? e : 0u);
+        prev_ent[s] = ld_off<int4>(pent, 16u * le);
         prev_disp[s] = 0.f;
-        if (RGBD) prev_disp[s] = pdis[le];
+        if (RGBD) prev_disp[s] = ld_off<float>(pdis, 4u * le);
     }
     if (threadIdx.x == 0) s_nlog = 0;
     constexpr int ACC_CHUNKS = RGBD ? 6 : 2;                  // 16-byte chunks of a slot that a pass of this kind can touch (RGB: sx .. n)
-    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += blockDim.x) {
-        const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);      // i / 6, i / 2
-        reinterpret_cast<uint4*>(w_acc)[__mul24(wi, 6) + (i - __mul24(wi, ACC_CHUNKS))] = make_uint4(0u, 0u, 0u, 0u);
+    // (RGB-D: every chunk of a slot, i.e. the first 6 nslots chunks of the array; RGB: chunks 0 and 1 of each slot)
+    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256)
+        reinterpret_cast<uint4*>(w_acc)[RGBD ? i : __mul24(i >> 1, 6) + (i & 1)] = make_uint4(0u, 0u, 0u, 0u);
+    // (the idle lanes of the last round store the last quad once more: same value, same place -- no branch)
+    if (!interior || no_tile) {
+#pragma unroll
+        for (int k = 0; k < TILE_LOADS; k++) {
+            if ((outside >> (4 * k)) & 1u) tile_reg[k].x = 0xFFFFFFFFu;
+            if ((outside >> (4 * k + 1)) & 1u) tile_reg[k].y = 0xFFFFFFFFu;
+            if ((outside >> (4 * k + 2)) & 1u) tile_reg[k].z = 0xFFFFFFFFu;
+            if ((outside >> (4 * k + 3)) & 1u) tile_reg[k].w = 0xFFFFFFFFu;
+        }
     }
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) {
-        const int i = threadIdx.x + 256 * k;
-        if (256 * (k + 1) <= TWW * TW || i < TWW * TW) tile[i] = (no_tile || (!interior && ((outside >> k) & 1u))) ? -1 : tile_reg[k];
+        const unsigned int e = 256 * (k + 1) <= NQ ? threadIdx.x + 256u * k : min(threadIdx.x + 256u * k, (unsigned int)(NQ - 1));
+        reinterpret_cast<uint4*>(tile)[e] = tile_reg[k];
     }
     __syncthreads();
     const float inv_gx = p.inv_gx;
@@ -511,18 +568,18 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const int lx = lxh[s], ly = lyh[s];
-        const int* __restrict__ t = &tile[__mul24(ly, TWW) + lx];
+        const int* __restrict__ t = &tile[__mul24(ly, TWP) + lx];
         const int index = in_image[s] ? t[0] : 0;
         int new_index = index;
-        const int nl[4] = {t[-TWW], t[-1], t[1], t[TWW]};                           // N, W, E, S
+        const int nl[4] = {t[-TWP], t[-1], t[1], t[TWP]};                           // N, W, E, S
         const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
         bool eligible = in_image[s] && bounds != 0 && !(dbg & 4);
         if (eligible) {
             // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W; the label changes
             // more than twice along the ring = the pixel is a bridge.  Bit k of `ring`: ring pixel k carries the pixel's label
-            const unsigned int ring = (t[-TWW - 1] == index ? 1u : 0u) | (nl[0] == index ? 2u : 0u) | (t[-TWW + 1] == index ? 4u : 0u) |
-                                      (nl[2] == index ? 8u : 0u) | (t[TWW + 1] == index ? 16u : 0u) | (nl[3] == index ? 32u : 0u) |
-                                      (t[TWW - 1] == index ? 64u : 0u) | (nl[1] == index ? 128u : 0u);
+            const unsigned int ring = (t[-TWP - 1] == index ? 1u : 0u) | (nl[0] == index ? 2u : 0u) | (t[-TWP + 1] == index ? 4u : 0u) |
+                                      (nl[2] == index ? 8u : 0u) | (t[TWP + 1] == index ? 16u : 0u) | (nl[3] == index ? 32u : 0u) |
+                                      (t[TWP - 1] == index ? 64u : 0u) | (nl[1] == index ? 128u : 0u);
             eligible = __popc((ring ^ (ring >> 1)) & 0x7Fu) <= 2;
         }
         SpRow own = zero_row;
@@ -587,20 +644,21 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
         unsigned flags = 0u;
         if (in_image[s]) {
-            if (new_index != index) lab[q[s]] = new_index;
+            if (new_index != index) st_off<int32_t>(lab, 4u * q[s], new_index);
             flags = (new_index != index) ? 1u : 0u;
             if (RGBD) {
                 if (inlier && (!prev_inlier[s] || index != new_index)) flags |= 2u;
                 if (prev_inlier[s] && (!inlier || (inlier && index != new_index))) flags |= 4u;
-                if (inlier != prev_inlier[s]) m.inlier[q[s]] = inlier;
+                if (inlier != prev_inlier[s]) st_off<unsigned char>(m.inlier, q[s], inlier);
             }
         }
         if (flags) {
             const uint32_t rgbf = (px[s] & 0x00FFFFFFu) | (flags << 24);
             add_delta(index, new_index, x[s], y[s], rgbf, disp[s]);
             const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < LOGN by construction
-            cent[(size_t)tile_id * LOGN + slot] = make_int4(index, new_index, x[s] | (y[s] << 16), (int)rgbf);
-            if (RGBD) cdis[(size_t)tile_id * LOGN + slot] = disp[s];
+            const unsigned int ce = (unsigned int)tile_id * LOGN + slot;
+            st_off<int4>(cent, 16u * ce, make_int4(index, new_index, x[s] | (y[s] << 16), (int)rgbf));
+            if (RGBD) st_off<float>(cdis, 4u * ce, disp[s]);
         }
     }
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
@@ -615,11 +673,19 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     // The record's nine int32 sums and six int64 sums are addressed by field number (SumRec: int32 fields from byte 0, int64
     // fields from byte 64)
     static_assert(WIN_MAX * 6 <= 32768, "i / 6 by multiplication");
-    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += blockDim.x) {
-        const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);
-        const int c = i - __mul24(wi, ACC_CHUNKS);
-        const uint4 v = reinterpret_cast<const uint4*>(w_acc)[__mul24(wi, 6) + c];
+    // A tile that logged nothing and replayed nothing has nothing to flush (most tiles of the later passes): no scan.
+    if (s_nlog == 0u && n_prev == 0u) {
+        if (threadIdx.x == 0) {
+            unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+            ccnt[tile_id] = 0u;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256) {
+        const uint4 v = reinterpret_cast<const uint4*>(w_acc)[RGBD ? i : __mul24(i >> 1, 6) + (i & 1)];
         if ((v.x | v.y | v.z | v.w) == 0u) continue;
+        const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);       // i / 6, i / 2
+        const int c = i - __mul24(wi, ACC_CHUNKS);
         SumRec* rec = &sw.r[w_label[wi]];
         if (c < 3) {
             int* f = &rec->sx + 4 * c;                             // (chunk 2: dn and three dwords of padding, always zero)
