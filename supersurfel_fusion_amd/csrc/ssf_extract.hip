@@ -314,6 +314,29 @@ template <typename T> __device__ __forceinline__ T ld_off(const void* __restrict
 template <typename T> __device__ __forceinline__ void st_off(void* __restrict__ base, unsigned int byte_off, const T& v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// XCD-aware tile order.  A launch's workgroups are dealt to the eight XCDs round-robin (workgroup b of the x-fastest linear
+// order runs on XCD b % 8: observed placement, only speed depends on it), so with tiles taken in grid order the neighbours
+// of a tile run on seven OTHER XCDs -- and every 128-byte line that two tiles share (the halo columns, the shifted tiles'
+// rows that straddle a line, the 32 inlier bytes a tile uses of a line, the window's sum records) is fetched once per L2:
+// the RGB-D pass moved 58 MB per 8-frame launch for 17-34 MB of data, at 3.9 TB/s -- it had become traffic-bound.
+// Here XCD x takes the x-th contiguous EIGHTH of the launch's (frame, tile row, tile column) order instead -- a whole frame
+// per XCD for an 8-frame launch -- so neighbouring tiles meet in one L2.  Bijective for any grid; tile ids (the log regions
+// of a tile) are those of the logical tile, the same in every pass.
+struct TileOrder { unsigned int ntx, ntile, magic_ntx, magic_ntile, total; int xcd; };
+__device__ __forceinline__ unsigned int xcd_share(unsigned int b, unsigned int nb) {
+    const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+static inline TileOrder tile_order(dim3 grid) {
+    TileOrder o;
+    o.ntx = grid.x; o.ntile = grid.x * grid.y; o.total = o.ntile * grid.z;
+    o.magic_ntx = (unsigned int)((0x100000000ull + o.ntx - 1) / o.ntx);        // n / d == umulhi(n, ceil(2^32 / d)) for n d < 2^32 / d ... n < 2^20 here
+    o.magic_ntile = (unsigned int)((0x100000000ull + o.ntile - 1) / o.ntile);
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SSF_PASS_XCD"); on = e ? atoi(e) : 1; }
+    o.xcd = on;
+    return o;
+}
 #ifndef SSF_PASS_NPREV_RGBD
 #define SSF_PASS_NPREV_RGBD 1
 #endif
@@ -327,18 +350,27 @@ template <typename T> __device__ __forceinline__ void st_off(void* __restrict__ 
 #define PASS_ACC_DW 24
 #define PASS_ACC_WIDE_DW 12
 template <bool RGBD, int NPX, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg) {
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg, TileOrder ord) {
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
     __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
-    m = batch_slot(m, blockIdx.z);
+    // this workgroup's (frame, tile row, tile column): see TileOrder
+    unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (ord.xcd) {
+        const unsigned int lin = blockIdx.x + ord.ntx * blockIdx.y + ord.ntile * blockIdx.z;
+        const unsigned int t = xcd_share(lin, ord.total);
+        bz = __umulhi(t, ord.magic_ntile);
+        const unsigned int r = t - bz * ord.ntile;
+        by = __umulhi(r, ord.magic_ntx); bx = r - by * ord.ntx;
+    }
+    m = batch_slot(m, bz);
     const bool odd = (pass & 1) != 0;
     const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
     const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
-    const int X0 = __builtin_amdgcn_readfirstlane(blockIdx.x * TWX - (OX ? 0 : TWX - 2)), Y0 = __builtin_amdgcn_readfirstlane(blockIdx.y * TILE);  // OX = 0: tiles start at 2 (mod 4)
+    const int X0 = __builtin_amdgcn_readfirstlane((int)bx * TWX - (OX ? 0 : TWX - 2)), Y0 = __builtin_amdgcn_readfirstlane((int)by * TILE);  // OX = 0: tiles start at 2 (mod 4)
     int32_t* __restrict__ lab = m.label;
     // this thread's pass pixels: local columns 4j+1, 4j+2 of pass rows; pixel s of the thread is element threadIdx.x + 256 s
     int x[NPX], y[NPX], lxh[NPX], lyh[NPX]; bool in_image[NPX]; unsigned int q[NPX];
@@ -351,7 +383,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         in_image[s] = x[s] >= 0 && x[s] < p.W && y[s] < p.H;
         q[s] = in_image[s] ? __umul24((unsigned int)y[s], (unsigned int)p.W) + (unsigned int)x[s] : 0u;      // (W, H < 2^16)
     }
-    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int tile_id = (int)(by * ord.ntx + bx);
     const int lp = (pass + 2) % 3, lc = pass % 3;
     const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
     // The previous pass' entry count of this tile (uniform, needed only further down).  Behind `pass > 0` the compiler waits
@@ -1908,21 +1940,23 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     dim3 grid = tile_grid(p);
     grid.x = (p.W + (twx - 2) + twx - 1) / twx;
     grid.z = nb;
+    const TileOrder ord = tile_order(grid);
     // occupancy target of the RGB-D variant: 6 waves per SIMD (73 registers, no spills).  Forcing 8 (64 registers, 9 spilled
     // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
     static int waves = 0;
-    if (!waves) { const char* e = getenv("SSF_PASS_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 6; }
+    if (!waves) { const char* e = getenv("SSF_PASS_WAVES"); const int w = e ? atoi(e) : 6; waves = (w == 7 || w == 8) ? w : 6; }
     // (Round 3 measured two more forms of this pass against the 256-thread kernel -- one wave per tile with the changeable
     // pixels compacted: 22 / 31 us per 8-frame launch against 15 / 20; four waves that compact the changeable pixels into an
     // LDS list and RELEASE the waves the list does not need: 17 / 22 us, same frame rate -- both bit-exact, both slower; they
     // live in the history, not in the source.)
     if (npx == 2) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
     } else if (rgbd) {
-        if (waves == 8) hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-        else hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
-    } else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg);
+        if (waves == 8) hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+        else if (waves == 7) hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+        else hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+    } else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
 }
 static size_t passes_lds_bytes(const PassGeom& g) {
     size_t off = ((size_t)(g.rw + 2) * (g.rh + 2) * 4 + 15) & ~(size_t)15;
