@@ -341,7 +341,7 @@ static inline TileOrder tile_order(dim3 grid) {
 #define SSF_PASS_NPREV_RGBD 1
 #endif
 #ifndef SSF_PASS_NPREV_RGB
-#define SSF_PASS_NPREV_RGB 0
+#define SSF_PASS_NPREV_RGB 1
 #endif
 #define PASS_F32 9                  // F_SX .. F_DN: 32-bit accumulators; F_DXX .. F_DD: 64-bit
 #define PASS_F64 (F_COUNT - PASS_F32)
