@@ -275,6 +275,9 @@ __device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int n
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched);
+#ifndef SSF_ICP_GO_WAIT_TICKS
+#define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
+#endif
 template <bool P2P, bool ACC>
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
@@ -294,11 +297,16 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         if (threadIdx.x < 64) {
             int ok = 0, told = 0;
             if (threadIdx.x == 0) {
-                for (int spin = 0; spin < (1 << 22); spin++) {
+                // (the bound is WALL-CLOCK time -- the constant-rate counter behind wall_clock64(), 100 MHz on this part --, looked
+                // at every 64 polls: a quarter of a second, not a spin count whose length in seconds depends on how long a poll
+                // of fine-grained memory takes under load.  The host's own round trip is 3-5 us.)
+                const unsigned long long t0 = wall_clock64();
+                for (unsigned int spin = 0; spin < (1u << 24); spin++) {
                     const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (v == go_seq) { ok = 1; told = 1; break; }
                     if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
                     if (v == (go_seq | SSF_ICP_GO_MATCH)) { ok = 2; told = 1; break; }       // the loop is over: associate under the pose in go->T
+                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SSF_ICP_GO_WAIT_TICKS) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
