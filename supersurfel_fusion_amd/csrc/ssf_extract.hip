@@ -1285,11 +1285,18 @@ __global__ __launch_bounds__(256) void k_init_samples(SegParams p, FrameMaps m, 
 #define ACC_REP 8
 #define EVAL_NS 16
 #define EVAL_REP 8
+// FAST = the reference's sixteen samples (every launch file): per pixel all planes of its superpixel are read from LDS first,
+// the sixteen tests follow, and the votes go out as LDS atomics nobody waits for -- TWO samples per 32-bit counter (16-bit
+// fields: a tile has 1024 pixels), in the layout [pair][window cell][replica]: eight atomics per pixel instead of sixteen,
+// lanes of different superpixels on different banks (with [cell][sample][replica] the bank was (8 sample + replica) % 32
+// whatever the cell: every atomic of a wave fought over eight banks), and 16 KB of counters instead of 32 (five workgroups
+// per CU instead of three).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
     __shared__ float4 w_plane[EVAL_WIN * EVAL_NS];
     // EVAL_REP replicas of every counter (lane & 7): the 64 pixels of a wave sit in a handful of superpixels, and
     // same-address LDS atomics serialise (SQ_LDS_BANK_CONFLICT was 80 % of the LDS cycles with one replica)
-    __shared__ int w_cnt[EVAL_WIN * EVAL_NS * EVAL_REP];
+    __shared__ __attribute__((aligned(16))) int w_cnt[EVAL_WIN * (FAST ? EVAL_NS / 2 : EVAL_NS) * EVAL_REP];
     m = batch_slot(m, blockIdx.z);
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
     const int ns = p.nb_samples;
@@ -1319,13 +1326,60 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
         wp_ok[k] = l >= 0;
         wp[k] = m.samples[(size_t)(l >= 0 ? l : 0) * ns + sk];
     }
-    for (int i = threadIdx.x; i < n_planes * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
+    if (FAST) {
+        for (int i = threadIdx.x; i < EVAL_WIN * (EVAL_NS / 2) * EVAL_REP / 4; i += 256) reinterpret_cast<int4*>(w_cnt)[i] = make_int4(0, 0, 0, 0);
+    } else
+        for (int i = threadIdx.x; i < n_planes * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
 #pragma unroll
     for (int k = 0; k < PLANE_ROUNDS; k++) {
         const int i = threadIdx.x + 256 * k;
         if (i < n_planes) w_plane[i] = wp_ok[k] ? wp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    // The reference's sample count (16 in every launch file) has a path of its own: per pixel, ALL planes of its superpixel
+    // are read from LDS first, the sixteen tests follow, then the votes go out as LDS atomics nobody waits for.  (In the
+    // general loop below every (pixel, sample) step waited for its plane's LDS read AND for the previous step's atomic:
+    // 64 exposed LDS round trips per thread at three waves per SIMD were what the kernel spent its time on.)
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < PX; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int x = X0 + i % TILE, y = Y0 + i / TILE;
+            if (x >= p.W || y >= p.H) continue;
+            const int l = pl[k];
+            const float d = pd[k];
+            const int ws = win.slot(l);
+            if (ws >= 0) {
+                const float4* __restrict__ plane = &w_plane[ws * EVAL_NS];
+                unsigned int votes = 0u;
+#pragma unroll
+                for (int sk = 0; sk < EVAL_NS; sk++) {
+                    const float4 th = plane[sk];
+                    const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
+                    const float dd = (d - dp) * (d - dp);
+                    // (no short circuit: behind `isfinite(th.z) &&` the compiler read th.z, waited, tested, and only then read
+                    // th.x / th.y -- two dependent LDS trips per sample.  A plane that is not finite fails `dd < thresh` anyway.)
+                    const unsigned int vote = (unsigned int)(dd < p.thresh_disp) & (unsigned int)(isfinite(th.z) ? 1 : 0);
+                    votes |= vote << sk;
+                }
+                int* __restrict__ c = &w_cnt[ws * EVAL_REP + (lane_id() & (EVAL_REP - 1))];
+#pragma unroll
+                for (int pr = 0; pr < EVAL_NS / 2; pr++) {        // samples pr (low half) and pr + 8 (high half) share a counter
+                    const unsigned int v = ((votes >> pr) & 1u) | (((votes >> (pr + EVAL_NS / 2)) & 1u) << 16);
+                    if (v) atomicAdd(&c[pr * EVAL_WIN * EVAL_REP], (int)v);
+                }
+            } else {
+                for (int sk = 0; sk < EVAL_NS; sk++) {             // label outside the window: exact global path
+                    const float4 th = ld_global_f4(&m.samples[(size_t)l * EVAL_NS + sk]);
+                    if (isfinite(th.z)) {
+                        const float dp = (th.x * (float)x + th.y * (float)y) + th.z;
+                        const float dd = (d - dp) * (d - dp);
+                        if (dd < p.thresh_disp) atomicAdd(&m.sample_score[(size_t)l * EVAL_NS + sk], 1);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < PX; k++) {
         const int i = threadIdx.x + 256 * k;
@@ -1351,8 +1405,16 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
     __syncthreads();
     for (int i = threadIdx.x; i < win.size() * ns; i += blockDim.x) {
         int c = 0;
+        if (FAST) {
+            const int wi = i / EVAL_NS, sk = i % EVAL_NS, pr = sk & (EVAL_NS / 2 - 1);
+            unsigned int packed = 0u;
 #pragma unroll
-        for (int r = 0; r < EVAL_REP; r++) c += w_cnt[i * EVAL_REP + r];
+            for (int r = 0; r < EVAL_REP; r++) packed += (unsigned int)w_cnt[(pr * EVAL_WIN + wi) * EVAL_REP + r];   // (fields < 2^13 each: no carry)
+            c = (int)(sk < EVAL_NS / 2 ? (packed & 0xFFFFu) : (packed >> 16));
+        } else {
+#pragma unroll
+            for (int r = 0; r < EVAL_REP; r++) c += w_cnt[i * EVAL_REP + r];
+        }
         if (c) atomicAdd(&m.sample_score[(size_t)win.label_of(i / ns, p.gy) * ns + i % ns], c);
     }
 }
@@ -1363,6 +1425,19 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
 // accumulated into them since ingest).
 __device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int ns) {
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ns == 16) {
+        // the sixteen scores in ONE round of loads, the winner's plane in a second: written as the loop below, every step was
+        // a dependent trip to memory (score, wait, maybe the plane) -- sixteen to thirty-two of them in front of the barrier
+        typedef int32_t Score4 __attribute__((ext_vector_type(4), aligned(4)));
+        const Score4* __restrict__ sc = reinterpret_cast<const Score4*>(&m.sample_score[(size_t)l * 16]);
+        const Score4 s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3];
+        const int sv[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+        float bw = 0.f; int bk = -1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const float w = (float)sv[k]; if (w > bw) { bw = w; bk = k; } }
+        if (bk >= 0) { best = m.samples[(size_t)l * 16 + bk]; best.w = bw; }
+        return best;
+    }
     for (int k = 0; k < ns; k++) {
         float4 th = m.samples[(size_t)l * ns + k];
         th.w = (float)m.sample_score[(size_t)l * ns + k];
@@ -2038,7 +2113,8 @@ void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 static inline dim3 batch_tile_grid(const SegParams& p, int nb) { dim3 g = tile_grid(p); g.z = nb; return g; }
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb) {
     ScopedKernel sk("eval_samples", st);
-    hipLaunchKernelGGL(k_eval_samples, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
+    if (p.nb_samples == EVAL_NS) hipLaunchKernelGGL(k_eval_samples<true>, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
+    else hipLaunchKernelGGL(k_eval_samples<false>, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac) {
     ScopedKernel sk("init_disp", st);

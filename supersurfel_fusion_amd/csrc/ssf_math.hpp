@@ -123,10 +123,22 @@ SSF_HD M3 quat_to_rot_quirk(const float* q /* x, y, z, w */) {
 // ---- specified roots: IEEE double ops only (see DESIGN.md "arithmetic spec") -----------------
 SSF_HD double bits_to_f64(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 SSF_HD uint64_t f64_to_bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+// RN(x / 3.0) -- the IEEE quotient, bit for bit -- in three operations instead of the division's eleven: q = RN(x c) with
+// c = RN(1/3) is within 1.25 ulp of x / 3, so e = x - 3 q is a multiple (at most 4) of ulp(q) and exact in one fused
+// operation; q + e c = x / 3 + e (c - 1/3) differs from the true quotient by less than 2^-53 ulp, while x / 3 cannot lie
+// closer than ulp / 6 to a midpoint between two doubles (x is an even multiple of ulp / 2, three times a midpoint an odd
+// one): the final rounding returns RN(x / 3).  For normal x away from the ends of the exponent range -- the specified
+// cube root works on [0.008, 1.2].  (tools/probe/div3_check.c: 1.5e9 values against the division, no difference.)
+// Twelve of these per pixel in k_render_moments, whose time is this conversion's double-precision arithmetic.
+SSF_HD double div3_exact(double x) {
+    const double c = 0x1.5555555555555p-2;
+    const double q = x * c;
+    return fma(fma(-3.0, q, x), c, q);
+}
 SSF_HD double cbrt_spec(double a) {          // a > 0
     double y = bits_to_f64(f64_to_bits(a) / 3 + 0x2A9F7893782DA1CEull);
 #pragma unroll
-    for (int i = 0; i < 4; i++) y = (2.0 * y + a / (y * y)) / 3.0;
+    for (int i = 0; i < 4; i++) y = div3_exact(2.0 * y + a / (y * y));
     return y;
 }
 SSF_HD double root5_spec(double a) {         // a > 0
