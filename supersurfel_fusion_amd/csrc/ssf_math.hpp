@@ -135,10 +135,41 @@ SSF_HD double div3_exact(double x) {
     const double q = x * c;
     return fma(fma(-3.0, q, x), c, q);
 }
-SSF_HD double cbrt_spec(double a) {          // a > 0
-    double y = bits_to_f64(f64_to_bits(a) / 3 + 0x2A9F7893782DA1CEull);
+// b / 3 for a 64-bit pattern from 32-bit pieces: two multiply-high and a handful of adds instead of the compiler's 64 x 64
+// multiply-high (four quarter-rate 64-bit multiply-adds).  hi = 3 qh + r, lo = 3 t + s, 2^32 = 3 * 0x55555555 + 1:
+// r 2^32 + lo = 3 (r * 0x55555555 + t) + (r + s).  (tools/probe/div3_check.c: 2e9 patterns.)
+SSF_HD uint64_t div3_u64(uint64_t b) {
+    const uint32_t hi = (uint32_t)(b >> 32), lo = (uint32_t)b;
+    const uint32_t qh = (uint32_t)(((uint64_t)hi * 0xAAAAAAABull) >> 33), t = (uint32_t)(((uint64_t)lo * 0xAAAAAAABull) >> 33);
+    uint32_t qh2 = qh + qh, t2 = t + t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(qh2), "+v"(t2));       // (3 q as q + q + q: left to itself the compiler multiplies by -3 at a quarter of the rate)
+#endif
+    const uint32_t r = hi - (qh2 + qh), sm = lo - (t2 + t);            // remainders, 0 .. 2
+    const uint32_t rc = ((0u - (r & 1u)) & 0x55555555u) | ((0u - (r >> 1)) & 0xAAAAAAAAu);      // r * 0x55555555
+    const uint32_t ql = rc + t + ((r + sm) >= 3u ? 1u : 0u);
+    return ((uint64_t)qh << 32) | ql;
+}
+// n / d, bit for bit, for POSITIVE NORMAL operands of moderate exponent (the cube root's: [0.008, 1.2] / [0.04, 1.2]): the
+// IEEE division the compiler emits for gfx950 is v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal, the
+// quotient, one correction (v_div_fmas) and v_div_fixup; for such operands the scaling is the identity, v_div_fmas is a
+// plain fused multiply-add and the fix-up returns its input -- the eight operations below are the same operations on the
+// same values.  (Host code divides.)
+SSF_HD double div_inrange(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0); r = fma(r, e, r);
+    e = fma(-d, r, 1.0); r = fma(r, e, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+#else
+    return n / d;
+#endif
+}
+SSF_HD double cbrt_spec(double a) {          // a > 0 (normal, moderate exponent: see div_inrange)
+    double y = bits_to_f64(div3_u64(f64_to_bits(a)) + 0x2A9F7893782DA1CEull);
 #pragma unroll
-    for (int i = 0; i < 4; i++) y = div3_exact(2.0 * y + a / (y * y));
+    for (int i = 0; i < 4; i++) y = div3_exact(2.0 * y + div_inrange(a, y * y));
     return y;
 }
 SSF_HD double root5_spec(double a) {         // a > 0
