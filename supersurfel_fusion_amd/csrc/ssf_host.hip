@@ -289,8 +289,10 @@ static RcclApi* rccl_api() {
 // that also drives the track chain 30-70 us per frame (two hipMemcpyAsync, for pageable memory incl. the staging
 // copy).  In ssf_process_sequence the frames are known ahead, so a worker thread copies them into a ring of device
 // buffers on a stream of its own; the submitting thread only makes the extract stream wait for the copy's event.
-// A sequence starts with small batches (a quarter, then half of extract_batch, then full ones): the first frame can
+// A sequence starts with small batches (3/8, then 5/8 of extract_batch, then full ones): the first frame can
 // only be tracked when the whole first batch has been extracted, and a full batch of 8 takes twice as long as one of 2.
+// (Round 3, at the faster relabelling pass, two sweeps of three runs each over the driver's 20 frames: 3,5 7253-7378 frames/s |
+// 2,4 7168-7315 | 2,5 7243-7350 | 2,6 6920-7108 | 1,3 7162-7245 | 1,2,4 6811-6858 | 4 6665-6985: tools/ramp_probe.sh.)
 // (SSF_SEQ_RAMP="a,b,..": sizes of the leading batches for experiments, each clamped to [1, batch].  Measured over the
 // driver's 20 timed frames, batch 8, three runs each: 2,4 (the default) 5900-5990 frames/s | 2,2 5880-5980 | 2 5760-5820 |
 // 3 5680-5810 | 2,8 5700-5810 | 1 5600-5780 | 4 5530-5560)
@@ -301,7 +303,7 @@ static const SeqRamp& seq_ramp() {
         r.n = 0;
         const char* e = getenv("SSF_SEQ_RAMP");
         if (e) { for (const char* q = e; *q && r.n < 8;) { r.size[r.n++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
-        else { r.n = 2; r.size[0] = -4; r.size[1] = -2; }          // (negative: batch / |value|)
+        else { r.n = 2; r.size[0] = -3; r.size[1] = -5; }          // (negative: |value| eighths of the batch, rounded)
         return r;
     }();
     return ramp;
@@ -309,7 +311,7 @@ static const SeqRamp& seq_ramp() {
 static inline int seq_batch_size(int b, int batch) {
     const SeqRamp& r = seq_ramp();
     if (b >= r.n) return batch;
-    const int v = r.size[b] < 0 ? batch / -r.size[b] : r.size[b];
+    const int v = r.size[b] < 0 ? (-r.size[b] * batch + 4) / 8 : r.size[b];
     return std::min(batch, std::max(1, v));
 }
 static inline int seq_batch_of(int i, int batch) {
