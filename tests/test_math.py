@@ -146,6 +146,21 @@ def test_kernel_arithmetic_bitwise_oracle_vs_product(oracle_lib, product_lib):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_lab_of_8bit_colours_bitwise_oracle_vs_product(oracle_lib, product_lib):
+    """rgbToLab for the colours k_render_moments meets -- 8-bit channels: every grey, a 16^3 lattice, 20 000 random ones.
+    The product's specified cube root divides by three with a multiply and two fused operations (div3_exact) and takes the
+    start value's 64-bit pattern apart in 32-bit pieces (div3_u64); the oracle divides.  Same bits, colour by colour."""
+    rng = np.random.default_rng(2024)
+    cols = [np.float64([g, g, g]) for g in range(256)]
+    lat = np.arange(0, 256, 17, dtype=np.float64)
+    cols += [np.float64([r, g, b]) for r in lat for g in lat for b in lat]
+    cols += list(rng.integers(0, 256, (20000, 3)).astype(np.float64))
+    Lo, Lp = oracle_lib.lib, product_lib.lib
+    for c in cols:
+        a, b = call3(Lo, "ssf_dbg_rgb_to_lab", c), call3(Lp, "ssf_dbg_rgb_to_lab", c)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (c, a, b)
+
+
 def test_principal_frame_recovers_known_axes(oracle_lib):
     """eigenDecomposition by repeated squaring: major axis, normal and eigenvalues of a known
     covariance (rows = major, normal x major, normal; supersurfel_fusion_kernels.cu:48-111)."""

@@ -609,3 +609,19 @@ def test_association_inside_the_waiting_icp_launch(oracle_lib, product_lib):
     iters = [r["icp_iters"] for r in got]
     assert n >= 1, ("no frame's association ran in a waiting launch", iters)
     assert n == sum(1 for r in got if 0 < r["icp_iters"] < 10), (n, iters)
+
+
+def test_relabelling_passes_bit_exact_in_grid_order_too():
+    """The relabelling pass takes its tiles in an XCD-aware order by default (each XCD a contiguous eighth of the launch:
+    DESIGN.md section 4.1.3).  Only speed may depend on that: the per-pass comparison against the oracle is repeated in a
+    process whose passes take their tiles in plain grid order (SSF_PASS_XCD=0; the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSF_PASS_XCD="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_every_relabelling_pass_bit_exact or test_segmentation_parameter_space_batched"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-1000:]
