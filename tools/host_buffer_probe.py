@@ -11,7 +11,7 @@ nf = 24 + 1200
 frames = bench.render_frames(64)
 model, nvis = synthetic.seed_model_cam0(bench.N_MODEL, bench.W, bench.H, stamp=30)
 order = [(i % 126) if (i % 126) < 64 else 126 - (i % 126) for i in range(nf)]
-for kind in ("device", "pageable", "pinned"):
+for kind in os.environ.get("PROBE_KINDS", "device,pageable,pinned").split(","):
     if kind == "device":
         dev = torch.device("cuda", 0)
         keep = [(torch.from_numpy(f[0]).to(dev), torch.from_numpy(f[1]).to(dev)) for f in frames]
@@ -19,7 +19,7 @@ for kind in ("device", "pageable", "pinned"):
         keep = [(torch.from_numpy(f[0]).pin_memory(), torch.from_numpy(f[1]).pin_memory()) for f in frames]
     else:
         keep = [(torch.from_numpy(np.ascontiguousarray(f[0])), torch.from_numpy(np.ascontiguousarray(f[1]))) for f in frames]
-    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=2, extract_batch=8))
+    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=int(os.environ.get("PROBE_DEPTH", "2")), extract_batch=int(os.environ.get("PROBE_BATCH", "8"))))
     f.set_model(model, nvis, 30)
     pr = [keep[k][0].data_ptr() for k in order]; pd = [keep[k][1].data_ptr() for k in order]
     f.process_prepared(f.prepare_sequence(pr[:24], pd[:24]), on_device=(kind == "device"))
