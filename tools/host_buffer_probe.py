@@ -7,7 +7,7 @@ import torch
 import bench
 from supersurfel_fusion_amd import binding, synthetic
 lib = binding.load_product()
-nf = 24 + 1200
+nf = 24 + int(os.environ.get('PROBE_NF', '1200'))
 frames = bench.render_frames(64)
 model, nvis = synthetic.seed_model_cam0(bench.N_MODEL, bench.W, bench.H, stamp=30)
 order = [(i % 126) if (i % 126) < 64 else 126 - (i % 126) for i in range(nf)]
