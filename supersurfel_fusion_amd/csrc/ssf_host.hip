@@ -1277,7 +1277,7 @@ static inline void store_fence() {
 // to rest and stop chaining launches on this handle.
 static void icp_chain_reset(ssf_handle* h) {
     (void)hipStreamSynchronize(h->stream);
-    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, 2 * SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
     (void)hipStreamSynchronize(h->stream);
     h->icp_chain = false; h->ahead.valid = false;
@@ -1635,7 +1635,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->oov[1].live, OC) && dalloc(h, &h->d_state_oov, OC) && dalloc(h, &h->d_bc_oov, (OC + 255) / 256 + 8) &&
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, 64) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
-         dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, SSF_ICP_REPLICAS * 32);
+         dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, 2 * SSF_ICP_REPLICAS * 32)     /* second half: the counted record of k_icp */;
     {
         const int bw = bin_count_words(h->cam);
         if (const char* e = getenv("SSF_BIN_MIN_ROWS")) h->bin_min_rows = atoi(e);          // (measurement switch; < 0: never)
@@ -1656,7 +1656,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         for (int c8 = 0; c8 < 256; c8++) lut[c8] = srgb_expand((float)c8 / 255.0f);
         (void)hipMemcpy(h->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
     }
-    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, 2 * SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
     (void)hipMemsetAsync(h->d_part, 0, 2 * (size_t)h->part_words * sizeof(uint32_t), h->stream);
     (void)hipMemsetAsync(h->d_part_ticket, 0, 128 * sizeof(uint32_t), h->stream);
@@ -2490,7 +2490,7 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     (void)hipEventRecord(e1, h->stream);
     (void)hipStreamSynchronize(h->stream);
     float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipMemsetAsync(h->d_icp_replicas, 0, SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
+    (void)hipMemsetAsync(h->d_icp_replicas, 0, 2 * SSF_ICP_REPLICAS * 32 * sizeof(long long), h->stream);
     (void)hipMemsetAsync(h->d_tickets, 0, 512 * sizeof(unsigned int), h->stream);
     (void)hipStreamSynchronize(h->stream);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -264,6 +264,87 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
             __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- the counted record: the end of an accumulating launch in ONE trip instead of three ------------------------------------
+// icp_fold / grid_arrive / icp_publish above cost three DEPENDENT trips to the coherence point after the last row: the
+// returning adds into a replica (their return is the proof they were performed), the arrival ticket (two levels), the last
+// workgroup's read of the replicas -- 4-5 us of an 8 us launch that runs three times per frame on the critical chain.
+// Here every word proves its own completeness: a workgroup adds (sum << 10) + 1 to each of the 30 words of its replica --
+// fire and forget, no return, no ticket --, so the low ten bits of a word count the workgroups that have contributed to it
+// (at most 512 per replica: 4096 workgroups over 8 replicas) and the rest is the exact sum (terms are 32-bit fixed point,
+// at most 2^17 rows per replica: < 2^48; term 27, a 64-bit fixed-point sum, travels as its low 40 bits and the rest in word
+// 29).  A fixed workgroup -- the last of the grid: it starts last -- collects: 240 threads EXCHANGE one word each with zero
+// (a returning read-modify-write: what it returns has been performed, and it leaves the record clean for the next launch
+// whatever lands when), add what they got to what they had, and repeat until every word's count says that all workgroups of
+// its replica are in; then the record is decoded, summed over the replicas and published exactly like icp_publish's.
+// Exact integers throughout: the published record is the old one bit for bit.  The wait is bounded by wall-clock time.
+#define ICP_CNT_BITS 10
+#define ICP_CNT_WORDS 30
+#ifndef SSF_ICP_COLLECT_WAIT_TICKS
+#define SSF_ICP_COLLECT_WAIT_TICKS 5000000ull      // 50 ms of the 100 MHz wall clock
+#endif
+__device__ __forceinline__ void icp_fold_counted(const unsigned long long* red, unsigned long long* __restrict__ counted) {
+    if (threadIdx.x < ICP_CNT_WORDS) {
+        const int k = threadIdx.x == 29 ? 27 : (int)threadIdx.x;
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < ICP_SLOTS; sidx++) tot += red[k * ICP_SLOTS + sidx];
+        long long v = (long long)tot;
+        if (threadIdx.x == 27) v = (long long)(tot & ((1ull << 40) - 1ull));            // term 27: low 40 bits here ...
+        if (threadIdx.x == 29) v = (long long)tot >> 40;                                // ... the rest (signed) in word 29
+        unsigned long long* rep = counted + (size_t)(blockIdx.x % SSF_ICP_REPLICAS) * 32;
+        (void)__hip_atomic_fetch_add(&rep[threadIdx.x], ((unsigned long long)v << ICP_CNT_BITS) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void icp_collect_counted(unsigned long long* __restrict__ counted, long long* __restrict__ sums, Mailbox* mb,
+                                                    unsigned long long seq) {
+    __shared__ long long part[SSF_ICP_REPLICAS * 32];
+    __shared__ int s_expired;
+    static_assert(SSF_ICP_REPLICAS * ICP_CNT_WORDS <= 256, "one word per thread of the collecting workgroup");
+    const int r = threadIdx.x / ICP_CNT_WORDS, k = threadIdx.x - r * ICP_CNT_WORDS;
+    const bool mine = r < SSF_ICP_REPLICAS;
+    // workgroups b with b % 8 == r
+    const unsigned int expect = mine ? (gridDim.x + SSF_ICP_REPLICAS - 1u - (unsigned int)r) / SSF_ICP_REPLICAS : 0u;
+    unsigned long long acc = 0ull;
+    if (threadIdx.x == 0) s_expired = 0;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned int round = 0;; round++) {
+        bool done = !mine || (unsigned int)(acc & ((1ull << ICP_CNT_BITS) - 1ull)) == expect;
+        if (!done) {
+            acc += __hip_atomic_exchange(&counted[r * 32 + k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = (unsigned int)(acc & ((1ull << ICP_CNT_BITS) - 1ull)) == expect;
+        }
+        if (__syncthreads_and(done ? 1 : 0)) break;
+        if (threadIdx.x == 0 && (round & 15u) == 15u && wall_clock64() - t0 > SSF_ICP_COLLECT_WAIT_TICKS) s_expired = 1;
+        __syncthreads();
+        if (s_expired) return;                   // (no record: the host's own bounded wait reports it and puts the buffers back to rest)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (mine) {
+        const unsigned long long cnt = acc & ((1ull << ICP_CNT_BITS) - 1ull);
+        part[r * 32 + k] = (long long)(acc - cnt) >> ICP_CNT_BITS;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        __shared__ unsigned long long pay[30];
+        long long tot = 0;
+        if (threadIdx.x < ICP_CNT_WORDS)
+            for (int q = 0; q < SSF_ICP_REPLICAS; q++) tot += part[q * 32 + threadIdx.x];
+        // term 27 = (word 29 << 40) + word 27
+        const long long hi27 = (long long)shfl_u64((unsigned long long)tot, 29);
+        if (threadIdx.x == 27) tot = (long long)(((unsigned long long)hi27 << 40) + (unsigned long long)tot);
+        if (threadIdx.x >= 29) tot = 0;
+        if (threadIdx.x < 29) {
+            sums[threadIdx.x] = tot;
+            pay[threadIdx.x] = (unsigned long long)tot;
+        }
+        const unsigned long long check = (unsigned long long)wsum64(tot) + seq;
+        if (threadIdx.x == 0) pay[29] = check;
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the LDS writes have landed
+        if (threadIdx.x < 40)
+            __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // Rows sorted by image tile (k_bin_* below) are handed to the launch's workgroups so that ONE XCD works on one contiguous
 // eighth of them -- an eighth of the image: its L2 then holds an eighth of the frame's (label, depth) table instead of
 // all of it.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): logical block =
@@ -275,6 +356,7 @@ __device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int n
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched);
+#define SSF_ICP_DBG_COUNTED 0x40000000          // bit of k_icp's `dbg` argument: end the launch with the counted record
 #ifndef SSF_ICP_GO_WAIT_TICKS
 #define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
 #endif
@@ -374,6 +456,14 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     if (dbg & 4) {                              // probe: fold only
         icp_fold(red, replicas);
         return;
+    }
+    if constexpr (!P2P) {
+        if (dbg & SSF_ICP_DBG_COUNTED) {            // the counted record (second half of the replica buffer): see icp_fold_counted
+            unsigned long long* counted = reinterpret_cast<unsigned long long*>(replicas) + SSF_ICP_REPLICAS * 32;
+            icp_fold_counted(red, counted);
+            if (blockIdx.x == gridDim.x - 1) icp_collect_counted(counted, sums, mb, seq);
+            return;
+        }
     }
     icp_fold(red, replicas);
     if (threadIdx.x == 0) s_last = grid_arrive(ticket);
@@ -1867,8 +1957,11 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     int grid = (n_visible + per_block - 1) / per_block;
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
     if (grid > 4096) grid = 4096;
-    const int dbg = dbg_arg < 0 ? 0 : dbg_arg;
-    const bool acc = per_lane > 1 && dbg == 0;       // (the probe switches live in the one-row-per-thread form)
+    // the counted record (one trip at the end of the launch instead of three): single GPU, no probe switches
+    static int counted = -1;
+    if (counted < 0) { const char* e = getenv("SSF_ICP_COUNTED"); counted = e ? atoi(e) : 1; }
+    const bool acc = per_lane > 1 && dbg_arg <= 0;   // (the probe switches live in the one-row-per-thread form)
+    const int dbg = (dbg_arg < 0 ? 0 : dbg_arg) | ((counted && !pv && dbg_arg < 0) ? SSF_ICP_DBG_COUNTED : 0);
     const P2PView none{};
     const P2PView& v = pv ? *pv : none;
     if (pv && acc) hipLaunchKernelGGL((k_icp<true, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
