@@ -276,11 +276,13 @@ __device__ __forceinline__ void icp_publish(long long* __restrict__ replicas, lo
 // (a returning read-modify-write: what it returns has been performed, and it leaves the record clean for the next launch
 // whatever lands when), add what they got to what they had, and repeat until every word's count says that all workgroups of
 // its replica are in; then the record is decoded, summed over the replicas and published exactly like icp_publish's.
-// Exact integers throughout: the published record is the old one bit for bit.  The wait is bounded by wall-clock time.
+// Exact integers throughout: the published record is the old one bit for bit.  The wait is bounded by wall-clock time
+// (SSF_ICP_COLLECT_WAIT_TICKS).
 #define ICP_CNT_BITS 10
 #define ICP_CNT_WORDS 30
 #ifndef SSF_ICP_COLLECT_WAIT_TICKS
-#define SSF_ICP_COLLECT_WAIT_TICKS 5000000ull      // 50 ms of the 100 MHz wall clock
+#define SSF_ICP_COLLECT_WAIT_TICKS 400000000ull    // 4 s of the 100 MHz wall clock: below the host's own 5 s wait for the record, far above
+                                                   // anything a part shared with other processes delays a workgroup by
 #endif
 __device__ __forceinline__ void icp_fold_counted(const unsigned long long* red, unsigned long long* __restrict__ counted) {
     if (threadIdx.x < ICP_CNT_WORDS) {
