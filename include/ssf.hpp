@@ -15,10 +15,43 @@
 #include <vector>
 #include "ssf.h"
 
+/* The reference's pose / matrix types (core/include/supersurfel_fusion/matrix_types.h:26-42), at GLOBAL scope as there,
+ * so that the nodes' lines compile as they stand:
+ *     Transform3 pose = ssf.getPose();
+ *     tf::Matrix3x3(pose.R.rows[0].x, pose.R.rows[0].y, ... ), tf::Vector3(pose.t.x, pose.t.y, pose.t.z)
+ * (node/supersurfel_fusion_node.cpp:87-91, node/supersurfel_fusion_rgbd_benchmark_node.cpp:616-620).  The reference gets
+ * float3 from <cuda_runtime.h>; a translation unit that already has HIP's or CUDA's vector types keeps those (same three
+ * floats x, y, z), any other gets the plain struct below.  SSF_NO_MATRIX_TYPES: the includer brings its own
+ * matrix_types.h. */
+#ifndef SSF_NO_MATRIX_TYPES
+#if !defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H) && !defined(__VECTOR_TYPES_H__) && !defined(SSF_HAVE_FLOAT3)
+#define SSF_HAVE_FLOAT3
+struct float3 { float x, y, z; };
+#endif
+#ifndef MATRIX_TYPES_HPP            /* the reference header's own guard: both may be included, in either order */
+#define MATRIX_TYPES_HPP
+struct Cov3 { float xx, xy, xz, yy, yz, zz; };                          /* matrix_types.h:26-31 */
+struct Mat33 { float3 rows[3]; };                                       /* matrix_types.h:33-36 */
+struct Transform3 { Mat33 R; float3 t; };                               /* matrix_types.h:38-42: camera-to-map */
+#endif
+#endif
+
 namespace supersurfel_fusion {
 
 struct CamParam { float fx, fy, cx, cy; int height, width; };          /* cam_param.hpp:27-31 */
-struct Transform3 { float R[9]; float t[3]; };                          /* matrix_types.h:38-42, row-major */
+using ::Transform3; using ::Mat33; using ::Cov3; using ::float3;       /* the reference's are global; both spellings work */
+
+/* Transform3 <-> the C ABI's 12 floats (row-major R, then t) */
+inline Transform3 transform3_from_rt(const float v[12]) {
+    Transform3 p;
+    for (int r = 0; r < 3; r++) { p.R.rows[r].x = v[3 * r]; p.R.rows[r].y = v[3 * r + 1]; p.R.rows[r].z = v[3 * r + 2]; }
+    p.t.x = v[9]; p.t.y = v[10]; p.t.z = v[11];
+    return p;
+}
+inline void transform3_to_rt(const Transform3& p, float v[12]) {
+    for (int r = 0; r < 3; r++) { v[3 * r] = p.R.rows[r].x; v[3 * r + 1] = p.R.rows[r].y; v[3 * r + 2] = p.R.rows[r].z; }
+    v[9] = p.t.x; v[10] = p.t.y; v[11] = p.t.z;
+}
 
 /* host copy of a supersurfel set in the reference's SoA layout (supersurfels.hpp:34-40) */
 struct HostSupersurfels {
@@ -131,17 +164,17 @@ public:
         check(ssf_get_plane_depth(need(), v.data()));
         return v;
     }
-    Transform3 getPose() const {
-        Transform3 p; float v[12];
+    /* getPose(): supersurfel_fusion.hpp:89 -- `const Transform3&`, camera-to-map, valid until the next call on this
+     * object (the reference returns a reference to its member; so does this, refreshed from the library) */
+    const Transform3& getPose() const {
+        float v[12];
         check(ssf_get_pose(need(), v));
-        for (int i = 0; i < 9; i++) p.R[i] = v[i];
-        for (int i = 0; i < 3; i++) p.t[i] = v[9 + i];
-        return p;
+        pose_ = transform3_from_rt(v);
+        return pose_;
     }
     void setPose(const Transform3& p) {
         float v[12];
-        for (int i = 0; i < 9; i++) v[i] = p.R[i];
-        for (int i = 0; i < 3; i++) v[9 + i] = p.t[i];
+        transform3_to_rt(p, v);
         check(ssf_set_pose(need(), v));
     }
     int getnbSupersurfels() const { int n = 0; check(ssf_get_counts(need(), &n, nullptr, nullptr, nullptr)); return n; }
@@ -181,6 +214,7 @@ private:
     void check(int rc) const { if (rc != SSF_OK) throw std::runtime_error(std::string(ssf_last_error(h_))); }
     ssf_handle* h_ = nullptr;
     ssf_frame_result last_{};
+    mutable Transform3 pose_{};
     int width_ = 0, height_ = 0;
     int pipeline_depth_ = 0, extract_batch_ = 1; bool depth_prefilter_ = true;
 };

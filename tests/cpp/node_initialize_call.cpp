@@ -82,8 +82,9 @@ int main(int argc, char** argv) {
             ssf.processFrame(rgb[k].data(), depth[k].data());
             pod.processFrame(rgb[k].data(), depth[k].data());
             const supersurfel_fusion::Transform3 a = ssf.getPose(), b = pod.getPose();
-            for (int i = 0; i < 9; i++) same = same && a.R[i] == b.R[i];
-            for (int i = 0; i < 3; i++) same = same && a.t[i] == b.t[i];
+            float va[12], vb[12];
+            supersurfel_fusion::transform3_to_rt(a, va); supersurfel_fusion::transform3_to_rt(b, vb);
+            for (int i = 0; i < 12; i++) same = same && va[i] == vb[i];
             same = same && ssf.getnbSupersurfels() == pod.getnbSupersurfels() && ssf.getnbVisible() == pod.getnbVisible();
         }
         std::printf("node_call_equals_pod_config %d n=%d\n", same ? 1 : 0, ssf.getnbSupersurfels());

@@ -30,8 +30,8 @@ int main(int argc, char** argv) {
             const Transform3 p = a.getPose();
             std::printf("frame %d n=%d vis=%d stamp=%d icp=%d/%d pose", k, a.getnbSupersurfels(), a.getnbVisible(), a.getStamp(),
                         a.lastResult().icp_valid, a.lastResult().icp_iters);
-            for (int i = 0; i < 9; i++) std::printf(" %.9g", p.R[i]);
-            for (int i = 0; i < 3; i++) std::printf(" %.9g", p.t[i]);
+            for (int r = 0; r < 3; r++) std::printf(" %.9g %.9g %.9g", p.R.rows[r].x, p.R.rows[r].y, p.R.rows[r].z);
+            std::printf(" %.9g %.9g %.9g", p.t.x, p.t.y, p.t.z);
             std::printf("\n");
         }
         HostSupersurfels m = a.getModel();
@@ -45,8 +45,9 @@ int main(int argc, char** argv) {
         std::printf("sequence n=%d last_n=%d\n", (int)res.size(), res.back().n_model);
         bool same = b.getnbSupersurfels() == a.getnbSupersurfels();
         const Transform3 pa = a.getPose(), pb = b.getPose();
-        for (int i = 0; i < 9; i++) same = same && pa.R[i] == pb.R[i];
-        for (int i = 0; i < 3; i++) same = same && pa.t[i] == pb.t[i];
+        float va[12], vb[12];
+        transform3_to_rt(pa, va); transform3_to_rt(pb, vb);
+        for (int i = 0; i < 12; i++) same = same && va[i] == vb[i];
         std::printf("sequence_equals_frames %d\n", same ? 1 : 0);
         SupersurfelFusion c;
         try { c.getPose(); return 6; } catch (const std::logic_error&) { std::printf("uninitialised_throws 1\n"); }

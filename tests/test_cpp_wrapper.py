@@ -146,6 +146,47 @@ def test_the_reference_nodes_initialize_call_on_the_hip_library(product_lib, tmp
     _run_node_call(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
 
 
+def _run_node_pose(oracle_lib, lib_path, lib_name, tmp_path):
+    """tests/cpp/node_pose_use.cpp: the pose block of both reference nodes (node/supersurfel_fusion_node.cpp:87-91,
+    node/supersurfel_fusion_rgbd_benchmark_node.cpp:616-620), verbatim, against include/ssf.hpp and a tf:: double: the nine +
+    three values a node would broadcast are ssf_get_pose's, and those are the oracle's."""
+    W, H, n = 640, 480, 3          # at 640x480 the ICP is accepted from frame 1 on: the pose the node reads has moved
+    frames = [util.frame(k, W, H) for k in range(n)]
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        for rgb, depth in frames:
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes()); f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+    exe = tmp_path / "node_pose_use"
+    libdir = os.path.dirname(lib_path)
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "node_pose_use.cpp"), "-o", str(exe), "-L", libdir, "-l" + lib_name, "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    K = synthetic.intrinsics(W, H)
+    r = subprocess.run([str(exe), str(W), str(H), str(n), str(raw)] + [repr(float(K[k])) for k in ("fx", "fy", "cx", "cy")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=50000, depth_prefilter=1))
+    moved = False
+    for k, (rgb, depth) in enumerate(frames):
+        res = fo.process_frame(rgb, depth)
+        tok = lines[k].split()
+        assert tok[:4] == ["frame", str(k), "node_pose_equals_abi", "1"], lines[k]
+        pose = np.array([float(x) for x in tok[5:17]], np.float32)
+        assert np.array_equal(pose.view(np.uint32), res["pose"].astype(np.float32).view(np.uint32)), lines[k]
+        moved = moved or not np.array_equal(pose, np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32))
+    assert moved, "the test sequence never left the identity pose"
+
+
+def test_the_reference_nodes_pose_lines_compile_and_read_the_pose(oracle_lib, tmp_path):
+    _run_node_pose(oracle_lib, ORACLE_LIB, "ssf_oracle", tmp_path)
+
+
+@pytest.mark.gpu
+def test_the_reference_nodes_pose_lines_on_the_hip_library(oracle_lib, product_lib, tmp_path):
+    _run_node_pose(oracle_lib, os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
+
+
 def test_model_device_view_has_the_reference_layout(oracle_lib):
     """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
     import ctypes as C
