@@ -221,6 +221,38 @@ def render_frames(n, tum_shaped=False):
     return frames
 
 
+def launch_plan(gpus, env, device_count, argv):
+    """What `python bench.py --gpus N ...` has to do given how it was started (pure: tests/test_bench_launcher.py).
+      ("run", None)      this process is a rank (N == 1, or launched by torch.distributed.run with WORLD_SIZE == N)
+      ("spawn", cmd)     N > 1 and no WORLD_SIZE in the environment: re-exec under torch.distributed.run, one rank per GPU
+      ("error", text)    the box cannot run it (fewer than N GPUs; --gpus disagrees with the launcher's WORLD_SIZE)"""
+    if gpus < 1:
+        return "error", "--gpus must be >= 1 (got %d)" % gpus
+    if "WORLD_SIZE" in env:                                   # under a launcher (the driver's form for N > 1)
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            return "error", "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (gpus, world, gpus)
+        if device_count < 1:
+            return "error", "bench.py needs a GPU (the product has no CPU fallback)"
+        local = int(env.get("LOCAL_RANK", "0"))
+        if local >= device_count:
+            return "error", "LOCAL_RANK %d but only %d GPU(s) visible" % (local, device_count)
+        return "run", None
+    if device_count < gpus:
+        return "error", ("--gpus %d but %d GPU(s) visible on this box" % (gpus, device_count)) if device_count else "bench.py needs a GPU (the product has no CPU fallback)"
+    if gpus == 1:
+        return "run", None
+    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def error_line(text, gpus):
+    """the one JSON line of a run that cannot start: same keys a reader of the contract looks for, value null"""
+    return json.dumps({"metric": "frames_per_sec", "value": None, "unit": "frames/s", "n_gpus": gpus, "error": text})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,19 +296,31 @@ def main():
         a.steps, a.warmup, a.rendered_frames = min(a.steps, 64), min(a.warmup, 8), min(a.rendered_frames, 16)
     P = W * H
 
+    # how was this started?  N > 1 without a launcher: start one (one rank per GPU); a box that cannot run it gets one
+    # JSON line with "error" and a non-zero exit, not a traceback
+    plan, detail = launch_plan(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:])
+    if plan == "error":
+        if int(os.environ.get("RANK", "0")) == 0:
+            os.dup2(saved_stdout, 1)
+            print(error_line(detail, a.gpus), flush=True)
+        sys.stderr.write("bench.py: %s\n" % detail)
+        sys.exit(2)
+    if plan == "spawn":
+        os.dup2(saved_stdout, 1)                   # the ranks inherit the real stdout: rank 0 prints the line
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", "16")     # torch.distributed.run would set 1 (and say so): the cpu_baseline leg of rank 0 uses OpenMP
+        os.execve(sys.executable, detail, env)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if a.config == 4:
         N_MODEL = 500000 * world                       # BASELINE config 4: ~2 M supersurfels over 4 GPUs -> 500 k per rank
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     affinity = pin_to_gpu_numa_node(local) if a.pin else dict(pinned=False, reason="--pin 0")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
 
     lib = binding.load_product()       # raises when libssf_hip.so is missing: no fallback
     K, Wm = a.steps, a.warmup
@@ -366,6 +410,9 @@ def main():
     else:
         f, drv = make_engine(exchange and a.py_driver)
     eng = drv if drv is not None else f
+    comm_info = f.comm_info()
+    if exchange and drv is None and comm_info["ranks"] != world:
+        raise RuntimeError("the attached exchange reports %d rank(s), the launcher %d" % (comm_info["ranks"], world))
 
     def step(i):
         if drv is not None:
@@ -648,7 +695,10 @@ def main():
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp), "baseline_config": a.config,
-                       "exchange": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
+                       "exchange": (a.comm if native_ok and drv is None else "torch.distributed") if exchange else "none",
+                       "exchange_note": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
+                       # what the attached exchange itself reports (ncclCommCount / opened regions): must equal n_gpus
+                       "exchange_ranks_reported": comm_info["ranks"], "exchange_backend_attached": comm_info["backend"],
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,

@@ -336,6 +336,10 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
  * torch.distributed backend through the stage seams). */
 int ssf_comm_unique_id(uint8_t* id128);
 int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
+/* what is attached: *backend = 0 none, 1 RCCL, 2 peer-to-peer regions; *ranks = the number of ranks the exchange
+ * itself reports (ncclCommCount of the communicator; the number of opened regions + 1), 1 when nothing is attached;
+ * *my_rank likewise (ncclCommUserRank).  A launcher prints these next to cfg.nranks: they must agree. */
+int ssf_comm_info(ssf_handle* h, int* backend, int* ranks, int* my_rank);
 int ssf_get_global_counts(ssf_handle* h, int64_t* out5);
 
 /* ---- multi-GPU, native: peer to peer over xGMI, no collective launches ---------------------------

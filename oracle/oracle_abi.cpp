@@ -153,6 +153,13 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
 // the checker has no RCCL: the native multi-GPU entry points report that (sharded.py covers N > 1 on CPU)
 int ssf_comm_unique_id(uint8_t* id128) { (void)id128; g_create_err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
 int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) { (void)id128; if (h) h->s.err = "the CPU checker has no RCCL"; return SSF_ERR_DEVICE; }
+int ssf_comm_info(ssf_handle* h, int* backend, int* ranks, int* my_rank) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    if (backend) *backend = 0;
+    if (ranks) *ranks = 1;
+    if (my_rank) *my_rank = 0;
+    return SSF_OK;
+}
 int ssf_p2p_export(ssf_handle* h, uint8_t* handle64) { (void)handle64; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles) { (void)handles; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes) { (void)region; (void)bytes; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }

@@ -66,7 +66,7 @@ ABI_SYMBOLS = [
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
-    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_rehome_begin", "ssf_rehome_end", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
+    "ssf_comm_unique_id", "ssf_comm_attach", "ssf_comm_info", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_rehome_begin", "ssf_rehome_end", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -416,6 +416,12 @@ class Fusion:
             raise SsfError(obj[1])
         ident = np.frombuffer(obj[0], np.uint8).copy()
         self._ck(self.L.lib.ssf_comm_attach(self.h, _ptr(ident)), "ssf_comm_attach")
+
+    def comm_info(self):
+        """what exchange is attached and how many ranks it reports itself: dict(backend 'none' | 'rccl' | 'p2p', ranks, rank)"""
+        b, n, r = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.L.lib.ssf_comm_info(self.h, C.byref(b), C.byref(n), C.byref(r)), "ssf_comm_info")
+        return dict(backend=("none", "rccl", "p2p")[b.value], ranks=n.value, rank=r.value)
 
     # peer-to-peer exchange (ssf_p2p_* in ssf.h): the ranks of one node trade their records through each other's HBM
     P2P_HANDLE_BYTES = 64

@@ -262,6 +262,8 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     std::string err;
 };
 static RcclApi* rccl_api() {
@@ -279,6 +281,8 @@ static RcclApi* rccl_api() {
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) {
         api.err = "librccl lacks a required symbol"; api.lib = nullptr; return nullptr;
     }
@@ -1900,6 +1904,22 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) {
     std::memcpy(&id, id128, 128);
     NCK(api->CommInitRank(&h->comm, h->cfg.nranks, id, h->cfg.rank));
     h->all_valid = false; h->all_pending = false;
+    return SSF_OK;
+}
+int ssf_comm_info(ssf_handle* h, int* backend, int* ranks, int* my_rank) {
+    if (!h) return SSF_ERR_INVALID_ARG;
+    int b = 0, n = 1, r = 0;
+    if (h->comm) {
+        b = 1; n = h->cfg.nranks; r = h->cfg.rank;
+        RcclApi* api = rccl_api();
+        if (api && api->CommCount && api->CommUserRank) { NCK(api->CommCount(h->comm, &n)); NCK(api->CommUserRank(h->comm, &r)); }
+    } else if (h->p2p.on) {
+        b = 2; n = (int)h->p2p.opened.size() + 1; r = h->cfg.rank;
+        if (h->p2p.opened.empty()) n = h->cfg.nranks;        // ranks of one process (ssf_p2p_attach_local): nothing was opened through IPC
+    }
+    if (backend) *backend = b;
+    if (ranks) *ranks = n;
+    if (my_rank) *my_rank = r;
     return SSF_OK;
 }
 // ---- multi-GPU (native, peer to peer: no collective launches) ---------------------------------------------------

@@ -1,0 +1,74 @@
+"""bench.py's launcher decision (`python bench.py --gpus N` must start its own ranks, or end in ONE JSON line with "error"
+-- never a traceback): the pure function, and the real script on this GPU-less box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _plan(*a, **k):
+    import bench
+    return bench.launch_plan(*a, **k)
+
+
+def test_one_gpu_runs_in_process():
+    assert _plan(1, {}, 1, []) == ("run", None)
+    assert _plan(1, {}, 8, ["--steps", "20"]) == ("run", None)
+
+
+def test_more_gpus_than_the_box_has_is_an_error_record():
+    kind, text = _plan(2, {}, 1, [])
+    assert kind == "error" and "--gpus 2" in text and "1 GPU" in text
+    kind, text = _plan(1, {}, 0, [])
+    assert kind == "error" and "needs a GPU" in text
+    assert _plan(0, {}, 8, [])[0] == "error"
+
+
+def test_n_gpus_without_a_launcher_spawns_one_rank_per_gpu():
+    kind, cmd = _plan(4, {"MASTER_PORT": "29777"}, 8, ["--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert kind == "spawn"
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]         # the script's own arguments, untouched
+
+
+def test_under_a_launcher_the_process_is_a_rank():
+    assert _plan(8, {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"}, 8, []) == ("run", None)
+    assert _plan(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 1, []) == ("run", None)
+    kind, text = _plan(4, {"WORLD_SIZE": "2"}, 8, [])
+    assert kind == "error" and "WORLD_SIZE=2" in text
+    kind, text = _plan(2, {"WORLD_SIZE": "2", "LOCAL_RANK": "1"}, 1, [])
+    assert kind == "error" and "LOCAL_RANK 1" in text
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="box has a GPU")
+def test_the_script_itself_ends_in_one_json_error_line_here():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 2, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] is None and "error" in rec and "Traceback" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_gpus_on_a_one_gpu_box_is_the_error_record_not_a_traceback():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs: the launch itself is the driver's scale run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 2
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2 and "2 but 1 GPU" in json.loads(lines[0])["error"]
+    assert "Traceback" not in r.stderr
