@@ -437,7 +437,11 @@ int ssf_apply_deformation(ssf_handle* h, const float* node_positions, const floa
  *                      when table_rows records do not suffice.
  *   ssf_rehome_end     `table` holds n records -- the tables of all ranks one after the other in rank order, or any selection
  *                      in that order that contains every record addressed to this rank: those are appended, the ones
- *                      flagged visible behind the visible block, the others behind the out-of-view rows.
+ *                      flagged visible behind the visible block, the others behind the out-of-view rows.  Returns 0, a
+ *                      negative ssf_status, or the POSITIVE number of arrivals a full shard had to turn away (in table
+ *                      order; their source shards have already let them go, so they are lost to the map -- the same rule
+ *                      as an arrival at a full shard inside a frame, which counts as removed).  Never fails for lack of
+ *                      room: an error on one rank after the others have committed could not be rolled back.
  * No frame may be pending in the extract pipeline.  Both calls are no-ops for an unsharded handle. */
 int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out);
 int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n);

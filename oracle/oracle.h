@@ -137,7 +137,7 @@ void apply_deformation(State& s, const float* npos, const float* nrot, const flo
                        const float* w4, const int32_t* idx4);
 int  shard_owner(const State& s, int f, const Pose& pose);
 int  rehome_begin(State& s, int32_t* table, int cap);
-bool rehome_end(State& s, const int32_t* table, int n);
+int  rehome_end(State& s, const int32_t* table, int n);
 void rot_to_quat(const Mat33& m, float* q /* x, y, z, w */);    // matrix_math.cuh:529-618
 Mat33 quat_to_rot(const float* q);                              // matrix_math.cuh:512-527 (wy quirk kept)
 // host solvers (pinned against the reference's vendored Eigen by oracle/_ref)

@@ -399,8 +399,7 @@ int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out) 
 int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n) {
     if (!h || n < 0 || (!table && n > 0)) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty()) { h->s.err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
-    if (!rehome_end(h->s, table, n)) { h->s.err = "ssf_rehome_end: no room for the arriving rows"; return SSF_ERR_CAPACITY; }
-    return SSF_OK;
+    return rehome_end(h->s, table, n);           // >= 0: the number of arrivals a full shard turned away
 }
 int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device) {
     (void)on_device;

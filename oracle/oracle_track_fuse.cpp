@@ -684,29 +684,33 @@ int rehome_begin(State& s, int32_t* table, int cap) {
     return w;
 }
 // rehome_end: the records addressed to this rank arrive, in table order: those flagged visible behind the visible
-// block, the others behind the out-of-view rows.  false (nothing changed) when the shard has no room for them.
-bool rehome_end(State& s, const int32_t* table, int n) {
+// block, the others behind the out-of-view rows.  A full shard turns the surplus away, in table order (as migrate_in does
+// inside a frame): returns their number (0 = every arrival has a row).
+int rehome_end(State& s, const int32_t* table, int n) {
     const ssf_config& c = s.cfg;
-    int av = 0, ao = 0;
+    int av = 0, ao = 0, turned_away = 0, room = c.nb_supersurfels_max - s.n_model;
+    std::vector<char> take(n > 0 ? n : 1, 0);
     for (int j = 0; j < n; j++) {
         const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * j];
-        if (w[0] - 1 == c.rank) { if (w[1]) av++; else ao++; }
+        if (w[0] - 1 != c.rank) continue;
+        if (room <= 0) { turned_away++; continue; }
+        room--; take[j] = 1;
+        if (w[1]) av++; else ao++;
     }
-    if (av + ao == 0) return true;
-    if (s.n_model + av + ao > c.nb_supersurfels_max) return false;
+    if (av + ao == 0) return turned_away;
     Surfels& M = s.model;
     // make room for the visible arrivals between the two blocks: the out-of-view rows move up by av (from the back)
     for (int i = s.n_model - 1; i >= s.n_visible; i--) { M.copy_row(i + av, M, i); s.model_lab[i + av] = s.model_lab[i]; }
     int kv = s.n_visible, ko = s.n_model + av;
     for (int j = 0; j < n; j++) {
+        if (!take[j]) continue;
         const int32_t* w = &table[(size_t)SSF_MIGRANT_WORDS * j];
-        if (w[0] - 1 != c.rank) continue;
         const int k = w[1] ? kv++ : ko++;
         slot_to_row(M, k, w);
         s.model_lab[k] = rgbToLab(M.col[k]);
     }
     s.n_visible += av; s.n_model += av + ao;
-    return true;
+    return turned_away;
 }
 
 // applyDeformation, deformation_graph_kernels.cu:27-73

@@ -573,9 +573,13 @@ class Fusion:
         return table[:n.value].copy()
 
     def rehome_end(self, table):
-        """table: the records of all ranks in rank order (those addressed to this rank are appended)"""
+        """table: the records of all ranks in rank order (those addressed to this rank are appended).  Returns the number of
+        arrivals a full shard had to turn away (lost to the map, like an arrival at a full shard inside a frame)"""
         table = np.ascontiguousarray(table, np.int32).reshape(-1, MIGRANT_WORDS)
-        self._ck(self.L.lib.ssf_rehome_end(self.h, _ptr(table), len(table)), "ssf_rehome_end")
+        rc = self.L.lib.ssf_rehome_end(self.h, _ptr(table), len(table))
+        if rc < 0:
+            self._ck(rc, "ssf_rehome_end")
+        return rc
 
     def bilateral_filter(self, depth):
         depth = np.ascontiguousarray(depth, np.float32)

@@ -25,6 +25,7 @@
 #include <utility>
 #include <vector>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>          // types only: the library is resolved at run time (dlopen), never linked
 #include "../../include/ssf.h"
 #include "ssf_device.hpp"
@@ -486,6 +487,7 @@ struct ssf_handle {
     // first ICP iteration of the next submitted frame, accumulated ahead by the row-move kernel of the frame just
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
+    double wait_launched_us = 0.0; long long n_waiter_match_repairs = 0; long long dbg_stall_before_match_us = 0;     // see process_oldest: SSF_ICP_GO_MATCH has no acknowledgement
     bool icp_ahead = true;
     // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
@@ -1028,12 +1030,15 @@ static int store_from_dense(ssf_handle* h, int n, int n_visible) {
     HCK(hipStreamSynchronize(h->stream));
     HCK(hipMemcpy(h->d_cnt, &c, sizeof(c), hipMemcpyHostToDevice));
     h->n_model = n; h->n_visible = n_visible; h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = n_oov;
-    // the shard sizes the ranks exchanged at the end of the last frame (read lazily at the start of the next) describe the
-    // map that has just been replaced: dropped, the next frame exchanges them afresh (every rank replaces its shard in the
-    // same call sequence -- ssf_set_model, ssf_apply_deformation, ssf_rehome_* -- so the exchange numbers stay in step)
-    h->all_valid = false; h->all_pending = false;
     return SSF_OK;
 }
+// The shard sizes the ranks exchanged at the end of the last frame (read lazily at the start of the next) describe the map
+// before a call that replaces it: dropped, the next frame exchanges them afresh.  Called at the TOP of every such entry
+// point (ssf_set_model, ssf_apply_deformation, ssf_rehome_begin / _end), before any early return: whether a rank then
+// actually rewrites its shard depends on the rank (an empty shard, nothing leaving, nothing arriving), but all ranks make
+// the same call sequence, and every rank must enter the next frame in the same state -- a rank that kept the old record
+// would skip an exchange its peers perform (their exchange numbers / the RCCL collective order would go out of step).
+static inline void drop_shard_sizes(ssf_handle* h) { h->all_valid = false; h->all_pending = false; }
 
 static inline P2PView p2p_view(ssf_handle* h, unsigned long long seq) { P2PView v = h->p2p.view; v.seq = seq; return v; }
 // exchange != 0 (native multi-rank frame calls with the peer-to-peer backend): the association tables are traded with
@@ -1258,6 +1263,7 @@ static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo*
     const unsigned long long seq = ++h->icp_seq;
     const unsigned long long go_seq = ++h->go_count;
     IcpGo* slot = h->go + (go_seq % SSF_ICP_GO_SLOTS);
+    h->wait_launched_us = now_us();               // (before the launch call: no workgroup of it can have started waiting earlier)
     Rt none; none.R = m3_identity(); none.t = v3(0, 0, 0);
     const P2PView pv = h->p2p.view;               // (the number of the peer exchange arrives with the go word)
     const MatchArgs ma{h->cfg.range_min, h->cfg.range_max, h->id_offset, h->cc->d_best, h->cc->d_matched, h->d_cand};
@@ -1396,8 +1402,16 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     bool matched_by_waiter = false;
     if (waiting && !timing && icp_waiter_can_match(h)) {
         icp_end(h, &valid);
+        if (h->dbg_stall_before_match_us > 0) usleep((useconds_t)h->dbg_stall_before_match_us);      // (test hook: a stalled host thread)
         icp_release_waiting(wait_slot, wait_go_seq, &h->pose, 0, true);
         matched_by_waiter = true;
+        // The word has no acknowledgement.  A waiting workgroup gives up after SSF_ICP_GO_WAIT_TICKS (0.25 s) and tells the rest
+        // of its launch to leave; if this thread was stalled that long (descheduled, a debugger, SIGSTOP) between the launch and
+        // the store above, the word may have found only the late-dispatched part of the grid and the association would cover a
+        // subset of the rows -- silently.  The host's own clock bounds the device's: no workgroup started waiting before
+        // wait_launched_us, so below 0.1 s on this side nobody has given up.  Past it the association is run again as a launch
+        // of its own: match_row only takes minima and sets flags, so a partial pass followed by a full one is the full one.
+        if (now_us() - h->wait_launched_us > 100000.0) { matched_by_waiter = false; h->n_waiter_match_repairs++; }
     } else {
         if (waiting) icp_release_waiting(wait_slot, wait_go_seq, nullptr);
         icp_end(h, &valid);
@@ -2224,6 +2238,7 @@ int ssf_set_model(ssf_handle* h, const ssf_surfels* in, int n, int n_visible, in
     if (!h || !in || n < 0 || n > h->cfg.nb_supersurfels_max || n_visible < 0 || n_visible > n) return SSF_ERR_INVALID_ARG;
     if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    drop_shard_sizes(h);
     SurfelSoA& s = h->dense;                       // upload the logical order, then split it into the two stores
     hipStream_t st = h->stream;
     const size_t N = n;
@@ -2324,6 +2339,8 @@ int ssf_export_model_txt(ssf_handle* h, const char* path) {
 
 int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const float* nt, int m, const float* w4, const int32_t* idx4) {
     if (!h || !np || !nr || !nt || !w4 || !idx4 || m <= 0) return SSF_ERR_INVALID_ARG;
+    drop_shard_sizes(h);
+    h->ahead.valid = false;
     const size_t n = h->n_model;
     if (n == 0) return SSF_OK;
     float *d_np, *d_nr, *d_nt, *d_w, *d_nodes; int32_t* d_i;
@@ -2353,6 +2370,7 @@ int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out) 
     if (!h || !n_out || table_rows < 0 || (!table && table_rows > 0)) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty() || h->fusing) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
     *n_out = 0;
+    drop_shard_sizes(h);
     const int n = h->n_model;
     if (h->cfg.nranks <= 1 || n == 0) return SSF_OK;
     hipStream_t st = h->stream;
@@ -2378,18 +2396,24 @@ int ssf_rehome_begin(ssf_handle* h, int32_t* table, int table_rows, int* n_out) 
 int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n_rec) {
     if (!h || n_rec < 0 || (!table && n_rec > 0)) return SSF_ERR_INVALID_ARG;
     if (!h->pending.empty() || h->fusing) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
-    // the records addressed to this rank, split by the block they arrive in (table order kept)
+    drop_shard_sizes(h);
+    // the records addressed to this rank, split by the block they arrive in (table order kept).  A full shard turns the
+    // surplus away, in table order, as a frame's migration does (k_migrate_in): their source shards have already let them
+    // go, so they are lost to the map -- the call still succeeds on every rank (an error here would leave the ranks in
+    // different states with nothing to roll back) and returns their number
     std::vector<int32_t> vis, oov;
+    const int n = h->n_model, nv = h->n_visible;
+    int room = h->cfg.nb_supersurfels_max - n, turned_away = 0;
     for (int j = 0; j < n_rec; j++) {
         const int32_t* w = table + (size_t)SSF_MIGRANT_WORDS * j;
         if (w[0] - 1 != h->cfg.rank) continue;
+        if (room <= 0) { turned_away++; continue; }
+        room--;
         std::vector<int32_t>& dst = w[1] ? vis : oov;
         dst.insert(dst.end(), w, w + SSF_MIGRANT_WORDS);
     }
     const int av = (int)(vis.size() / SSF_MIGRANT_WORDS), ao = (int)(oov.size() / SSF_MIGRANT_WORDS);
-    if (av + ao == 0) return SSF_OK;
-    const int n = h->n_model, nv = h->n_visible;
-    if ((long long)n + av + ao > h->cfg.nb_supersurfels_max) { h->err = "ssf_rehome_end: no room for the arriving rows"; return SSF_ERR_CAPACITY; }
+    if (av + ao == 0) return turned_away;
     hipStream_t st = h->stream;
     { int rc = materialise(h); if (rc) return rc; }
     int32_t* d_rec = nullptr;
@@ -2407,7 +2431,7 @@ int ssf_rehome_end(ssf_handle* h, const int32_t* table, int n_rec) {
     { int rc = copy_soa(h, h->dense, scratch, (size_t)n + av + ao); if (rc) return rc; }
     { int rc = store_from_dense(h, n + av + ao, nv + av); if (rc) return rc; }
     HCK(hipStreamSynchronize(st));
-    return SSF_OK;
+    return turned_away;
 }
 
 int ssf_bilateral_filter(ssf_handle* h, const void* in, void* out, int on_device) {
@@ -2464,6 +2488,10 @@ int ssf_dbg_sequence_marks(ssf_handle* h, double* out320) {
 }
 // frames whose association ran inside a waiting ICP launch (SSF_ICP_GO_MATCH) since the handle was created
 long long ssf_dbg_waiter_matches(ssf_handle* h) { return h ? h->n_waiter_matches : -1; }
+// ... and the frames whose association was run again as a launch of its own because the host's word to the waiting launch came
+// too late to be trusted; the test hook that makes it late (a stall of the calling thread in front of the word)
+long long ssf_dbg_waiter_match_repairs(ssf_handle* h) { return h ? h->n_waiter_match_repairs : -1; }
+void ssf_dbg_stall_before_match_us(ssf_handle* h, long long us) { if (h) h->dbg_stall_before_match_us = us; }
 int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
     if (!h || !out64) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 64; i++) out64[i] = h->seq_done_us[i];

@@ -213,6 +213,57 @@ def test_config5_tum_shaped_three_threads_deformation_and_rehoming(fast_oracle, 
     assert want[-1]["icp_valid"] == 1
 
 
+def test_an_empty_rank_stays_in_step_through_deformation_and_rehoming(oracle_lib, product_lib):
+    """Three ranks with 100 m tiles: the room's eight octant tiles hash to ranks 0 and 2, so rank 1's shard is EMPTY and stays
+    empty.  Frames -> deformation -> re-homing sweep -> frames: rank 1 takes the early return of every one of those calls
+    (nothing to deform, nothing leaves, nothing arrives) while its peers rewrite their shards; all three must still enter the
+    next frame agreeing on whether the shard sizes are exchanged afresh -- a rank that kept the record of the last frame
+    skipped an exchange its peers performed and the frame call timed out."""
+    from supersurfel_fusion_amd import synthetic
+    world, tile, W, H = 3, 100.0, 320, 240
+    frames = [util.frame(k, W, H) for k in range(6)]
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=8192))
+    fs = [binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, nb_supersurfels_max=8192, rank=r, nranks=world, shard_tile=tile)) for r in range(world)]
+    for f in fs:
+        f.p2p_configure(all_ranks_on_this_device=True, timeout_s=20.0)
+    regions = [f.p2p_region()[0] for f in fs]
+    for f in fs:
+        f.p2p_attach_local(regions)
+
+    def drive_all(part):
+        out, errors = [None] * world, []
+
+        def drive(r):
+            try:
+                out[r] = [fs[r].process_frame(a, d) for a, d in part]
+            except Exception as e:
+                errors.append((r, e))
+        threads = [threading.Thread(target=drive, args=(r,), daemon=True) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        return out
+
+    want = [fo.process_frame(r, d) for r, d in frames[:3]]
+    got = drive_all(frames[:3])
+    assert fs[1].counts()["n_model"] == 0 and min(fs[0].counts()["n_model"], fs[2].counts()["n_model"]) > 0
+    for f in [fo] + fs:
+        f.apply_deformation(*util.deformation_for(f.get_model(), 16, angle=0.01, shift=0.02))
+    util.rehome_in_process(fs)
+    assert fs[1].counts()["n_model"] == 0
+    want += [fo.process_frame(r, d) for r, d in frames[3:]]
+    got2 = drive_all(frames[3:])
+    outs = [(np.stack([x["pose"] for x in got[r] + got2[r]]), np.array([[x[k] for k in KEYS] for x in got[r] + got2[r]], np.int64)) for r in range(world)]
+    models = [f.get_model() for f in fs]
+    models[1] = {name: v[:0] for name, v in models[1].items()}          # (get_model of an empty shard hands back one placeholder row)
+    check_against_unsharded(world, tile, want, outs, fo.get_model(), models)
+    g = fs[1].global_counts()
+    assert g["n_model"] == want[-1]["n_model"] and g["n_visible"] == want[-1]["n_visible"]
+
+
 def test_rehoming_across_processes(fast_oracle, tmp_path):
     """the deformation + re-homing sweep with the ranks as separate processes (tables traded through files, as the IPC handles
     are), frames on the native exchange before and after it"""

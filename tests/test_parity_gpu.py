@@ -611,6 +611,26 @@ def test_association_inside_the_waiting_icp_launch(oracle_lib, product_lib):
     assert n == sum(1 for r in got if 0 < r["icp_iters"] < 10), (n, iters)
 
 
+def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, product_lib):
+    """The host's word SSF_ICP_GO_MATCH has no acknowledgement: a calling thread stalled for longer than the waiting launch's
+    0.25 s bound (descheduled, debugger, SIGSTOP -- here a test hook sleeps 0.35 s in front of the word) posts it after the
+    resident workgroups have given up, and only the late-dispatched part of the grid would associate.  The host bounds the
+    device's wait with its own clock and runs the association again as a launch of its own: results stay the oracle's."""
+    import ctypes as C
+    fo, nv = seeded(oracle_lib, 50000, 640, 480)
+    fh, _ = seeded(product_lib, 50000, 640, 480)
+    L = product_lib.lib
+    L.ssf_dbg_stall_before_match_us.argtypes = [C.c_void_p, C.c_longlong]; L.ssf_dbg_stall_before_match_us.restype = None
+    L.ssf_dbg_waiter_match_repairs.argtypes = [C.c_void_p]; L.ssf_dbg_waiter_match_repairs.restype = C.c_longlong
+    L.ssf_dbg_stall_before_match_us(fh.h, 350000)
+    for k in range(4):
+        rgb, depth = util.frame(k, 640, 480, noise=True, holes=0.02)
+        ro, rh = fo.process_frame(rgb, depth), fh.process_frame(rgb, depth)
+        util.same_result(ro, rh)
+    util.compare_state(fo, fh)
+    assert L.ssf_dbg_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
+
+
 def test_relabelling_passes_bit_exact_in_grid_order_too():
     """The relabelling pass takes its tiles in an XCD-aware order by default (each XCD a contiguous eighth of the launch:
     DESIGN.md section 4.1.3).  Only speed may depend on that: the per-pass comparison against the oracle is repeated in a
@@ -625,3 +645,10 @@ def test_relabelling_passes_bit_exact_in_grid_order_too():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-1000:]
+
+
+def test_rehoming_into_a_full_shard_turns_the_surplus_away(product_lib):
+    """ssf_rehome_end on the product: same rule as the oracle's (tests/test_sharded.py): surplus arrivals turned away in table
+    order, their number returned, never an error after the source ranks have committed"""
+    from test_sharded import rehoming_into_a_full_shard
+    assert rehoming_into_a_full_shard(product_lib) > 0

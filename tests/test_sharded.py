@@ -142,6 +142,47 @@ def test_rehoming_after_a_deformation(world, oracle_lib):
     assert util.rehome_in_process(fs) == [0] * world                 # nothing left to move
 
 
+def rehoming_into_a_full_shard(lib):
+    """ssf_rehome_end at a shard without room: the surplus arrivals are turned away in table order and their number is
+    returned (never an error: the source ranks have already let the rows go, an error on one rank could not be rolled back);
+    the rows that fit arrive as usual.  Shared by the CPU test (oracle) and tests/test_parity_gpu.py (product)."""
+    from supersurfel_fusion_amd import synthetic
+    world, tile = 2, 0.25
+    whole = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096))
+    whole.process_frame(*util.frame(0, W, H))
+    m = whole.get_model()
+    ok = m["confidences"] > 0
+    src = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=1, nranks=world, shard_tile=tile))
+    src.set_model(m, whole.counts()["n_visible"], 1)                             # rank 1 holding the whole map: rank 0's rows must leave
+    theirs = ok & (synthetic.tile_owner(m["positions"], world, tile) == 0)
+    table = src.rehome_begin()
+    assert len(table) == int(theirs.sum()) > 8 and (table[:, 0] == 1).all()
+    S = ((W + 15) // 16) * ((H + 15) // 16)          # (a handle's capacity cannot be below its superpixel count)
+    n0 = S + 11
+    room = 5
+    dst = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=n0 + room, rank=0, nranks=world, shard_tile=tile))
+    pick = np.flatnonzero(ok)[np.arange(n0) % int(ok.sum())]
+    dst.set_model({k: v[pick] for k, v in m.items()}, n0 // 2, 1)
+    before = dst.get_model()
+    turned = dst.rehome_end(table)
+    assert turned == len(table) - room
+    after = dst.get_model()
+    assert dst.counts()["n_model"] == n0 + room
+    nvis_arr = int(table[:room, 1].sum())
+    assert dst.counts()["n_visible"] == n0 // 2 + nvis_arr
+    # the first `room` records of the table are the ones that arrived: visible-flagged behind the visible block, the others at the end
+    arrived = np.concatenate([after["positions"][n0 // 2:n0 // 2 + nvis_arr], after["positions"][n0 + nvis_arr:]])
+    want = np.concatenate([table[:room][table[:room, 1] == 1][:, 2:5], table[:room][table[:room, 1] == 0][:, 2:5]]).view(np.float32)
+    assert np.array_equal(arrived.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(after["positions"][:n0 // 2], before["positions"][:n0 // 2])
+    assert dst.rehome_end(table[:0]) == 0
+    return turned
+
+
+def test_rehoming_into_a_full_shard_turns_the_surplus_away(oracle_lib):
+    assert rehoming_into_a_full_shard(oracle_lib) > 0
+
+
 def _rehome_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -9,6 +9,8 @@
 #   config3|4|5  bench.py --config N
 #   trace        rocprofv3 --kernel-trace --stats of the profile command
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (separate) + the two SQ passes, summarised
+#   prof3        the profile command of the trace / pmc steps that follow becomes BASELINE config 3 (1280x960, 1 M rows in view,
+#                10 forced ICP iterations; outputs tagged _config3)
 #   env:K=V      export K=V for the steps that follow (A/B of kernel variants on the same box)
 #   py:<file>    python tools/<file> (a probe), output to <file>.txt
 set -u
@@ -18,9 +20,11 @@ mkdir -p $O
 cd $R
 TAG=""
 PROF="python $R/bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"
+PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)"
 lastline() { [ -s "$1" ] && tail -n 1 "$1" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$2', round(d['value'],1), d.get('unit'), 'frac', round(d['roofline']['frac'],4), d['roofline'].get('kernel'), 'seq_ms', d.get('sequential_ms_per_frame'))" 2>/dev/null >> $O/summary.txt; }
 for step in "$@"; do
   case $step in
+    prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; TAG="${TAG}_config3";;
     env:*) export "${step#env:}"; TAG="${TAG}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=\n' '_')";;
     suite)
       ( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 ) > $O/pytest_gpu$TAG.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu$TAG.log
@@ -40,7 +44,7 @@ for step in "$@"; do
     trace)
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace$TAG -o trace -- $PROF > $O/trace$TAG.log 2>&1 )
       DB=$(find $O/trace$TAG -name "*.db" | head -1)
-      [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/rocprof_summary$TAG.txt "bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)" > /dev/null 2>&1
+      [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/rocprof_summary$TAG.txt "$PROFNOTE" > /dev/null 2>&1
       [ -n "$DB" ] && python tools/rocprof_dist.py $DB > $O/rocprof_distribution$TAG.txt 2>&1;;
     pmc)
       ( cd /tmp && export TMPDIR=/tmp
