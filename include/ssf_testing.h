@@ -8,6 +8,7 @@
  */
 #ifndef SSF_TESTING_H
 #define SSF_TESTING_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -32,6 +33,11 @@ int ssf_dbg_lab_to_rgb(const float* lab3, float* rgb3);
 int ssf_dbg_sym_inverse(const float* cov6, float* inv6);            /* returns 1 when invertible */
 int ssf_dbg_principal_frame(const float* cov6, float* vecs9, float* vals3);
 int ssf_dbg_plane_solve(const float* rows12, float* theta3);        /* returns 1 when accepted */
+/* the connectivity guard of a relabelling pass, isUnchangeable (TPS_RGBD_kernels.cuh:178-233), on a 3 x 3 label patch
+ * (row-major): 1 when the centre pixel's label may not change.  The three decision helpers -- this one, the plane solve and
+ * the principal frame -- are pinned to the reference's own text by tests/golden/ref_decision_vectors.npz
+ * (oracle/ref_decision_vectors.cpp). */
+int ssf_dbg_connectivity_guard(const int32_t* labels9);
 /* the matrix helpers the fuse / deformation kernels are built from, pinned against the reference's own headers by
  * tests/golden/ref_math_vectors.npz (oracle/ref_math_vectors.cpp): square(Cov3) (matrix_math.cuh:184), Cov3 * float3
  * (:164), mult_ABAt (:442), Mat33 * Mat33 (:381), Mat33 * float3 (:484), float3 * Mat33 (:491), rotMatToQuat (:529),

@@ -136,6 +136,7 @@ void fuse_end(State& s, const int32_t* table, ssf_frame_result* out);
 void apply_deformation(State& s, const float* npos, const float* nrot, const float* ntrans, int m,
                        const float* w4, const int32_t* idx4);
 int  shard_owner(const State& s, int f, const Pose& pose);
+bool ring_unchangeable(int index, const int ring[8]);        // the connectivity guard on an explicit ring (test hook)
 int  rehome_begin(State& s, int32_t* table, int cap);
 int  rehome_end(State& s, const int32_t* table, int n);
 void rot_to_quat(const Mat33& m, float* q /* x, y, z, w */);    // matrix_math.cuh:529-618

@@ -464,6 +464,10 @@ int ssf_dbg_principal_frame(const float* c, float* vecs, float* vals) {
     for (int r = 0; r < 3; r++) { vecs[3 * r] = m.r[r].x; vecs[3 * r + 1] = m.r[r].y; vecs[3 * r + 2] = m.r[r].z; }
     vals[0] = v.x; vals[1] = v.y; vals[2] = v.z; return 0;
 }
+int ssf_dbg_connectivity_guard(const int32_t* g) {       // 3 x 3 label patch, row-major -> 1: the centre is a bridge
+    const int ring[8] = {g[0], g[1], g[2], g[5], g[8], g[7], g[6], g[3]};
+    return ring_unchangeable(g[4], ring) ? 1 : 0;
+}
 int ssf_dbg_plane_solve(const float* r, float* th) {
     float a = 0, b = 0, c = 0;
     const bool ok = solvePlaneEquations(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);

@@ -47,17 +47,21 @@ int boundary_at(const State& s, const std::vector<int32_t>& lab, int x, int y) {
     return b;
 }
 
-// TPS_RGBD_kernels.cuh:178-233: ring walk NW,N,NE,E,SE,S,SW,W without closing W->NW.
-static bool is_unchangeable(const State& s, const std::vector<int32_t>& lab, int x, int y) {
-    const int index = lab_at(s, lab, x, y);
+// TPS_RGBD_kernels.cuh:178-233: ring walk NW,N,NE,E,SE,S,SW,W without closing W->NW.  ring[k]: label of ring pixel k.
+bool ring_unchangeable(int index, const int ring[8]) {
     int jump = 0;
-    bool prev = (lab_at(s, lab, x - 1, y - 1) == index);
-    const int ox[7] = {0, 1, 1, 1, 0, -1, -1}, oy[7] = {-1, -1, 0, 1, 1, 1, 0};
-    for (int k = 0; k < 7; k++) {
-        bool cur = (lab_at(s, lab, x + ox[k], y + oy[k]) == index);
+    bool prev = (ring[0] == index);
+    for (int k = 1; k < 8; k++) {
+        bool cur = (ring[k] == index);
         if (prev != cur) { jump++; prev = cur; }
     }
     return jump > 2;
+}
+static bool is_unchangeable(const State& s, const std::vector<int32_t>& lab, int x, int y) {
+    const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+    int ring[8];
+    for (int k = 0; k < 8; k++) ring[k] = lab_at(s, lab, x + ox[k], y + oy[k]);
+    return ring_unchangeable(lab_at(s, lab, x, y), ring);
 }
 
 // the 9 inlier-only disparity sums of one pixel (TPS_RGBD_kernels.cu:142-150, .cuh:445-466)

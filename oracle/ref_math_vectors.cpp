@@ -31,7 +31,9 @@ static void open_arr(const char* name, bool first = false) { std::printf("%s\"%s
 static void put(float v) {
     if (!first_in_row) std::printf(", ");
     first_in_row = false;
-    if (std::isnan(v)) std::printf("\"nan\""); else if (std::isinf(v)) std::printf(v > 0 ? "\"inf\"" : "\"-inf\""); else std::printf("%.9g", (double)v);
+    if (std::isnan(v)) std::printf("\"nan\""); else if (std::isinf(v)) std::printf(v > 0 ? "\"inf\"" : "\"-inf\"");
+    else if (v == 0.0f && std::signbit(v)) std::printf("-0.0");       // ("-0" would be read back as the integer 0: the sign is part of the bits compared)
+    else std::printf("%.9g", (double)v);
 }
 static void close_arr() { std::printf("]"); }
 static void put3(float3 v) { put(v.x); put(v.y); put(v.z); }

@@ -609,10 +609,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (eligible) {
             // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W; the label changes
             // more than twice along the ring = the pixel is a bridge.  Bit k of `ring`: ring pixel k carries the pixel's label
-            const unsigned int ring = (t[-TWP - 1] == index ? 1u : 0u) | (nl[0] == index ? 2u : 0u) | (t[-TWP + 1] == index ? 4u : 0u) |
-                                      (nl[2] == index ? 8u : 0u) | (t[TWP + 1] == index ? 16u : 0u) | (nl[3] == index ? 32u : 0u) |
-                                      (t[TWP - 1] == index ? 64u : 0u) | (nl[1] == index ? 128u : 0u);
-            eligible = __popc((ring ^ (ring >> 1)) & 0x7Fu) <= 2;
+            eligible = !guard_unchangeable(guard_ring(index, t[-TWP - 1], nl[0], t[-TWP + 1], nl[2], t[TWP + 1], nl[3], t[TWP - 1], nl[1]));
         }
         SpRow own = zero_row;
         if (in_image[s] && (RGBD || eligible)) own = row_of(index);

@@ -2583,6 +2583,8 @@ int ssf_dbg_principal_frame(const float* c, float* vecs, float* vals) {
     const float o[9] = {m.r0.x, m.r0.y, m.r0.z, m.r1.x, m.r1.y, m.r1.z, m.r2.x, m.r2.y, m.r2.z};
     std::memcpy(vecs, o, sizeof(o)); vals[0] = v.x; vals[1] = v.y; vals[2] = v.z; return 0;
 }
+// img9: a 3 x 3 label patch, row-major; returns 1 when the centre pixel is a bridge (its label may not change)
+int ssf_dbg_connectivity_guard(const int32_t* g) { return guard_unchangeable(guard_ring(g[4], g[0], g[1], g[2], g[5], g[8], g[7], g[6], g[3])) ? 1 : 0; }
 int ssf_dbg_plane_solve(const float* r, float* th) {
     float a = 0, b = 0, c = 0;
     const bool ok = plane_solve(a, b, c, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);

@@ -279,6 +279,16 @@ SSF_HD void principal_frame(Sym3 A, M3& vecs, V3& vals) {
     principal_finish(A, principal_power(principal_start(A, false)), principal_power(principal_start(A, true)), vecs, vals);
 }
 
+// connectivity guard of a relabelling pass, isUnchangeable (TPS_RGBD_kernels.cuh:178-233): walk the ring NW, N, NE, E, SE, S,
+// SW, W (not closed W -> NW); the pixel is a bridge -- its label may not change -- when "carries my label" flips more than
+// twice along the walk.  `ring`: bit k = ring pixel k carries the pixel's own label; flips = set bits of ring ^ (ring >> 1)
+// among the seven adjacent pairs.
+SSF_HD unsigned int guard_ring(int index, int nw, int n, int ne, int e, int se, int s, int sw, int w) {
+    return (nw == index ? 1u : 0u) | (n == index ? 2u : 0u) | (ne == index ? 4u : 0u) | (e == index ? 8u : 0u) |
+           (se == index ? 16u : 0u) | (s == index ? 32u : 0u) | (sw == index ? 64u : 0u) | (w == index ? 128u : 0u);
+}
+SSF_HD bool guard_unchangeable(unsigned int ring) { return __builtin_popcount((ring ^ (ring >> 1)) & 0x7Fu) > 2; }
+
 // 3x3 plane normal equations, TPS_RGBD_kernels.cu:27-59 (its guard only rejects -inf; kept)
 SSF_HD bool plane_solve(float& ta, float& tb, float& tc, float x1, float y1, float z1, float d1,
                         float x2, float y2, float z2, float d2, float x3, float y3, float z3, float d3) {

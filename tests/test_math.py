@@ -183,3 +183,75 @@ def test_sym_inverse_threshold(oracle_lib):
     ok = np.float32([1e-2, 0, 0, 1e-2, 0, 1e-2]); bad = np.float32([1e-4, 0, 0, 1e-4, 0, 1e-4]); o = np.zeros(6, np.float32)
     assert L.ssf_dbg_sym_inverse(fptr(ok), fptr(o)) == 1 and np.allclose(o[[0, 3, 5]], 100.0, rtol=1e-6)
     assert L.ssf_dbg_sym_inverse(fptr(bad), fptr(o)) == 0
+
+
+# ---- the three DECISION helpers against the reference's own text -------------------------------------------------------------
+# tests/golden/ref_decision_vectors.npz = outputs of isUnchangeable (TPS_RGBD_kernels.cuh:178-233), solvePlaneEquations
+# (TPS_RGBD_kernels.cu:27-59) and eigenDecomposition (supersurfel_fusion_kernels.cu:48-111), cut out of the reference's files by
+# line range at build time and compiled as they stand (oracle/ref_decision_vectors.cpp, oracle/Makefile `decision`).  They gate
+# integer results (may a pixel change its label; which RANSAC sample / plane a superpixel gets; which axis is the normal).
+DECISIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_decision_vectors.npz")
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_connectivity_guard_is_the_references_on_every_ring_pattern(which, oracle_lib, product_lib):
+    """all 2^8 "neighbour carries my label" patterns x two label alphabets (foreign pixels alike / all different): the guard
+    only compares for equality, so this is its whole truth table -- the oracle's ring walk and the product's bit mask +
+    population count (csrc/ssf_math.hpp guard_ring / guard_unchangeable, what k_update_pass executes) must both be it"""
+    L = (oracle_lib if which == "oracle" else product_lib).lib
+    L.ssf_dbg_connectivity_guard.argtypes = [C.c_void_p]
+    want = np.load(DECISIONS)["guard_unchangeable"].astype(np.int32).reshape(2, 256)
+    ox, oy = (-1, 0, 1, 1, 1, 0, -1, -1), (-1, -1, -1, 0, 1, 1, 1, 0)
+    n_bridge = 0
+    for alphabet in range(2):
+        for pat in range(256):
+            img = np.full(9, 7, np.int32)
+            for k in range(8):
+                img[(1 + oy[k]) * 3 + (1 + ox[k])] = 7 if (pat >> k) & 1 else (100 + k if alphabet else 3)
+            got = L.ssf_dbg_connectivity_guard(fptr(img))
+            assert got == want[alphabet, pat], (alphabet, pat, got)
+            n_bridge += got
+    assert (want[0] == want[1]).all() and 0 < n_bridge < 512       # equality only; both outcomes occur (372 bridges of 512)
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_plane_solve_bit_exact_against_the_references_text(which, oracle_lib, product_lib):
+    """4096 triples as the extract stage forms them (pixel rows of a RANSAC sample; rows of a superpixel's normal equations) +
+    degenerate and non-finite ones: accept / reject and, when accepted, the three plane coefficients bit for bit -- including
+    the guard `!isfinite(den) && den < eps` that only ever rejects -inf (kept as the reference wrote it)"""
+    L = (oracle_lib if which == "oracle" else product_lib).lib
+    g = np.load(DECISIONS)
+    rows, ok, th = g["plane_rows"].reshape(-1, 12), g["plane_ok"].astype(np.int32), g["plane_theta"].reshape(-1, 3)
+    assert len(rows) == 4160 and 0 < (ok == 0).sum() < 64
+    for i in range(len(rows)):
+        o, rc = call(L, "ssf_dbg_plane_solve", rows[i])
+        assert rc == ok[i], (i, rows[i])
+        if rc:
+            assert same_bits(o, th[i]), (i, rows[i], o, th[i])
+    nonfinite = ~np.isfinite(th).all(axis=1) & (ok == 1)
+    assert nonfinite.sum() > 10                      # accepted solves with inf / NaN coefficients exist and are compared too
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_principal_frame_bit_exact_against_the_references_text(which, oracle_lib, product_lib):
+    """eigenDecomposition on 1024 SPD matrices at supersurfel scales (thin discs; axis-aligned and round ones for the ties of
+    the column choice): the three axes and the three eigenvalue quotients, 0 bits of difference.
+    What this does NOT pin: the generator defines the CUDA intrinsic rsqrtf (used by the reference's normalize,
+    vector_math.cuh:247-252) as the correctly rounded 1.0f / sqrtf(x) -- this build's specification for oracle and product alike;
+    on a CUDA device rsqrtf may differ by <= 2 ulp, i.e. every axis component by a relative 2^-22 (and the eigenvalue quotients
+    by as much: they are ratios of expressions linear in the axis).  The column choice, the ten normalised squarings and the
+    branch selection of the quotients involve no stand-in."""
+    L = (oracle_lib if which == "oracle" else product_lib).lib
+    g = np.load(DECISIONS)
+    cov, vecs, vals = g["eig_cov"].reshape(-1, 6), g["eig_vecs"].reshape(-1, 9), g["eig_vals"].reshape(-1, 3)
+    L.ssf_dbg_principal_frame.argtypes = [C.c_void_p] * 3
+    for i in range(len(cov)):
+        v, w = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        L.ssf_dbg_principal_frame(fptr(np.ascontiguousarray(cov[i])), fptr(v), fptr(w))
+        assert same_bits(v, vecs[i]), (i, cov[i], v, vecs[i])
+        assert same_bits(w, vals[i]), (i, cov[i], w, vals[i])
+    # the vectors mean something: unit axes, rows[1] = rows[2] x rows[0], eigenvalues ordered major >= minor >= normal on the generic cases
+    V = vecs.reshape(-1, 3, 3)
+    generic = np.arange(len(V)) % 128 > 1
+    assert np.abs(np.linalg.norm(V[generic][:, 0], axis=1) - 1).max() < 1e-5 and np.abs(np.linalg.norm(V[generic][:, 2], axis=1) - 1).max() < 1e-5
+    assert (vals[generic][:, 0] >= vals[generic][:, 2]).all()

@@ -138,6 +138,8 @@ def row_hash(model):
     """a 32-bit key per model row that depends only on the row's content (so that a shard and the unsharded map derive
     the same per-row quantities, whatever the order of their rows)"""
     n = len(model["confidences"])
+    if n == 0:
+        return np.zeros(0, np.uint64)
     w = np.concatenate([np.ascontiguousarray(model[name]).reshape(n, -1).view(np.uint32) for name in ("positions", "stamps", "dims")], axis=1).astype(np.uint64)
     h = np.zeros(n, np.uint64)
     for j in range(w.shape[1]):
