@@ -221,6 +221,34 @@ def render_frames(n, tum_shaped=False):
     return frames
 
 
+def other_config(cfg_n, steps, pin):
+    """bench.py --config <cfg_n> in a process of its own -> what the driver's line carries about it: frames/s, the dominant
+    kernel with its roofline fraction and (when a PMC file stamped with the current kernel sources exists for that
+    configuration) its HBM traffic, the whole-frame roofline fraction"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg_n), "--steps", str(steps), "--extras", "0",
+           "--cpu-frames", "0", "--pin", str(pin)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return dict(error="bench.py --config %d ended with %d: %s" % (cfg_n, r.returncode, r.stderr[-400:]))
+        d = json.loads(lines[-1])
+    except Exception as e:                   # a sub-run must never take the headline line with it
+        return dict(error=repr(e))
+    rf, fr = d.get("roofline") or {}, d.get("frame_roofline") or {}
+    return dict(frames_per_sec=d["value"], ms_per_frame=d["ms_per_step"], frames=d["steps"], workload=d["config"]["workload"],
+                n_visible=d["config"]["n_visible"], icp_iters_mean=d["config"]["icp_iters_mean"], stage_ms=d.get("stage_ms"),
+                sequential_ms_per_frame=d.get("sequential_ms_per_frame"),
+                roofline=dict(kernel=rf.get("kernel"), frac=rf.get("frac"), achieved_GBs=rf.get("achieved"), avg_launch_us=rf.get("avg_launch_us"),
+                              algo_bytes_per_launch=rf.get("algo_bytes_per_launch"), traffic=rf.get("traffic"), traffic_note=rf.get("traffic_note")),
+                frame_roofline_frac=fr.get("frac"),
+                per_kernel={k: dict(avg_us=v["avg_us"], achieved_GBs=v.get("achieved_GBs")) for k, v in (d.get("per_kernel") or {}).items()
+                            if k in ("icp_accumulate", "match", "update_insert", "reorder_move_icp", "reorder_move", "update_pass_rgbd", "render_moments", "bilateral_prefilter", "apply_deformation")},
+                command=" ".join(["bench.py"] + cmd[2:]))
+
+
 def launch_plan(gpus, env, device_count, argv):
     """What `python bench.py --gpus N ...` has to do given how it was started (pure: tests/test_bench_launcher.py).
       ("run", None)      this process is a rank (N == 1, or launched by torch.distributed.run with WORLD_SIZE == N)
@@ -557,8 +585,9 @@ def main():
         # a hash of the kernel sources it was taken at -- bench.py cannot run the profiler on itself).  A file taken
         # at other sources, or at another extract batch, does not describe this binary: traffic = null then.
         import glob
-        traffic, traffic_note = None, "no profiles/pmc_r*.json"
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9].json")))
+        traffic, traffic_note = None, "no profiles/pmc_r*%s.json" % ("" if a.config == 2 else "_config%d" % a.config)
+        # (the default workload: profiles/pmc_rNN.json; another BASELINE configuration: profiles/pmc_rNN_config<k>.json)
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9]%s.json" % ("" if a.config == 2 else "_config%d" % a.config))))
         if pmcs:
             pmc_path = pmcs[-1]; pmc_name = "profiles/" + os.path.basename(pmc_path)
             pmc = json.load(open(pmc_path))
@@ -672,6 +701,12 @@ def main():
             extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt)
             fx.close()
         extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
+        # ---- the other single-GPU BASELINE configurations beside the headline: config 3 (1280x960, 1 M rows in view, 10 forced
+        # iterations: the HBM-bound stress) and config 5 (TUM-shaped input, pre-filter in the frame, one deformation), each as
+        # this same script in a process of its own, outside every timed region of this one (>= 64 / >= 240 frames) -----------------
+        if a.config == 2:
+            for cfg_n, nsteps in ((3, 64), (5, 240)):
+                extras["config%d" % cfg_n] = other_config(cfg_n, nsteps, a.pin)
 
     # whole-frame view: algorithmic bytes of one frame over the measured frame time
     it_mean = float(np.mean(iters))

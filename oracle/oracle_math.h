@@ -274,13 +274,16 @@ static inline int64_t fx_quant(double v, double scale, double lim) {
     if (t < -lim) t = -lim;
     return (int64_t)std::llrint(t);          // round-half-even (default rounding mode)
 }
-static inline int32_t fx_quant32(float v, float scale) {
-    float t = rintf(v * scale);
+// 32-bit terms: rint, then a conversion that saturates like the hardware's v_cvt_i32_f32 (NaN -> 0, >= 2^31 -> INT_MAX,
+// <= -2^31 -> INT_MIN)
+static inline int32_t fx_quant32r(float v) {
+    float t = rintf(v);
     if (!(t == t)) return 0;
-    if (t >= 2147483520.0f) return 2147483647;       // saturate like v_cvt_i32_f32
+    if (t >= 2147483648.0f) return 2147483647;
     if (t <= -2147483648.0f) return (int32_t)0x80000000;
     return (int32_t)t;
 }
+static inline int32_t fx_quant32(float v, float scale) { return fx_quant32r(v * scale); }
 
 // counter-based RNG (replaces cuRAND XORWOW, whose CUDA sequence is not observable here).
 static inline uint32_t rng_u32(uint64_t seed, uint32_t stream, uint32_t& counter) {

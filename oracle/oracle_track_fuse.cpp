@@ -91,12 +91,19 @@ void icp_accumulate(State& s, int64_t* sums) {
         const float dn1 = dot(d, ns), dn2 = dot(d, nt);
         const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
         const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
+        // fixed point (this build's, A4): JtJ at 2^20 = the two rows scaled by 2^10 before their products, Jtr at 2^24 = the
+        // two residuals scaled by 2^14 times the scaled rows -- powers of two, so the same real numbers as scaling the sums, 14 scalings per
+        // row instead of 27
+        float X1[6], X2[6];
+        for (int i = 0; i < 6; i++) { X1[i] = x1[i] * 1024.0f; X2[i] = x2[i] * 1024.0f; }
+        static_assert(SSF_ICP_SCALE_JTJ == 1024.0 * 1024.0 && SSF_ICP_SCALE_JTR == 16777216.0, "scales of the ICP record");
+        const float D1 = dn1 * 16384.0f, D2 = dn2 * 16384.0f;                 // 2^14 x 2^10 (the scaled rows) = 2^24
         int k = 0;
         for (int i = 0; i < 6; i++)
             for (int j = i; j < 6; j++, k++)
-                part[k] += (int64_t)fx_quant32(x1[i] * x1[j] + x2[i] * x2[j], (float)SSF_ICP_SCALE_JTJ);
+                part[k] += (int64_t)fx_quant32r(X1[i] * X1[j] + X2[i] * X2[j]);
         for (int i = 0; i < 6; i++)
-            part[21 + i] += (int64_t)fx_quant32(dn1 * x1[i] + dn2 * x2[i], (float)SSF_ICP_SCALE_JTR);
+            part[21 + i] += (int64_t)fx_quant32r(D1 * X1[i] + D2 * X2[i]);
         part[27] += fx_quant((double)(dn2 * dn2), SSF_ICP_SCALE_R, 4611686018427387904.0);
         part[28] += 1;
     }

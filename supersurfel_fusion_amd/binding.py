@@ -173,10 +173,18 @@ def load_product():
     CPU fallback.  torch is imported first so that exactly one HIP runtime (the one torch
     ships, SONAME libamdhip64.so.7) lives in the process."""
     import torch  # noqa: F401  (loads libamdhip64 before our library resolves it)
-    # SSF_PRODUCT_VARIANT=<tag>: a differently compiled build of the SAME sources next to the product (csrc/variants/<tag>/,
-    # e.g. with in-kernel cycle counters: tools/build_variant.sh) -- for A/B probes on the GPU box, never for tests
+    # SSF_PRODUCT_VARIANT=<tag>: a differently compiled build of the SAME sources next to the product (csrc/variants/<tag>/):
+    # `lab` = -DSSF_EXPERIMENTS, the environment switches and measurement arms behind DESIGN.md's A/B tables (built by
+    # csrc/Makefile; the product itself reads no environment variable); others by tools/build_variant.sh
     tag = os.environ.get("SSF_PRODUCT_VARIANT")
     return Library(os.path.join(_HERE, "csrc", "variants", tag, "libssf_hip.so") if tag else PRODUCT_LIB)
+
+
+def load_lab():
+    """The laboratory build of the product sources (csrc/variants/lab, -DSSF_EXPERIMENTS): for the tests and tools that
+    exercise a measurement arm or an environment switch."""
+    import torch  # noqa: F401
+    return Library(os.path.join(_HERE, "csrc", "variants", "lab", "libssf_hip.so"))
 
 
 def _ptr(a):

@@ -23,6 +23,21 @@
 #include "ssf_math.hpp"
 #include "../../include/ssf.h"
 
+// SSF_EXPERIMENTS: the laboratory build (csrc/variants/lab/libssf_hip.so, `make lab`): the measurement arms and environment
+// switches behind DESIGN.md's A/B tables.  The PRODUCT library is built without it: it reads no environment variable and
+// contains no kernel arm that lost its A/B; a switch evaluates to its default at compile time.
+#ifdef SSF_EXPERIMENTS
+#include <stdlib.h>
+static inline int ssf_env_int_(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define SSF_ENV_INT(name, dflt) ssf_env_int_("SSF_" name, dflt)
+#define SSF_ENV_SET(name) (getenv("SSF_" name) != nullptr)
+#define SSF_ENV_STR(name) getenv("SSF_" name)
+#else
+#define SSF_ENV_INT(name, dflt) (dflt)
+#define SSF_ENV_SET(name) (false)
+#define SSF_ENV_STR(name) ((const char*)nullptr)
+#endif
+
 namespace ssf {
 
 struct SurfelSoA {
@@ -222,6 +237,7 @@ struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; 
 #define SSF_ICP_GO_MATCH (1ull << 62)
 #define SSF_ICP_GO_SLOTS 4
 struct MatchArgs { float zmin, zmax; long long id_offset; unsigned long long* best; uint8_t* matched; int32_t* cand; };    // launch_match's arguments
+int icp_variant_mode();              // 0: the product's k_icp; other values: measurement arms that cannot take SSF_ICP_GO_MATCH
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg = -1, IcpGo* go = nullptr,
@@ -230,8 +246,10 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 // streams of `out`; out_idx[j] = the row's index in the visible array) under transform T (model -> camera): see k_bin_* in
 // ssf_track_fuse.hip.  count / cursor: bin_count_words(cam) words each, count zero at rest.  launch_icp(by_tile = 1) /
 // launch_match(orig = out_idx) then take `out` as their rows.
+#ifdef SSF_EXPERIMENTS
 void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out, int32_t* out_idx);
 int bin_count_words(const Cam& cam);
+#endif
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S,

@@ -332,8 +332,7 @@ static inline TileOrder tile_order(dim3 grid) {
     o.ntx = grid.x; o.ntile = grid.x * grid.y; o.total = o.ntile * grid.z;
     o.magic_ntx = (unsigned int)((0x100000000ull + o.ntx - 1) / o.ntx);        // n / d == umulhi(n, ceil(2^32 / d)) for n d < 2^32 / d ... n < 2^20 here
     o.magic_ntile = (unsigned int)((0x100000000ull + o.ntile - 1) / o.ntile);
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("SSF_PASS_XCD"); on = e ? atoi(e) : 1; }
+    static const int on = SSF_ENV_INT("PASS_XCD", 1);          // (lab: 0 = tiles in grid order; the product: always the XCD-aware order)
     o.xcd = on;
     return o;
 }
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
     };
     if (dbg & 2) return;
-#ifdef SSF_PASS_JUNK
+#if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_JUNK)
     // measurement only: SSF_PASS_JUNK extra vector instructions per wave (is the pass bound by instruction issue?)
     {
         float junk = __uint_as_float(threadIdx.x | 0x3f800000u);
@@ -735,468 +734,14 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     }
 }
 
-// ---- resident relabelling: all passes of a phase in one launch -----------------------------------------------------
-// k_update_pass above pays, forty times per frame, a launch, a trip to memory for the label tile and the pixel operands,
-// and the window rows' arithmetic in every one of its 2520 workgroups (8 frames) -- read, when this kernel was written, as a
-// latency chain per wave (it turned out to be instruction issue: see the diet above k_update_pass).  k_passes keeps the STATE ON THE CHIP instead: the frame is cut into
-// regions (80 x 60 pixels, say), one workgroup per region stays resident for all passes of a phase (20 at the reference's
-// seg_iter) with its region of the label map (+ a one-pixel halo) and of the inlier mask in LDS.  Per pass a workgroup
-//   1. replays its previous pass' sum deltas into the lagging sums buffer, reads the (quiescent) sums of the grid cells
-//      around its region and builds their rows (means, plane) in LDS -- once per region instead of once per 32 x 32 tile;
-//   2. refreshes its halo from the border pixels its neighbours published before the barrier;
-//   3. decides its pass pixels from the LDS snapshot (same arithmetic as k_update_pass, same "all reads before any
-//      write" schedule: decisions live in registers across a workgroup barrier), applies them to LDS, accumulates the
-//      sum deltas in LDS;
-//   4. flushes the deltas to the other sums buffer, publishes its border pixels, and meets the other workgroups OF ITS
-//      FRAME at a barrier (one 64-bit word per frame and phase: frames of a batch do not wait for each other).
-// HBM traffic per pass: the pixel operands (re-read: L2 / Infinity-Cache hits) and a few hundred bytes per region.
-// Exchange between workgroups follows the rules this library already lives by: everything another
-// workgroup reads in the same launch is written and read with device-scope atomics performed at the coherence point
-// (returning atomics where completion must be known before the arrival), no cache write-back / invalidate.
-// The sums are double buffered exactly as before (pass k reads sums[k & 1]); a region's deltas of pass k go to
-// sums[(k + 1) & 1] before barrier k and to sums[k & 1] right after it -- when every workgroup of the frame has finished
-// reading that buffer -- so both buffers are complete when the launch ends and no log is kept.  The border pixels use
-// two label maps the same way (m.label / m.label_alt by pass parity).
-// Residency: every workgroup of a frame must be on the chip at once.  launch_update_passes sizes the grid well below what
-// the part holds (<= PASSES_MAX_WGS workgroups of 256 threads), the host serialises these launches across the extract
-// contexts of a handle, and every wait is bounded by wall-clock time: a launch that cannot make progress (several
-// processes oversubscribing one GPU) raises its abort word -- all its workgroups leave, the host reports SSF_ERR_DEVICE --
-// it does not hang the device.
-#define PASSES_NW_MAX 96            // window cells (rows / accumulators in LDS)
-#ifndef PASSES_NT
-#define PASSES_NT 512               // threads per workgroup (8 waves: two per SIMD, so that LDS latencies of one overlap the other's issue)
-#endif
-#define PASSES_MAXS (1280 / PASSES_NT + (1280 % PASSES_NT ? 1 : 0))       // pass pixels per thread: regions of up to 5120 pixels
-#define PASSES_RING_SLOTS (768 / PASSES_NT + (768 % PASSES_NT ? 1 : 0))   // border / halo pixels per thread: rings of up to 768 pixels
-#define PASSES_MAX_WGS 512          // 2 workgroups per CU: at ~128 registers per thread that is half of the register file, the
-                                    // other half stays free for the track chain's kernels and the other extract launches
-struct PassGeom {
-    int rw, rh, nrx, nry;           // region size (multiples of 4 / 2), regions per row / column
-    int nw_cap;                     // upper bound of a region's window cells (sizes the rows / accumulators in LDS)
-    int wait_ms;                    // bound of a barrier wait
-    unsigned long long ticks_per_ms;
-};
-__device__ __forceinline__ long long ld_agent_i64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// the record of superpixel k as the row arithmetic wants it, read with device-scope loads (other workgroups of this launch
-// have added to it): four 16-byte pieces would be one round trip each anyway
-struct SumVals { int sx, sy, sr, sg, sb, n, dx, dy, dn; long long dxx, dyy, dxy, dxd, dyd, dd; };
-__device__ __forceinline__ SumVals ld_sums_agent(const SpSums& s, int k, bool planes) {
-    const long long* q = reinterpret_cast<const long long*>(&s.r[k]);
-    SumVals v;
-    const long long a0 = ld_agent_i64(q), a1 = ld_agent_i64(q + 1), a2 = ld_agent_i64(q + 2);
-    long long a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-    if (planes) {
-        a3 = ld_agent_i64(q + 3); a4 = ld_agent_i64(q + 4);
-        b0 = ld_agent_i64(q + 8); b1 = ld_agent_i64(q + 9); b2 = ld_agent_i64(q + 10); b3 = ld_agent_i64(q + 11); b4 = ld_agent_i64(q + 12); b5 = ld_agent_i64(q + 13);
-    }
-    v.sx = (int)(unsigned int)a0; v.sy = (int)(unsigned int)((unsigned long long)a0 >> 32);
-    v.sr = (int)(unsigned int)a1; v.sg = (int)(unsigned int)((unsigned long long)a1 >> 32);
-    v.sb = (int)(unsigned int)a2; v.n = (int)(unsigned int)((unsigned long long)a2 >> 32);
-    v.dx = (int)(unsigned int)a3; v.dy = (int)(unsigned int)((unsigned long long)a3 >> 32);
-    v.dn = (int)(unsigned int)a4;
-    v.dxx = b0; v.dyy = b1; v.dxy = b2; v.dxd = b3; v.dyd = b4; v.dd = b5;
-    return v;
-}
-// mergeTPSRGBCoeffs / mergeTPSRGBDCoeffs (TPS_RGBD_kernels.cu:224-276): the arithmetic of row_from_sums, on values
-__device__ __forceinline__ SpRow row_from_vals(const SumVals& v, bool planes) {
-    SpRow row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float n = (float)v.n;
-    row.cx = (float)v.sx / n; row.cy = (float)v.sy / n;
-    row.r = (float)v.sr / n; row.g = (float)v.sg / n; row.b = (float)v.sb / n;
-    row.size = n;
-    if (planes) {
-        const double inv = 1.0 / SSF_DISP_SCALE;
-        const float dx = (float)v.dx, dy = (float)v.dy, dn = (float)v.dn;
-        const float dxx = (float)v.dxx, dyy = (float)v.dyy, dxy = (float)v.dxy;
-        const float dxd = (float)((double)v.dxd * inv), dyd = (float)((double)v.dyd * inv);
-        const float dd = (float)((double)v.dd * inv);
-        float ta, tb, tc;
-        if (!plane_solve(ta, tb, tc, dxx, dxy, dx, dxd, dxy, dyy, dy, dyd, dx, dy, dn, dd)) {
-            ta = 0.f; tb = 0.f; tc = __uint_as_float(0xFFE00000u);
-        }
-        row.ta = ta; row.tb = tb; row.tc = tc;
-    }
-    return row;
-}
-// one field of a sums record += v, RETURNING (the value that comes back proves the add has been performed)
-__device__ __forceinline__ unsigned long long flush_field_done(const SpSums& s, int l, int field, long long v) {
-    int* ip = nullptr; long long* lp = nullptr;
-    switch (field) {
-        case F_SX: ip = &s.r[l].sx; break; case F_SY: ip = &s.r[l].sy; break; case F_SR: ip = &s.r[l].sr; break;
-        case F_SG: ip = &s.r[l].sg; break; case F_SB: ip = &s.r[l].sb; break; case F_N: ip = &s.r[l].n; break;
-        case F_DX: ip = &s.r[l].dx; break; case F_DY: ip = &s.r[l].dy; break; case F_DN: ip = &s.r[l].dn; break;
-        case F_DXX: lp = &s.r[l].dxx; break; case F_DYY: lp = &s.r[l].dyy; break; case F_DXY: lp = &s.r[l].dxy; break;
-        case F_DXD: lp = &s.r[l].dxd; break; case F_DYD: lp = &s.r[l].dyd; break; default: lp = &s.r[l].dd; break;
-    }
-    if (ip) return (unsigned long long)(unsigned int)atomicAdd(ip, (int)v);
-    return atomicAdd(reinterpret_cast<unsigned long long*>(lp), (unsigned long long)v);
-}
-// the slow path's global adds, RETURNING: sign * the RGB sums / the 9 disparity sums of one pixel
-__device__ __forceinline__ unsigned long long rgb_sums_add_done(const SpSums& s, int k, int x, int y, int ir, int ig, int ib, int sign) {
-    unsigned int a = (unsigned int)atomicAdd(&s.r[k].sx, sign * x); a ^= (unsigned int)atomicAdd(&s.r[k].sy, sign * y);
-    a ^= (unsigned int)atomicAdd(&s.r[k].sr, sign * ir); a ^= (unsigned int)atomicAdd(&s.r[k].sg, sign * ig);
-    a ^= (unsigned int)atomicAdd(&s.r[k].sb, sign * ib); a ^= (unsigned int)atomicAdd(&s.r[k].n, sign);
-    return a;
-}
-__device__ __forceinline__ unsigned long long disp_sums_add_done(const SpSums& s, int k, int x, int y, float d, int sign) {
-    unsigned long long a = (unsigned int)atomicAdd(&s.r[k].dx, sign * x); a ^= (unsigned int)atomicAdd(&s.r[k].dy, sign * y);
-    a ^= (unsigned int)atomicAdd(&s.r[k].dn, sign);
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dxx), (unsigned long long)((long long)sign * x * x));
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dyy), (unsigned long long)((long long)sign * y * y));
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dxy), (unsigned long long)((long long)sign * x * y));
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dxd), (unsigned long long)(sign * fx64((double)((float)x * d), SSF_DISP_SCALE, SSF_DISP_LIM)));
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dyd), (unsigned long long)(sign * fx64((double)((float)y * d), SSF_DISP_SCALE, SSF_DISP_LIM)));
-    a ^= atomicAdd(reinterpret_cast<unsigned long long*>(&s.r[k].dd), (unsigned long long)(sign * fx64((double)d, SSF_DISP_SCALE, SSF_DISP_LIM)));
-    return a;
-}
-// one entry of a workgroup's overflow list applied to buffer s (see k_passes)
-__device__ __forceinline__ unsigned long long replay_overflow(const SpSums& s, const int4& en, float d) {
-    const unsigned fl = (unsigned)en.w >> 24; const int px_x = en.z & 0xFFFF, px_y = (en.z >> 16) & 0xFFFF;
-    const int ir = en.w & 255, ig = (en.w >> 8) & 255, ib = (en.w >> 16) & 255;
-    unsigned long long a = 0;
-    if ((fl & 1u) && en.x >= 0) a ^= rgb_sums_add_done(s, en.x, px_x, px_y, ir, ig, ib, -1);
-    if ((fl & 1u) && en.y >= 0) a ^= rgb_sums_add_done(s, en.y, px_x, px_y, ir, ig, ib, +1);
-    if (fl & 2u) a ^= disp_sums_add_done(s, en.y, px_x, px_y, d, +1);
-    if (fl & 4u) a ^= disp_sums_add_done(s, en.x, px_x, px_y, d, -1);
-    return a;
-}
-extern __shared__ __attribute__((aligned(16))) unsigned char passes_lds[];
-template <bool RGBD>
-__global__ __launch_bounds__(PASSES_NT) void k_passes(SegParams p, FrameMaps m, PassGeom g, int k0, int k1, unsigned int* abort_host) {
-    m = batch_slot(m, blockIdx.y);
-    const int tid = threadIdx.x;
-    const int rj = (int)blockIdx.x / g.nrx, ri = (int)blockIdx.x - rj * g.nrx;
-    const int x0 = ri * g.rw, y0 = rj * g.rh;
-    const int rw = min(g.rw, p.W - x0), rh = min(g.rh, p.H - y0);          // (partial regions at the right / lower edge)
-    const int TWW = g.rw + 2;
-    // LDS carve (16-byte aligned pieces): label tile + halo | inlier mask | window rows | window accumulators: this pass'
-    // deltas and the previous pass' (see step 4)
-    int* lab = reinterpret_cast<int*>(passes_lds);
-    size_t off = ((size_t)TWW * (g.rh + 2) * 4 + 15) & ~(size_t)15;
-    unsigned char* inl = passes_lds + off; off += ((size_t)g.rw * g.rh + 15) & ~(size_t)15;
-    SpRow* w_row = reinterpret_cast<SpRow*>(passes_lds + off); off += sizeof(SpRow) * (size_t)g.nw_cap;
-    unsigned long long* w_acc = reinterpret_cast<unsigned long long*>(passes_lds + off); off += (size_t)8 * g.nw_cap * F_COUNT;
-    unsigned long long* w_prev = reinterpret_cast<unsigned long long*>(passes_lds + off);
-    __shared__ unsigned int s_nover[2], s_flag;
-    // window of grid cells around the region (margin 2, less when it would not fit)
-    int margin = 2;
-    const int tcx0 = x0 / p.cell, tcy0 = y0 / p.cell, tcx1 = (x0 + rw - 1) / p.cell, tcy1 = (y0 + rh - 1) / p.cell;
-    while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > g.nw_cap) margin--;
-    const int wcx0 = tcx0 - margin, wcy0 = tcy0 - margin;
-    const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin, nw = nwx * nwy;     // (<= g.nw_cap <= PASSES_NW_MAX: the launcher's choice)
-    const float inv_gx = 1.0f / (float)p.gx;
-    auto slot_of = [&](int l) -> int {
-        const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
-        const int wx = (l - cyl * p.gx) - wcx0, wy = cyl - wcy0;
-        return (wx >= 0 && wx < nwx && wy >= 0 && wy < nwy) ? wy * nwx + wx : -1;
-    };
-    // ---- load the region: labels + halo (the launch before this one has completed: plain loads), inlier mask
-    for (int i = tid; i < TWW * (g.rh + 2); i += PASSES_NT) {
-        const int ly = i / TWW, lx = i - ly * TWW;
-        const int x = x0 - 1 + lx, y = y0 - 1 + ly;
-        lab[i] = (x >= 0 && x < p.W && y >= 0 && y < p.H) ? m.label[(size_t)y * p.W + x] : -1;
-    }
-    if (RGBD)
-        for (int i = tid; i < g.rw * g.rh; i += PASSES_NT) {
-            const int ly = i / g.rw, lx = i - ly * g.rw;
-            inl[i] = (lx < rw && ly < rh) ? m.inlier[(size_t)(y0 + ly) * p.W + x0 + lx] : 0;
-        }
-    for (int i = tid; i < nw * F_COUNT; i += PASSES_NT) { w_acc[i] = 0ull; w_prev[i] = 0ull; }
-    if (tid == 0) { s_nover[0] = 0u; s_nover[1] = 0u; s_flag = 0u; }
-    // border ring of the region (published every pass) and halo ring around it (refreshed every pass)
-    const int n_ring = 2 * rw + 2 * max(rh - 2, 0), n_halo = 2 * (rw + 2) + 2 * rh;
-    auto ring_pos = [&](int i, int& lx, int& ly) {                 // border pixel i of the region, region coordinates
-        if (i < rw) { lx = i; ly = 0; } else if (i < 2 * rw) { lx = i - rw; ly = rh - 1; }
-        else { const int j = i - 2 * rw; const int h2 = rh - 2; if (j < h2) { lx = 0; ly = 1 + j; } else { lx = rw - 1; ly = 1 + j - h2; } }
-    };
-    auto halo_pos = [&](int i, int& lx, int& ly) {                 // halo pixel i, region coordinates (-1 .. rw / rh)
-        if (i < rw + 2) { lx = i - 1; ly = -1; } else if (i < 2 * (rw + 2)) { lx = i - (rw + 2) - 1; ly = rh; }
-        else { const int j = i - 2 * (rw + 2); if (j < rh) { lx = -1; ly = j; } else { lx = rw; ly = j - rh; } }
-    };
-    // overflow lists of this workgroup (deltas of labels OUTSIDE the window: rare), two of them, alternating by pass: slices
-    // of the per-pass log areas of k_update_pass, which this mode does not use
-    const int over_cap = (g.rw * g.rh) / 4;
-    const int nbx = g.rw >> 2, npp = nbx * (g.rh >> 1) * 2;        // pass pixels of a full region
-    const int G = g.nrx * g.nry;
-    unsigned long long* bar = m.pbar + (RGBD ? 1 : 0);
-    const unsigned long long wait_ticks = (unsigned long long)g.wait_ms * g.ticks_per_ms;
-    const SpSums B0 = m.sums[0], B1 = m.sums[1];
-    constexpr int NFL = (PASSES_NW_MAX * F_COUNT + PASSES_NT - 1) / PASSES_NT, NRING = PASSES_RING_SLOTS;
-#ifdef SSF_PASSES_PROFILE
-    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, prof_t = 0;
-#define PASSES_TICK(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += now_ - prof_t; prof_t = now_; } } while (0)
-    if (tid == 0) prof_t = __builtin_readcyclecounter();
+// ---- resident relabelling (all passes of a phase in one launch): a measurement arm that lost its A/B (DESIGN.md section
+// 4.1.1) -- lab/passes_resident.inc, compiled only into the lab variant of the library
+#ifdef SSF_EXPERIMENTS
+#include "lab/passes_resident.inc"
 #else
-#define PASSES_TICK(i) do { } while (0)
+bool update_passes_resident(const SegParams&, int) { return false; }
+bool launch_update_passes(hipStream_t, const SegParams&, FrameMaps&, int, int, int, bool, unsigned int*) { return false; }
 #endif
-    __syncthreads();
-    const int ox4[4] = {0, 1, 0, 1}, oy4[4] = {0, 1, 1, 0};            // pass order, TPS_RGBD.cu:190-268
-    for (int k = k0; k < k1; k++) {
-        const int OX = ox4[k & 3], OY = oy4[k & 3];
-        const bool odd = (k & 1) != 0;
-        const SpSums sr = odd ? B1 : B0, sw = odd ? B0 : B1;          // read / write buffer of this pass
-        // border pixels: pass k0 publishes into label_alt (m.label is still being read by workgroups that start late), the
-        // next pass into m.label, and so on; the halo comes from where the previous pass published
-        const bool rel = ((k - k0) & 1) != 0;
-        int32_t* map_pub = rel ? m.label : m.label_alt;
-        const int32_t* map_halo = rel ? m.label_alt : m.label;
-        int4* over_ent = (rel ? m.log.ent[1] : m.log.ent[0]) + (size_t)blockIdx.x * over_cap;       // this pass' list
-        float* over_dis = (rel ? m.log.disp[1] : m.log.disp[0]) + (size_t)blockIdx.x * over_cap;
-        const int4* over_ent_prev = (rel ? m.log.ent[0] : m.log.ent[1]) + (size_t)blockIdx.x * over_cap;   // the previous pass'
-        const float* over_dis_prev = (rel ? m.log.disp[0] : m.log.disp[1]) + (size_t)blockIdx.x * over_cap;
-        unsigned int* n_over = &s_nover[rel ? 1 : 0];
-        const unsigned int n_over_prev = s_nover[rel ? 0 : 1];
-        // ---- 1. / 2.  ONE round trip for everything this pass needs from memory -- every request is issued before the
-        // first result is looked at: the sums of the window's cells (device-scope loads: the read buffer is complete, see the
-        // header), the halo from where the neighbours published, the pixel operands of this thread's pass pixels
-        const bool have_row = tid < nw;
-        int row_cell = -1;
-        if (have_row) { const int cx = wcx0 + tid % nwx, cy = wcy0 + tid / nwx; if (cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy) row_cell = cy * p.gx + cx; }
-        SumVals sv = {};
-        if (row_cell >= 0) sv = ld_sums_agent(sr, row_cell, RGBD);
-        int halo_v[NRING], halo_i[NRING];
-#pragma unroll
-        for (int j = 0; j < NRING; j++) {
-            halo_i[j] = -1; halo_v[j] = -1;
-            const int i = tid + PASSES_NT * j;
-            if (k > k0 && i < n_halo) {
-                int lx, ly; halo_pos(i, lx, ly);
-                const int x = x0 + lx, y = y0 + ly;
-                if (x >= 0 && x < p.W && y >= 0 && y < p.H) {
-                    halo_i[j] = (ly + 1) * TWW + lx + 1;
-                    halo_v[j] = __hip_atomic_load(&map_halo[(size_t)y * p.W + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        // this thread's pass pixels: block b = e >> 1 of the 4 x 2 blocks of the region, pixel e & 1 of the block's pair
-        int plx[PASSES_MAXS], ply[PASSES_MAXS]; uint32_t px[PASSES_MAXS]; float disp[PASSES_MAXS]; bool live[PASSES_MAXS];
-#pragma unroll
-        for (int s2 = 0; s2 < PASSES_MAXS; s2++) {
-            const int e = tid + PASSES_NT * s2;
-            const int b = e >> 1, by = b / nbx, bx = b - by * nbx;
-            plx[s2] = 4 * bx + (OX ? 1 + (e & 1) : 3 * (e & 1)); ply[s2] = 2 * by + OY;
-            live[s2] = e < npp && plx[s2] < rw && ply[s2] < rh;
-            px[s2] = 0u; disp[s2] = 0.f;
-            if (live[s2]) {
-                const size_t q = (size_t)(y0 + ply[s2]) * p.W + x0 + plx[s2];
-                px[s2] = m.rgba[q];
-                if (RGBD) disp[s2] = m.disp[q];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NRING; j++) if (halo_i[j] >= 0) lab[halo_i[j]] = halo_v[j];
-        if (have_row) {
-            SpRow row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (row_cell >= 0) row = row_from_vals(sv, RGBD);
-            w_row[tid] = row;
-        }
-        if (tid == 0) *n_over = 0u;                                    // this pass' overflow list starts empty
-        __syncthreads();
-        PASSES_TICK(0);
-        auto row_of = [&](int l) -> SpRow {
-            const int ws = slot_of(l);
-            if (ws >= 0) return w_row[ws];
-            return row_from_vals(ld_sums_agent(sr, l, RGBD), RGBD);    // drifted out of the window: exact slow path
-        };
-        // ---- 3a. decisions from the snapshot (arithmetic of k_update_pass, line by line)
-        int new_index[PASSES_MAXS]; unsigned char dflags[PASSES_MAXS], dinl[PASSES_MAXS];
-#pragma unroll
-        for (int s2 = 0; s2 < PASSES_MAXS; s2++) {
-            new_index[s2] = -1; dflags[s2] = 0; dinl[s2] = 0;
-            if (!live[s2]) continue;
-            const int lx = plx[s2] + 1, ly = ply[s2] + 1;                 // halo coordinates
-            const int x = x0 + plx[s2], y = y0 + ply[s2];
-            const int index = lab[ly * TWW + lx];
-            int ni = index;
-            const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};
-            int nl[4];
-#pragma unroll
-            for (int q2 = 0; q2 < 4; q2++) nl[q2] = lab[(ly + ny[q2]) * TWW + lx + nx[q2]];
-            const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
-            bool eligible = bounds != 0;
-            if (eligible) {
-                // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W
-                const int ox[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, oy[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
-                bool prev = lab[(ly + oy[0]) * TWW + lx + ox[0]] == index;
-                int jump = 0;
-#pragma unroll
-                for (int q2 = 1; q2 < 8; q2++) {
-                    const bool cur = lab[(ly + oy[q2]) * TWW + lx + ox[q2]] == index;
-                    if (prev != cur) { jump++; prev = cur; }
-                }
-                eligible = !(jump > 2);
-            }
-            const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            SpRow own = zero_row;
-            if (RGBD || eligible) own = row_of(index);
-            float disp_energy = 0.f;
-            unsigned char inlier = 0xff;
-            if (RGBD) {
-                const float dp = (own.ta * (float)x + own.tb * (float)y) + own.tc;
-                disp_energy = (dp - disp[s2]) * (dp - disp[s2]);
-                if (!isfinite(disp_energy) || disp_energy > p.thresh_disp || dp < 0.f) { disp_energy = p.thresh_disp; inlier = 0; }
-            }
-            if (eligible) {
-                const float cr = (float)(px[s2] & 255u), cg = (float)((px[s2] >> 8) & 255u), cb = (float)((px[s2] >> 16) & 255u);
-                const float posx = (float)x, posy = (float)y;
-                const float size = own.size;
-                const float sc = size / (size - 1.f);
-                const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
-                const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
-                const float dsize = size - (float)p.min_size;
-                float best = dot3(dcol, dcol) + p.lambda_pos * (dpx * dpx + dpy * dpy);
-                if (RGBD) best = best + p.lambda_disp * disp_energy;
-                best = best - p.lambda_size * fminf(dsize, 0.f);
-                best = best + p.lambda_bound * (float)bounds;
-#pragma unroll
-                for (int q2 = 0; q2 < 4; q2++) {
-                    const int i_n = nl[q2];
-                    if (i_n == -1 || i_n == index) continue;
-                    const SpRow nb = row_of(i_n);
-                    const float ndx = posx - nb.cx, ndy = posy - nb.cy;
-                    const V3 ndc = v3(cr - nb.r, cg - nb.g, cb - nb.b);
-                    const float ndsize = (nb.size + 1.f) - (float)p.min_size;
-                    float n_de = 0.f; unsigned char n_inlier = 0xff;
-                    if (RGBD) {
-                        const float dp = (nb.ta * (float)x + nb.tb * (float)y) + nb.tc;
-                        n_de = (dp - disp[s2]) * (dp - disp[s2]);
-                        if (!isfinite(n_de) || n_de > p.thresh_disp || dp < 0.f) { n_de = p.thresh_disp; n_inlier = 0; }
-                    }
-                    const int b = (nl[0] != i_n) + (nl[1] != i_n) + (nl[2] != i_n) + (nl[3] != i_n);
-                    float e2 = dot3(ndc, ndc) + p.lambda_pos * (ndx * ndx + ndy * ndy);
-                    if (RGBD) e2 = e2 + p.lambda_disp * n_de;
-                    e2 = e2 - p.lambda_size * fminf(ndsize, 0.f);
-                    e2 = e2 + p.lambda_bound * (float)b;
-                    if (e2 < best) { best = e2; ni = i_n; if (RGBD) inlier = n_inlier; }
-                }
-            }
-            unsigned flags = (ni != index) ? 1u : 0u;
-            if (RGBD) {
-                const unsigned char prev_inlier = inl[ply[s2] * g.rw + plx[s2]];
-                if (inlier && (!prev_inlier || index != ni)) flags |= 2u;
-                if (prev_inlier && (!inlier || (inlier && index != ni))) flags |= 4u;
-                if (inlier != prev_inlier) flags |= 8u;                 // (the mask byte changes)
-            }
-            new_index[s2] = ni; dflags[s2] = (unsigned char)flags; dinl[s2] = inlier;
-        }
-        __syncthreads();                                               // every decision has read the snapshot
-        PASSES_TICK(1);
-        // ---- 3b. apply: labels and mask in LDS; sum deltas into the window's LDS accumulators; for a label OUTSIDE the
-        // window (rare) an entry of this pass' overflow list
-#pragma unroll
-        for (int s2 = 0; s2 < PASSES_MAXS; s2++) {
-            if (!live[s2] || !dflags[s2]) continue;
-            const int li = (ply[s2] + 1) * TWW + plx[s2] + 1;
-            const int from = lab[li], to = new_index[s2];
-            if (dflags[s2] & 1u) lab[li] = to;
-            if (RGBD && (dflags[s2] & 8u)) inl[ply[s2] * g.rw + plx[s2]] = dinl[s2];
-            const unsigned fl = dflags[s2] & 7u;
-            if (!fl) continue;
-            const int px_x = x0 + plx[s2], px_y = y0 + ply[s2];
-            const uint32_t rgbf = (px[s2] & 0x00FFFFFFu) | (fl << 24);
-            const int wf = slot_of(from), wt = slot_of(to);
-            if (fl & 1u) {
-                if (wf >= 0) lds_rgb(&w_acc[wf * F_COUNT], -1, px_x, px_y, rgbf);
-                if (wt >= 0) lds_rgb(&w_acc[wt * F_COUNT], +1, px_x, px_y, rgbf);
-            }
-            if ((fl & 2u) && wt >= 0) lds_disp(&w_acc[wt * F_COUNT], +1, px_x, px_y, disp[s2]);
-            if ((fl & 4u) && wf >= 0) lds_disp(&w_acc[wf * F_COUNT], -1, px_x, px_y, disp[s2]);
-            const unsigned keep = (((fl & 1u) && (wf < 0 || wt < 0)) ? 1u : 0u) | (((fl & 2u) && wt < 0) ? 2u : 0u) | (((fl & 4u) && wf < 0) ? 4u : 0u);
-            if (keep) {
-                const unsigned int e = atomicAdd(n_over, 1u);
-                over_ent[e] = make_int4(wf < 0 ? from : -1, wt < 0 ? to : -1, px_x | (px_y << 16), (int)((rgbf & 0x00FFFFFFu) | (keep << 24)));
-                over_dis[e] = disp[s2];
-            }
-        }
-        __syncthreads();
-        PASSES_TICK(2);
-        // ---- 4. the write buffer receives this pass' deltas AND the previous pass' (which it still lacks: the buffers
-        // alternate), in one returning atomic per non-zero accumulator; the border pixels go to this pass' map; all requests
-        // are issued before the first return value is looked at; then the frame's barrier
-        unsigned long long r_fl[NFL], r_over = 0;
-#pragma unroll
-        for (int j = 0; j < NFL; j++) {
-            r_fl[j] = 0;
-            const int i = tid + PASSES_NT * j;
-            if (i < nw * F_COUNT) {
-                const long long cur = (long long)w_acc[i], v = cur + (long long)w_prev[i];
-                w_prev[i] = (unsigned long long)cur; w_acc[i] = 0ull;
-                if (v != 0) { const int wi = i / F_COUNT; r_fl[j] = flush_field_done(sw, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i - wi * F_COUNT, v); }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NRING; j++) {
-            const int i = tid + PASSES_NT * j;
-            if (i < n_ring) {
-                int lx, ly; ring_pos(i, lx, ly);
-                // (write-through device-scope store; drained by this wave's s_waitcnt vmcnt(0) below before the workgroup arrives,
-                // read with device-scope loads: the publish / consume pair of cdna_hip_programming.md, Guideline 16)
-                __hip_atomic_store(&map_pub[(size_t)(y0 + ly) * p.W + x0 + lx], lab[(ly + 1) * TWW + lx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        {   // overflow lists (rare): this pass' entries and the previous pass' go to the write buffer as well
-            const unsigned int n_cur = *n_over;
-            for (unsigned int e = tid; e < n_cur; e += PASSES_NT) r_over ^= replay_overflow(sw, over_ent[e], over_dis[e]);
-            for (unsigned int e = tid; e < n_over_prev; e += PASSES_NT) r_over ^= replay_overflow(sw, over_ent_prev[e], over_dis_prev[e]);
-        }
-#pragma unroll
-        for (int j = 0; j < NFL; j++) asm volatile("" :: "v"(r_fl[j]));
-        asm volatile("" :: "v"(r_over));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the border's and the overflow list's stores too)
-        __syncthreads();
-        PASSES_TICK(3);
-        {   // (also behind the LAST pass: its deltas still have to go into the buffer the others may be reading)
-            if (tid == 0) {
-                const unsigned int target = (unsigned int)G * (unsigned int)(k - k0 + 1);
-                __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long t0 = wall_clock64();
-                unsigned int spins = 0, bad = 0;
-                for (;;) {
-                    const unsigned long long w = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((w >> 32) != 0ull) { bad = 1; break; }
-                    if ((unsigned int)w >= target) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    if ((++spins & 255u) == 0u && wall_clock64() - t0 > wait_ticks) {
-                        __hip_atomic_fetch_or(bar, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        bad = 1; break;
-                    }
-                }
-                s_flag = bad;
-            }
-            __syncthreads();
-            PASSES_TICK(4);
-            if (s_flag) return;                                          // (the frames of this batch are lost; the host reports it)
-        }
-    }
-#ifdef SSF_PASSES_PROFILE
-    if (tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 27))
-        printf("k_passes<%d> wg %d of %d x %d frames, %d passes: cycles load %llu decide %llu apply %llu flush %llu barrier %llu\n", (int)RGBD, (int)blockIdx.x,
-               (int)gridDim.x, (int)gridDim.y, k1 - k0, prof[0], prof[1], prof[2], prof[3], prof[4]);
-#endif
-    // ---- the last pass' deltas also go to its read buffer (every workgroup of the frame is past the last barrier: nobody
-    // reads it any more in this launch), the region goes home
-    if (k1 > k0) {
-        const bool odd = ((k1 - 1) & 1) != 0, rel = ((k1 - 1 - k0) & 1) != 0;
-        const SpSums sr = odd ? B1 : B0;
-        for (int i = tid; i < nw * F_COUNT; i += PASSES_NT) {
-            const long long v = (long long)w_prev[i];
-            if (v != 0) { const int wi = i / F_COUNT; flush_field(sr, (wcy0 + wi / nwx) * p.gx + wcx0 + wi % nwx, i - wi * F_COUNT, v); }
-        }
-        const int4* oe = (rel ? m.log.ent[1] : m.log.ent[0]) + (size_t)blockIdx.x * over_cap;
-        const float* od = (rel ? m.log.disp[1] : m.log.disp[0]) + (size_t)blockIdx.x * over_cap;
-        const unsigned int nover = s_nover[rel ? 1 : 0];
-        for (unsigned int e = tid; e < nover; e += PASSES_NT) { const unsigned long long a = replay_overflow(sr, oe[e], od[e]); asm volatile("" :: "v"(a)); }
-    }
-    for (int i = tid; i < g.rw * g.rh; i += PASSES_NT) {
-        const int ly = i / g.rw, lx = i - ly * g.rw;
-        if (lx < rw && ly < rh) {
-            const size_t q = (size_t)(y0 + ly) * p.W + x0 + lx;
-            m.label[q] = lab[(ly + 1) * TWW + lx + 1];
-            if (RGBD) m.inlier[q] = inl[i];
-        }
-    }
-}
 
 // ---- RANSAC plane initialisation ---------------------------------------------------------------
 __device__ __forceinline__ size_t tex_index(float x, float y, int W, int H) {   // point sampling, clamp
@@ -1963,13 +1508,15 @@ void launch_bilateral_batch(hipStream_t st, const BatchIn& in, float* out0, size
     int radius = (int)lrint((double)sigma_space * 1.5);
     if (radius < 1) radius = 1;
     const float ss = -0.5f / (sigma_space * sigma_space), sc = -0.5f / (sigma_color * sigma_color);
-    static const bool generic_only = getenv("SSF_BILATERAL_GENERIC") != nullptr;
+    static const bool generic_only = SSF_ENV_SET("BILATERAL_GENERIC");
     const dim3 grid((W + BIL_TILE - 1) / BIL_TILE, (H + BIL_TILE - 1) / BIL_TILE, nb);
     if (radius == 7 && !generic_only) {
-        static const int waves = getenv("SSF_BIL_WAVES") ? atoi(getenv("SSF_BIL_WAVES")) : 2;
-        if (waves == 3) hipLaunchKernelGGL(k_bilateral_r7<3>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
-        else if (waves == 4) hipLaunchKernelGGL(k_bilateral_r7<4>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
-        else hipLaunchKernelGGL(k_bilateral_r7<2>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
+#ifdef SSF_EXPERIMENTS
+        static const int waves = SSF_ENV_INT("BIL_WAVES", 2);       // (3 and 4 waves per SIMD spill: measured slower)
+        if (waves == 3) { hipLaunchKernelGGL(k_bilateral_r7<3>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc); return; }
+        if (waves == 4) { hipLaunchKernelGGL(k_bilateral_r7<4>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc); return; }
+#endif
+        hipLaunchKernelGGL(k_bilateral_r7<2>, grid, dim3(256), 0, st, in, out0, slab, W, H, ss, sc);
         return;
     }
     hipLaunchKernelGGL(k_bilateral, grid, dim3(256), 0, st, in, out0, slab, W, H, radius, ss, sc);
@@ -1987,8 +1534,7 @@ void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameM
 }
 // pass pixels per thread (tile width / 32) for a launch over nb frames; SSF_PASS_NPX = 1 / 2 forces it (measurement)
 int pass_tile_npx(int nb) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("SSF_PASS_NPX"); forced = e ? atoi(e) : 0; }
+    static const int forced = SSF_ENV_INT("PASS_NPX", 0);
     if (forced == 1 || forced == 2) return forced;
     (void)nb;
     return 1;       // measured (profiles/bench_r02_npx*.json): the 64-wide tiles cut the pass's HBM traffic from 1.25x to 1.01x of
@@ -1996,14 +1542,18 @@ int pass_tile_npx(int nb) {
                     // how many workgroups are resident -- and cost a single-frame launch 50 % more (8 -> 12 us)
 }
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
+#ifdef SSF_EXPERIMENTS
     static const char* per_pass_names[64] = {nullptr};
     static int per_pass = -1;
     if (per_pass < 0) {
-        per_pass = getenv("SSF_PROFILE_PER_PASS") ? 1 : 0;
+        per_pass = SSF_ENV_SET("PROFILE_PER_PASS") ? 1 : 0;
         static char buf[64][16];
         for (int i = 0; i < 64; i++) { snprintf(buf[i], 16, "pass_%02d", i); per_pass_names[i] = buf[i]; }
     }
     ScopedKernel sk(per_pass ? per_pass_names[k & 63] : (rgbd ? "update_pass_rgbd" : "update_pass_rgb"), st);
+#else
+    ScopedKernel sk(rgbd ? "update_pass_rgbd" : "update_pass_rgb", st);
+#endif
     // OX = 0: tiles shifted left by (tile width - 2): [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
     // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.  All passes of a
     // frame use the same tile width (the log layout depends on it): 64 when the launch covers several frames.
@@ -2015,93 +1565,24 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     const TileOrder ord = tile_order(grid);
     // occupancy target of the RGB-D variant: 6 waves per SIMD (73 registers, no spills).  Forcing 8 (64 registers, 9 spilled
     // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
-    static int waves = 0;
-    if (!waves) { const char* e = getenv("SSF_PASS_WAVES"); const int w = e ? atoi(e) : 6; waves = (w == 7 || w == 8) ? w : 6; }
+    static const int waves_env = SSF_ENV_INT("PASS_WAVES", 6);
+    const int waves = (waves_env == 7 || waves_env == 8) ? waves_env : 6; (void)waves;
     // (Round 3 measured two more forms of this pass against the 256-thread kernel -- one wave per tile with the changeable
     // pixels compacted: 22 / 31 us per 8-frame launch against 15 / 20; four waves that compact the changeable pixels into an
     // LDS list and RELEASE the waves the list does not need: 17 / 22 us, same frame rate -- both bit-exact, both slower; they
     // live in the history, not in the source.)
+#ifdef SSF_EXPERIMENTS
+    // the instantiations that lost their A/B: 64-wide tiles (two pass pixels per thread), 7 / 8 waves per SIMD for the RGB-D pass
     if (npx == 2) {
         if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
         else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-    } else if (rgbd) {
-        if (waves == 8) hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-        else if (waves == 7) hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-        else hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-    } else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-}
-static size_t passes_lds_bytes(const PassGeom& g) {
-    size_t off = ((size_t)(g.rw + 2) * (g.rh + 2) * 4 + 15) & ~(size_t)15;
-    off += ((size_t)g.rw * g.rh + 15) & ~(size_t)15;
-    off += sizeof(SpRow) * (size_t)g.nw_cap;
-    off += (size_t)2 * 8 * g.nw_cap * F_COUNT;        // this pass' accumulators and the previous pass'
-    return off;
-}
-// Geometry of the resident relabelling launch for nb frames, or rw = 0 when it does not qualify.  Regions are multiples of
-// 4 x 2 pixels (the pass pattern's period); the smallest region from the list that keeps the grid within PASSES_MAX_WGS
-// workgroups is taken (more, smaller regions = more of the chip busy per pass; the window rows are built per region).
-static PassGeom passes_geometry(const SegParams& p, int nb) {
-    PassGeom g{};
-    static int mode = -1;
-    // OFF by default: measured on MI355X (round 3, profiles/resident_passes_r03.txt) the resident form is bit-exact but SLOWER
-    // than the per-pass launches -- 12-15 us per pass for one frame against 9.6, 16-21 us for eight frames against 12-16 --
-    // because what a kernel boundary gives for ~2 us (completion of the flush + a grid-wide barrier) costs three dependent
-    // trips to memory in software here (returning atomics, arrival, poll).  SSF_RESIDENT_PASSES=1 selects it.
-    if (mode < 0) { const char* e = getenv("SSF_RESIDENT_PASSES"); mode = e ? atoi(e) : 0; }
-    if (!mode || nb < 1) return g;
-    static int max_wgs = 0, forced_rw = 0, forced_rh = 0, wait_ms = 0;
-    if (!max_wgs) {
-        const char* e = getenv("SSF_PASSES_MAX_WGS"); max_wgs = e ? std::max(64, atoi(e)) : PASSES_MAX_WGS;
-        if (const char* r = getenv("SSF_PASSES_REGION")) { forced_rw = atoi(r); const char* x = strchr(r, 'x'); forced_rh = x ? atoi(x + 1) : 0; }
-        const char* w = getenv("SSF_PASSES_WAIT_MS"); wait_ms = w ? std::max(1, atoi(w)) : 2000;
+        return;
     }
-    // (the LARGEST region that qualifies: the frame's barrier costs with the number of workgroups that meet at it -- 256
-    // regions of 40 x 30 met in 7 us per pass, measured -- and a workgroup works off 1200 pass pixels in ~2 us)
-    static const int cand[][2] = {{80, 60}, {40, 60}, {40, 30}, {20, 30}};
-    const int floor_i = 0;
-    for (int c = 0; c < (int)(sizeof(cand) / sizeof(cand[0])) + 1; c++) {
-        int rw, rh;
-        if (forced_rw > 0 && forced_rh > 0) { if (c > 0) break; rw = forced_rw & ~3; rh = forced_rh & ~1; }
-        else { if (c < floor_i || c >= (int)(sizeof(cand) / sizeof(cand[0]))) continue; rw = cand[c][0]; rh = cand[c][1]; }
-        if (rw < 4 || rh < 2) continue;
-        const int nrx = (p.W + rw - 1) / rw, nry = (p.H + rh - 1) / rh;
-        if ((long long)nrx * nry * nb > max_wgs) continue;
-        if ((rw / 4) * (rh / 2) * 2 > PASSES_NT * PASSES_MAXS) continue;             // pass pixels per thread
-        if (2 * (rw + 2) + 2 * rh > PASSES_NT * PASSES_RING_SLOTS) continue;          // halo pixels per thread
-        // window cells: a region of r pixels touches at most (r + cell - 2) / cell + 1 cells, + margin 2 either side (the
-        // kernel shrinks the margin by itself when that exceeds nw_cap)
-        const int cx = (rw + p.cell - 2) / p.cell + 1, cy = (rh + p.cell - 2) / p.cell + 1;
-        int nw_cap = (cx + 4) * (cy + 4);
-        if (cx * cy > PASSES_NW_MAX) continue;                                  // not even margin 0 fits
-        nw_cap = std::min(nw_cap, PASSES_NW_MAX);
-        // the overflow lists live in the (otherwise unused) pass-log area: NT * 256 entries per frame
-        const size_t NT32 = (size_t)((p.W + 30 + 31) / 32) * ((p.H + 31) / 32), NT64 = (size_t)((p.W + 62 + 63) / 64) * ((p.H + 31) / 32);
-        if ((size_t)nrx * nry * (size_t)(rw * rh / 4) > std::max(NT32, 2 * NT64) * 256) continue;
-        PassGeom t{}; t.rw = rw; t.rh = rh; t.nrx = nrx; t.nry = nry; t.nw_cap = nw_cap; t.wait_ms = wait_ms;
-        if (passes_lds_bytes(t) > 64 * 1024) continue;                          // (what a launch may ask for without further ado)
-        return t;
-    }
-    return g;
-}
-bool update_passes_resident(const SegParams& p, int nb) { return passes_geometry(p, nb).rw > 0; }
-bool launch_update_passes(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k0, int k1, bool rgbd, unsigned int* abort_flag) {
-    PassGeom g = passes_geometry(p, nb);
-    if (g.rw == 0) return false;
-    if (k1 <= k0) return true;
-    static unsigned long long ticks_per_ms = 0;
-    if (!ticks_per_ms) {
-        int dev = 0, khz = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
-        ticks_per_ms = (unsigned long long)khz;
-    }
-    g.ticks_per_ms = ticks_per_ms;
-    const size_t lds = passes_lds_bytes(g);
-    ScopedKernel sk(rgbd ? "passes_rgbd" : "passes_rgb", st);
-    const dim3 grid(g.nrx * g.nry, nb);
-    if (rgbd) hipLaunchKernelGGL(k_passes<true>, grid, dim3(PASSES_NT), lds, st, p, m, g, k0, k1, abort_flag);
-    else hipLaunchKernelGGL(k_passes<false>, grid, dim3(PASSES_NT), lds, st, p, m, g, k0, k1, abort_flag);
-    return true;
+    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord); return; }
+    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord); return; }
+#endif
+    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

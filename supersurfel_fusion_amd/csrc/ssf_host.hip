@@ -307,7 +307,7 @@ static const SeqRamp& seq_ramp() {
     static const SeqRamp ramp = [] {              // (initialised once, also when several handles are driven by several threads)
         SeqRamp r;
         r.n = 0;
-        const char* e = getenv("SSF_SEQ_RAMP");
+        const char* e = SSF_ENV_STR("SEQ_RAMP");
         if (e) { for (const char* q = e; *q && r.n < 8;) { r.size[r.n++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
         else { r.n = 2; r.size[0] = -3; r.size[1] = -5; }          // (negative: |value| eighths of the batch, rounded)
         return r;
@@ -560,13 +560,13 @@ static bool dalloc(ssf_handle* h, T** p, size_t count) {
     void* q = nullptr;
     // (SSF_ALLOC_GUARD=bytes: that much unused memory on both sides of every buffer -- a probe for out-of-bounds accesses
     // between the small buffers of handles that live side by side, tools/p2p_first_frame_stress.py)
-    static const size_t guard = getenv("SSF_ALLOC_GUARD") ? (size_t)atoll(getenv("SSF_ALLOC_GUARD")) & ~(size_t)255 : 0;
+    static const size_t guard = (size_t)SSF_ENV_INT("ALLOC_GUARD", 0) & ~(size_t)255;          // (lab: poisoned guard zones around every buffer)
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     if (hipMalloc(&q, bytes + 2 * guard) != hipSuccess) return false;
     h->allocs.push_back(q);
     if (guard) {                                   // poisoned guard zones, checked by ssf_destroy
-        static const int poison_all = getenv("SSF_GUARD_BYTE") ? atoi(getenv("SSF_GUARD_BYTE")) & 255 : 0xA5;
-        static const int only = getenv("SSF_GUARD_ONLY") ? atoi(getenv("SSF_GUARD_ONLY")) : -1;      // poison this allocation's zones, zero the others'
+        static const int poison_all = SSF_ENV_INT("GUARD_BYTE", 0xA5) & 255;
+        static const int only = SSF_ENV_INT("GUARD_ONLY", -1);      // poison this allocation's zones, zero the others'
         const int poison = (only < 0 || (int)h->guarded.size() == only) ? poison_all : 0;
         (void)hipMemset(q, poison, guard);
         (void)hipMemset((char*)q + guard + bytes, poison, guard);
@@ -583,7 +583,7 @@ static void check_guards(ssf_handle* h) {
             const char* zone = (const char*)g.base + (side ? g.guard + g.bytes : 0);
             if (hipMemcpy(host.data(), zone, g.guard, hipMemcpyDeviceToHost) != hipSuccess) continue;
             size_t first = g.guard, last = 0, n = 0;
-            static const int poison = getenv("SSF_GUARD_BYTE") ? atoi(getenv("SSF_GUARD_BYTE")) & 255 : 0xA5;
+            static const int poison = SSF_ENV_INT("GUARD_BYTE", 0xA5) & 255;
             for (size_t i = 0; i < g.guard; i++) if (host[i] != (unsigned char)poison) { if (first == g.guard) first = i; last = i; n++; }
             if (n) std::fprintf(stderr, "[ssf guard] allocation #%d (%zu bytes): %zu bytes modified %s it, offsets %zu..%zu relative to the %s (rank %d)\n",
                                 idx, g.bytes, n, side ? "BEHIND" : "IN FRONT OF", side ? first : g.guard - 1 - last, side ? last : g.guard - 1 - first,
@@ -685,7 +685,7 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
             // several cameras on one GPU -- captures that ran side by side left, once in ~100 first frames, a graph whose
             // first replay differed from the eager chain: tools/p2p_probe.py, round 2)
             static std::mutex capture_mutex;
-            static const bool unlocked = getenv("SSF_CAPTURE_UNLOCKED") != nullptr;          // (control runs of that probe)
+            static const bool unlocked = SSF_ENV_SET("CAPTURE_UNLOCKED");          // (control runs of that probe)
             std::unique_lock<std::mutex> capture_lock(capture_mutex, std::defer_lock);
             if (!unlocked) capture_lock.lock();
             bool ok = (h->capture_stream || hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) == hipSuccess) &&
@@ -1256,8 +1256,8 @@ static int comm_counts(ssf_handle* h) {
 // launch the NEXT iteration now, to wait on the device for its transform; returns the sequence number of its record
 // (match_capable: the launch can be told to do the frame's association instead of an iteration -- SSF_ICP_GO_MATCH)
 static bool icp_waiter_can_match(const ssf_handle* h) {
-    static const bool off = getenv("SSF_NO_MATCH_IN_WAITER") != nullptr;          // (measurement switch)
-    return !off && !h->p2p.on && !h->comm && h->cfg.nranks == 1 && !h->bins_valid && h->cfg.profile == 0;
+    static const bool off = SSF_ENV_SET("NO_MATCH_IN_WAITER");          // (measurement switch)
+    return !off && !h->p2p.on && !h->comm && h->cfg.nranks == 1 && !h->bins_valid && h->cfg.profile == 0 && icp_variant_mode() == 0;
 }
 static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo** slot_out, unsigned long long* go_seq_out) {
     const unsigned long long seq = ++h->icp_seq;
@@ -1325,12 +1325,21 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     // a large visible set: its ICP / association fields once more, sorted by the image tile they project to under the
     // frame's initial transform (ssf_track_fuse.hip, k_bin_*): the iterations and the association stream that copy
     h->bins_valid = false;
+#ifdef SSF_EXPERIMENTS
     if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0) {
+        if (!h->d_bin_idx) {                       // first use: the copy's buffers (44 B per row of capacity)
+            const size_t N = (size_t)h->cfg.nb_supersurfels_max, bw = (size_t)bin_count_words(h->cam);
+            const bool ok = dalloc(h, &h->bins.pos, 3 * N) && dalloc(h, &h->bins.lab, 3 * N) && dalloc(h, &h->bins.r2, 3 * N) && dalloc(h, &h->bins.conf, N) &&
+                            dalloc(h, &h->d_bin_idx, N) && dalloc(h, &h->d_bin_count, bw) && dalloc(h, &h->d_bin_cursor, bw);
+            if (!ok) { h->err = "allocation of the tile-sorted copy failed"; return SSF_ERR_DEVICE; }
+            HCK(hipMemsetAsync(h->d_bin_count, 0, bw * 4, h->stream));
+        }
         Rt T0; T0.R = h->icp.R_init; T0.t = h->icp.t_init;
         launch_bin_rows(h->stream, h->cam, h->model[h->mcur], h->n_visible, T0, h->d_bin_count, h->d_bin_cursor, h->bins, h->d_bin_idx);
         HCK(hipGetLastError());
         h->bins_valid = true;
     }
+#endif
     int again = h->icp.active ? 1 : 0, valid = 0;
     // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
     // already launched and waits on the device for its transform
@@ -1430,7 +1439,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     if (exchanging) {
         // rows whose fused position crossed a tile edge move to the rank that owns their new tile: every rank's
         // migrant table (one slot per frame supersurfel, at most one rank fills a slot) is summed in HBM
-        static const int migrate = getenv("SSF_NO_MIGRATE") ? 0 : 1;                  // (bisecting switch of tools/p2p_first_frame_stress.py)
+        static const int migrate = SSF_ENV_SET("NO_MIGRATE") ? 0 : 1;                  // (bisecting switch of tools/p2p_first_frame_stress.py)
         rc = fuse_begin(h, migrate);
         if (rc) { h->fusing = false; return rc; }
         if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320, h->mb_dev);
@@ -1521,7 +1530,7 @@ void ssf_destroy(ssf_handle* h) {
         if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
-    if (!h->guarded.empty() && !getenv("SSF_GUARD_ONLY")) check_guards(h);
+    if (!h->guarded.empty() && !SSF_ENV_SET("GUARD_ONLY")) check_guards(h);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1550,16 +1559,16 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int W = cfg->width, H = cfg->height, c = cfg->cell_size;
     h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
-    if (const char* e = getenv("SSF_ICP_AHEAD")) h->icp_ahead = atoi(e) != 0;      // measurement switches (tools/)
-    if (const char* e = getenv("SSF_ICP_CHAIN")) h->icp_chain = atoi(e) != 0;
-    if (getenv("SSF_NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
+    h->icp_ahead = SSF_ENV_INT("ICP_AHEAD", 1) != 0;      // (lab: measurement switches, tools/)
+    h->icp_chain = SSF_ENV_INT("ICP_CHAIN", 1) != 0;
+    if (SSF_ENV_SET("NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         // own track stream: highest priority (ICP -> fuse is the serial chain of the pipeline; its short kernels
         // should not queue behind the wide extract launches of the low-priority context streams)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const int prio = getenv("SSF_TRACK_PRIORITY") ? atoi(getenv("SSF_TRACK_PRIORITY")) : greatest;
+        const int prio = SSF_ENV_INT("TRACK_PRIORITY", greatest);
         if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio) != hipSuccess) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; }
         h->own_stream = true;
     }
@@ -1625,7 +1634,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             // other contexts, launched microseconds later, compete for the part.  SSF_CTX0_PRIORITY=0 switches it off.)
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            static const bool ctx0_up = !(getenv("SSF_CTX0_PRIORITY") && atoi(getenv("SSF_CTX0_PRIORITY")) == 0);
+            static const bool ctx0_up = SSF_ENV_INT("CTX0_PRIORITY", 1) != 0;
             const int prio = (ci == 0 && ctx0_up && least - greatest >= 2) ? least - 1 : least;
             ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio) == hipSuccess; c.own_stream = ok;
         }
@@ -1654,14 +1663,9 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->d_live_scratch, N) && dalloc(h, &h->d_bf_in, P) && dalloc(h, &h->d_bf_out, P) &&
          dalloc(h, &h->d_icp, 64) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
          dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, 2 * SSF_ICP_REPLICAS * 32)     /* second half: the counted record of k_icp */;
-    {
-        const int bw = bin_count_words(h->cam);
-        if (const char* e = getenv("SSF_BIN_MIN_ROWS")) h->bin_min_rows = atoi(e);          // (measurement switch; < 0: never)
-        if (bw > 16384) h->bin_min_rows = -1;                                              // (the histogram lives in LDS)
-        ok = ok && dalloc(h, &h->bins.pos, 3 * N) && dalloc(h, &h->bins.lab, 3 * N) && dalloc(h, &h->bins.r2, 3 * N) && dalloc(h, &h->bins.conf, N) &&
-             dalloc(h, &h->d_bin_idx, N) && dalloc(h, &h->d_bin_count, (size_t)bw) && dalloc(h, &h->d_bin_cursor, (size_t)bw);
-        if (ok) (void)hipMemsetAsync(h->d_bin_count, 0, (size_t)bw * 4, h->stream);
-    }
+#ifdef SSF_EXPERIMENTS
+    h->bin_min_rows = SSF_ENV_INT("BIN_MIN_ROWS", -1);          // (lab, lab/tile_bins.inc: < 0 never; its buffers are allocated on first use)
+#endif
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
              hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess;
@@ -1745,7 +1749,7 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
             bool ok = true;
             u->d_rgb.assign(u->ring, nullptr); u->d_depth.assign(u->ring, nullptr);
             for (int i = 0; i < u->ring && ok; i++) ok = dalloc(h, &u->d_rgb[i], 3 * P) && dalloc(h, &u->d_depth[i], P);
-            if (ok && !getenv("SSF_UPLOAD_PAGEABLE")) {     // page-locked staging (optional: without it the copies go through the runtime's)
+            if (ok && !SSF_ENV_SET("UPLOAD_PAGEABLE")) {     // page-locked staging (optional: without it the copies go through the runtime's)
                 u->p_rgb.assign(u->ring, nullptr); u->p_depth.assign(u->ring, nullptr);
                 bool pin = true;
                 for (int i = 0; i < u->ring && pin; i++)
@@ -1958,7 +1962,7 @@ static int p2p_region(ssf_handle* h) {
     // plain memory is used: all accesses to a region are system-scope atomics that meet in the same memory, and round 2's
     // campaigns (profiles/p2p_campaigns_r02.txt) ran 2600 create-attach-run cycles clean with it against 211 bad ones with
     // an UNCACHED region (hipDeviceMallocUncached; SSF_P2P_REGION_UNCACHED=1 brings that mapping back for experiments).
-    static const bool uncached = getenv("SSF_P2P_REGION_UNCACHED") != nullptr;
+    static const bool uncached = SSF_ENV_SET("P2P_REGION_UNCACHED");
     if (uncached && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) h->p2p.fine = true;
     else if (!uncached && !h->p2p.same_device && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) == hipSuccess) h->p2p.fine = true;
     else {
@@ -2066,8 +2070,14 @@ int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVA
 // visible rows from which a frame's tracking streams a tile-sorted copy of them (default: never; 0: always)
 int ssf_debug_set_bin_min_rows(ssf_handle* h, int n) {
     if (!h) return SSF_ERR_INVALID_ARG;
+#ifdef SSF_EXPERIMENTS
     h->bin_min_rows = bin_count_words(h->cam) > 16384 ? -1 : n;
     return SSF_OK;
+#else
+    if (n < 0) return SSF_OK;                      // "never" is what the product does
+    h->err = "the tile-sorted copy of the visible rows is a measurement arm of the lab build (csrc/variants/lab), not of this library";
+    return SSF_ERR_STATE;
+#endif
 }
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;

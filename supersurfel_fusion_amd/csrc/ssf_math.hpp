@@ -337,24 +337,26 @@ SSF_HD long long fx64(double v, double scale, double lim) {
     return llrint(t);
 #endif
 }
-SSF_HD int fx32(float v, float scale) {
+// 32-bit fixed point of an already scaled value: round to nearest even, then convert SATURATING exactly as the hardware's
+// v_cvt_i32_f32 does (ISA manual; checked on the part by tools/probe/cvt_i32_f32.hip): NaN -> 0, t >= 2^31 -> INT_MAX,
+// t <= -2^31 -> INT_MIN, anything else is exact -- two instructions per term, no compare / select (27 terms per row in k_icp).
+// (Until round 3 the specification also sent 2^31 - 128, the largest float below 2^31, to INT_MAX: one compare and one
+// select per term for a value no term can take; oracle and product changed together.)
+SSF_HD int fx32r(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // The values of the host branch below without its three branches (the compiler kept them as nested exec-mask regions: 27
-    // terms per row in k_icp): v_cvt_i32_f32 itself turns a NaN into 0 and saturates out-of-range values (ISA manual; checked on
-    // the part by tools/probe/cvt_i32_f32.hip), which leaves one case to patch -- 2^31 - 128, the largest float below 2^31,
-    // which the specification sends to INT_MAX too.
-    const float t = rintf(v * scale);
+    const float t = rintf(v);
     int r;
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(t));
-    return t >= 2147483520.0f ? 2147483647 : r;
+    return r;
 #else
-    float t = rintf(v * scale);
+    float t = rintf(v);
     if (!(t == t)) return 0;
-    if (t >= 2147483520.0f) return 2147483647;
+    if (t >= 2147483648.0f) return 2147483647;
     if (t <= -2147483648.0f) return (int)0x80000000;
     return (int)t;
 #endif
 }
+SSF_HD int fx32(float v, float scale) { return fx32r(v * scale); }
 #define SSF_DISP_SCALE 1073741824.0            /* 2^30 */
 #define SSF_DISP_LIM 4503599627370496.0        /* 2^52 */
 #define SSF_MOM_SCALE 16777216.0               /* 2^24 */

@@ -53,42 +53,67 @@ __device__ __forceinline__ void st6(float* __restrict__ p, size_t i, Sym3 c) {
 // the 29 terms of one visible supersurfel (position, cached Lab, normal row) under transform (R, t), each handed to
 // emit(k, value) as soon as it is computed (k is a compile-time constant after unrolling): JtJ k = 0..20 (fixed point 2^20),
 // Jtr 21..26 (2^24), squared residual 27 (2^44), inlier count 28
-template <typename Emit>
-__device__ __forceinline__ void icp_row_terms(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
-                                              const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm, int dbg, Emit emit) {
+// The 29 terms of one visible supersurfel (position, cached Lab, normal row) under transform (R, t), each handed to
+// emit(k, value) as soon as it is computed (k is a compile-time constant after unrolling): JtJ k = 0..20 (fixed point 2^20),
+// Jtr 21..26 (2^24), squared residual 27 (2^44), inlier count 28.  Gates: dense_registration_kernels.cuh:217-249.
+// Fixed point: JtJ at 2^20 -- the two rows scaled by 2^10 once instead of 21 sums by 2^20 --, Jtr at 2^24 -- the two residuals
+// scaled by 2^14 once, times the scaled rows (the specification, DESIGN.md section 2: the checker performs the same
+// operations).
+// UNIFORM = false: a row that is no inlier emits nothing (its lane leaves).  UNIFORM = true (the wave-reduction arm): EVERY lane
+// emits all 29 terms, a row that is no inlier as zeros -- emit is then called in uniform control flow, as cross-lane
+// operations need.
+template <bool UNIFORM, typename Emit>
+__device__ __forceinline__ void icp_row_terms_(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                               const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm, int dbg, Emit emit,
+                                               bool live = true) {
     const V3 ps = add(m3_mulv(R, mpos), t);
     if (dbg & 1) { if (ps.z > 1e30f) emit(28, 1ll); return; }
     const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
     const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
-    if (!(u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return;
-    const size_t q = (size_t)v * cam.W + u;
+    bool ok = live && u >= 0 && u < cam.W && v >= 0 && v < cam.H;
+    if (!UNIFORM && !ok) return;
+    size_t q = ok ? (size_t)v * cam.W + u : 0;
+    if (dbg & 16) q = (blockIdx.x * blockDim.x + threadIdx.x) & 0x7ffffu;          // probe: the lanes of a wave gather ADJACENT pixels (the first 2^19 of the table)
     const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
-    const int tid = (int)pl.x;
+    const int tid = (dbg & 8) ? (int)(q & 1023) : (int)pl.x;     // probe (8): the frame supersurfel does not depend on the pixel's word -- two trips instead of three
     const float zt = __uint_as_float(pl.y);
     float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];         // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
     // (keeps the gather whole: left alone, the compiler fetches the confidence first, tests it, and only then the
     // rest -- a second dependent round trip)
     asm volatile("" : "+v"(f0.y), "+v"(f1.x));
-    if (!(f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f)) return;
+    ok = ok && (f0.x > 0.0f && zt >= 0.2f && zt <= 5.0f);
+    if (!UNIFORM && !ok) return;
     const float dist_color = len3(sub(mlab, v3(f0.y, f0.z, f0.w)));
     const V3 pt = v3(zt * ((float)u - cam.cx) / cam.fx, zt * ((float)v - cam.cy) / cam.fy, zt);
     const V3 nt = v3(f1.x, f1.y, f1.z);
     const V3 ns = unit3(m3_mulv(R, mnrm));
-    if (!(dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f)) return;
+    ok = ok && (dist_color < 20.0f && len3(sub(ps, pt)) < 0.1f && fabsf(dot3(nt, ns)) > 0.8f);
+    if (!UNIFORM && !ok) return;
     const V3 d = sub(pt, ps), c1 = cross3(pt, ns), c2 = cross3(ps, nt);
     const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
     const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
     const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
     if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) emit(0, 1ll); return; }
+    // (UNIFORM: a lane that is no inlier carries zeros -- every term of it is then exactly 0, whatever the lane had computed)
+    const float m10 = (UNIFORM && !ok) ? 0.0f : 1024.0f, m14 = (UNIFORM && !ok) ? 0.0f : 16384.0f;
+    float X1[6], X2[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { X1[i] = UNIFORM && !ok ? 0.0f : x1[i] * m10; X2[i] = UNIFORM && !ok ? 0.0f : x2[i] * m10; }
+    const float D1 = UNIFORM && !ok ? 0.0f : dn1 * m14, D2 = UNIFORM && !ok ? 0.0f : dn2 * m14;      // 2^14 x 2^10 (the scaled rows) = 2^24
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = i; j < 6; j++, k++) emit(k, (long long)fx32(x1[i] * x1[j] + x2[i] * x2[j], 1048576.0f));
+        for (int j = i; j < 6; j++, k++) emit(k, (long long)fx32r(X1[i] * X1[j] + X2[i] * X2[j]));
 #pragma unroll
-    for (int i = 0; i < 6; i++) emit(21 + i, (long long)fx32(dn1 * x1[i] + dn2 * x2[i], 16777216.0f));
-    emit(27, fx64((double)(dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
-    emit(28, 1ll);
+    for (int i = 0; i < 6; i++) emit(21 + i, (long long)fx32r(D1 * X1[i] + D2 * X2[i]));
+    emit(27, fx64((double)(UNIFORM && !ok ? 0.0f : dn2 * dn2), 17592186044416.0, 4611686018427387904.0));
+    emit(28, (UNIFORM && !ok) ? 0ll : 1ll);
+}
+template <typename Emit>
+__device__ __forceinline__ void icp_row_terms(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
+                                              const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm, int dbg, Emit emit) {
+    icp_row_terms_<false>(cam, pix2, fpack, R, t, mpos, mlab, mnrm, dbg, emit);
 }
 // one row per thread: every term straight into the workgroup's LDS table (lane & 15 spreads the same-address traffic)
 __device__ __forceinline__ void icp_row(const Cam& cam, const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
@@ -139,7 +164,7 @@ __device__ __forceinline__ void atomic_store_done(int* p, int v) {
 // SSF_ARRIVE_FENCED (an experiment build, tools/build_variant.sh fenced -DSSF_ARRIVE_FENCED): real
 // agent-scope release / acquire ordering around the arrival ticket -- one fence per workgroup, not per atomic -- to tell
 // whether the first-frame divergence seen with UNCACHED exchange regions (round 2) was the relaxed arrival protocol's.
-#ifdef SSF_ARRIVE_FENCED
+#if defined(SSF_EXPERIMENTS) && defined(SSF_ARRIVE_FENCED)
 #define SSF_ARRIVE_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 #define SSF_ARRIVE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #else
@@ -347,14 +372,9 @@ __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restri
             __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// Rows sorted by image tile (k_bin_* below) are handed to the launch's workgroups so that ONE XCD works on one contiguous
-// eighth of them -- an eighth of the image: its L2 then holds an eighth of the frame's (label, depth) table instead of
-// all of it.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): logical block =
-// the (b / 8)-th block of that XCD's share.  Bijective for any grid size.
-__device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int nb) {
-    const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
-}
+#ifdef SSF_EXPERIMENTS
+#include "lab/icp_arms.inc"
+#endif
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched);
@@ -362,7 +382,7 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
 #ifndef SSF_ICP_GO_WAIT_TICKS
 #define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
 #endif
-template <bool P2P, bool ACC>
+template <bool P2P, int MODE>          // MODE 0: the product's form; 1: rows' terms summed in registers (SSF_ICP_PER_LANE); 2: DPP row reduction (SSF_ICP_WRED)
 __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         if (!s_go) return;
         T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
         T.t = v3(s_T[9], s_T[10], s_T[11]);
-        if constexpr (!P2P && !ACC) {
+        if constexpr (!P2P && MODE == 0) {
             if (s_go == 2) {
                 // findBestMatches in the launch that was waiting for the next iteration (k_match's rows, k_match's arithmetic)
                 if (ma.best && !by_tile)
@@ -432,20 +452,15 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     // iteration, not a trip to HBM.)
     // (by_tile: `model` is the tile-sorted copy of the visible rows -- pos / lab / r2 streams only -- and the blocks are dealt
     // to the XCDs in contiguous shares; the sums are exact integers, so the order of the rows does not matter)
+#ifdef SSF_EXPERIMENTS
     const unsigned int blk = by_tile ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    if (ACC) {
-        // several rows per thread (SSF_ICP_PER_LANE, measurement only): the rows' terms are summed in registers and go to the
-        // workgroup's LDS table once per thread
-        long long acc[29];
-#pragma unroll
-        for (int k = 0; k < 29; k++) acc[k] = 0;
-        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
-            icp_row_terms(cam, pix2, fpack, R, t, ld3(model.pos, id), ld3(model.lab, id), ld3(model.r2, id), 0, [&](int k, long long v) { acc[k] += v; });
-        if (acc[28] != 0) {
-#pragma unroll
-            for (int k = 0; k < 29; k++) atomicAdd(&red[k * ICP_SLOTS + slot], (unsigned long long)acc[k]);
-        }
-    } else
+#else
+    const unsigned int blk = blockIdx.x; (void)by_tile;
+#endif
+#ifdef SSF_EXPERIMENTS
+    if (MODE != 0) icp_lab_arm<MODE>(cam, model, n_visible, pix2, fpack, R, t, red, slot, blk);
+    else
+#endif
         for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
             // the row's three fields in ONE round trip (left alone, the compiler fetches colour and normal only behind the
             // test of the projected position: a second dependent trip in every iteration)
@@ -651,102 +666,22 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     // (orig != nullptr: `model` is the tile-sorted copy, orig[j] the row's index in the visible array; blocks dealt to the XCDs
     // in contiguous shares -- see xcd_block)
+#ifdef SSF_EXPERIMENTS
     const int j = (orig ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= n_visible) return;
     const int id = orig ? orig[j] : j;
+#else
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, id = j; (void)orig;
+    if (j >= n_visible) return;
+#endif
     cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
 }
 
-// ---- image-space order for the model side of ICP / association ------------------------------------------------------------
-// The visible rows sit in arrival order (the reference's: supersurfel_fusion.cu:469-472), so consecutive rows project to
-// unrelated pixels: every gather of the frame's (label, depth) table is a line of its own, and each of the eight L2s
-// ends up pulling the whole table (PMC, round 2: k_match moved 2.8x, k_icp 1.5x their algorithmic bytes).  For large
-// visible sets (BASELINE config 3: 1 M rows, ten iterations per frame) the rows' ICP / association fields are therefore
-// copied once per frame into a TILE-SORTED array: key = the 32 x 32 pixel tile the row projects to under the frame's
-// initial transform (rows that project nowhere: one more bin at the end).  Counting sort in three launches -- per-tile
-// counts (LDS histogram per 4096 rows, one global atomic per non-empty bin), exclusive scan (one workgroup), scatter
-// (the histogram again, one returning atomic per non-empty bin for the segment's base) -- 88 B per row of traffic, against
-// 36-44 B per row and ITERATION saved from going to memory.  The order inside a bin is arrival order of the atomics, i.e.
-// arbitrary: every consumer is order-free (exact integer sums, atomicMin with the row's own index in the key), so the
-// results stay bit-identical; the stored model keeps the reference's order.
-#define BIN_TILE 32
-#define BIN_ROWS_PER_WG 4096
-__device__ __forceinline__ int bin_of(const Cam& cam, const M3& R, const V3& t, const V3& pos, int nbx, int nbins) {
-    const V3 ps = add(m3_mulv(R, pos), t);
-    const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx), v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
-    if (!(ps.z > 0.0f && u >= 0 && u < cam.W && v >= 0 && v < cam.H)) return nbins - 1;
-    return (v / BIN_TILE) * nbx + u / BIN_TILE;
-}
-extern __shared__ __attribute__((aligned(16))) unsigned int bin_lds[];
-__global__ __launch_bounds__(256) void k_bin_count(Cam cam, const float* __restrict__ pos, int n, Rt T, int nbx, int nbins, uint32_t* __restrict__ count) {
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bin_lds[i] = 0u;
-    __syncthreads();
-    const int base = blockIdx.x * BIN_ROWS_PER_WG;
-    for (int k = threadIdx.x; k < BIN_ROWS_PER_WG; k += blockDim.x) {
-        const int i = base + k;
-        if (i < n) atomicAdd(&bin_lds[bin_of(cam, T.R, T.t, ld3(pos, i), nbx, nbins)], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) { const unsigned int c = bin_lds[i]; if (c) atomicAdd(&count[i], c); }
-}
-// exclusive scan of the bin counts -> cursor (the scatter's running position per bin); the counts are left zeroed for the next frame
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ count, uint32_t* __restrict__ cursor, int nbins) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0u;
-    __syncthreads();
-    for (int b0 = 0; b0 < nbins; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        const uint32_t c = i < nbins ? count[i] : 0u;
-        if (i < nbins) count[i] = 0u;
-        uint32_t v = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(v, o, 64); if (lane() >= o) v += up; }
-        if (lane() == 63) wsum[threadIdx.x >> 6] = v;
-        __syncthreads();
-        uint32_t before = carry;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wsum[w];
-        if (i < nbins) cursor[i] = before + v - c;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + v;
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(256) void k_bin_scatter(Cam cam, SurfelSoA M, int n, Rt T, int nbx, int nbins, uint32_t* __restrict__ cursor,
-                                                     SurfelSoA out /* pos, lab, r2, conf */, int32_t* __restrict__ out_idx) {
-    unsigned int* hist = bin_lds;                     // rows of this segment per bin, then: next free position of the bin's run
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0u;
-    __syncthreads();
-    const int base = blockIdx.x * BIN_ROWS_PER_WG;
-    constexpr int PER = BIN_ROWS_PER_WG / 256;
-    int bin[PER];
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = base + threadIdx.x + 256 * k;
-        bin[k] = -1;
-        if (i < n) { bin[k] = bin_of(cam, T.R, T.t, ld3(M.pos, i), nbx, nbins); atomicAdd(&hist[bin[k]], 1u); }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) { const unsigned int c = hist[i]; hist[i] = c ? atomicAdd(&cursor[i], c) : 0u; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int i = base + threadIdx.x + 256 * k;
-        if (bin[k] < 0) continue;
-        const size_t j = atomicAdd(&hist[bin[k]], 1u);
-        st3(out.pos, j, ld3(M.pos, i)); st3(out.lab, j, ld3(M.lab, i)); st3(out.r2, j, ld3(M.r2, i));
-        out.conf[j] = M.conf[i]; out_idx[j] = i;
-    }
-}
-void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out, int32_t* out_idx) {
-    const int nbx = (cam.W + BIN_TILE - 1) / BIN_TILE, nbins = nbx * ((cam.H + BIN_TILE - 1) / BIN_TILE) + 1;
-    ScopedKernel sk("bin_rows", st);
-    const int nwg = (n + BIN_ROWS_PER_WG - 1) / BIN_ROWS_PER_WG;
-    hipLaunchKernelGGL(k_bin_count, dim3(nwg), dim3(256), (size_t)nbins * 4, st, cam, model.pos, n, T, nbx, nbins, count);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, count, cursor, nbins);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nwg), dim3(256), (size_t)nbins * 4, st, cam, model, n, T, nbx, nbins, cursor, out, out_idx);
-}
-int bin_count_words(const Cam& cam) { return ((cam.W + BIN_TILE - 1) / BIN_TILE) * ((cam.H + BIN_TILE - 1) / BIN_TILE) + 1; }
+// ---- image-space order for the model side of ICP / association: a tile-sorted copy of the visible rows (k_bin_*), measured
+// a loss at BASELINE config 3 -- lab/tile_bins.inc, compiled only into the lab variant
+#ifdef SSF_EXPERIMENTS
+#include "lab/tile_bins.inc"
+#endif
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
 // filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
@@ -1942,34 +1877,38 @@ __global__ __launch_bounds__(256) void k_p2p_migr_gather(P2PView pv, int32_t* __
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
+// measurement arms of k_icp (lab build, environment read once): 0 = the product's form; only that one can be told to do the
+// association (SSF_ICP_GO_MATCH) -- the host asks before it sends that word
+int icp_variant_mode() {
+    static const int mode = SSF_ENV_INT("ICP_WRED", 0) ? 2 : (SSF_ENV_INT("ICP_PER_LANE", 0) > 1 ? 1 : 0);
+    return mode;
+}
 void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                 Rt T, long long* replicas, unsigned int* ticket,
                 long long* sums29, Mailbox* mb, unsigned long long seq, int dbg_arg, IcpGo* go, unsigned long long go_seq,
                 const P2PView* pv, int by_tile, const MatchArgs* match) {
     ScopedKernel sk("icp_accumulate", st);
     const MatchArgs ma = match ? *match : MatchArgs{0.f, 0.f, 0, nullptr, nullptr, nullptr};
-    // rows per thread: 1.  SSF_ICP_PER_LANE=n (measurement): n rows per thread with their terms summed in REGISTERS and one
-    // LDS atomic per term and thread (k_icp<., true>) -- measured at BASELINE config 3 (1 M rows in view): 35-38 us per
-    // iteration for n = 2, 4, 8 against 29-30 us: the kernel is bound by its chain of dependent gathers (row -> pixel ->
-    // frame supersurfel), which eight waves per SIMD hide better than three
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("SSF_ICP_PER_LANE"); forced = e ? std::max(1, atoi(e)) : 0; }
-    const int per_lane = forced ? forced : 1;
+    // one row per thread, <= 4096 workgroups (grid-stride beyond).  (lab: SSF_ICP_PER_LANE=n rows per thread with register sums,
+    // SSF_ICP_WRED=1 the DPP row reduction -- lab/icp_arms.inc, both measured slower: DESIGN.md section 4.3)
+    const int mode = dbg_arg > 0 && dbg_arg != 4 ? 0 : icp_variant_mode();      // (the probe switches live in the one-row-per-thread form)
+    const int per_lane = mode == 1 ? std::max(2, SSF_ENV_INT("ICP_PER_LANE", 0)) : 1;
     const int per_block = 256 * per_lane;
     int grid = (n_visible + per_block - 1) / per_block;
     if (grid < 1) grid = 1;              // an empty shard still publishes its (zero) record
     if (grid > 4096) grid = 4096;
     // the counted record (one trip at the end of the launch instead of three): single GPU, no probe switches
-    static int counted = -1;
-    if (counted < 0) { const char* e = getenv("SSF_ICP_COUNTED"); counted = e ? atoi(e) : 1; }
-    const bool acc = per_lane > 1 && dbg_arg <= 0;   // (the probe switches live in the one-row-per-thread form)
+    static const int counted = SSF_ENV_INT("ICP_COUNTED", 1);
     const int dbg = (dbg_arg < 0 ? 0 : dbg_arg) | ((counted && !pv && dbg_arg < 0) ? SSF_ICP_DBG_COUNTED : 0);
     const P2PView none{};
     const P2PView& v = pv ? *pv : none;
-    if (pv && acc) hipLaunchKernelGGL((k_icp<true, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
-    else if (pv) hipLaunchKernelGGL((k_icp<true, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
-    else if (acc) hipLaunchKernelGGL((k_icp<false, true>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
-    else hipLaunchKernelGGL((k_icp<false, false>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
+#ifdef SSF_EXPERIMENTS
+    if (mode == 2 && !pv) { hipLaunchKernelGGL((k_icp<false, 2>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
+    if (mode == 1 && pv) { hipLaunchKernelGGL((k_icp<true, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
+    if (mode == 1) { hipLaunchKernelGGL((k_icp<false, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
+#endif
+    if (pv) hipLaunchKernelGGL((k_icp<true, 0>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
+    else hipLaunchKernelGGL((k_icp<false, 0>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma);
 }
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,

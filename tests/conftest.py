@@ -54,3 +54,12 @@ def product_lib():
     if not os.path.exists(binding.PRODUCT_LIB):
         _make(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc"))
     return binding.load_product()
+
+
+@pytest.fixture(scope="session")
+def lab_lib():
+    """The laboratory build of the product sources (-DSSF_EXPERIMENTS: measurement arms, environment switches)"""
+    from supersurfel_fusion_amd import binding
+    if not os.path.exists(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "variants", "lab", "libssf_hip.so")):
+        _make(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc"))
+    return binding.load_lab()

@@ -72,3 +72,15 @@ def test_product_never_links_or_loads_the_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "libssf_oracle" not in txt and "oracle/" not in txt and "oracle_" not in txt, fn
+
+
+def test_the_product_library_reads_no_environment_variable(product_lib):
+    """every measurement switch (SSF_...) lives in the lab build of the sources (csrc/variants/lab, -DSSF_EXPERIMENTS): the
+    library a node links holds no such name -- and so no getenv of one"""
+    import subprocess
+    out = subprocess.run(["strings", product_lib.path], stdout=subprocess.PIPE, text=True).stdout.splitlines()
+    assert [l for l in out if l.startswith("SSF_")] == []
+    for src in ("ssf_extract.hip", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
+        txt = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", src)).read()
+        body = txt.split("#ifdef SSF_EXPERIMENTS\n#include <stdlib.h>")[0] if src == "ssf_device.hpp" else txt
+        assert "getenv(" not in body, src

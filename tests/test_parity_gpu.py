@@ -564,10 +564,11 @@ def test_an_arrival_at_a_full_shard_is_counted_as_removed(oracle_lib, product_li
 
 
 @pytest.mark.parametrize("pipelined", [False, True])
-def test_tile_sorted_rows_bit_exact(pipelined, oracle_lib, product_lib):
-    """ICP and association streaming the TILE-SORTED copy of the visible rows (k_bin_*, launch_icp(by_tile) / launch_match(orig):
-    forced for every frame here; off by default -- measured slower): exact integer sums and
-    atomicMin keys that carry the row's own index make every result independent of the order of the rows."""
+def test_tile_sorted_rows_bit_exact(pipelined, oracle_lib, lab_lib):
+    """(LAB build) ICP and association streaming the TILE-SORTED copy of the visible rows (lab/tile_bins.inc, launch_icp(by_tile) /
+    launch_match(orig): forced for every frame here; not in the product -- measured slower): exact integer
+    sums and atomicMin keys that carry the row's own index make every result independent of the order of the rows."""
+    product_lib = lab_lib
     fo, nv = seeded(oracle_lib, 50000, 640, 480)
     kw = dict(pipeline_depth=2, extract_batch=2) if pipelined else {}
     fh, _ = seeded(product_lib, 50000, 640, 480, **kw)
@@ -634,12 +635,12 @@ def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, p
 def test_relabelling_passes_bit_exact_in_grid_order_too():
     """The relabelling pass takes its tiles in an XCD-aware order by default (each XCD a contiguous eighth of the launch:
     DESIGN.md section 4.1.3).  Only speed may depend on that: the per-pass comparison against the oracle is repeated in a
-    process whose passes take their tiles in plain grid order (SSF_PASS_XCD=0; the switch is read once per process)."""
+    process that loads the LAB build with its passes taking their tiles in plain grid order (SSF_PASS_XCD=0, read once per process)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSF_PASS_XCD="0")
+    env = dict(os.environ, SSF_PASS_XCD="0", SSF_PRODUCT_VARIANT="lab")      # (the product reads no environment variable: the lab build does)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-q", "-m", "gpu", "-x",
                         "-k", "test_every_relabelling_pass_bit_exact or test_segmentation_parameter_space_batched"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
@@ -652,3 +653,18 @@ def test_rehoming_into_a_full_shard_turns_the_surplus_away(product_lib):
     order, their number returned, never an error after the source ranks have committed"""
     from test_sharded import rehoming_into_a_full_shard
     assert rehoming_into_a_full_shard(product_lib) > 0
+
+
+def test_the_product_refuses_the_measurement_arms_and_reads_no_environment(product_lib, lab_lib):
+    """The product library contains no environment switch (no `SSF_...` string at all) and refuses the one measurement arm that
+    has an API; the lab build of the same sources has both."""
+    import subprocess
+    names = lambda path: [l for l in subprocess.run(["strings", path], stdout=subprocess.PIPE, text=True).stdout.splitlines() if l.startswith("SSF_")]
+    assert names(product_lib.path) == []
+    assert len(names(lab_lib.path)) > 10
+    f = binding.Fusion(product_lib, util.make_cfg(product_lib, 160, 128, nb_supersurfels_max=2048))
+    with pytest.raises(binding.SsfError, match="lab build"):
+        f.set_bin_min_rows(0)
+    f.set_bin_min_rows(-1)
+    g = binding.Fusion(lab_lib, util.make_cfg(lab_lib, 160, 128, nb_supersurfels_max=2048))
+    g.set_bin_min_rows(0)

@@ -25,7 +25,8 @@ lastline() { [ -s "$1" ] && tail -n 1 "$1" | python -c "import json,sys; d=json.
 for step in "$@"; do
   case $step in
     prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; TAG="${TAG}_config3";;
-    env:*) export "${step#env:}"; TAG="${TAG}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=\n' '_')";;
+    env:*) export "${step#env:}"; case "${step#env:}" in SSF_*) export SSF_PRODUCT_VARIANT=${SSF_PRODUCT_VARIANT:-lab};; esac;    # (the switches live in the lab build)
+            TAG="${TAG}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=\n' '_')";;
     suite)
       ( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 ) > $O/pytest_gpu$TAG.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu$TAG.log
       timeout 600 python __graft_entry__.py smoke > $O/smoke$TAG.log 2>&1; tail -n 3 $O/pytest_gpu$TAG.log >> $O/summary.txt;;

@@ -13,5 +13,10 @@ model, nvis = (synthetic.seed_model_cam0_visible if "--config3" in sys.argv else
 f.set_model(model, nvis, 30)
 rgb, depth = util.frame(0, W, H)
 f.stage_extract(rgb, depth); f.icp_begin()
-names = {0: "full", 4: "no tail", 6: "no accumulation, no tail", 7: "loads only"}
-print("per_lane", os.environ.get("SSF_ICP_PER_LANE"), "nvis", nvis, {names[d]: "%.1f us" % lib.lib.ssf_dbg_time_icp(f.h, 200, d) for d in (0, 4, 6, 7)})
+names = {0: "full", 4: "no tail", 6: "no accumulation, no tail", 7: "loads only", 12: "no tail, frame supersurfel independent of the pixel word (2 trips)",
+         20: "no tail, lanes gather adjacent pixels", 28: "no tail, both", 14: "no accumulation, no tail, 2 trips", 22: "no accumulation, no tail, adjacent pixels"}
+print("per_lane", os.environ.get("SSF_ICP_PER_LANE"), "wred", os.environ.get("SSF_ICP_WRED"), "nvis", nvis)
+for d in (0, 4, 6, 7, 12, 20, 28, 14, 22):
+    if os.environ.get("SSF_ICP_WRED") and d not in (0, 4):
+        continue
+    print("   %-75s %.1f us" % (names[d], lib.lib.ssf_dbg_time_icp(f.h, 200, d)))
