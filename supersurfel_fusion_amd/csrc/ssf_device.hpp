@@ -48,12 +48,16 @@ struct SurfelSoA {
 
 // exact sums of one superpixel: one 128-byte record (two cache lines: the nine int32 sums, the six int64 sums), so
 // that a workgroup building the rows of its cell window touches 2 lines per superpixel instead of 15
+// `stamp` (in what used to be padding; no sum): the last relabelling pass that flushed a delta into THIS copy of the record --
+// what lets a tile of a later pass prove that the superpixels around it have not changed (clean-tile skipping, k_update_pass)
 struct alignas(64) SumRec {
-    int32_t sx, sy, sr, sg, sb, n, dx, dy, dn; int32_t pad0[7];
+    int32_t sx, sy, sr, sg, sb, n, dx, dy, dn; int32_t stamp; int32_t pad0[6];
     long long dxx, dyy, dxy, dxd, dyd, dd; long long pad1[2];
 };
-static_assert(offsetof(SumRec, dn) == 32 && offsetof(SumRec, dxx) == 64 && offsetof(SumRec, dd) == 104 && sizeof(SumRec) == 128,
+static_assert(offsetof(SumRec, dn) == 32 && offsetof(SumRec, stamp) == 36 && offsetof(SumRec, dxx) == 64 && offsetof(SumRec, dd) == 104 && sizeof(SumRec) == 128,
               "k_update_pass flushes its accumulators by field offset");
+#define SSF_STAMP_NEVER (-1000)           // "no pass has touched this yet" (stamps are compared with pass numbers 0 .. 4 seg_iter)
+#define SSF_CHANGE_BLOCK_LOG2 5           // labels / inlier flags: one "last changed in pass" stamp per 32 x 32 pixel block of the image
 struct SpSums { SumRec* r; };
 
 // device-side counters shared by the fuse kernels (no host round trip between them)
@@ -112,6 +116,7 @@ struct FrameMaps {
     // (pos.xyz, 0) (unused)
     uint2* pix2; float4* fpack;
     uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
+    int32_t* bstamp;      // per 32 x 32 block of the image: the last relabelling pass that changed a label / inlier flag in it (ingest: never)
     // resident relabelling (k_passes, launch_update_passes): second label map -- only the border pixels of the resident
     // regions are ever valid in it -- and the frame's barrier words (one 64-bit word per phase: arrivals | abort << 32),
     // zeroed by ingest
@@ -145,7 +150,7 @@ SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     m.sp = slab_shift(m.sp, o); m.samples = slab_shift(m.samples, o); m.sample_score = slab_shift(m.sample_score, o);
     m.moments = slab_shift(m.moments, o); m.filt = slab_shift(m.filt, o); m.epoch = slab_shift(m.epoch, o);
     m.label_alt = slab_shift(m.label_alt, o); m.pbar = slab_shift(m.pbar, o);
-    m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
+    m.bstamp = slab_shift(m.bstamp, o); m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
     return m;
 }
 SSF_HD SurfelSoA batch_slot(SurfelSoA s, size_t o) {
@@ -199,7 +204,9 @@ struct Mailbox {
 void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameMaps& m, int nb, uint32_t epoch0);
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
 int pass_tile_npx(int nb);     // 1: 32-wide relabelling tiles, 2: 64-wide (log regions of 512 entries per tile)
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0);
+// skip_from: the first pass of its phase whose tiles may prove themselves clean (phase start + 4: a tile compares with the pass of
+// the same pattern four passes back, which must have used the same energy)
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0, int skip_from = 1 << 30);
 // Passes [k0, k1) of one phase (all RGB or all RGB-D) in ONE launch whose workgroups keep their region of the label map
 // in LDS from pass to pass (k_passes in ssf_extract.hip); returns false -- nothing launched -- when the geometry does
 // not qualify (the caller then launches the passes one by one).  Both sums buffers are complete afterwards.

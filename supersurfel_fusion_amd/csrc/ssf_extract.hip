@@ -39,7 +39,14 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
     m = batch_slot(m, blockIdx.y);
     const int cell = blockIdx.x;
     if (cell == 0 && threadIdx.x == 0) m.epoch[0] = epoch0 + blockIdx.y;
+#ifdef SSF_EXPERIMENTS
+    if (cell == 0 && threadIdx.x >= 1 && threadIdx.x < 64) m.epoch[threadIdx.x] = 0u;       // clean-tile counters per pass (ssf_dbg_pass_skips)
+#endif
     if (cell == 0 && threadIdx.x < 16) m.pbar[threadIdx.x] = 0ull;          // barrier words of the resident relabelling launches
+    if (cell == 0) {                                                        // no block of the image has changed in any pass yet
+        const int nblk = ((p.W + 31) >> SSF_CHANGE_BLOCK_LOG2) * ((p.H + 31) >> SSF_CHANGE_BLOCK_LOG2);
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) m.bstamp[i] = SSF_STAMP_NEVER;
+    }
     const int cx0 = (cell % p.gx) * p.cell, cy0 = (cell / p.gx) * p.cell;
     const int w = min(p.cell, p.W - cx0), h = min(p.cell, p.H - cy0);
     int sx = 0, sy = 0, sr = 0, sg = 0, sb = 0, n = 0;
@@ -69,7 +76,8 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
         SumRec rec;                                  // whole-record stores (16-byte pieces), both buffers
         rec.sx = t[0]; rec.sy = t[1]; rec.sr = t[2]; rec.sg = t[3]; rec.sb = t[4]; rec.n = t[5];
         rec.dx = 0; rec.dy = 0; rec.dn = 0;
-        for (int j = 0; j < 7; j++) rec.pad0[j] = 0;
+        rec.stamp = SSF_STAMP_NEVER;
+        for (int j = 0; j < 6; j++) rec.pad0[j] = 0;
         rec.dxx = 0; rec.dyy = 0; rec.dxy = 0; rec.dxd = 0; rec.dyd = 0; rec.dd = 0; rec.pad1[0] = 0; rec.pad1[1] = 0;
         m.sums[0].r[cell] = rec; m.sums[1].r[cell] = rec;
         SpRow z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -348,14 +356,26 @@ static inline TileOrder tile_order(dim3 grid) {
 // then the six 64-bit sums (chunks 3-5; RGB passes never touch them).  Zeroed and scanned a chunk at a time.
 #define PASS_ACC_DW 24
 #define PASS_ACC_WIDE_DW 12
+// clean-tile skipping: built in round 4, exact, and of no use -- on the bench's frames 3-28 % of the tiles of a pass can prove
+// themselves clean (profiles/clean_tiles_r04.txt): the 100-400 relabellings of a late pass are spread over the whole image.
+// A measurement arm of the lab build (lab/pass_skip.inc, SSF_PASS_SKIP=1); the product compiles none of it.
+#ifdef SSF_EXPERIMENTS
+#include "lab/pass_skip.inc"
+#define SSF_SKIP_STAMP(rec) ((rec).stamp = pass)
+#else
+#define SSF_SKIP_STAMP(rec) ((void)0)
+#endif
 template <bool RGBD, int NPX, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg, TileOrder ord) {
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
     __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
+#ifdef SSF_EXPERIMENTS
+    __shared__ int s_clean, s_far;
+#endif
     // this workgroup's (frame, tile row, tile column): see TileOrder
     unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (ord.xcd) {
@@ -396,6 +416,14 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     if (NPREV_FORM == 0) { if (pass > 0) n_prev_word = pcnt[tile_id]; }
     else if (NPREV_FORM == 1) n_prev_word = pcnt[tile_id];
     else { int lane_zero = 0; asm volatile("" : "+v"(lane_zero)); n_prev_word = pcnt[tile_id + lane_zero]; }
+#ifdef SSF_EXPERIMENTS
+    // (lab: clean-tile skipping, lab/pass_skip.inc -- the change stamps of the image blocks this tile + halo overlaps)
+    const int nbkx = (p.W + 31) >> SSF_CHANGE_BLOCK_LOG2;
+    const bool may_skip = pass >= skip_from && NPX == 1;
+    int stamp_max = may_skip ? skip_block_stamps<TWX>(m, p, X0, Y0, nbkx) : SSF_STAMP_NEVER;
+#else
+    (void)skip_from;
+#endif
     // operands that do not depend on the label tile: in flight while the tile is staged
     uint32_t px[NPX]; float disp[NPX]; unsigned char prev_inlier[NPX];
 #pragma unroll
@@ -478,6 +506,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             const bool inside = cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy;
             const int k = cy * p.gx + cx;
             if (threadIdx.x < 64) w_label[i] = inside ? k : -1;
+#ifdef SSF_EXPERIMENTS
+            if (may_skip && inside && threadIdx.x < 64) stamp_max = max(stamp_max, ld_off<int>(sr.r, (unsigned int)(k * (int)sizeof(SumRec) + (int)offsetof(SumRec, stamp))));
+#endif
             if (inside && !(dbg & 1)) {
                 if (threadIdx.x < 64) {
                     SpRow row = zero_row;
@@ -508,6 +539,12 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (RGBD) prev_disp[s] = ld_off<float>(pdis, 4u * le);
     }
     if (threadIdx.x == 0) s_nlog = 0;
+#ifdef SSF_EXPERIMENTS
+    if (threadIdx.x < 64) {                        // (wave 0 holds all the stamps: one ballot -- lab/pass_skip.inc "clean tiles")
+        const bool clean = may_skip && window_ok && n_prev == 0u && __ballot(stamp_max > pass - 5) == 0ull && !(dbg & 64);
+        if (threadIdx.x == 0) { s_far = 0; s_clean = clean ? 1 : 0; }
+    }
+#endif
     constexpr int ACC_CHUNKS = RGBD ? 6 : 2;                  // 16-byte chunks of a slot that a pass of this kind can touch (RGB: sx .. n)
     // (RGB-D: every chunk of a slot, i.e. the first 6 nslots chunks of the array; RGB: chunks 0 and 1 of each slot)
     for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256)
@@ -528,6 +565,16 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         reinterpret_cast<uint4*>(tile)[e] = tile_reg[k];
     }
     __syncthreads();
+#ifdef SSF_EXPERIMENTS
+    if (s_clean) {
+        if (threadIdx.x == 0) {
+            unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+            ccnt[tile_id] = 0u;
+            atomicAdd(&m.epoch[1 + (pass & 31)], 1u);          // (ssf_dbg_pass_skips)
+        }
+        return;
+    }
+#endif
     const float inv_gx = p.inv_gx;
     auto slot_of = [&](int l) -> int {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
@@ -537,6 +584,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     auto row_of = [&](int l) -> SpRow {
         const int ws = slot_of(l);
         if (ws >= 0) return *reinterpret_cast<const SpRow*>(reinterpret_cast<const char*>(w_row) + __umul24((unsigned int)ws, (unsigned int)sizeof(SpRow)));
+#ifdef SSF_EXPERIMENTS
+        s_far = 1;                                            // (its sums are not among the stamps the clean-tile test reads)
+#endif
         return row_from_sums(sr, l, RGBD, zero_row);          // drifted out of the window: exact slow path
     };
     // sum deltas of one relabelled pixel: LDS accumulators of the window, global atomics outside it
@@ -550,13 +600,13 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                 atomicAdd(&a[F_SX], (unsigned int)-px_x); atomicAdd(&a[F_SY], (unsigned int)-px_y); atomicAdd(&a[F_SR], (unsigned int)-ir);
                 atomicAdd(&a[F_SG], (unsigned int)-ig); atomicAdd(&a[F_SB], (unsigned int)-ib); atomicAdd(&a[F_N], 0xFFFFFFFFu);
             } else { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
-                     atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
+                     atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); SSF_SKIP_STAMP(sw.r[from]); }
             if (wt >= 0) {
                 unsigned int* a = &w_acc[__umul24((unsigned int)wt, PASS_ACC_DW)];
                 atomicAdd(&a[F_SX], (unsigned int)px_x); atomicAdd(&a[F_SY], (unsigned int)px_y); atomicAdd(&a[F_SR], (unsigned int)ir);
                 atomicAdd(&a[F_SG], (unsigned int)ig); atomicAdd(&a[F_SB], (unsigned int)ib); atomicAdd(&a[F_N], 1u);
             } else { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
-                     atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
+                     atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); SSF_SKIP_STAMP(sw.r[to]); }
         }
         if (RGBD && (fl & 6u)) {
             // the nine disparity terms of the pixel, converted once: added to `to` (flag 2), taken from `from` (flag 4)
@@ -572,7 +622,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                     atomicAdd(&a[F_DX], (unsigned int)px_x); atomicAdd(&a[F_DY], (unsigned int)px_y); atomicAdd(&a[F_DN], 1u);
                     lds_add_i64(&b[F_DXX - PASS_F32], xx); lds_add_i64(&b[F_DYY - PASS_F32], yy); lds_add_i64(&b[F_DXY - PASS_F32], xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], xd); lds_add_i64(&b[F_DYD - PASS_F32], yd); lds_add_i64(&b[F_DD - PASS_F32], dd);
-                } else disp_sums_add(sw, to, px_x, px_y, d, +1);
+                } else { disp_sums_add(sw, to, px_x, px_y, d, +1); SSF_SKIP_STAMP(sw.r[to]); }
             }
             if (fl & 4u) {
                 if (wf >= 0) {
@@ -580,7 +630,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                     atomicAdd(&a[F_DX], (unsigned int)-px_x); atomicAdd(&a[F_DY], (unsigned int)-px_y); atomicAdd(&a[F_DN], 0xFFFFFFFFu);
                     lds_add_i64(&b[F_DXX - PASS_F32], -xx); lds_add_i64(&b[F_DYY - PASS_F32], -yy); lds_add_i64(&b[F_DXY - PASS_F32], -xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], -xd); lds_add_i64(&b[F_DYD - PASS_F32], -yd); lds_add_i64(&b[F_DD - PASS_F32], -dd);
-                } else disp_sums_add(sw, from, px_x, px_y, d, -1);
+                } else { disp_sums_add(sw, from, px_x, px_y, d, -1); SSF_SKIP_STAMP(sw.r[from]); }
             }
         }
     };
@@ -681,6 +731,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             }
         }
         if (flags) {
+#ifdef SSF_EXPERIMENTS
+            if (NPX == 1) st_off<int>(m.bstamp, 4u * (unsigned int)((y[s] >> SSF_CHANGE_BLOCK_LOG2) * nbkx + (x[s] >> SSF_CHANGE_BLOCK_LOG2)), pass);
+#endif
             const uint32_t rgbf = (px[s] & 0x00FFFFFFu) | (flags << 24);
             add_delta(index, new_index, x[s], y[s], rgbf, disp[s]);
             const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < LOGN by construction
@@ -697,6 +750,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                 add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
     __syncthreads();
+#ifdef SSF_EXPERIMENTS
+    if (s_far && NPX == 1) skip_stamp_blocks<TWX>(m, p, X0, Y0, nbkx, pass);      // (a label from outside the window was met)
+#endif
     // flush: the accumulators are scanned a 16-byte chunk at a time (most are zero); one global atomic per sum that is not.
     // The record's nine int32 sums and six int64 sums are addressed by field number (SumRec: int32 fields from byte 0, int64
     // fields from byte 64)
@@ -715,6 +771,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);       // i / 6, i / 2
         const int c = i - __mul24(wi, ACC_CHUNKS);
         SumRec* rec = &sw.r[w_label[wi]];
+        SSF_SKIP_STAMP(*rec);
         if (c < 3) {
             int* f = &rec->sx + 4 * c;                             // (chunk 2: dn and three dwords of padding, always zero)
             if (v.x) atomicAdd(f, (int)v.x);
@@ -1541,7 +1598,7 @@ int pass_tile_npx(int nb) {
                     // the algorithmic bytes but not its time -- the kernel is bound by instruction issue, not by memory or by
                     // how many workgroups are resident -- and cost a single-frame launch 50 % more (8 -> 12 us)
 }
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg, int skip_from) {
 #ifdef SSF_EXPERIMENTS
     static const char* per_pass_names[64] = {nullptr};
     static int per_pass = -1;
@@ -1557,6 +1614,8 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     // OX = 0: tiles shifted left by (tile width - 2): [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
     // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.  All passes of a
     // frame use the same tile width (the log layout depends on it): 64 when the launch covers several frames.
+    static const int skip_on = SSF_ENV_INT("PASS_SKIP", 0);          // (lab: 1 = tiles may prove themselves clean and leave, lab/pass_skip.inc)
+    if (!skip_on) skip_from = 1 << 30;
     const int npx = pass_tile_npx(nb);
     const int twx = TILE * npx;
     dim3 grid = tile_grid(p);
@@ -1574,15 +1633,15 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
 #ifdef SSF_EXPERIMENTS
     // the instantiations that lost their A/B: 64-wide tiles (two pass pixels per thread), 7 / 8 waves per SIMD for the RGB-D pass
     if (npx == 2) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
+        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
         return;
     }
-    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord); return; }
-    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord); return; }
+    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from); return; }
+    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from); return; }
 #endif
-    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
-    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord);
+    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
+    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

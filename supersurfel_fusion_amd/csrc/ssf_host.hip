@@ -652,7 +652,7 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, b
         (void)launch_update_passes(st, p, c.maps, nb, 0, k1, false, abort_flag);
         if (multi) resident_turn_end(h, st);
     } else
-        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false);
+        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false, 0, 4);
     // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
     if (h->cfg.seg_use_ransac) {
         launch_init_samples(st, p, c.maps, nb, k1 & 1);
@@ -666,7 +666,7 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, b
         if (multi) resident_turn_end(h, st);
         k = std::max(k1, k2);
     } else
-        for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true);
+        for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true, 0, k1 + 4);
     launch_plane_filter(st, p, c.maps, nb, k & 1);             // final merge (table + planes) + smoothing sweeps
     launch_render_moments(st, p, h->cam, c.maps, nb);
 }
@@ -1602,7 +1602,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         };
         FrameMaps& m = c.maps;
         take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
-        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 1); take(m.pix2, P); take(m.fpack, 4 * S);
+        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 64); take(m.bstamp, (size_t)(((h->cfg.width + 31) >> 5) * ((h->cfg.height + 31) >> 5))); take(m.pix2, P); take(m.fpack, 4 * S);
         take(m.label_alt, P); take(m.pbar, 16);
         for (int b = 0; b < 2; b++) take(m.sums[b].r, S);
         for (int b = 0; b < 3; b++) { take(m.log.ent[b], NT * 256); take(m.log.disp[b], NT * 256); take(m.log.count[b], NT); }
@@ -2556,6 +2556,14 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
 }
 
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
+// lab build: tiles of the last extracted frame (slot 0 of the active context) that proved themselves clean, per pass
+// (FrameMaps::epoch[1 + pass], counted by k_update_pass under SSF_EXPERIMENTS; tools/skip_probe.py)
+int ssf_dbg_pass_skips(ssf_handle* h, uint32_t* out64) {
+    if (!h || !h->active.ctx || !out64) return SSF_ERR_INVALID_ARG;
+    HCK(hipStreamSynchronize(h->active.ctx->stream));
+    HCK(hipMemcpy(out64, h->active.ctx->maps.epoch, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SSF_OK;
+}
 double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg, int nb) {
     if (!h || !h->active.ctx) return -1.0;
     ExtractCtx& c = *h->active.ctx;                   // all slots of the batch context (nb <= extract_batch)
