@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
                     SpRow row = zero_row;
                     row_means_from_sums(sr, k, row);
                     w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
+                    w_row[i].pad0 = row.size / (row.size - 1.f);      // the pixel's own-energy scale n / (n - 1): one division per window cell instead of one per pass pixel
                     if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
                 } else {
                     float ta, tb, tc;
@@ -587,7 +588,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #ifdef SSF_EXPERIMENTS
         s_far = 1;                                            // (its sums are not among the stamps the clean-tile test reads)
 #endif
-        return row_from_sums(sr, l, RGBD, zero_row);          // drifted out of the window: exact slow path
+        SpRow far = row_from_sums(sr, l, RGBD, zero_row);     // drifted out of the window: exact slow path
+        far.pad0 = far.size / (far.size - 1.f);
+        return far;
     };
     // sum deltas of one relabelled pixel: LDS accumulators of the window, global atomics outside it
     auto add_delta = [&](int from, int to, int px_x, int px_y, uint32_t rgbf, float d) {
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         float best = 0.f;
         if (eligible) {
             const float size = own.size;
-            const float sc = size / (size - 1.f);
+            const float sc = own.pad0;                        // size / (size - 1), divided once per superpixel (w_row / row_of)
             const float dpx = sc * (posx - own.cx), dpy = sc * (posy - own.cy);
             const V3 dcol = v3(sc * (cr - own.r), sc * (cg - own.g), sc * (cb - own.b));
             const float dsize = size - (float)p.min_size;

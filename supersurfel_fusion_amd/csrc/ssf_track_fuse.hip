@@ -652,7 +652,11 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     if (!(lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f)) return -1;
     const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) |
                                    (unsigned long long)(uint32_t)(id_offset + id);
-    atomicMin(&best[f], key);     // (reading the table first to skip hopeless candidates was measured slower: 72 vs 49 us at 860 k rows)
+    // (Reading the table first to skip hopeless candidates is slower, measured twice: as a trip of its own in front of the atomic,
+    // round 2, 72 against 49 us at 860 k rows; fetched past the L1 in the SAME trip as the frame supersurfel's line, round 4, 117
+    // against 55 us -- a million coherent reads of 4800 hot words cost more than the atomics they save.  Test-before-set of the
+    // `matched` byte: no difference, 55.0 against 55.1 us.  profiles/atomic_scope_r04.txt has the part's atomic rates.)
+    atomicMin(&best[f], key);
     return f;
 }
 // (Measured and removed, round 2: trading the association tables with the peers in THIS launch's last workgroup instead of

@@ -52,8 +52,20 @@ def frames_of(cfg):
     return [(np.ascontiguousarray(r, np.uint8), np.ascontiguousarray(d, np.float32)) for r, d in fr]
 
 
+def spread_over_devices(world):
+    """On a node with at least `world` GPUs every rank process takes its own device (the stores of the exchange then cross
+    xGMI and the regions are fine-grained); on the one-GPU box all ranks share device 0."""
+    try:
+        import torch
+        return torch.cuda.is_available() and torch.cuda.device_count() >= world > 1
+    except Exception:
+        return False
+
+
 def make_config(lib, cfg, rank, world, capacity):
     kw = dict(pipeline_depth=cfg.get("depth", 2), extract_batch=cfg.get("batch", 2)) if cfg.get("pipelined") else {}
+    if cfg.get("own_device"):
+        kw["device_id"] = rank
     if cfg.get("tum"):
         args = dict(replay.BENCHMARK_LAUNCH, nb_supersurfels_max=capacity, rank=rank, nranks=world, shard_tile=cfg.get("tile", 0.25), **kw)
         return lib.default_config(**args)
@@ -83,10 +95,11 @@ def main():
     world, d = cfg["world"], cfg["dir"]
     lib = binding.load_product()
     model, nvis, cap = seed_shard(cfg, rank, world)
-    f = binding.Fusion(lib, make_config(lib, cfg, rank, world, cap))
+    own = spread_over_devices(world)                                     # a multi-GPU node: one device per rank, as in production
+    f = binding.Fusion(lib, make_config(lib, dict(cfg, own_device=own), rank, world, cap))
     if model is not None:
         f.set_model(model, nvis, 30)
-    f.p2p_configure(all_ranks_on_this_device=True, timeout_s=120.0)     # (the ranks are processes that share the box's one GPU)
+    f.p2p_configure(all_ranks_on_this_device=not own, timeout_s=120.0)   # (one GPU per box here: the ranks are processes that share it)
     f.p2p_attach(np.concatenate(trade(d, "h", rank, world, f.p2p_export())))
     frames = frames_of(cfg)
     k_def = cfg.get("deform_after", -1)

@@ -632,15 +632,20 @@ def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, p
     assert L.ssf_dbg_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
 
 
-def test_relabelling_passes_bit_exact_in_grid_order_too():
-    """The relabelling pass takes its tiles in an XCD-aware order by default (each XCD a contiguous eighth of the launch:
-    DESIGN.md section 4.1.3).  Only speed may depend on that: the per-pass comparison against the oracle is repeated in a
-    process that loads the LAB build with its passes taking their tiles in plain grid order (SSF_PASS_XCD=0, read once per process)."""
+@pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_SKIP=1"])
+def test_relabelling_passes_bit_exact_under_the_lab_switches(switch):
+    """Two arms of the relabelling pass that only exist in the LAB build of the sources (the product reads no environment variable),
+    each in a process of its own (the switches are read once per process):
+      SSF_PASS_XCD=0   tiles in plain grid order instead of the XCD-aware order (DESIGN.md section 4.1.3): only speed may differ;
+      SSF_PASS_SKIP=1  clean-tile skipping (lab/pass_skip.inc, section 4.1.5): a tile that can prove that nothing it depends on has
+                       changed for four passes leaves after its loads -- exact by construction, measured useless.
+    The per-pass comparison against the oracle (drift-out-of-window parameter sets included) must hold under both."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSF_PASS_XCD="0", SSF_PRODUCT_VARIANT="lab")      # (the product reads no environment variable: the lab build does)
+    name, value = switch.split("=")
+    env = dict(os.environ, SSF_PRODUCT_VARIANT="lab", **{name: value})
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-q", "-m", "gpu", "-x",
                         "-k", "test_every_relabelling_pass_bit_exact or test_segmentation_parameter_space_batched"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)

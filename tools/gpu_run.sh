@@ -11,6 +11,10 @@
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (separate) + the two SQ passes, summarised
 #   prof3        the profile command of the trace / pmc steps that follow becomes BASELINE config 3 (1280x960, 1 M rows in view,
 #                10 forced ICP iterations; outputs tagged _config3)
+#   prof5 / prof2  the same for BASELINE config 5 / back to the default workload
+#   driver       the driver's exact command (python bench.py --gpus 1 --steps 20 --warmup 5, everything on)
+#   gpus2        python bench.py --gpus 2 ... on this one-GPU box: must end in the JSON error record
+#   sharded1     every multi-GPU exchange on one rank (RCCL, then the peer-to-peer regions)
 #   env:K=V      export K=V for the steps that follow (A/B of kernel variants on the same box)
 #   py:<file>    python tools/<file> (a probe), output to <file>.txt
 set -u
@@ -25,6 +29,15 @@ lastline() { [ -s "$1" ] && tail -n 1 "$1" | python -c "import json,sys; d=json.
 for step in "$@"; do
   case $step in
     prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; TAG="${TAG}_config3";;
+    prof5) PROF="python $R/bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (TUM-shaped frames, pre-filter in the frame, pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; TAG="${TAG}_config5";;
+    prof2) PROF="python $R/bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; TAG="";;
+    driver)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err; lastline $O/bench_driver_command.json driver_command;;
+    gpus2)
+      timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_gpus2.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$? $(cat $O/bench_gpus2.json)" >> $O/summary.txt;;
+    sharded1)
+      timeout 400 python bench.py --force-sharded --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err; lastline $O/bench_one_rank_rccl.json one_rank_rccl
+      timeout 400 python bench.py --force-sharded --comm p2p --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_p2p.json 2> $O/bench_one_rank_p2p.err; lastline $O/bench_one_rank_p2p.json one_rank_p2p;;
     env:*) export "${step#env:}"; case "${step#env:}" in SSF_*) export SSF_PRODUCT_VARIANT=${SSF_PRODUCT_VARIANT:-lab};; esac;    # (the switches live in the lab build)
             TAG="${TAG}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=\n' '_')";;
     suite)
