@@ -2536,6 +2536,32 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
 }
 
 
+// What a plain stream copy reaches on THIS box (nominal AND measured-achievable peak): 16 bytes per lane,
+// grid-stride, `mib` MiB read + the same written, best of `reps` -- the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s (79 % of
+// the 8 TB/s spec).  bench.py reports it beside torch's own copy kernel, which reaches ~15 % less (`hbm_peak_measured_GBs`).
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+double ssf_dbg_stream_copy_GBs(int mib, int reps) {
+    if (mib < 16 || reps < 1) return -1.0;
+    const size_t bytes = (size_t)mib << 20, n = bytes / sizeof(float4);
+    float4 *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(a); return -1.0; }
+    (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 0, bytes);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    double best = 0.0;
+    for (int r = 0; r < reps + 2; r++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, 0, a, b, n);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 2 && ms > 0.f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+    return best;
+}
+
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
 // (bit0: skip the per-surfel math, bit1: skip the LDS accumulation, bit2: skip arrival counting + tail)
 double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
