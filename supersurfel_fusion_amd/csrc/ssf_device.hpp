@@ -131,7 +131,9 @@ struct FrameMaps {
 // identically out of consecutive slabs, so frame b of a batch lives at (every pointer) + b * slab.
 // The extract kernels take the batch index from the grid (blockIdx.z, or .y for 1-D kernels): one
 // launch relabels the tiles of all frames of the batch.  srgb_lut is shared.
+#ifndef SSF_MAX_BATCH
 #define SSF_MAX_BATCH 8
+#endif
 // (byte arithmetic on a char pointer, not on an integer: a pointer that went through an integer loses its address
 // space, and every access through it becomes a FLAT instruction -- which also ties LDS waits to outstanding loads)
 template <typename T> SSF_HD T* slab_shift(T* p, size_t off) {

@@ -72,3 +72,33 @@ def test_two_gpus_on_a_one_gpu_box_is_the_error_record_not_a_traceback():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2 and "2 but 1 GPU" in json.loads(lines[0])["error"]
     assert "Traceback" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_the_bench_line_keeps_the_drivers_contract():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's form, with the slow legs shortened): ONE JSON line on stdout with
+    the contract's keys, the metric's configuration, `roofline` and `cpu_baseline` objects of the prescribed shape, and figures that
+    are consistent with each other (value = steps / time, the dominant kernel's share below the step time, achieved below peak)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--extras", "0",
+                        "--cpu-frames", "4", "--profile-frames", "16"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "frames_per_sec" and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    c = d["config"]
+    assert "workload" in c and c["width"] == 640 and c["height"] == 480 and 900000 < c["n_model"] < 1100000 and c["exchange"] == "none"
+    assert abs(d["value"] * d["ms_per_step"] / 1000.0 - 1.0) < 1e-6 and d["value"] > 1000
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.02 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - rf["algo_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) < 1e-3 * rf["achieved"]
+    assert sum(rf["kernel_share_ms_per_frame"].values()) < d["ms_per_step"] * 1.5      # (per-kernel brackets are taken in a separate, unpipelined-timer run)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0.5 < cb["value"] < d["value"] and "sample" in cb
+    assert d["frame_roofline"]["frac"] < 1.0 and d["kernel_source_sha"]

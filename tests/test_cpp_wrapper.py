@@ -187,6 +187,18 @@ def test_the_reference_nodes_pose_lines_on_the_hip_library(oracle_lib, product_l
     _run_node_pose(oracle_lib, os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "libssf_hip.so"), "ssf_hip", tmp_path)
 
 
+def test_ssf_hpp_uses_hips_float3_when_the_translation_unit_has_one():
+    """tests/cpp/node_pose_hip_float3.cpp (compile-only): with <hip/hip_vector_types.h> included first, include/ssf.hpp builds
+    Transform3 / Mat33 on HIP's float3 instead of declaring its own -- the guard the header documents"""
+    inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(inc, "hip", "hip_vector_types.h")):
+        pytest.skip("no ROCm headers on this box")
+    cmd = ["g++", "-std=c++14", "-D__HIP_PLATFORM_AMD__", "-Wall", "-Werror", "-I", inc, "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "tests", "cpp"), "-c", os.path.join(ROOT, "tests", "cpp", "node_pose_hip_float3.cpp"), "-o", os.devnull]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_model_device_view_has_the_reference_layout(oracle_lib):
     """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
     import ctypes as C
