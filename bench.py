@@ -550,14 +550,20 @@ def main():
     # ---- roofline of the dominant kernel: per-kernel hipEvent times on the library's stream ----
     # (same submission pattern as the timed region: batched / pipelined when configured)
     stage = np.zeros(3)
-    ns = npk = -(-max(a.profile_frames // 2, 1) // batch) * batch     # whole batches
+    ns = batch                                        # one whole batch for the stage split
+    # per-kernel brackets: ONE batch at a time, the device drained in between -- a launch's duration is then the kernel's own
+    # (with two batches in flight the extract launches of one run beside the track kernels of the other and every bracket
+    # measures the contention too: 17 instead of 13.5 us for the dominant launch); `reps` such batches
+    reps = max(1, a.profile_frames // (2 * batch))
+    npk = reps * batch
     f.set_profile(2)                                  # stage split only (one event synchronise per frame)
     for r in run(base, ns, native=False):
         stage += np.array(r["stage_ms"]) / ns
     f.set_profile(1); f.reset_kernel_times()          # per-kernel hipEvent brackets
     cnt_before = f.counts()
-    run(base + ns, npk, native=False)
-    torch.cuda.synchronize(dev)
+    for rep in range(reps):
+        run(base + ns + rep * batch, batch, native=False)
+        torch.cuda.synchronize(dev)
     kt = f.kernel_times()
     f.set_profile(0)
     counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S, batch=batch)

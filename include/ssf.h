@@ -409,6 +409,10 @@ int ssf_get_preview_image(ssf_handle* h, uint8_t* out /* H*W*3 */);
  * 3); this call materialises the dense, packed copy on demand.  Valid until the next call on the handle.  (For the
  * CPU checker "device" pointers are host pointers.) */
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_model);
+/* getFrame() as the reference returns it (supersurfel_fusion.hpp:86; the nodes copy its arrays out whole,
+ * supersurfel_fusion_node.cpp:423-427): the frame supersurfels of the last processed frame as device arrays in the reference's
+ * layout (orientations packed as Mat33), *n = the number of superpixels; valid until the next call on the handle. */
+int ssf_get_frame_device(ssf_handle* h, ssf_surfels* out_device_ptrs, int* n_frame);
 int ssf_export_model_txt(ssf_handle* h, const char* path);
 
 /* ---- "next" row: depth pre-filter ----------------------------------------------------------- */

@@ -70,6 +70,53 @@ struct HostSupersurfels {
     }
 };
 
+/* ---- getModel() / getFrame() as the reference returns them: device-resident arrays the callers hand to thrust ----------------
+ * The reference's Supersurfels (supersurfels.hpp:32-40) holds seven thrust::device_vectors and its nodes copy them out with
+ *     thrust::host_vector<float3> positions(ssf.getModel().positions.begin(), ssf.getModel().positions.begin() + ssf.getnbSupersurfels());
+ *     thrust::host_vector<Mat33> orientations(ssf.getFrame().orientations);
+ * (node/supersurfel_fusion_node.cpp:306-310,423-427,688-690; ...benchmark_node.cpp:189-193,305-306).  A node built for AMD has
+ * rocThrust (hipcc, /opt/rocm/include/thrust): when <thrust/...> was included before this header, Supersurfels is a VIEW of the
+ * library's device arrays with the same seven member names -- each a DeviceArray<T>: begin() / end() as thrust::device_ptr<T>,
+ * size(), and a conversion to thrust::host_vector<T> for the whole-array form -- and getModel() / getFrame() return
+ * `const Supersurfels&` exactly as supersurfel_fusion.hpp:86-87: those lines compile as they stand (tests/cpp/node_model_copy.cpp,
+ * compiled by hipcc against rocThrust).  The view covers the n valid rows (the reference's vectors have capacity
+ * nb_supersurfels_max; its callers stop at getnbSupersurfels()); it is valid until the next call on the object.  Without
+ * thrust (plain g++) getModel() / getFrame() hand back host copies (HostSupersurfels), also available as getModelHost() /
+ * getFrameHost() in both builds.  SSF_NO_THRUST_VIEW: keep the host-copy form although thrust is there. */
+#if defined(THRUST_VERSION) && !defined(SSF_NO_THRUST_VIEW)
+#define SSF_THRUST_VIEW 1
+}  /* namespace supersurfel_fusion */
+#include <thrust/device_ptr.h>
+#include <thrust/host_vector.h>
+#include <thrust/copy.h>
+namespace supersurfel_fusion {
+template <typename T> struct DeviceArray {
+    typedef thrust::device_ptr<T> iterator;
+    typedef thrust::device_ptr<T> const_iterator;
+    T* ptr = nullptr; size_t n = 0;
+    iterator begin() const { return thrust::device_pointer_cast(ptr); }
+    iterator end() const { return thrust::device_pointer_cast(ptr) + n; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() const { return ptr; }
+    operator thrust::host_vector<T>() const { thrust::host_vector<T> v(n); thrust::copy(begin(), end(), v.begin()); return v; }
+};
+struct Supersurfels {                                                    /* supersurfels.hpp:32-40, as views */
+    DeviceArray<float3> positions, colors;
+    DeviceArray<int2> stamps;
+    DeviceArray<Mat33> orientations;
+    DeviceArray<Cov3> shapes;
+    DeviceArray<float2> dims;
+    DeviceArray<float> confidences;
+    void bind(const ssf_surfels& v, size_t n) {
+        positions.ptr = reinterpret_cast<float3*>(v.positions); colors.ptr = reinterpret_cast<float3*>(v.colors);
+        stamps.ptr = reinterpret_cast<int2*>(v.stamps); orientations.ptr = reinterpret_cast<Mat33*>(v.orientations);
+        shapes.ptr = reinterpret_cast<Cov3*>(v.shapes); dims.ptr = reinterpret_cast<float2*>(v.dims); confidences.ptr = v.confidences;
+        positions.n = colors.n = stamps.n = orientations.n = shapes.n = dims.n = confidences.n = n;
+    }
+};
+#endif
+
 class SupersurfelFusion {
 public:
     SupersurfelFusion() = default;
@@ -183,18 +230,36 @@ public:
     int getnbSuperpixels() const { int s = 0; check(ssf_get_counts(need(), nullptr, nullptr, nullptr, &s)); return s; }
     /* getModel() / getFrame(): the reference returns device-resident thrust vectors and the node copies
      * [0, nbSupersurfels) to the host (supersurfel_fusion_node.cpp:306-310); here the copy comes back directly */
-    HostSupersurfels getModel() {
+    HostSupersurfels getModelHost() {
         HostSupersurfels m; m.resize(getnbSupersurfels());
         ssf_surfels v = m.view();
         check(ssf_get_model(need(), 0, m.size, &v));
         return m;
     }
-    HostSupersurfels getFrame() {
+    HostSupersurfels getFrameHost() {
         HostSupersurfels m; m.resize(getnbSuperpixels());
         ssf_surfels v = m.view();
         check(ssf_get_frame(need(), &v));
         return m;
     }
+#ifdef SSF_THRUST_VIEW
+    /* supersurfel_fusion.hpp:86-87: `const Supersurfels&`, device-resident (views: see Supersurfels above) */
+    const Supersurfels& getModel() {
+        ssf_surfels v; int n = 0;
+        check(ssf_get_model_device(need(), &v, &n));
+        model_view_.bind(v, (size_t)n);
+        return model_view_;
+    }
+    const Supersurfels& getFrame() {
+        ssf_surfels v; int n = 0;
+        check(ssf_get_frame_device(need(), &v, &n));
+        frame_view_.bind(v, (size_t)n);
+        return frame_view_;
+    }
+#else
+    HostSupersurfels getModel() { return getModelHost(); }
+    HostSupersurfels getFrame() { return getFrameHost(); }
+#endif
     /* getModel() as the reference returns it: device-resident arrays in the reference's layout (orientations =
      * packed Mat33), n rows, valid until the next call (supersurfel_fusion.hpp:87; the node copies
      * [0, nbSupersurfels) out array by array, supersurfel_fusion_node.cpp:306-310) */
@@ -215,6 +280,9 @@ private:
     ssf_handle* h_ = nullptr;
     ssf_frame_result last_{};
     mutable Transform3 pose_{};
+#ifdef SSF_THRUST_VIEW
+    Supersurfels model_view_, frame_view_;
+#endif
     int width_ = 0, height_ = 0;
     int pipeline_depth_ = 0, extract_batch_ = 1; bool depth_prefilter_ = true;
 };

@@ -337,6 +337,14 @@ int ssf_get_superpixels(ssf_handle* h, float* o) {
     return SSF_OK;
 }
 // for the checker a device pointer is a host pointer: its arrays already have the reference's layout
+int ssf_get_frame_device(ssf_handle* h, ssf_surfels* o, int* n) {           // (the checker's "device" is the host)
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    Surfels& F = h->s.frame;
+    o->positions = &F.pos[0].x; o->colors = &F.col[0].x; o->stamps = F.stamps.data(); o->orientations = &F.orient[0].r[0].x;
+    o->shapes = &F.shape[0].xx; o->dims = F.dims.data(); o->confidences = F.conf.data();
+    if (n) *n = h->s.S;
+    return SSF_OK;
+}
 int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
     Surfels& M = h->s.model;

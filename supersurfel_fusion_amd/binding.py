@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "ssf_stage_icp_accumulate", "ssf_stage_icp_update", "ssf_stage_icp_end", "ssf_stage_match",
     "ssf_stage_fuse", "ssf_get_pose", "ssf_set_pose", "ssf_get_counts", "ssf_get_model",
     "ssf_get_frame", "ssf_set_model", "ssf_get_index_map", "ssf_get_boundary_map",
-    "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device",
+    "ssf_get_inlier_map", "ssf_get_plane_depth", "ssf_get_superpixels", "ssf_get_model_device", "ssf_get_frame_device",
     "ssf_export_model_txt", "ssf_apply_deformation", "ssf_get_kernel_times",
     "ssf_reset_kernel_times", "ssf_set_profile", "ssf_bilateral_filter", "ssf_submit_frame",
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",

@@ -466,7 +466,7 @@ struct ssf_handle {
     std::vector<void*> allocs;
     struct Guarded { void* base; size_t bytes, guard; };
     std::vector<Guarded> guarded;         // SSF_ALLOC_GUARD (debug): see dalloc
-    float* d_bf_in = nullptr; float* d_bf_out = nullptr; float* d_orient9 = nullptr;
+    float* d_bf_in = nullptr; float* d_bf_out = nullptr; float* d_orient9 = nullptr; float* d_frame_orient9 = nullptr;
     long long* d_icp = nullptr;
     uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
     // multi-GPU migration: this shard's migrant table (SSF_MIGRANT_WORDS x S int32), state between the two fuse halves
@@ -2309,6 +2309,19 @@ int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
     o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = h->d_orient9; o->shapes = s.shape;
     o->dims = s.dims; o->confidences = s.conf;
     if (n) *n = h->n_model;
+    return SSF_OK;
+}
+int ssf_get_frame_device(ssf_handle* h, ssf_surfels* o, int* n) {
+    if (!h || !o) return SSF_ERR_INVALID_ARG;
+    if (!h->have_frame) { h->err = "no frame has been processed yet"; return SSF_ERR_STATE; }
+    if (!h->d_frame_orient9 && !dalloc(h, &h->d_frame_orient9, 9 * (size_t)h->S)) { h->err = "allocation failed"; return SSF_ERR_DEVICE; }
+    const SurfelSoA& s = h->cc->frame;
+    launch_pack_orient(h->stream, s, h->S, h->d_frame_orient9);
+    HCK(hipGetLastError());
+    HCK(hipStreamSynchronize(h->stream));
+    o->positions = s.pos; o->colors = s.col; o->stamps = s.stamps; o->orientations = h->d_frame_orient9; o->shapes = s.shape;
+    o->dims = s.dims; o->confidences = s.conf;
+    if (n) *n = h->S;
     return SSF_OK;
 }
 int ssf_get_preview_image(ssf_handle* h, uint8_t* o) {

@@ -199,6 +199,47 @@ def test_ssf_hpp_uses_hips_float3_when_the_translation_unit_has_one():
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _build_node_model_copy(lib_dir, lib_name, exe):
+    """tests/cpp/node_model_copy.cpp by hipcc against rocThrust: the nodes' thrust copy-out lines of getModel() / getFrame(), verbatim"""
+    if not (os.path.exists(HIPCC) and os.path.exists("/opt/rocm/include/thrust/host_vector.h")):
+        pytest.skip("no hipcc / rocThrust on this box")
+    cmd = [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "node_model_copy.cpp"), "-o", str(exe),
+           "-L", lib_dir, "-l" + lib_name, "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-4000:]
+
+
+def test_the_reference_nodes_model_copy_lines_compile_against_rocthrust(product_lib, tmp_path):
+    """`thrust::host_vector<float3> positions(ssf.getModel().positions.begin(), ... + ssf.getnbSupersurfels());` and
+    `thrust::host_vector<Mat33> orientations(ssf.getFrame().orientations);` (supersurfel_fusion_node.cpp:306-310,423-427;
+    ...benchmark_node.cpp:189-193) compile as they stand when thrust is there: getModel() / getFrame() are `const Supersurfels&`
+    views of device arrays then (include/ssf.hpp).  Compile + link here; the GPU twin runs it."""
+    _build_node_model_copy(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc"), "ssf_hip", tmp_path / "node_model_copy")
+
+
+@pytest.mark.gpu
+def test_the_reference_nodes_model_copy_lines_on_the_hip_library(product_lib, tmp_path):
+    """... and copy out exactly what ssf_get_model / ssf_get_frame hand to the host: every array, bit for bit"""
+    W, H, n = 640, 480, 3
+    raw = tmp_path / "frames.bin"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            rgb, depth = util.frame(k, W, H)
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes()); f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+    exe = tmp_path / "node_model_copy"
+    _build_node_model_copy(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc"), "ssf_hip", exe)
+    K = synthetic.intrinsics(W, H)
+    r = subprocess.run([str(exe), str(W), str(H), str(n), str(raw)] + [repr(float(K[k])) for k in ("fx", "fy", "cx", "cy")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("model_range_form 1 n=") and int(lines[0].split("n=")[1]) > 500, r.stdout
+    assert lines[1] == "model_whole_array_form 1" and lines[2].startswith("frame_whole_array_form 1 valid="), r.stdout
+
+
 def test_model_device_view_has_the_reference_layout(oracle_lib):
     """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
     import ctypes as C
