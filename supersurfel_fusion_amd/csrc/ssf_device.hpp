@@ -280,7 +280,11 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate = 0);
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate = 0,
+                 int tail_in_move = 0 /* the launch ends without turning the class totals into counters: launch_move_rows(totals) does */);
+// launch_move_rows(totals != nullptr): the fuse launch ended without its tail; every block of the move kernel takes the old
+// counts from here (the host mirrors them) and the class totals from the partition's replicas, block 0 finalises the counters
+struct MoveTotals { int from_tot, nv /* visible rows before the frame */, head_old, tail_old /* out-of-view span before the frame */; };
 // Multi-GPU migration (ssf_stage_fuse_begin / _end in ssf.h).  launch_fuse(migrate = 1) marks an updated row whose new
 // position belongs to another rank's world tile as leaving (partition class "dropped", confidence kept);
 // launch_pack_emigrants writes those rows to slot f of the migrant table (SSF_MIGRANT_WORDS words per slot, other
@@ -318,7 +322,8 @@ struct NextFrameIcp {
 // first ICP iteration
 void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
                       const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
-                      const Counters* cnt /* [2]: see launch_fuse */, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next);
+                      Counters* cnt /* [2]: see launch_fuse */, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next,
+                      const MoveTotals* totals = nullptr);
 // stable compaction of the live out-of-view rows of src (span from the device counters) into dst starting at
 // new_head (dst.live must be zero where it matters); set_span != 0: cnt->oov_head / oov_tail := the new span
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,

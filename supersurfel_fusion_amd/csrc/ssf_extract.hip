@@ -361,7 +361,7 @@ static inline TileOrder tile_order(dim3 grid) {
 // A measurement arm of the lab build (lab/pass_skip.inc, SSF_PASS_SKIP=1); the product compiles none of it.
 #ifdef SSF_EXPERIMENTS
 #include "lab/pass_skip.inc"
-#define SSF_SKIP_STAMP(rec) ((rec).stamp = pass)
+#define SSF_SKIP_STAMP(rec) do { if (skip_from < (1 << 29)) (rec).stamp = pass; } while (0)      /* (only when the arm is switched on: the lab build's default path stays the product's) */
 #else
 #define SSF_SKIP_STAMP(rec) ((void)0)
 #endif
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
         if (flags) {
 #ifdef SSF_EXPERIMENTS
-            if (NPX == 1) st_off<int>(m.bstamp, 4u * (unsigned int)((y[s] >> SSF_CHANGE_BLOCK_LOG2) * nbkx + (x[s] >> SSF_CHANGE_BLOCK_LOG2)), pass);
+            if (NPX == 1 && skip_from < (1 << 29)) st_off<int>(m.bstamp, 4u * (unsigned int)((y[s] >> SSF_CHANGE_BLOCK_LOG2) * nbkx + (x[s] >> SSF_CHANGE_BLOCK_LOG2)), pass);
 #endif
             const uint32_t rgbf = (px[s] & 0x00FFFFFFu) | (flags << 24);
             add_delta(index, new_index, x[s], y[s], rgbf, disp[s]);
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     }
     __syncthreads();
 #ifdef SSF_EXPERIMENTS
-    if (s_far && NPX == 1) skip_stamp_blocks<TWX>(m, p, X0, Y0, nbkx, pass);      // (a label from outside the window was met)
+    if (s_far && NPX == 1 && skip_from < (1 << 29)) skip_stamp_blocks<TWX>(m, p, X0, Y0, nbkx, pass);      // (a label from outside the window was met)
 #endif
     // flush: the accumulators are scanned a 16-byte chunk at a time (most are zero); one global atomic per sum that is not.
     // The record's nine int32 sums and six int64 sums are addressed by field number (SumRec: int32 fields from byte 0, int64

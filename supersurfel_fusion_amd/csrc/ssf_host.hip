@@ -471,6 +471,7 @@ struct ssf_handle {
     uint8_t* d_state = nullptr; int32_t* d_cand = nullptr; Counters* d_cnt = nullptr;
     // multi-GPU migration: this shard's migrant table (SSF_MIGRANT_WORDS x S int32), state between the two fuse halves
     int32_t* d_migrants = nullptr; PartitionWs fuse_ws{}; bool fuse_first = false, fuse_migrate = false, fusing = false;
+    MoveTotals fuse_totals{0, 0, 0, 0}; bool move_totals_on = true;      // (lab: SSF_MOVE_TOTALS=0 keeps the fuse launch's tail)
     // model store: model[mcur] = dense array of the visible rows (ping-pong), oov[ocur] = out-of-view rows (deque
     // with live flags, host mirror of the span below), dense = materialised [visible | out-of-view] view for the
     // consumers of the whole model (get/set model, export, deformation)
@@ -1083,6 +1084,11 @@ static int fuse_begin(ssf_handle* h, int migrate) {
             if (h->oov_head < h->n_visible + h->S + 256 || h->oov[h->ocur].cap - h->oov_tail < 2 * h->S + 256 ||
                 span > h->oov_live + h->oov_live / 4 + 65536) { int rc2 = oov_recentre(h); if (rc2) return rc2; }
         }
+        // a single shard: the fuse launch ends without its three-trip tail, the move kernel works the counters out from the class
+        // totals (MoveTotals: the counts the frame starts from are mirrored here).  A sharded map keeps the tail: arrivals from
+        // other ranks change the counters between the two launches (launch_migrate_in).
+        h->fuse_totals.from_tot = (h->cfg.nranks == 1 && !h->comm && !h->p2p.on && !h->fuse_migrate && h->move_totals_on) ? 1 : 0;
+        h->fuse_totals.nv = h->n_visible; h->fuse_totals.head_old = h->oov_head; h->fuse_totals.tail_old = h->oov_tail;
         PartitionWs& ws = h->fuse_ws;
         {
             uint32_t* set = h->d_part + (size_t)h->part_set * h->part_words;
@@ -1095,7 +1101,7 @@ static int fuse_begin(ssf_handle* h, int migrate) {
                     h->S, nvis_g > 0 ? 1 : 0, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks, h->cfg.shard_tile, h->d_cnt,
                     h->cam, h->oov[h->ocur], h->oov_tail - h->oov_head, h->cc->maps.plane_depth, h->cfg.delta_t,
                     h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws,
-                    h->fuse_migrate ? 1 : 0);
+                    h->fuse_migrate ? 1 : 0, h->fuse_totals.from_tot);
         if (h->fuse_migrate)
             launch_pack_emigrants(h->stream, M, h->cc->d_best, h->cc->d_matched, h->id_offset, h->n_visible, h->d_state, h->S,
                                   nvis_g > 0 ? 1 : 0, h->cfg.nranks, h->cfg.shard_tile, h->d_migrants);
@@ -1147,7 +1153,8 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         // frame does not have to wait for the row moves to learn them)
         if (h->comm || h->p2p.on) { int rg = comm_gather_counts(h); if (rg) return rg; }
         launch_move_rows(h->stream, h->cam, M, h->model[h->mcur ^ 1], h->oov[h->ocur], h->n_visible + (h->fuse_migrate ? 2 : 1) * h->S, h->oov_tail - h->oov_head,
-                         h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr);
+                         h->d_state, h->d_state_oov, h->d_bc_oov, ws, h->d_cnt, h->mb_dev, seq, have_next ? &next : nullptr,
+                         h->fuse_totals.from_tot ? &h->fuse_totals : nullptr);
         h->mcur ^= 1;
     } else {
         launch_first_frame(h->stream, M, h->cc->frame, h->pose, h->S, h->cfg.nb_supersurfels_max, h->cfg.rank, h->cfg.nranks,
@@ -1559,6 +1566,10 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int W = cfg->width, H = cfg->height, c = cfg->cell_size;
     h->gx = (W + c - 1) / c; h->gy = (H + c - 1) / c; h->S = h->gx * h->gy;
     if (cfg->nb_supersurfels_max < h->S) { delete h; g_create_err = "nb_supersurfels_max < nbSuperpixels"; return SSF_ERR_INVALID_ARG; }
+#ifndef SSF_MOVE_TOTALS_DEFAULT
+#define SSF_MOVE_TOTALS_DEFAULT 1
+#endif
+    h->move_totals_on = SSF_ENV_INT("MOVE_TOTALS", SSF_MOVE_TOTALS_DEFAULT) != 0;      // (-DSSF_MOVE_TOTALS_DEFAULT=0: a product build that keeps the fuse launch's tail, for the A/B)
     h->icp_ahead = SSF_ENV_INT("ICP_AHEAD", 1) != 0;      // (lab: measurement switches, tools/)
     h->icp_chain = SSF_ENV_INT("ICP_CHAIN", 1) != 0;
     if (SSF_ENV_SET("NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
@@ -2313,7 +2324,7 @@ int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
 }
 int ssf_get_frame_device(ssf_handle* h, ssf_surfels* o, int* n) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    if (!h->have_frame) { h->err = "no frame has been processed yet"; return SSF_ERR_STATE; }
+    if (!h->cc) { h->err = "no frame has been processed yet"; return SSF_ERR_STATE; }
     if (!h->d_frame_orient9 && !dalloc(h, &h->d_frame_orient9, 9 * (size_t)h->S)) { h->err = "allocation failed"; return SSF_ERR_DEVICE; }
     const SurfelSoA& s = h->cc->frame;
     launch_pack_orient(h->stream, s, h->S, h->d_frame_orient9);

@@ -1011,15 +1011,30 @@ __device__ __forceinline__ void insert_chunk(SurfelSoA M, SurfelSoA F, Rt pose, 
 // per group of PART_GROUP blocks, and replicated frame totals) with atomics.  The LAST block to finish turns the
 // totals into the frame's counters and publishes them; the move kernel that follows derives its prefixes from the
 // group sums and the states themselves.  No scan kernel, no separate classify kernel.
-__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed);
+__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed, int keep_inserted = 0);
 __device__ __forceinline__ void mailbox_counters(const Counters& c, Mailbox* mb, unsigned long long seq);
+// the frame's counters from the counters it started with (+ what the fuse launch accumulated in them) and the eight class
+// totals a0 a1 a2 c0 c1 c2 b0 b2 of the partition
+__device__ __forceinline__ Counters frame_counters(const Counters& c_in, const uint32_t* tot) {
+    const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
+    const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
+    Counters c = c_in;
+    c.n_model = c_in.n_model + c_in.n_inserted;   // the insertion reports its rows in n_inserted only
+    c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
+    c.n_visible = a0 + b0 + c0; c.n_removed = (a2 + b2 + c2) - c_in.n_emigrated;     // emigrants are dropped, not removed
+    c.mv_nv = c_in.n_visible; c.mv_a0 = a0; c.mv_b0 = b0; c.mv_nc = c_in.n_inserted;
+    c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
+    c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
+    c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
+    return c;
+}
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, const int32_t* __restrict__ cand, int S,
                                                        int do_update, int capacity, int rank, int nranks, float tile, Counters* cnt,
                                                        int nupd, int nchunks, int nb_vis, int nb_oov, OovStore O, ClassifyArgs ca,
                                                        uint8_t* __restrict__ state_vis, uint8_t* __restrict__ state_oov,
-                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws, int migrate) {
+                                                       uint32_t* __restrict__ bc_oov, PartitionWs ws, int migrate, int tail_in_move) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     __shared__ int wave_tot[16];
     __shared__ int hist[4][6];
@@ -1060,6 +1075,12 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         ShardArgs sh; sh.rank = rank; sh.nranks = nranks; sh.migrate = (migrate && nranks > 1) ? 1 : 0; sh.tile = tile;
         update_group(M, F, pose, stamp, id_offset, n_visible, best, matched, S, cnt, b * UPD_PER_WG, ca, state_vis, ws, sh);
     }
+    // tail_in_move (a single shard): the launch ENDS here.  What follows -- three dependent trips to the coherence point: the
+    // adds' acknowledgements, the two-level arrival ticket, the last block's read-back -- only existed to turn the class totals
+    // into the frame's counters before the row moves; the kernel boundary in front of k_move_rows completes every atomic of this
+    // launch for free, every block of the move kernel sums the eight replicas of the totals it needs itself (64 words), and its
+    // block 0 finalises and publishes the counters (move_totals / the head of k_move_rows).
+    if (tail_in_move) return;
     // the atomics above (and cnt->n_updated / n_inserted) are device-scope, complete (vmcnt(0) + barrier) before this
     // block counts its arrival; the last block reads them back with device-scope atomic loads (same protocol as the
     // ICP record)
@@ -1082,19 +1103,9 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
         c_in.n_inserted = __hip_atomic_load(&cnt->n_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written in this launch
         c_in.n_updated = __hip_atomic_load(&cnt->n_updated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c_in.n_emigrated = __hip_atomic_load(&cnt->n_emigrated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int a0 = (int)tot[0], a1 = (int)tot[1], a2 = (int)tot[2], c0 = (int)tot[3], c1 = (int)tot[4], c2 = (int)tot[5];
-        const int b0 = (int)tot[6], b2 = (int)tot[7], b1 = c_in.oov_live - b0 - b2;
-        Counters c = c_in;
-        c.n_model = c_in.n_model + c_in.n_inserted;   // the insertion reports its rows in n_inserted only
-        c.n_state0 = a0 + b0 + c0; c.n_state1 = a1 + b1 + c1; c.n_state2 = a2 + b2 + c2;
-        c.n_visible = a0 + b0 + c0; c.n_removed = (a2 + b2 + c2) - c_in.n_emigrated;     // emigrants are dropped, not removed
-        c.mv_nv = c_in.n_visible; c.mv_a0 = a0; c.mv_b0 = b0; c.mv_nc = c_in.n_inserted;
-        c.mv_head_old = c_in.oov_head; c.mv_tail_old = c_in.oov_tail; c.mv_head_new = c_in.oov_head - a1;
-        c.oov_head = c_in.oov_head - a1; c.oov_tail = c_in.oov_tail + c1;
-        c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
         // the frame's counters are final here; the move kernel that follows in the stream sends them to the host first
         // thing (cnt[1]), so that this launch does not end on the acknowledgement of writes to host memory
-        cnt[1] = finalise_counters(cnt, c, 1);
+        cnt[1] = finalise_counters(cnt, frame_counters(c_in, tot), 1);
     }
 }
 
@@ -1208,21 +1219,56 @@ template <bool ICP, bool P2P>
 __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, OovStore O, const uint8_t* __restrict__ state_vis,
                                                    const uint8_t* __restrict__ state_oov,
                                                    const uint32_t* __restrict__ bc_oov, PartitionWs ws,
-                                                   const Counters* __restrict__ cnt, int nb_vis, NextIcp nx, Mailbox* mb,
-                                                   unsigned long long cnt_seq, P2PView pv) {
+                                                   Counters* cnt, int nb_vis, NextIcp nx, Mailbox* mb,
+                                                   unsigned long long cnt_seq, P2PView pv, MoveTotals mt) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
-    // the frame's counters (finalised by the fuse launch, cnt[1]) go to the host while the rows move
+    // the frame's counters go to the host while the rows move: finalised by the fuse launch (cnt[1]), or -- mt.from_tot, a
+    // single shard: the fuse launch ended without its tail -- worked out HERE by block 0 from the class totals (the kernel
+    // boundary has completed every atomic of the fuse launch), which also clears the other set of partition sums for the next
+    // frame.  No other block of this launch reads a word that block 0 changes: they take the old counts from the launch's
+    // arguments (the host mirrors them), the insertion count from cnt->n_inserted (stored, not accumulated: left alone) and
+    // the totals from the replicas.
     if (blockIdx.x == 0 && threadIdx.x == 255) {
-        int w[sizeof(Counters) / sizeof(int)];                    // (all words requested before the first store to the host)
-        const int* src = reinterpret_cast<const int*>(&cnt[1]);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) w[i] = __builtin_nontemporal_load(&src[i]);
         Counters c;
-        __builtin_memcpy(&c, w, sizeof(c));
+        if (mt.from_tot) {
+            uint32_t tot[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int r = 0; r < PART_REPLICAS; r++) v += __builtin_nontemporal_load(&ws.tot[r * 8 + k]);
+                tot[k] = v;
+            }
+            const Counters c_in = *cnt;
+            c = finalise_counters(cnt, frame_counters(c_in, tot), 1, /*keep_inserted=*/1);     // (the other blocks read cnt->n_inserted; the next frame's insertion stores it anew)
+            cnt[1] = c;
+        } else {
+            int w[sizeof(Counters) / sizeof(int)];                    // (all words requested before the first store to the host)
+            const int* src = reinterpret_cast<const int*>(&cnt[1]);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(Counters) / sizeof(int)); i++) w[i] = __builtin_nontemporal_load(&src[i]);
+            __builtin_memcpy(&c, w, sizeof(c));
+        }
         mailbox_counters(c, mb, cnt_seq);
     }
+    if (mt.from_tot && blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 255)
+        for (int i = threadIdx.x - 64; i < ws.words; i += 191) ws.other[i] = 0u;      // the other set: next frame's sums
     // out-of-view blocks: nothing moves in most of them (bc_oov: see classify_oov_block) -- leave at once
     if ((int)blockIdx.x >= nb_vis && bc_oov[blockIdx.x - nb_vis] == 0u) return;
+    // the frozen inputs of the move (Counters::mv_*): from the fuse launch's last block, or from the arguments + the replicas
+    __shared__ uint32_t s_tot[8];
+    if (mt.from_tot && threadIdx.x < 8) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < PART_REPLICAS; r++) v += ws.tot[r * 8 + threadIdx.x];
+        s_tot[threadIdx.x] = v;
+    }
+    const int mv_nv = mt.from_tot ? mt.nv : cnt->mv_nv, mv_nc = mt.from_tot ? cnt->n_inserted : cnt->mv_nc;
+    const int mv_head_old = mt.from_tot ? mt.head_old : cnt->mv_head_old, mv_tail_old = mt.from_tot ? mt.tail_old : cnt->mv_tail_old;
+    auto mv_a0 = [&]() -> int { return mt.from_tot ? (int)s_tot[0] : cnt->mv_a0; };          // (s_tot: valid behind the next barrier)
+    auto mv_b0 = [&]() -> int { return mt.from_tot ? (int)s_tot[6] : cnt->mv_b0; };
+    auto mv_head_new = [&]() -> int { return mt.from_tot ? mt.head_old - (int)s_tot[1] : cnt->mv_head_new; };
+    auto new_n_visible = [&]() -> int { return mt.from_tot ? (int)(s_tot[0] + s_tot[6] + s_tot[3]) : cnt->n_visible; };
     __shared__ int hist[4][6];
     __shared__ uint32_t base[6];                  // rows of each class in the blocks before this one
     __shared__ unsigned long long red[ICP ? 29 * ICP_SLOTS : 1];
@@ -1233,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
     bool keep = false;
     V3 pos, lab, nrm;
     if ((int)blockIdx.x < nb_vis) {
-        const int nv = cnt->mv_nv, n_rows = nv + cnt->mv_nc;              // mv_nc = rows appended in this frame (insertions + arrivals)
+        const int nv = mv_nv, n_rows = nv + mv_nc;                        // mv_nc = rows appended in this frame (insertions + arrivals)
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         // the row itself is requested now, together with its state byte (not behind it: a row that turns out to be removed is
         // fetched for nothing, every other row saves a dependent trip to memory): the loads travel while the prefix below
@@ -1295,19 +1341,19 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             for (int w = 0; w < wv; w++) before += hist[w][cls];
             const size_t r = (size_t)base[cls] + before + in_wave;
             if (cls == 0 || cls == 3) {
-                const size_t j = cls == 0 ? r : (size_t)cnt->mv_a0 + cnt->mv_b0 + r;
+                const size_t j = cls == 0 ? r : (size_t)mv_a0() + mv_b0() + r;
                 store_row(Vn, j, row);
                 if (ICP) { pos = row.pos; lab = row.lab; nrm = row.r2; keep = true; }
             } else {
-                const size_t j = (cls == 1 ? (size_t)cnt->mv_head_new : (size_t)cnt->mv_tail_old) + r;
+                const size_t j = (cls == 1 ? (size_t)mv_head_new() : (size_t)mv_tail_old) + r;
                 store_row(O.rows, j, row);
                 O.live[j] = 1;
             }
         }
     } else {
         const int ob = blockIdx.x - nb_vis;
-        const long long phys = (long long)cnt->mv_head_old + (long long)ob * blockDim.x + threadIdx.x;
-        if (phys < cnt->mv_tail_old) {             // (both bytes in one round trip)
+        const long long phys = (long long)mv_head_old + (long long)ob * blockDim.x + threadIdx.x;
+        if (phys < mv_tail_old) {                  // (both bytes in one round trip)
             int lv = (int)O.live[phys], st = (int)state_oov[phys];
             asm volatile("" : "+v"(lv), "+v"(st));
             if (lv) cls = st;
@@ -1326,7 +1372,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         if (cls == 0) {
             int before = 0;
             for (int w = 0; w < wv; w++) before += hist[w][0];
-            const size_t j = (size_t)cnt->mv_a0 + base[0] + before + in_wave;
+            const size_t j = (size_t)mv_a0() + base[0] + before + in_wave;
             if (ICP) { copy_row_keep(O.rows, (size_t)phys, Vn, j, pos, lab, nrm); keep = true; }
             else copy_row(O.rows, (size_t)phys, Vn, j);
         }
@@ -1342,12 +1388,12 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
         // global row counter.  The few out-of-view blocks with rows that come back into view go there directly.
         // No rows at all: no record is published, and the host does not ask for one (ICP needs visible rows).
         const int nkeep = __syncthreads_count(keep);
-        if (P2P && cnt->n_visible == 0) {          // an empty shard still owes its peers a (zero) record
+        if (P2P && new_n_visible() == 0) {         // an empty shard still owes its peers a (zero) record
             if (blockIdx.x == 0) icp_publish<true>(nx.replicas, nx.sums, nx.mb, nx.seq, pv, pv.seq);
             return;
         }
         const bool vis = (int)blockIdx.x < nb_vis;
-        const int nbr = (cnt->mv_nv + cnt->mv_nc + 255) / 256;
+        const int nbr = (mv_nv + mv_nc + 255) / 256;
         if (vis ? (int)blockIdx.x >= nbr : nkeep == 0) return;
         __shared__ int s_last;
         icp_fold(red, nx.replicas);
@@ -1368,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_move_rows(SurfelSoA V, SurfelSoA Vn, Oo
             }
             int last = 0;
             if (report) {
-                const unsigned int total = (unsigned int)cnt->n_visible;
+                const unsigned int total = (unsigned int)new_n_visible();
                 const unsigned int before = rows ? __hip_atomic_fetch_add(&nx.ticket[65], rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 last = rows != 0u && before + rows == total;
                 if (last) __hip_atomic_store(&nx.ticket[65], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1584,11 +1630,11 @@ __global__ void k_oov_set_span(Counters* cnt, int new_head) { cnt->oov_head = ne
 // counters to the host-mapped mailbox, reset the per-frame ones for the next frame
 // finalise_counters: the frame's counters become final in device memory (cnt[0] = the values the next frame starts
 // from, per-frame ones reset; cnt[1] = the values to publish); mailbox_counters writes a set of values to the host
-__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed) {
+__device__ __forceinline__ Counters finalise_counters(Counters* cnt, Counters c, int shrink_by_removed, int keep_inserted) {
     if (shrink_by_removed) c.n_model = c.n_model - c.n_state2;
     c.last[0] = c.n_model; c.last[1] = c.n_visible; c.last[2] = c.n_removed; c.last[3] = c.n_inserted; c.last[4] = c.n_updated;
     Counters next = c;
-    next.n_inserted = 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
+    next.n_inserted = keep_inserted ? c.n_inserted : 0; next.n_updated = 0; next.n_removed = 0; next.n_state0 = 0; next.n_state1 = 0; next.n_state2 = 0;
     next.n_emigrated = 0;
     cnt[0] = next;
     return c;
@@ -1927,7 +1973,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
                  int capacity, int rank, int nranks, float tile, Counters* cnt, const Cam& cam, OovStore oov,
                  int span_upper, const float* plane_depth, int delta_t, float conf_thresh, float zmin, float zmax,
-                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate) {
+                 uint8_t* state_vis, uint8_t* state_oov, uint32_t* bc_oov, const PartitionWs& ws, int migrate, int tail_in_move) {
     ScopedKernel sk("update_insert", st);
     const int nchunks = (S + 255) / 256, nb_oov = (span_upper + 255) / 256, nb_vis = (n_visible + 255) / 256;
     ClassifyArgs ca; ca.cam = cam; ca.plane_depth = plane_depth; ca.delta_t = delta_t; ca.conf_thresh = conf_thresh; ca.zmin = zmin; ca.zmax = zmax;
@@ -1935,7 +1981,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int 
     hipLaunchKernelGGL(k_update_insert, dim3(nupd + nchunks + nb_vis + (nb_oov + OOV_PER_WG - 1) / OOV_PER_WG), dim3(256), 0, st, model,
                        frame, pose, stamp, id_offset,
                        n_visible, best, matched, cand, S, do_update, capacity, rank, nranks, tile, cnt, nupd, nchunks, nb_vis, nb_oov, oov, ca,
-                       state_vis, state_oov, bc_oov, ws, migrate);
+                       state_vis, state_oov, bc_oov, ws, migrate, tail_in_move);
 }
 void launch_pack_emigrants(hipStream_t st, SurfelSoA model, const unsigned long long* best, const uint8_t* matched, long long id_offset,
                            int n_visible, const uint8_t* state_vis, int S, int do_update, int nranks, float tile, int32_t* table) {
@@ -1957,8 +2003,9 @@ void launch_first_frame(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pos
 }
 void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelSoA vis_dst, OovStore oov, int nv_upper, int span_upper,
                       const uint8_t* state_vis, const uint8_t* state_oov, const uint32_t* bc_oov, const PartitionWs& ws,
-                      const Counters* cnt, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next) {
+                      Counters* cnt, Mailbox* mb, unsigned long long cnt_seq, const NextFrameIcp* next, const MoveTotals* totals) {
     const int nb_vis = std::max(1, (nv_upper + 255) / 256), nb_oov = (span_upper + 255) / 256;
+    const MoveTotals mt = totals ? *totals : MoveTotals{0, 0, 0, 0};
     NextIcp nx{};
     const dim3 grid(nb_vis + nb_oov);
     if (next) {
@@ -1967,14 +2014,14 @@ void launch_move_rows(hipStream_t st, const Cam& cam, SurfelSoA vis_src, SurfelS
         ScopedKernel sk("reorder_move_icp", st);
         if (next->pv)
             hipLaunchKernelGGL((k_move_rows<true, true>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, *next->pv);
+                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, *next->pv, mt);
         else
             hipLaunchKernelGGL((k_move_rows<true, false>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
+                               bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{}, mt);
     } else {
         ScopedKernel sk("reorder_move", st);
         hipLaunchKernelGGL((k_move_rows<false, false>), grid, dim3(256), 0, st, vis_src, vis_dst, oov, state_vis, state_oov,
-                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{});
+                           bc_oov, ws, cnt, nb_vis, nx, mb, cnt_seq, P2PView{}, mt);
     }
 }
 void launch_oov_compact(hipStream_t st, OovStore src, OovStore dst, int span_upper, int new_head, uint32_t* bc_oov, Counters* cnt,
