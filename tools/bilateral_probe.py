@@ -14,7 +14,7 @@ from supersurfel_fusion_amd import binding, synthetic  # noqa: E402
 
 
 def main():
-    lib = binding.load_product()
+    lib = (binding.load_lab() if (os.environ.get("SSF_BIL_WAVES") or os.environ.get("SSF_BILATERAL_GENERIC")) else binding.load_product())
     olib = binding.Library(os.path.join(ROOT, "oracle", "_build", "libssf_oracle.so"))
     dev = torch.device("cuda", 0)
     for (W, H) in ((640, 480), (1280, 960)):

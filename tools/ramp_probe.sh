@@ -1,5 +1,6 @@
 #!/bin/bash
 # The driver's 20-frame form under different leading extract batches (SSF_SEQ_RAMP): bash tools/ramp_probe.sh "2,4" "1,2,4" ...
+export SSF_PRODUCT_VARIANT=lab      # (the switch lives in the lab build of the sources)
 for ramp in "$@"; do
   for r in 1 2 3; do
     if [ "$ramp" = default ]; then unset SSF_SEQ_RAMP; else export SSF_SEQ_RAMP=$ramp; fi
