@@ -6,7 +6,8 @@
 //   eigenDecomposition   core/src/supersurfel_fusion_kernels.cu:48-111                  (principal frame of a supersurfel)
 // They are self-contained __device__ functions of plain C arithmetic inside .cu / .cuh files that cannot be included whole
 // (kernels, textures, curand).  oracle/Makefile therefore cuts exactly those line ranges out of the reference's files AT BUILD
-// TIME into oracle/_ref/decision_*.inc (git-ignored, never committed, never shipped -- the recipe checks that each range still
+// TIME into oracle/_ref/decision_*.inc (git-ignored, deleted again right after this file is compiled: never committed, never
+// shipped -- the recipe checks that each range still
 // starts at the function's signature) and this file #includes them: what is evaluated below is the reference's text, compiled
 // by g++ against NVIDIA's CUDA runtime headers from the image (as ref_math_vectors.cpp) with -ffp-contract=off.
 //
