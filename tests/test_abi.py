@@ -84,3 +84,8 @@ def test_the_product_library_reads_no_environment_variable(product_lib):
         txt = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", src)).read()
         body = txt.split("#ifdef SSF_EXPERIMENTS\n#include <stdlib.h>")[0] if src == "ssf_device.hpp" else txt
         assert "getenv(" not in body, src
+
+
+def test_comm_info_without_an_exchange(oracle_lib):
+    f = binding.Fusion(oracle_lib, oracle_lib.default_config(width=160, height=128, fx=131.25, fy=131.25, cx=79.5, cy=63.5, nb_supersurfels_max=2048))
+    assert f.comm_info() == dict(backend="none", ranks=1, rank=0)

@@ -37,7 +37,9 @@ def test_one_rank_communicator_equals_plain_run(depth_ahead, batch, one_rank_gro
     W, H, nf = 320, 240, 7
     plain = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H))
     comm = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+    assert plain.comm_info() == dict(backend="none", ranks=1, rank=0)
     comm.comm_attach()
+    assert comm.comm_info() == dict(backend="rccl", ranks=1, rank=0)      # what ncclCommCount / ncclCommUserRank say (bench.py prints it)
     frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
     want = [plain.process_frame(*fr) for fr in frames]
     got, nsub = [], 0

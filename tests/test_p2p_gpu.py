@@ -53,6 +53,7 @@ def test_ranks_in_one_process_bit_exact(world, pipelined, nf, oracle_lib, produc
     regions = [f.p2p_region()[0] for f in fs]
     for f in fs:
         f.p2p_attach_local(regions)
+    assert [f.comm_info() for f in fs] == [dict(backend="p2p", ranks=world, rank=r) for r in range(world)]
     frames = [util.frame(k, W, H) for k in range(nf)]
     frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
     out, errors = [None] * world, []
