@@ -377,7 +377,8 @@ __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restri
 #endif
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
-                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched);
+                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched,
+                                         bool wave_agg = false);
 #define SSF_ICP_DBG_COUNTED 0x40000000          // bit of k_icp's `dbg` argument: end the launch with the counted record
 #ifndef SSF_ICP_GO_WAIT_TICKS
 #define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
@@ -621,7 +622,9 @@ __global__ void k_fern_codes(const uint8_t* __restrict__ rgb, const float* __res
 // the visible array, which is what the association key carries)
 __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model, int j, int id, const uint2* __restrict__ pix2,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
-                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+                                         long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched,
+                                         bool wave_agg) {
+    (void)wave_agg;
     // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
     // row -> pixel -> frame supersurfel -> atomic, three dependent round trips instead of five
     float m_conf = model.conf[j];
@@ -656,6 +659,9 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
     // round 2, 72 against 49 us at 860 k rows; fetched past the L1 in the SAME trip as the frame supersurfel's line, round 4, 117
     // against 55 us -- a million coherent reads of 4800 hot words cost more than the atomics they save.  Test-before-set of the
     // `matched` byte: no difference, 55.0 against 55.1 us.  profiles/atomic_scope_r04.txt has the part's atomic rates.)
+#ifdef SSF_EXPERIMENTS
+    if (wave_agg) return match_bid_wave(f, key, best);        // (lab: tile-sorted rows -- the lanes of a wave that bid for one frame supersurfel agree first)
+#endif
     atomicMin(&best[f], key);
     return f;
 }
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
     const int j = blockIdx.x * blockDim.x + threadIdx.x, id = j; (void)orig;
     if (j >= n_visible) return;
 #endif
-    cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched);
+    cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched, orig != nullptr);
 }
 
 // ---- image-space order for the model side of ICP / association: a tile-sorted copy of the visible rows (k_bin_*), measured
