@@ -2324,7 +2324,7 @@ int ssf_get_model_device(ssf_handle* h, ssf_surfels* o, int* n) {
 }
 int ssf_get_frame_device(ssf_handle* h, ssf_surfels* o, int* n) {
     if (!h || !o) return SSF_ERR_INVALID_ARG;
-    if (!h->cc) { h->err = "no frame has been processed yet"; return SSF_ERR_STATE; }
+    if (!h->cc || !h->cc->frame.pos) { h->err = "no frame has been processed yet"; return SSF_ERR_STATE; }
     if (!h->d_frame_orient9 && !dalloc(h, &h->d_frame_orient9, 9 * (size_t)h->S)) { h->err = "allocation failed"; return SSF_ERR_DEVICE; }
     const SurfelSoA& s = h->cc->frame;
     launch_pack_orient(h->stream, s, h->S, h->d_frame_orient9);
@@ -2564,7 +2564,12 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
 // grid-stride, `mib` MiB read + the same written, best of `reps` -- the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s (79 % of
 // the 8 TB/s spec).  bench.py reports it beside torch's own copy kernel, which reaches ~15 % less (`hbm_peak_measured_GBs`).
 __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+    // four independent 16-byte loads per lane in flight, then four stores (n is a multiple of 4 x the grid's threads: see the caller)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
+    }
 }
 double ssf_dbg_stream_copy_GBs(int mib, int reps) {
     if (mib < 16 || reps < 1) return -1.0;
@@ -2576,7 +2581,7 @@ double ssf_dbg_stream_copy_GBs(int mib, int reps) {
     double best = 0.0;
     for (int r = 0; r < reps + 2; r++) {
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, 0, a, b, n);
+        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 32), dim3(256), 0, 0, a, b, n);        // (2^26 float4 per GiB: a multiple of 4 x 2^21 threads)
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
