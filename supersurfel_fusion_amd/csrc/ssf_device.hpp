@@ -241,9 +241,19 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // go_seq | SSF_ICP_GO_MATCH (a launch made with `match`): the loop has ended and go->T holds the frame's final POSE -- the
 // waiting launch does the association (k_match's work) instead of an iteration: the association then starts ~1 us after
 // the host's decision instead of a launch latency later.
-struct IcpGo { float T[12]; unsigned long long pad[2]; unsigned long long flag; };       // one 128-byte slot
+// One slot = ONE 64-byte line: the host writes transform, peer-exchange number and flag word into its write-combining mapping
+// and fences once (one PCIe write of the whole line), and the sixteen lanes that POLL the slot fetch all of it with every poll --
+// the transform needs no trip of its own behind the word (it used to: ~1 us at the head of every chained iteration).  Should the
+// line ever arrive in pieces, the flag word says so: bits 0-31 the low half of go_seq, bits 32-61 a checksum of the other
+// fourteen words (icp_go_check), bit 62 "associate", bit 63 "leave" (no checksum: nothing else of the line is read then).
+struct alignas(64) IcpGo { float T[12]; unsigned long long flag; unsigned long long x; };
+static_assert(sizeof(IcpGo) == 64, "one line");
 #define SSF_ICP_GO_ABORT (1ull << 63)
 #define SSF_ICP_GO_MATCH (1ull << 62)
+#define SSF_ICP_GO_CHECK_MASK 0x3FFFFFFFu
+SSF_HD unsigned int icp_go_word_weight(unsigned int dword) {      // dword 0..11: the transform; 14, 15: x; 12, 13 (the flag itself): 0
+    return dword < 12u ? (2u * dword + 1u) * 0x9E3779B1u : (dword == 14u ? 0x85EBCA6Bu : (dword == 15u ? 0xC2B2AE35u : 0u));
+}
 #define SSF_ICP_GO_SLOTS 4
 struct MatchArgs { float zmin, zmax; long long id_offset; unsigned long long* best; uint8_t* matched; int32_t* cand; };    // launch_match's arguments
 int icp_variant_mode();              // 0: the product's k_icp; other values: measurement arms that cannot take SSF_ICP_GO_MATCH
@@ -253,11 +263,11 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
                 unsigned long long go_seq = 0, const struct P2PView* pv = nullptr, int by_tile = 0, const MatchArgs* match = nullptr);
 // Tile-sorted copy of the ICP / association fields of the n visible rows of `model` (pos, lab, r2, conf -> the same
 // streams of `out`; out_idx[j] = the row's index in the visible array) under transform T (model -> camera): see k_bin_* in
-// ssf_track_fuse.hip.  count / cursor: bin_count_words(cam) words each, count zero at rest.  launch_icp(by_tile = 1) /
+// ssf_track_fuse.hip.  count / cursor: bin_buffer_words(cam, capacity) words each.  launch_icp(by_tile = 1) /
 // launch_match(orig = out_idx) then take `out` as their rows.
 #ifdef SSF_EXPERIMENTS
-void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out, int32_t* out_idx);
-int bin_count_words(const Cam& cam);
+void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out);
+size_t bin_buffer_words(const Cam& cam, size_t capacity);
 #endif
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,

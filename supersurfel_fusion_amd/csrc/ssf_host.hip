@@ -1264,7 +1264,7 @@ static int comm_counts(ssf_handle* h) {
 // (match_capable: the launch can be told to do the frame's association instead of an iteration -- SSF_ICP_GO_MATCH)
 static bool icp_waiter_can_match(const ssf_handle* h) {
     static const bool off = SSF_ENV_SET("NO_MATCH_IN_WAITER");          // (measurement switch)
-    return !off && !h->p2p.on && !h->comm && h->cfg.nranks == 1 && !h->bins_valid && h->cfg.profile == 0 && icp_variant_mode() == 0;
+    return !off && !h->p2p.on && !h->comm && h->cfg.nranks == 1 && h->cfg.profile == 0 && icp_variant_mode() == 0;
 }
 static int icp_launch_waiting(ssf_handle* h, unsigned long long* seq_out, IcpGo** slot_out, unsigned long long* go_seq_out) {
     const unsigned long long seq = ++h->icp_seq;
@@ -1302,14 +1302,19 @@ static void icp_chain_reset(ssf_handle* h) {
 // the host's word to a waiting launch: its transform and "go", or "no further iteration"
 static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt* T, unsigned long long p2p_seq, bool match) {
     volatile IcpGo* s = slot;
+    const unsigned long long want = go_seq & 0xFFFFFFFFull;
     if (T) {
-        s->pad[0] = p2p_seq;
         const float v[12] = {T->R.r0.x, T->R.r0.y, T->R.r0.z, T->R.r1.x, T->R.r1.y, T->R.r1.z, T->R.r2.x, T->R.r2.y, T->R.r2.z,
                              T->t.x, T->t.y, T->t.z};
+        uint32_t w[12]; memcpy(w, v, sizeof w);
+        uint32_t sum = (uint32_t)p2p_seq * icp_go_word_weight(14) + (uint32_t)(p2p_seq >> 32) * icp_go_word_weight(15);
+        for (unsigned int i = 0; i < 12; i++) sum += w[i] * icp_go_word_weight(i);
+        // the whole line, then ONE fence: the write-combining buffer goes out as one 64-byte write (were it ever split, the
+        // checksum in the flag word keeps the kernel polling until the rest has landed)
         for (int i = 0; i < 12; i++) s->T[i] = v[i];
-        store_fence();                            // (the mapping is write-combining: transform before flag, flag out now)
-        s->flag = match ? (go_seq | SSF_ICP_GO_MATCH) : go_seq;
-    } else s->flag = go_seq | SSF_ICP_GO_ABORT;
+        s->x = p2p_seq;
+        s->flag = want | ((unsigned long long)((sum >> 2) & SSF_ICP_GO_CHECK_MASK) << 32) | (match ? SSF_ICP_GO_MATCH : 0ull);
+    } else s->flag = want | SSF_ICP_GO_ABORT;
     store_fence();
 }
 
@@ -1333,16 +1338,14 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     // frame's initial transform (ssf_track_fuse.hip, k_bin_*): the iterations and the association stream that copy
     h->bins_valid = false;
 #ifdef SSF_EXPERIMENTS
-    if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0) {
-        if (!h->d_bin_idx) {                       // first use: the copy's buffers (44 B per row of capacity)
-            const size_t N = (size_t)h->cfg.nb_supersurfels_max, bw = (size_t)bin_count_words(h->cam);
-            const bool ok = dalloc(h, &h->bins.pos, 3 * N) && dalloc(h, &h->bins.lab, 3 * N) && dalloc(h, &h->bins.r2, 3 * N) && dalloc(h, &h->bins.conf, N) &&
-                            dalloc(h, &h->d_bin_idx, N) && dalloc(h, &h->d_bin_count, bw) && dalloc(h, &h->d_bin_cursor, bw);
+    if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0 && !exchanging && h->cfg.nranks == 1) {
+        if (!h->d_bin_idx) {                       // first use: the copy's buffers (48 B per row of capacity; d_bin_idx: only the flag "this is the sorted copy" of launch_match)
+            const size_t N = (size_t)h->cfg.nb_supersurfels_max, bw = bin_buffer_words(h->cam, N);
+            const bool ok = bw && dalloc(h, &h->bins.pos, 12 * N) && dalloc(h, &h->d_bin_idx, 1) && dalloc(h, &h->d_bin_count, bw) && dalloc(h, &h->d_bin_cursor, bw);
             if (!ok) { h->err = "allocation of the tile-sorted copy failed"; return SSF_ERR_DEVICE; }
-            HCK(hipMemsetAsync(h->d_bin_count, 0, bw * 4, h->stream));
         }
         Rt T0; T0.R = h->icp.R_init; T0.t = h->icp.t_init;
-        launch_bin_rows(h->stream, h->cam, h->model[h->mcur], h->n_visible, T0, h->d_bin_count, h->d_bin_cursor, h->bins, h->d_bin_idx);
+        launch_bin_rows(h->stream, h->cam, h->model[h->mcur], h->n_visible, T0, h->d_bin_count, h->d_bin_cursor, h->bins);
         HCK(hipGetLastError());
         h->bins_valid = true;
     }
@@ -1370,8 +1373,11 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
                            h->d_icp_replicas, h->d_tickets + 8, h->d_icp, h->mb_dev, seq_rec, -1, nullptr, 0, h->p2p.on ? &pv : nullptr, h->bins_valid ? 1 : 0);
                 HCK(hipGetLastError());
             }
-            // the next iteration, should there be one (the loop may run cfg.icp_iter iterations at most)
-            if (h->icp.iter + 1 < h->cfg.icp_iter) {
+            // the next iteration, should there be one (the loop may run cfg.icp_iter iterations at most) -- and behind the LAST
+            // iteration the loop allows, a launch that can only be told to do the association: a loop that ends at the cap
+            // (BASELINE config 3: ten forced iterations) then starts its association ~1 us after the host's last step instead of
+            // a launch latency later (11-13 us between the tenth k_icp and k_match in the round-4 traces), like one that converges
+            if (h->icp.iter + 1 < h->cfg.icp_iter || (!timing && icp_waiter_can_match(h))) {
                 rc = icp_launch_waiting(h, &wait_seq_rec, &wait_slot, &wait_go_seq);
                 if (rc) return rc;
                 waiting = true;
@@ -2082,7 +2088,7 @@ int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVA
 int ssf_debug_set_bin_min_rows(ssf_handle* h, int n) {
     if (!h) return SSF_ERR_INVALID_ARG;
 #ifdef SSF_EXPERIMENTS
-    h->bin_min_rows = bin_count_words(h->cam) > 16384 ? -1 : n;
+    h->bin_min_rows = bin_buffer_words(h->cam, 1) == 0 ? -1 : n;
     return SSF_OK;
 #else
     if (n < 0) return SSF_OK;                      // "never" is what the product does

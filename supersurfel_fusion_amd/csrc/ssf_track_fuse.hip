@@ -323,14 +323,14 @@ __device__ __forceinline__ void icp_fold_counted(const unsigned long long* red, 
     }
 }
 __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restrict__ counted, long long* __restrict__ sums, Mailbox* mb,
-                                                    unsigned long long seq) {
+                                                    unsigned long long seq, unsigned int n_wg) {
     __shared__ long long part[SSF_ICP_REPLICAS * 32];
     __shared__ int s_expired;
     static_assert(SSF_ICP_REPLICAS * ICP_CNT_WORDS <= 256, "one word per thread of the collecting workgroup");
     const int r = threadIdx.x / ICP_CNT_WORDS, k = threadIdx.x - r * ICP_CNT_WORDS;
     const bool mine = r < SSF_ICP_REPLICAS;
     // workgroups b with b % 8 == r
-    const unsigned int expect = mine ? (gridDim.x + SSF_ICP_REPLICAS - 1u - (unsigned int)r) / SSF_ICP_REPLICAS : 0u;
+    const unsigned int expect = mine ? (n_wg + SSF_ICP_REPLICAS - 1u - (unsigned int)r) / SSF_ICP_REPLICAS : 0u;
     unsigned long long acc = 0ull;
     if (threadIdx.x == 0) s_expired = 0;
     __syncthreads();
@@ -379,6 +379,23 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched,
                                          bool wave_agg = false);
+__device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const V3& mp, const V3& m_r2, const V3& m_lab, int id,
+                                            const uint2* __restrict__ pix2, const float4* __restrict__ fpack, const Rt& pose, float zmin,
+                                            float zmax, long long id_offset, unsigned long long* __restrict__ best,
+                                            uint8_t* __restrict__ matched, bool wave_agg);
+#ifdef SSF_EXPERIMENTS
+// (lab) the association over the tile-sorted copy's 48-byte records, workgroups dealt to the XCDs in contiguous shares
+__device__ __forceinline__ void match_sorted_rows(const Cam& cam, const SurfelSoA& sorted, int n_visible, const uint2* __restrict__ pix2,
+                                                  const float4* __restrict__ fpack, const Rt& pose, const MatchArgs& ma) {
+    for (int j = (int)(xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x); j < n_visible; j += gridDim.x * blockDim.x) {
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(sorted.pos) + 3 * (size_t)j;
+        float4 a = rec[0], b = rec[1], c = rec[2];
+        asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x));
+        const int oid = __float_as_int(b.w);
+        ma.cand[oid] = match_values(cam, a.w, v3(a.x, a.y, a.z), v3(c.x, c.y, c.z), v3(b.x, b.y, b.z), oid, pix2, fpack, pose, ma.zmin, ma.zmax, ma.id_offset, ma.best, ma.matched, true);
+    }
+}
+#endif
 #define SSF_ICP_DBG_COUNTED 0x40000000          // bit of k_icp's `dbg` argument: end the launch with the counted record
 #ifndef SSF_ICP_GO_WAIT_TICKS
 #define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
@@ -390,55 +407,84 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                                              long long* __restrict__ sums, Mailbox* mb, unsigned long long seq, int dbg,
                                              IcpGo* go, unsigned long long go_seq, P2PView pv, int by_tile, MatchArgs ma) {
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
+    // Scalar arguments used only behind the wait for the host's word, fetched NOW: left alone the compiler re-loads them from the
+    // argument segment where they are used (it is short of scalar registers) -- `s_load_dword` + `s_waitcnt lgkmcnt(0)` right behind
+    // the barrier that ends the wait, a dependent trip at the head of every chained iteration (read off the ISA, round 4)
+    // (gridDim.x / blockDim.x come from the implicit arguments the same way: the workgroup is 256 threads by construction)
+    unsigned int n_wg = gridDim.x;
+    constexpr unsigned int WG = 256;
+    asm volatile("" : "+s"(dbg), "+s"(by_tile), "+s"(n_visible), "+s"(n_wg));
     __shared__ unsigned long long red[29 * ICP_SLOTS];
     __shared__ float s_T[12];
     __shared__ int s_go;
     __shared__ unsigned long long s_p2p_seq;
-    for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += blockDim.x) red[i] = 0ull;
+    for (int i = threadIdx.x; i < 29 * ICP_SLOTS; i += WG) red[i] = 0ull;
     if (go) {
         // launched ahead of its transform: wait for the host's word (bounded: a lost word must not hang the device)
-        // (wave 0: its first lane polls; the transform is then fetched by twelve lanes in ONE instruction -- read word by word by
-        // the polling lane it was twelve dependent trips to fine-grained memory at the head of every chained iteration)
+        // Wave 0 polls: sixteen lanes fetch the slot's whole 64-byte line in ONE instruction -- flag word, transform and the number
+        // of the peer exchange arrive together (IcpGo, ssf_device.hpp), validated by the checksum in the flag word.  (History:
+        // the polling lane read the transform word by word -- twelve dependent trips to fine-grained memory at the head of every
+        // chained iteration --, then twelve lanes fetched it in one trip behind the flag; now it needs no trip of its own.)
         if (threadIdx.x < 64) {
             int ok = 0, told = 0;
-            if (threadIdx.x == 0) {
-                // (the bound is WALL-CLOCK time -- the constant-rate counter behind wall_clock64(), 100 MHz on this part --, looked
-                // at every 64 polls: a quarter of a second, not a spin count whose length in seconds depends on how long a poll
-                // of fine-grained memory takes under load.  The host's own round trip is 3-5 us.)
-                const unsigned long long t0 = wall_clock64();
-                for (unsigned int spin = 0; spin < (1u << 24); spin++) {
-                    const unsigned long long v = __hip_atomic_load(&go->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (v == go_seq) { ok = 1; told = 1; break; }
-                    if (v == (go_seq | SSF_ICP_GO_ABORT)) { told = 1; break; }
-                    if (v == (go_seq | SSF_ICP_GO_MATCH)) { ok = 2; told = 1; break; }       // the loop is over: associate under the pose in go->T
-                    if ((spin & 63u) == 63u && wall_clock64() - t0 > SSF_ICP_GO_WAIT_TICKS) break;
-                    __builtin_amdgcn_s_sleep(1);
+            const unsigned int l = threadIdx.x, want = (unsigned int)go_seq;
+            const unsigned int* gw = reinterpret_cast<const unsigned int*>(go);
+            const unsigned int weight = icp_go_word_weight(l);
+            unsigned int w = 0u;
+            // (the bound is WALL-CLOCK time -- the constant-rate counter behind wall_clock64(), 100 MHz on this part --, looked
+            // at every 64 polls: a quarter of a second, not a spin count whose length in seconds depends on how long a poll
+            // of fine-grained memory takes under load.  The host's own round trip is 3-5 us.)
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned int spin = 0; spin < (1u << 24); spin++) {
+                w = l < 16u ? __hip_atomic_load(&gw[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                const unsigned int flo = (unsigned int)__builtin_amdgcn_readlane((int)w, 12), fhi = (unsigned int)__builtin_amdgcn_readlane((int)w, 13);
+                if (flo == want) {
+                    if (fhi & 0x80000000u) { told = 1; break; }                                  // SSF_ICP_GO_ABORT
+                    unsigned int sum = w * weight;                                               // (lanes >= 16: 0)
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                    sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
+                    if (((sum >> 2) & SSF_ICP_GO_CHECK_MASK) == (fhi & SSF_ICP_GO_CHECK_MASK)) {
+                        ok = (fhi & 0x40000000u) ? 2 : 1; told = 1;                              // SSF_ICP_GO_MATCH: the loop is over, associate under the pose in the line
+                        break;
+                    }
                 }
-                // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
-                // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
-                // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
-                // through the BAR cost the launch behind this one 3 us per frame.)
-                if (!told) __hip_atomic_store(&go->flag, go_seq | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                s_go = ok;
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > SSF_ICP_GO_WAIT_TICKS) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            ok = __builtin_amdgcn_readfirstlane(ok);
+            // gave up waiting (the host stalled for seconds): make that the decision of the whole launch -- workgroups
+            // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
+            // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
+            // through the BAR cost the launch behind this one 3 us per frame.)
+            if (!told && l == 0u) __hip_atomic_store(&go->flag, (unsigned long long)want | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (ok) {
-                // (the host stored the transform, fenced, then stored the word the first lane has just seen)
-                if (threadIdx.x < 12) s_T[threadIdx.x] = __hip_atomic_load(&go->T[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (l < 12u) s_T[l] = __uint_as_float(w);
                 // (a launch made ahead learns the number of its peer exchange with its transform: a dismissed launch must
                 // not use one up, the two slot parities of the exchange regions rely on consecutive numbers)
-                if (P2P && threadIdx.x == 12) s_p2p_seq = __hip_atomic_load(&go->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned int xlo = (unsigned int)__builtin_amdgcn_readlane((int)w, 14), xhi = (unsigned int)__builtin_amdgcn_readlane((int)w, 15);
+                if (P2P && l == 0u) s_p2p_seq = ((unsigned long long)xhi << 32) | xlo;
             }
+            if (l == 0u) s_go = ok;
         }
         __syncthreads();
         if (!s_go) return;
         T.R = m3(v3(s_T[0], s_T[1], s_T[2]), v3(s_T[3], s_T[4], s_T[5]), v3(s_T[6], s_T[7], s_T[8]));
         T.t = v3(s_T[9], s_T[10], s_T[11]);
-        if constexpr (!P2P && MODE == 0) {
+        if constexpr (!P2P && (MODE == 0 || MODE == 3)) {
             if (s_go == 2) {
                 // findBestMatches in the launch that was waiting for the next iteration (k_match's rows, k_match's arithmetic)
+                // (The pose is uniform, and said so HERE: read from LDS it was twelve VECTOR registers live through this branch --
+                // 72 registers for the kernel, seven waves per SIMD, where the iteration needs 46.  Not for the iteration itself:
+                // with its transform in scalar registers the kernel was 4 % SLOWER on the whole chain, same-box A/B round 4 --
+                // 11 077 against 11 494 frames/s, config 3 2105 against 2188.)
+                auto sT = [&](int i) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_T[i]))); };
+                T.R = m3(v3(sT(0), sT(1), sT(2)), v3(sT(3), sT(4), sT(5)), v3(sT(6), sT(7), sT(8)));
+                T.t = v3(sT(9), sT(10), sT(11));
+#ifdef SSF_EXPERIMENTS
+                if (MODE == 3) { if (ma.best) match_sorted_rows(cam, model, n_visible, pix2, fpack, T, ma); return; }
+#endif
                 if (ma.best && !by_tile)
-                    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x)
+                    for (int id = blockIdx.x * WG + threadIdx.x; id < n_visible; id += n_wg * WG)
                         ma.cand[id] = match_row(cam, model, id, id, pix2, fpack, T, ma.zmin, ma.zmax, ma.id_offset, ma.best, ma.matched);
                 return;
             }
@@ -454,7 +500,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     // (by_tile: `model` is the tile-sorted copy of the visible rows -- pos / lab / r2 streams only -- and the blocks are dealt
     // to the XCDs in contiguous shares; the sums are exact integers, so the order of the rows does not matter)
 #ifdef SSF_EXPERIMENTS
-    const unsigned int blk = by_tile ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned int blk = by_tile ? xcd_block(blockIdx.x, n_wg) : blockIdx.x;
 #else
     const unsigned int blk = blockIdx.x; (void)by_tile;
 #endif
@@ -462,7 +508,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
     if (MODE != 0) icp_lab_arm<MODE>(cam, model, n_visible, pix2, fpack, R, t, red, slot, blk);
     else
 #endif
-        for (int id = blk * blockDim.x + threadIdx.x; id < n_visible; id += gridDim.x * blockDim.x) {
+        for (int id = blk * WG + threadIdx.x; id < n_visible; id += n_wg * WG) {
             // the row's three fields in ONE round trip (left alone, the compiler fetches colour and normal only behind the
             // test of the projected position: a second dependent trip in every iteration)
             V3 mpos = ld3(model.pos, id), mlab = ld3(model.lab, id), mnrm = ld3(model.r2, id);
@@ -479,7 +525,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         if (dbg & SSF_ICP_DBG_COUNTED) {            // the counted record (second half of the replica buffer): see icp_fold_counted
             unsigned long long* counted = reinterpret_cast<unsigned long long*>(replicas) + SSF_ICP_REPLICAS * 32;
             icp_fold_counted(red, counted);
-            if (blockIdx.x == gridDim.x - 1) icp_collect_counted(counted, sums, mb, seq);
+            if (blockIdx.x == n_wg - 1) icp_collect_counted(counted, sums, mb, seq, n_wg);
             return;
         }
     }
@@ -624,12 +670,18 @@ __device__ __forceinline__ int match_row(const Cam& cam, const SurfelSoA& model,
                                          const float4* __restrict__ fpack, const Rt& pose, float zmin, float zmax,
                                          long long id_offset, unsigned long long* __restrict__ best, uint8_t* __restrict__ matched,
                                          bool wave_agg) {
-    (void)wave_agg;
     // everything this row contributes is requested at once (a visible row nearly always gets to the end): the chain is
     // row -> pixel -> frame supersurfel -> atomic, three dependent round trips instead of five
     float m_conf = model.conf[j];
     V3 mp = ld3(model.pos, j), m_r2 = ld3(model.r2, j), m_lab = ld3(model.lab, j);
     asm volatile("" : "+v"(m_conf), "+v"(mp.x), "+v"(m_r2.x), "+v"(m_lab.x));
+    return match_values(cam, m_conf, mp, m_r2, m_lab, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched, wave_agg);
+}
+__device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const V3& mp, const V3& m_r2, const V3& m_lab, int id,
+                                            const uint2* __restrict__ pix2, const float4* __restrict__ fpack, const Rt& pose, float zmin,
+                                            float zmax, long long id_offset, unsigned long long* __restrict__ best,
+                                            uint8_t* __restrict__ matched, bool wave_agg) {
+    (void)wave_agg;
     if (!(m_conf > 0.0f)) return -1;
     const M3 R = pose.R; const V3 t = pose.t;
     const M3 Rt_ = m3_transpose(R);
@@ -679,7 +731,12 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
 #ifdef SSF_EXPERIMENTS
     const int j = (orig ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= n_visible) return;
-    const int id = orig ? orig[j] : j;
+    if (orig) {                                   // (the copy's 48-byte records: lab/tile_bins.inc)
+        const MatchArgs ma{zmin, zmax, id_offset, best, matched, cand};
+        match_sorted_rows(cam, model, n_visible, pix2, fpack, pose, ma);
+        return;
+    }
+    const int id = j;
 #else
     const int j = blockIdx.x * blockDim.x + threadIdx.x, id = j; (void)orig;
     if (j >= n_visible) return;
@@ -1959,6 +2016,7 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     const P2PView none{};
     const P2PView& v = pv ? *pv : none;
 #ifdef SSF_EXPERIMENTS
+    if (by_tile && !pv) { hipLaunchKernelGGL((k_icp<false, 3>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
     if (mode == 2 && !pv) { hipLaunchKernelGGL((k_icp<false, 2>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
     if (mode == 1 && pv) { hipLaunchKernelGGL((k_icp<true, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
     if (mode == 1) { hipLaunchKernelGGL((k_icp<false, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }

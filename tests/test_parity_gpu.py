@@ -609,7 +609,28 @@ def test_association_inside_the_waiting_icp_launch(oracle_lib, product_lib):
     n = product_lib.lib.ssf_dbg_waiter_matches(fh.h)
     iters = [r["icp_iters"] for r in got]
     assert n >= 1, ("no frame's association ran in a waiting launch", iters)
-    assert n == sum(1 for r in got if 0 < r["icp_iters"] < 10), (n, iters)
+    assert n == sum(1 for r in got if r["icp_iters"] > 0), (n, iters)
+
+
+def test_a_loop_that_ends_at_the_iteration_cap_associates_in_a_waiting_launch_too(oracle_lib, product_lib):
+    """Behind the LAST iteration the loop allows, a launch is made ahead that can only be told to do the association: a loop
+    that runs into icp_iter (here: forced, BASELINE config 3's arrangement) starts its association ~1 us after the host's last
+    step, like one that converges.  Every result is the oracle's and every tracked frame took the path."""
+    import ctypes as C
+    fo, nv = seeded(oracle_lib, 50000, 640, 480, icp_force_iters=1)
+    fh, _ = seeded(product_lib, 50000, 640, 480, icp_force_iters=1, pipeline_depth=2, extract_batch=2)
+    frames = [util.frame(k, 640, 480, noise=True, holes=0.02) for k in range(6)]
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
+    product_lib.lib.ssf_dbg_waiter_matches.restype = C.c_longlong
+    product_lib.lib.ssf_dbg_waiter_matches.argtypes = [C.c_void_p]
+    iters = [r["icp_iters"] for r in got]
+    assert all(i == 10 for i in iters), iters
+    assert product_lib.lib.ssf_dbg_waiter_matches(fh.h) == len(got), (product_lib.lib.ssf_dbg_waiter_matches(fh.h), iters)
 
 
 def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, product_lib):

@@ -1,0 +1,14 @@
+#!/bin/bash
+# same-box A/B of the product against a variant build (tools/build_variant.sh <tag> ...), alternated: the metric's workload and
+# BASELINE config 3.   gpurun -- 'bash tools/ab_variant.sh <outdir> <tag> [rounds]'
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${1:?outdir}; mkdir -p $O; cd $R
+V=${2:?variant tag}; N=${3:-2}
+run() { # tag, args..., env via VAR
+  local tag=$1; shift
+  timeout 400 python bench.py "$@" --extras 0 --cpu-frames 0 --profile-frames 0 2> $O/$tag.err | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', round(d['value'],1))" >> $O/summary.txt
+}
+for r in $(seq 1 $N); do
+  unset SSF_PRODUCT_VARIANT; run product_c2_$r; run product_c3_$r --config 3; run product_s20_$r --steps 20 --warmup 5
+  export SSF_PRODUCT_VARIANT=$V; run ${V}_c2_$r; run ${V}_c3_$r --config 3; run ${V}_s20_$r --steps 20 --warmup 5
+done
+cat $O/summary.txt
