@@ -234,8 +234,8 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // replicas: SSF_ICP_REPLICAS x 29 zero-initialised i64 (left zeroed again by the kernel), ticket: 65 zeroed u32 (global + 64 group arrival counters)
 // pix2 / fpack: FrameMaps::pix2 / fpack of the frame
 // go != nullptr: the launch is made AHEAD of its transform (while the previous iteration is still running, so that its
-// launch latency is off the host round trip): the workgroups wait until the host stores go->flag == go_seq (then
-// the transform is in go->T) or go_seq | SSF_ICP_GO_ABORT (no further iteration: leave at once).  IcpGo lives in
+// launch latency is off the host round trip): the workgroups wait until the host's flag word carries go_seq (then
+// the transform is in go->T) or go_seq with SSF_ICP_GO_ABORT (no further iteration: leave at once).  IcpGo lives in
 // fine-grained DEVICE memory that the host writes directly (large BAR): ~1 us from the host's store to the kernel's
 // eyes (tools/probe/bar_write.hip), against ~5 us for a launch to start.
 // go_seq | SSF_ICP_GO_MATCH (a launch made with `match`): the loop has ended and go->T holds the frame's final POSE -- the
@@ -245,7 +245,7 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // and fences once (one PCIe write of the whole line), and the sixteen lanes that POLL the slot fetch all of it with every poll --
 // the transform needs no trip of its own behind the word (it used to: ~1 us at the head of every chained iteration).  Should the
 // line ever arrive in pieces, the flag word says so: bits 0-31 the low half of go_seq, bits 32-61 a checksum of the other
-// fourteen words (icp_go_check), bit 62 "associate", bit 63 "leave" (no checksum: nothing else of the line is read then).
+// fourteen words (icp_go_word_weight), bit 62 "associate", bit 63 "leave" (no checksum: nothing else of the line is read then).
 struct alignas(64) IcpGo { float T[12]; unsigned long long flag; unsigned long long x; };
 static_assert(sizeof(IcpGo) == 64, "one line");
 #define SSF_ICP_GO_ABORT (1ull << 63)
