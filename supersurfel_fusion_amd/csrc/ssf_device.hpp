@@ -196,7 +196,9 @@ struct Mailbox {
     // within its bound and gave up (the frames of that batch are invalid; the host reports SSF_ERR_DEVICE)
     unsigned int extract_abort;
 };
+#ifndef SSF_ICP_REPLICAS
 #define SSF_ICP_REPLICAS 8
+#endif
 // word w of Mailbox::icp_rec for payload p[0..29] (29 sums + checksum) and sequence number seq
 #define SSF_ICP_REC_WORD(w, p, seq) ((((w) & 7) == 7) ? (unsigned long long)(seq) : ((7 * ((w) >> 3) + ((w) & 7)) < 30 ? (unsigned long long)(p)[7 * ((w) >> 3) + ((w) & 7)] : 0ull))
 

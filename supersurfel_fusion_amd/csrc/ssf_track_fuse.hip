@@ -326,20 +326,34 @@ __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restri
                                                     unsigned long long seq, unsigned int n_wg) {
     __shared__ long long part[SSF_ICP_REPLICAS * 32];
     __shared__ int s_expired;
-    static_assert(SSF_ICP_REPLICAS * ICP_CNT_WORDS <= 256, "one word per thread of the collecting workgroup");
-    const int r = threadIdx.x / ICP_CNT_WORDS, k = threadIdx.x - r * ICP_CNT_WORDS;
-    const bool mine = r < SSF_ICP_REPLICAS;
-    // workgroups b with b % 8 == r
-    const unsigned int expect = mine ? (n_wg + SSF_ICP_REPLICAS - 1u - (unsigned int)r) / SSF_ICP_REPLICAS : 0u;
-    unsigned long long acc = 0ull;
+    // word w = 256 j + thread of the SSF_ICP_REPLICAS x 30 counted words: replica w / 30, word w % 30
+    constexpr int NW = SSF_ICP_REPLICAS * ICP_CNT_WORDS, WPT = (NW + 255) / 256;
+    constexpr unsigned long long CNT_MASK = (1ull << ICP_CNT_BITS) - 1ull;
+    int wr[WPT], wk[WPT]; bool mine[WPT]; unsigned int expect[WPT]; unsigned long long acc[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; j++) {
+        const int w = 256 * j + (int)threadIdx.x;
+        wr[j] = w / ICP_CNT_WORDS; wk[j] = w - wr[j] * ICP_CNT_WORDS;
+        mine[j] = w < NW;
+        // workgroups b with b % SSF_ICP_REPLICAS == replica
+        expect[j] = mine[j] ? (n_wg + SSF_ICP_REPLICAS - 1u - (unsigned int)wr[j]) / SSF_ICP_REPLICAS : 0u;
+        acc[j] = 0ull;
+    }
     if (threadIdx.x == 0) s_expired = 0;
     __syncthreads();
     const unsigned long long t0 = wall_clock64();
     for (unsigned int round = 0;; round++) {
-        bool done = !mine || (unsigned int)(acc & ((1ull << ICP_CNT_BITS) - 1ull)) == expect;
-        if (!done) {
-            acc += __hip_atomic_exchange(&counted[r * 32 + k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            done = (unsigned int)(acc & ((1ull << ICP_CNT_BITS) - 1ull)) == expect;
+        bool done = true;
+        unsigned long long got[WPT];
+#pragma unroll
+        for (int j = 0; j < WPT; j++) {           // (the exchanges of a round are independent: one trip)
+            const bool need = mine[j] && (unsigned int)(acc[j] & CNT_MASK) != expect[j];
+            got[j] = need ? __hip_atomic_exchange(&counted[wr[j] * 32 + wk[j]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; j++) {
+            acc[j] += got[j];
+            done = done && (!mine[j] || (unsigned int)(acc[j] & CNT_MASK) == expect[j]);
         }
         if (__syncthreads_and(done ? 1 : 0)) break;
         if (threadIdx.x == 0 && (round & 15u) == 15u && wall_clock64() - t0 > SSF_ICP_COLLECT_WAIT_TICKS) s_expired = 1;
@@ -347,10 +361,9 @@ __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restri
         if (s_expired) return;                   // (no record: the host's own bounded wait reports it and puts the buffers back to rest)
         __builtin_amdgcn_s_sleep(1);
     }
-    if (mine) {
-        const unsigned long long cnt = acc & ((1ull << ICP_CNT_BITS) - 1ull);
-        part[r * 32 + k] = (long long)(acc - cnt) >> ICP_CNT_BITS;
-    }
+#pragma unroll
+    for (int j = 0; j < WPT; j++)
+        if (mine[j]) part[wr[j] * 32 + wk[j]] = (long long)(acc[j] - (acc[j] & CNT_MASK)) >> ICP_CNT_BITS;
     __syncthreads();
     if (threadIdx.x < 64) {
         __shared__ unsigned long long pay[30];
