@@ -332,9 +332,15 @@ static inline int seq_batch_of(int i, int batch) {
 // (a longer ramp -- 2, 4, 4, 6 before the batches of 8 -- was measured in round 2: 6100-6150 against 5960-6260 frames/s over
 // 20 timed frames, i.e. nothing)
 struct Uploader {
-    // two workers, frames alternate between them: a pageable hipMemcpyAsync is a host memcpy into the runtime's staging
-    // buffer, and one thread sustains ~10 GB/s of it = 5000 frames/s at 2.1 MB per frame, less than the pipeline consumes
-    static const int NTH = 2;
+    // several workers, frames dealt to them in turn: a pageable hipMemcpyAsync is a host memcpy into a staging buffer, and one
+    // thread sustains 6-10 GB/s of it (box to box) = 3000-5000 frames/s at 2.1 MB per frame, less than the pipeline consumes.
+    // Two workers were the bottleneck on the slower hosts of the pool (6200 frames/s with host frames against 11 460 with frames in
+    // HBM, page-locked caller memory no better: tools/host_buffer_probe.py, round 4) and are not on the faster ones (9900 with 2,
+    // 3, 4 workers, 10 600 with 6: tools/upload_ab.sh); four.
+#ifndef SSF_UPLOAD_THREADS
+#define SSF_UPLOAD_THREADS 4
+#endif
+    static const int NTH = SSF_UPLOAD_THREADS;
     std::thread th[NTH];
     std::atomic<int> done[NTH];                // worker t: frames < done[t] of its residue class are enqueued
     std::atomic<int> processed{0};            // frames the caller has finished with (their ring slots may be reused)

@@ -19,7 +19,8 @@ for kind in os.environ.get("PROBE_KINDS", "device,pageable,pinned").split(","):
         keep = [(torch.from_numpy(f[0]).pin_memory(), torch.from_numpy(f[1]).pin_memory()) for f in frames]
     else:
         keep = [(torch.from_numpy(np.ascontiguousarray(f[0])), torch.from_numpy(np.ascontiguousarray(f[1]))) for f in frames]
-    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=int(os.environ.get("PROBE_DEPTH", "2")), extract_batch=int(os.environ.get("PROBE_BATCH", "8"))))
+    f = binding.Fusion(lib, bench.make_cfg(lib, bench.N_MODEL + 65536, pipeline_depth=int(os.environ.get("PROBE_DEPTH", "2")), extract_batch=int(os.environ.get("PROBE_BATCH", "8")),
+                                           prefilter=int(os.environ.get("PROBE_PREFILTER", "0"))))
     f.set_model(model, nvis, 30)
     pr = [keep[k][0].data_ptr() for k in order]; pd = [keep[k][1].data_ptr() for k in order]
     f.process_prepared(f.prepare_sequence(pr[:24], pd[:24]), on_device=(kind == "device"))
@@ -28,5 +29,5 @@ for kind in os.environ.get("PROBE_KINDS", "device,pageable,pinned").split(","):
     f.process_prepared(prep, on_device=(kind == "device"))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("%-9s frames: %.1f us/frame, %.0f frames/s" % (kind, 1e6 * dt / (nf - 24), (nf - 24) / dt))
+    print("%-9s prefilter %s frames: %.1f us/frame, %.0f frames/s" % (kind, os.environ.get("PROBE_PREFILTER", "0"), 1e6 * dt / (nf - 24), (nf - 24) / dt))
     f.close()
