@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--rendered-frames", type=int, default=64,
                     help="distinct orbit frames rendered; the sequence sweeps them back and forth (consecutive frames stay 1 degree apart)")
+    ap.add_argument("--seed-order", default="seeded", choices=["seeded", "image"],
+                    help="config 3 only: 'image' = the seeded rows in raster order of the superpixel they project to under camera 0 "
+                         "(the order a map built by the pipeline has), a measurement beside the BASELINE workload")
     ap.add_argument("--force-icp", action="store_true", help="always run icp_iter iterations (BASELINE config 3)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="2 (default): the configuration the metric is quoted on, 640x480 / ~1M supersurfels (N > 1: the same map "
@@ -370,6 +373,17 @@ def main():
 
     if a.config == 3:
         model, nvis = synthetic.seed_model_cam0_visible(N_MODEL, W, H, stamp=30)
+        if a.seed_order == "image":
+            # (a measurement, not the BASELINE workload: the seeded rows in the order a map BUILT by the pipeline has them -- every
+            # frame appends its new supersurfels in ascending frame id, i.e. raster order of their superpixels -- instead of the
+            # seeding's random order: what the gathers of k_icp / k_match cost when the rows are image-coherent by themselves)
+            R0, t0 = synthetic.orbit_pose(0)
+            Kc = synthetic.intrinsics(W, H)
+            pc = (model["positions"].astype(np.float64) - t0) @ R0
+            u = Kc["fx"] * pc[:, 0] / pc[:, 2] + Kc["cx"]; v = Kc["fy"] * pc[:, 1] / pc[:, 2] + Kc["cy"]
+            key = (np.clip(v, 0, H - 1).astype(np.int64) // 16) * ((W + 15) // 16) + np.clip(u, 0, W - 1).astype(np.int64) // 16
+            order = np.argsort(key[:nvis], kind="stable")
+            model = {k_: np.concatenate([val[:nvis][order], val[nvis:]]) for k_, val in model.items()}
     else:
         model, nvis = synthetic.seed_model_cam0(N_MODEL, W, H, stamp=30)
     if world > 1:
@@ -748,6 +762,7 @@ def main():
                                       if a.config == 3 else ""),
                        "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp), "baseline_config": a.config,
+                       "seed_order": a.seed_order,      # "seeded": the BASELINE workload; "image": a measurement beside it (see --seed-order)
                        "exchange": (a.comm if native_ok and drv is None else "torch.distributed") if exchange else "none",
                        "exchange_note": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        # what the attached exchange itself reports (ncclCommCount / opened regions): must equal n_gpus

@@ -724,6 +724,13 @@ __device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const 
     // round 2, 72 against 49 us at 860 k rows; fetched past the L1 in the SAME trip as the frame supersurfel's line, round 4, 117
     // against 55 us -- a million coherent reads of 4800 hot words cost more than the atomics they save.  Test-before-set of the
     // `matched` byte: no difference, 55.0 against 55.1 us.  profiles/atomic_scope_r04.txt has the part's atomic rates.)
+    // (Rows that are image-coherent by themselves -- a map the pipeline BUILT appends every frame's new supersurfels in ascending
+    // frame id -- pile their bids onto the same words: 56 -> 70 us at BASELINE config 3 with the seeded rows in raster order
+    // (bench.py --seed-order image; k_icp 23.4 -> 21.0 us, the frame +3 %).  Measured and removed, round 4: aggregating per wave when
+    // a quarter of the bidders have their neighbour lane's supersurfel (lab's match_bid_wave behind one cross-lane compare) brings
+    // that case back to 57 us, but the ballots push the WAITING launch this function is inlined into from 86 to 102 scalar
+    // registers and the whole chain loses 4-6 % on every BASELINE workload (10 968 against 11 647 frames/s, config 3 2102 against
+    // 2193, same box): profiles/track_chain_r04b.txt.)
 #ifdef SSF_EXPERIMENTS
     if (wave_agg) return match_bid_wave(f, key, best);        // (lab: tile-sorted rows -- the lanes of a wave that bid for one frame supersurfel agree first)
 #endif
