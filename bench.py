@@ -639,9 +639,76 @@ def main():
         roofline["peak_measured_note"] = "best of torch's copy kernel (%s GB/s) and the library's float4 stream copy (%s GB/s), 1 GiB read + 1 GiB written" % (
             "%.0f" % hbm_measured if hbm_measured else "n/a", "%.0f" % hbm_float4 if hbm_float4 else "n/a")
 
+    # ---- the same workload handed over differently (N = 1): host-resident frames (what the reference's caller has: cv::Mat,
+    # PCIe-inclusive) and with the library's depth pre-filter inside the frame (what the reference's processFrame does with
+    # OpenCV's bilateralFilter).  Never `value`: extra keys. -------------------------------------------------------------------
+    # ---- the steady-state rate: the same call over >= 600 frames, outside the timed region.  A short timed region (the
+    # driver's --steps 20) is mostly pipeline fill -- the first frame can only be tracked once its batch has been extracted --;
+    # this number says what the pipeline sustains (with the default --steps 1200, `value` is already that) -------------------
+    steady = None
+    if native_seq and world == 1 and a.extras:
+        ks = 720
+        prep_s = f.prepare_sequence([d_rgb[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)],
+                                    [d_depth[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        f.process_prepared(prep_s, on_device=True)
+        torch.cuda.synchronize(dev)
+        steady = dict(frames_per_sec=ks / (time.perf_counter() - t1), frames=ks,
+                      note="ssf_process_sequence over %d further frames of the same stream, same handle, outside the timed region" % ks)
+    extras = None
+    # (what the lines below still need of the timed handle, taken now: the extras run on handles of their own, and a handle that lives
+    # BESIDE another one gets hardware queues of its own from the runtime -- with four or more streams already alive that halves the
+    # newcomer's rate, which is what the node-call figures of rounds 2-4 measured; the timed handle is closed first and its streams go
+    # back to the library's pool, so every extra runs on the queues the timed region had)
+    gcounts_early = f.global_counts() if drv is None else None
+    n_superpixels = f.S
+    if rank == 0 and world == 1 and a.extras and not exchange and native_seq:
+        f.close()
+        extras = {}
+        nx = 720                                     # (outside the timed region: independent of --steps; 240 until round 4: a 25 ms region, +-10 % run to run)
+        host_frames = [(np.ascontiguousarray(h_frames[i][0]), np.ascontiguousarray(h_frames[i][1])) for i in range(nr)]
+        hsweep = Sweep(host_frames)
+        # the last one is what a node that swaps the library in gets from processFrame (supersurfel_fusion.cu:173-181): host images
+        # (cv::Mat) in, depth pre-filter inside the frame -- both together
+        # (host frames once more on a handle of pipeline_depth 1: their copy commands slow down with the number of hardware queues
+        # the process keeps busy -- profiles/host_frames_r03.txt --, so that is what INTEGRATION.md recommends to callers that feed
+        # host images; frames resident in HBM want the depth of the timed region)
+        variants = [("host_frames_pageable", dict(), False, depth), ("with_depth_prefilter", dict(prefilter=1), True, depth),
+                    ("host_frames_and_depth_prefilter", dict(prefilter=1), False, depth)]
+        if depth > 1:
+            variants += [("host_frames_pageable_depth1", dict(), False, 1), ("host_frames_and_depth_prefilter_depth1", dict(prefilter=1), False, 1)]
+        if os.environ.get("BENCH_EXTRAS_AGAIN"):
+            variants += [("host_frames_pageable_again", dict(), False, depth), ("host_frames_and_depth_prefilter_again", dict(prefilter=1), False, depth)]
+        for key, kw, on_dev, dpt in variants:
+            fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, dpt, batch, **kw))
+            fx.set_model(model_local, nvis_local, 30)
+            def seq(first, count):
+                if on_dev:
+                    return fx.prepare_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)], [d_depth[i].data_ptr() for i in range(first, first + count)])
+                return fx.prepare_sequence([hsweep[i][0].ctypes.data for i in range(first, first + count)], [hsweep[i][1].ctypes.data for i in range(first, first + count)])
+            fx.process_prepared(seq(0, a.warmup + 3 * batch), on_device=on_dev)
+            prep = seq(a.warmup + 3 * batch, nx)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fx.process_prepared(prep, on_device=on_dev)
+            torch.cuda.synchronize(dev)
+            extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt)
+            fx.close()
+        extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
+        # ---- the other single-GPU BASELINE configurations beside the headline: config 3 (1280x960, 1 M rows in view, 10 forced
+        # iterations: the HBM-bound stress) and config 5 (TUM-shaped input, pre-filter in the frame, one deformation), each as
+        # this same script in a process of its own, outside every timed region of this one (>= 64 / >= 240 frames) -----------------
+        if a.config == 2:
+            for cfg_n, nsteps in ((3, 64), (5, 240)):
+                extras["config%d" % cfg_n] = other_config(cfg_n, nsteps, a.pin)
+
     # ---- CPU baseline: the reference has no CPU implementation of this path, so the baseline
     # is the oracle restatement built -O3 -march=native ON THIS BOX, timed (i) single-threaded and (ii) with OpenMP over
     # all host cores; rank 0, bounded samples of the same workload --------------------------------------------------
+    # (LAST of everything this process measures: its OpenMP teams fault memory in on every NUMA node of the host, and host frames
+    # allocated afterwards -- the extras above -- were staged out of whatever the allocator recycled: the first extra ran at 4700
+    # instead of 8200 frames/s behind it, round 4)
     cpu = None
     if rank == 0 and a.cpu_frames > 0:
         import subprocess
@@ -685,61 +752,6 @@ def main():
                               "algorithm; the reference has no CPU path), g++ -O3 -march=native: %s" %
                               (W, H, N_MODEL, "; ".join("%s %d frames in %.1f s" % (k, v[1], v[2]) for k, v in legs.items())))
 
-    # ---- the same workload handed over differently (N = 1): host-resident frames (what the reference's caller has: cv::Mat,
-    # PCIe-inclusive) and with the library's depth pre-filter inside the frame (what the reference's processFrame does with
-    # OpenCV's bilateralFilter).  Never `value`: extra keys. -------------------------------------------------------------------
-    # ---- the steady-state rate: the same call over >= 600 frames, outside the timed region.  A short timed region (the
-    # driver's --steps 20) is mostly pipeline fill -- the first frame can only be tracked once its batch has been extracted --;
-    # this number says what the pipeline sustains (with the default --steps 1200, `value` is already that) -------------------
-    steady = None
-    if native_seq and world == 1 and a.extras:
-        ks = 720
-        prep_s = f.prepare_sequence([d_rgb[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)],
-                                    [d_depth[i].data_ptr() for i in range(base + ns + npk, base + ns + npk + ks)])
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        f.process_prepared(prep_s, on_device=True)
-        torch.cuda.synchronize(dev)
-        steady = dict(frames_per_sec=ks / (time.perf_counter() - t1), frames=ks,
-                      note="ssf_process_sequence over %d further frames of the same stream, same handle, outside the timed region" % ks)
-    extras = None
-    if rank == 0 and world == 1 and a.extras and not exchange and native_seq:
-        extras = {}
-        nx = 240                                     # (outside the timed region: independent of --steps)
-        host_frames = [(np.ascontiguousarray(h_frames[i][0]), np.ascontiguousarray(h_frames[i][1])) for i in range(nr)]
-        hsweep = Sweep(host_frames)
-        # the last one is what a node that swaps the library in gets from processFrame (supersurfel_fusion.cu:173-181): host images
-        # (cv::Mat) in, depth pre-filter inside the frame -- both together
-        # (host frames once more on a handle of pipeline_depth 1: their copy commands slow down with the number of hardware queues
-        # the process keeps busy -- profiles/host_frames_r03.txt --, so that is what INTEGRATION.md recommends to callers that feed
-        # host images; frames resident in HBM want the depth of the timed region)
-        variants = [("host_frames_pageable", dict(), False, depth), ("with_depth_prefilter", dict(prefilter=1), True, depth),
-                    ("host_frames_and_depth_prefilter", dict(prefilter=1), False, depth)]
-        if depth > 1:
-            variants += [("host_frames_pageable_depth1", dict(), False, 1), ("host_frames_and_depth_prefilter_depth1", dict(prefilter=1), False, 1)]
-        for key, kw, on_dev, dpt in variants:
-            fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, dpt, batch, **kw))
-            fx.set_model(model_local, nvis_local, 30)
-            def seq(first, count):
-                if on_dev:
-                    return fx.prepare_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)], [d_depth[i].data_ptr() for i in range(first, first + count)])
-                return fx.prepare_sequence([hsweep[i][0].ctypes.data for i in range(first, first + count)], [hsweep[i][1].ctypes.data for i in range(first, first + count)])
-            fx.process_prepared(seq(0, a.warmup + 3 * batch), on_device=on_dev)
-            prep = seq(a.warmup + 3 * batch, nx)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            fx.process_prepared(prep, on_device=on_dev)
-            torch.cuda.synchronize(dev)
-            extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt)
-            fx.close()
-        extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
-        # ---- the other single-GPU BASELINE configurations beside the headline: config 3 (1280x960, 1 M rows in view, 10 forced
-        # iterations: the HBM-bound stress) and config 5 (TUM-shaped input, pre-filter in the frame, one deformation), each as
-        # this same script in a process of its own, outside every timed region of this one (>= 64 / >= 240 frames) -----------------
-        if a.config == 2:
-            for cfg_n, nsteps in ((3, 64), (5, 240)):
-                extras["config%d" % cfg_n] = other_config(cfg_n, nsteps, a.pin)
-
     # whole-frame view: algorithmic bytes of one frame over the measured frame time
     it_mean = float(np.mean(iters))
     fb = dict(extract=180.0 * P, icp=(36.0 * counts["n_visible"] + 8.0 * P + 28.0 * counts["S"]) * it_mean,
@@ -749,7 +761,7 @@ def main():
                           peak=HBM_PEAK_GBS, unit="GB/s", frac=fbytes / (dt / K) / 1e9 / HBM_PEAK_GBS,
                           note="extract 180 B/pixel, ICP 36 B/visible supersurfel/iteration + frame tables, fuse: association 40 B/visible, "
                                "classify 28 B/row, row moves 2 B/slot + 208 B/visible row (the reference's full reorder would be 212 B/row)")
-    gcounts = f.global_counts() if drv is None else dict(n_model=last["global_n_model"], n_visible=last["global_n_visible"])
+    gcounts = gcounts_early if drv is None else dict(n_model=last["global_n_model"], n_visible=last["global_n_visible"])
     if rank == 0:
         gn, gv = gcounts["n_model"], gcounts["n_visible"]
         out = {
@@ -760,7 +772,7 @@ def main():
                                    "(~%d live, ~%d visible), reference rgbd_benchmark parameters, extract+ICP+fuse per frame%s"
                                    % (W, H, N_MODEL, gn, gv, " (BASELINE config 3: all seeded supersurfels visible, 10 forced ICP iterations)"
                                       if a.config == 3 else ""),
-                       "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": f.S,
+                       "width": W, "height": H, "n_model": int(gn), "n_visible": int(gv), "superpixels": n_superpixels,
                        "icp_iter_max": 10, "icp_iters_mean": float(np.mean(iters)), "icp_forced": bool(a.force_icp), "baseline_config": a.config,
                        "seed_order": a.seed_order,      # "seeded": the BASELINE workload; "image": a measurement beside it (see --seed-order)
                        "exchange": (a.comm if native_ok and drv is None else "torch.distributed") if exchange else "none",

@@ -290,6 +290,7 @@ static RcclApi* rccl_api() {
     return &api;
 }
 
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // ---- upload of host frames ahead of the pipeline (ssf_process_sequence with host buffers) --------------------------
 // The caller of the reference hands over host images (cv::Mat).  Copying them inside the submit call costs the thread
 // that also drives the track chain 30-70 us per frame (two hipMemcpyAsync, for pageable memory incl. the staging
@@ -357,13 +358,18 @@ struct Uploader {
     // the runtime a truly asynchronous DMA; left to the runtime, pageable copies of several threads serialise inside it
     std::vector<uint8_t*> p_rgb; std::vector<float*> p_depth;
     bool ready(int i) const { return done[i % NTH].load(std::memory_order_acquire) > i; }
+    // where the workers' time went, microseconds summed over the workers since the handle was created (ssf_dbg_upload_stats):
+    // waiting for a free ring slot | the staging memcpy | the two hipMemcpyAsync calls; frames
+    std::atomic<long long> us_ring{0}, us_memcpy{0}, us_enqueue{0}, frames_done{0};
     void run(int t) {
         if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
         for (int i = t; i < n && !stop.load(std::memory_order_relaxed); i += NTH) {
+            const double t0 = now_us();
             while (i >= processed.load(std::memory_order_acquire) + ring) {
                 if (stop.load(std::memory_order_relaxed)) return;
-                std::this_thread::sleep_for(std::chrono::microseconds(100));      // (the ring is a dozen frames ahead)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));       // (the ring is two batches ahead of the submitting thread)
             }
+            const double t1 = now_us();
             const int sl = i % ring;
             hipStream_t st = ctx_stream[(size_t)(ctx0 + seq_batch_of(i, batch)) % ctx_stream.size()];
             const void* src_rgb = rgb[i]; const void* src_depth = depth[i];
@@ -371,9 +377,12 @@ struct Uploader {
                 std::memcpy(p_rgb[sl], rgb[i], rgb_bytes); std::memcpy(p_depth[sl], depth[i], depth_bytes);
                 src_rgb = p_rgb[sl]; src_depth = p_depth[sl];
             }
+            const double t2 = now_us();
             if (hipMemcpyAsync(d_rgb[sl], src_rgb, rgb_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipMemcpyAsync(d_depth[sl], src_depth, depth_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { failed.store(1); return; }
             done[t].store(i + 1, std::memory_order_release);
+            const double t3 = now_us();
+            us_ring += (long long)(t1 - t0); us_memcpy += (long long)(t2 - t1); us_enqueue += (long long)(t3 - t2); frames_done++;
         }
     }
     // The workers live as long as the handle: a thread's first HIP call initialises the runtime's per-thread state (several
@@ -403,6 +412,37 @@ struct Uploader {
     }
 };
 
+// ---- streams outlive handles ---------------------------------------------------------------------------
+// The runtime maps streams onto hardware queues when they are created, and how it does that depends on the process' history: the
+// SECOND handle of a process (first one destroyed, its streams with it) ran the very same sequence at 6400 instead of 11 300 frames/s --
+// device-resident frames, nothing else changed (tools/host_buffer_probe.py with PROBE_KINDS=device,device; round 4: what had looked
+// like "slow hosts" in the node-call figures of bench.py was this: those figures are taken on later handles of the process).  A handle
+// therefore returns its streams to a pool when it is destroyed, and the next handle with the same device and priorities takes them:
+// every handle of a process runs on the queues the first one got.  (Handles that live side by side get streams of their own.)
+struct StreamPool {
+    std::mutex mu;
+    std::map<std::pair<int, int>, std::vector<hipStream_t>> idle;         // (device, priority) -> streams
+    static const int CAPTURE = 1 << 20;                                    // "priority" of the capture-only streams
+    hipStream_t take(int prio) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = idle[std::make_pair(dev, prio)];
+            if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
+        }
+        hipStream_t st = nullptr;
+        const hipError_t e = prio == CAPTURE ? hipStreamCreateWithFlags(&st, hipStreamNonBlocking) : hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
+        return e == hipSuccess ? st : nullptr;
+    }
+    void give(hipStream_t st, int prio) {
+        if (!st) return;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        idle[std::make_pair(dev, prio)].push_back(st);
+    }
+};
+static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }      // (never destroyed: the runtime may be gone by then)
+
 // ---- handle -----------------------------------------------------------------------------------------
 struct IcpLoop {
     bool active = false, valid = true, done = true;
@@ -422,7 +462,7 @@ struct ExtractCtx {
     SurfelSoA frame;
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
-    hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t stream = nullptr; bool own_stream = false; int stream_prio = 0;
     hipEvent_t ev_done = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool consumed_valid = false, timed = false;
     hipGraph_t graph[SSF_MAX_BATCH + 1] = {}; hipGraphExec_t exec[SSF_MAX_BATCH + 1] = {};
@@ -442,7 +482,7 @@ struct ssf_handle {
     ssf_config cfg;
     int S = 0, gx = 0, gy = 0;
     std::string err;
-    hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t stream = nullptr; bool own_stream = false; int stream_prio = 0;
     SegParams seg; Cam cam;
     std::vector<ExtractCtx> ctx; int open_ctx = 0, batch = 1;
     std::deque<std::pair<int, int>> pending;      // (context, slot) submitted, not yet processed (oldest first)
@@ -454,6 +494,7 @@ struct ssf_handle {
     long long n_waiter_matches = 0;           // frames whose association ran in a waiting ICP launch (debug)
     int seq_k = 0;                            // frame of the sequence the track loop is working on (debug marks)
     int seq_batches = 0;                      // batches launched by the running ssf_process_sequence (see seq_batch_size)
+    double us_wait_upload = 0.0;                          // the submitting thread's wait for uploads (ssf_dbg_upload_stats)
     Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
@@ -695,7 +736,7 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
             static const bool unlocked = SSF_ENV_SET("CAPTURE_UNLOCKED");          // (control runs of that probe)
             std::unique_lock<std::mutex> capture_lock(capture_mutex, std::defer_lock);
             if (!unlocked) capture_lock.lock();
-            bool ok = (h->capture_stream || hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) == hipSuccess) &&
+            bool ok = (h->capture_stream || (h->capture_stream = stream_pool().take(StreamPool::CAPTURE)) != nullptr) &&
                       hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 enqueue_segmentation(h, c, h->capture_stream);
@@ -712,7 +753,6 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
 }
 
 // Launch the extract stage of the open batch of context c (asynchronous; nothing is waited for).
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     const double t_launch0 = now_us();
     hipStream_t st = c.stream;
@@ -814,6 +854,7 @@ static int seq_submit(ssf_handle* h) {
     }
     Uploader& u = *h->up;
     const auto t0 = std::chrono::steady_clock::now();
+    const double w0 = now_us();
     for (unsigned long long spins = 0; !u.ready(i); spins++) {
         if (u.failed.load()) { h->err = "upload of a host frame failed"; return SSF_ERR_DEVICE; }
         if ((spins & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
@@ -821,6 +862,7 @@ static int seq_submit(ssf_handle* h) {
         }
         std::this_thread::yield();
     }
+    h->us_wait_upload += now_us() - w0;
     const int sl = i % u.ring;                    // (its copies are already in the stream of the context it goes to)
     int rc = submit_extract(h, u.d_rgb[sl], u.d_depth[sl], 1, nullptr);
     if (!rc) { h->seq_next++; rc = seq_flush_tail(h); }
@@ -1546,16 +1588,16 @@ void ssf_destroy(ssf_handle* h) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+        if (c.own_stream && c.stream) stream_pool().give(c.stream, c.stream_prio);          // (synchronised above)
     }
-    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    if (h->capture_stream) stream_pool().give(h->capture_stream, StreamPool::CAPTURE);
     if (!h->guarded.empty() && !SSF_ENV_SET("GUARD_ONLY")) check_guards(h);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->ev_resident) (void)hipEventDestroy(h->ev_resident);
     for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_pool().give(h->stream, h->stream_prio); }
     delete h;
 }
 
@@ -1592,8 +1634,9 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const int prio = SSF_ENV_INT("TRACK_PRIORITY", greatest);
-        if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio) != hipSuccess) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; }
-        h->own_stream = true;
+        h->stream = stream_pool().take(prio);
+        if (!h->stream) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; }
+        h->own_stream = true; h->stream_prio = prio;
     }
     SegParams& p = h->seg;
     p.W = W; p.H = H; p.cell = c; p.gx = h->gx; p.gy = h->gy; p.S = h->S; p.nb_samples = cfg->nb_samples;
@@ -1659,7 +1702,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             static const bool ctx0_up = SSF_ENV_INT("CTX0_PRIORITY", 1) != 0;
             const int prio = (ci == 0 && ctx0_up && least - greatest >= 2) ? least - 1 : least;
-            ok = hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio) == hipSuccess; c.own_stream = ok;
+            c.stream = stream_pool().take(prio); ok = c.stream != nullptr; c.own_stream = ok; c.stream_prio = prio;
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
@@ -1766,7 +1809,13 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
         if (!h->up) {
             Uploader* u = new (std::nothrow) Uploader();
             if (!u) { h->err = "out of memory"; return SSF_ERR_DEVICE; }
-            u->ring = (int)h->ctx.size() * h->batch + h->batch + 2;
+            // The submitting thread runs up to (contexts + 1) batches ahead of the frame being tracked (every context full + the open
+            // batch); a worker may start on frame i when frame i - ring has been processed and needs ~250 us for it (wake-up, 2.1 MB
+            // staging memcpy, two enqueues).  With a ring of only two frames more than that window (round 1-4) the submitting thread --
+            // the one that drives the track chain -- waited 18 us per frame for uploads and the replay ran at 6100-6300 frames/s on hosts
+            // with a slower memcpy (8800-10 000 on faster ones) against 11 400 with frames in HBM: tools/host_buffer_probe.py.  Two
+            // more batches of slack.
+            u->ring = ((int)h->ctx.size() + 3) * h->batch + 2;
             u->rgb_bytes = 3 * P; u->depth_bytes = 4 * P;
             (void)hipGetDevice(&u->device);
             bool ok = true;
@@ -2625,6 +2674,26 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
 // lab build: tiles of the last extracted frame (slot 0 of the active context) that proved themselves clean, per pass
 // (FrameMaps::epoch[1 + pass], counted by k_update_pass under SSF_EXPERIMENTS; tools/skip_probe.py)
+// streams waiting in the process-wide pool for the next handle (StreamPool)
+int ssf_dbg_pooled_streams(void) {
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    int n = 0;
+    for (auto& kv : sp.idle) n += (int)kv.second.size();
+    return n;
+}
+// host frames of sequences: [0] workers, [1] frames uploaded, microseconds summed over the workers [2] waiting for a ring slot,
+// [3] in the staging memcpy, [4] in the two hipMemcpyAsync calls, [5] the submitting thread's wait for uploads (tools/host_buffer_probe.py)
+int ssf_dbg_upload_stats(ssf_handle* h, double* out6) {
+    if (!h || !out6) return SSF_ERR_INVALID_ARG;
+    for (int i = 0; i < 6; i++) out6[i] = 0.0;
+    if (h->up) {
+        out6[0] = Uploader::NTH; out6[1] = (double)h->up->frames_done.load(); out6[2] = (double)h->up->us_ring.load();
+        out6[3] = (double)h->up->us_memcpy.load(); out6[4] = (double)h->up->us_enqueue.load();
+    }
+    out6[5] = h->us_wait_upload;
+    return SSF_OK;
+}
 int ssf_dbg_pass_skips(ssf_handle* h, uint32_t* out64) {
     if (!h || !h->active.ctx || !out64) return SSF_ERR_INVALID_ARG;
     HCK(hipStreamSynchronize(h->active.ctx->stream));

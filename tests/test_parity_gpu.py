@@ -694,3 +694,27 @@ def test_the_product_refuses_the_measurement_arms_and_reads_no_environment(produ
     f.set_bin_min_rows(-1)
     g = binding.Fusion(lab_lib, util.make_cfg(lab_lib, 160, 128, nb_supersurfels_max=2048))
     g.set_bin_min_rows(0)
+
+
+def test_a_later_handle_runs_on_the_streams_of_an_earlier_one(oracle_lib, product_lib):
+    """The runtime maps streams onto hardware queues at creation, depending on the process' history: the second handle of a process
+    ran the same sequence at 6400 instead of 11 300 frames/s (round 4).  A destroyed handle leaves its streams in a pool and the
+    next one takes them; results are the oracle's on both."""
+    L = product_lib.lib
+    L.ssf_dbg_pooled_streams.restype = __import__("ctypes").c_int
+    frames = [util.frame(k, 160, 128) for k in range(3)]
+    def run():
+        fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128))
+        fh = binding.Fusion(product_lib, util.make_cfg(product_lib, 160, 128, pipeline_depth=2, extract_batch=2))
+        idle_while_alive = L.ssf_dbg_pooled_streams()
+        for rgb, depth in frames:
+            util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
+        util.compare_state(fo, fh)
+        fh.close(); fo.close()
+        return idle_while_alive
+    run()
+    after_first = L.ssf_dbg_pooled_streams()
+    assert after_first >= 4, after_first                    # track stream + three extract contexts (+ the capture stream)
+    alive = run()
+    assert alive <= after_first - 4, (alive, after_first)   # the second handle took them
+    assert L.ssf_dbg_pooled_streams() >= after_first        # ... and gave them back

@@ -30,4 +30,18 @@ for kind in os.environ.get("PROBE_KINDS", "device,pageable,pinned").split(","):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%-9s prefilter %s frames: %.1f us/frame, %.0f frames/s" % (kind, os.environ.get("PROBE_PREFILTER", "0"), 1e6 * dt / (nf - 24), (nf - 24) / dt))
+    import ctypes as C
+    ht = (C.c_double * 8)()
+    lib.lib.ssf_dbg_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.lib.ssf_dbg_host_times(f.h, ht)
+    nfh = max(ht[3], 1.0)
+    print("          host thread, per frame: submit %.1f us | ICP loop %.1f us (until its first record %.1f) | association + fuse %.1f us; extract ready at activation %.0f %%"
+          % (ht[0] / nfh, ht[1] / nfh, ht[5] / nfh, ht[2] / nfh, 100.0 * ht[4] / nfh))
+    if kind != "device" and hasattr(lib.lib, "ssf_dbg_upload_stats"):
+        st = (C.c_double * 6)()
+        lib.lib.ssf_dbg_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.lib.ssf_dbg_upload_stats(f.h, st)
+        nfr = max(st[1], 1.0)
+        print("          upload: %d workers, %d frames; per frame and worker-thread: ring wait %.0f us, staging memcpy %.0f us, two hipMemcpyAsync %.0f us; "
+              "submitting thread waited %.0f us per frame for uploads" % (st[0], st[1], st[2] / nfr, st[3] / nfr, st[4] / nfr, st[5] / nfr))
     f.close()
