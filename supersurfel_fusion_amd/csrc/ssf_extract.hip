@@ -1511,28 +1511,60 @@ __device__ __forceinline__ v2f exp_neg_spec2(v2f x) {                  // exp_ne
     w.x = live0 ? w.x : 0.0f; w.y = live1 ? w.y : 0.0f;
     return w;
 }
+// one tap pair: weights of taps dx, dx + 1 of row DY (the definition's operations, two at a time)
+template <int DY>
+__device__ __forceinline__ v2f bilateral_pair_w(const v2f v, const v2f c2, int dx, float ss, float sc) {
+    const v2f space2 = {(float)(dx * dx + DY * DY), (float)((dx + 1) * (dx + 1) + DY * DY)};
+    const v2f dv = v - c2;
+    return exp_neg_spec2(space2 * ss + (dv * dv) * sc);
+}
+// Round 4: the row in GROUPS OF FOUR TAPS, each group ordered behind the previous one by data dependences.  Left to itself the
+// compiler computed every weight of the kernel before the first sum and kept the tile in registers: 208 vector registers (two
+// waves per SIMD), 833 `s_nop` behind packed operations whose dependent successor had nothing to hide behind (a v_pk_*_f32 result is
+// not forwarded to the next instruction; the Horner chain of the specified exp is exactly such a chain), and the odd tap of every
+// row behind a branch of its own (exp_neg_spec's early exit).  Now: 106 registers (four waves per SIMD: the other waves fill the
+// gaps), no branch -- 260 -> 242 us per 8-frame launch, BASELINE config 5 9480 -> 9920 frames/s (same box, alternated).
+// Measured on the way and not kept: a scheduling barrier (__builtin_amdgcn_sched_barrier) between the groups instead of the
+// dependences (changes nothing: 208 registers); the chains of a group advanced in lockstep through an asm statement per Horner step
+// (the `s_nop`s go, 949 -> 241, but the half-used pairs stay packed and the registers go up: 254-273 us); 5 or 6 waves by
+// __launch_bounds__ (spills).  Same operations on the same operands in the same order per tap, the sums taken tap by tap in the
+// definition's order: the bits do not change (tests/test_prefilter.py, tests/test_replay.py).
 template <int DY>
 __device__ __forceinline__ void bilateral_row7(const float* __restrict__ row, float center, float ss, float sc, float& sum1, float& sum2) {
     constexpr int R = 7;
     constexpr int E = DY * DY == 0 ? 7 : (DY * DY <= 9 ? 6 : (DY * DY == 16 ? 5 : (DY * DY == 25 ? 4 : (DY * DY == 36 ? 3 : 0))));
     static_assert((E + 1) * (E + 1) + DY * DY > R * R && E * E + DY * DY <= R * R, "half-width of the circle in this row");
+    constexpr int NT = 2 * E + 1;
     const v2f c2 = {center, center};
-    asm volatile("" ::: "memory");                  // (this row's LDS reads stay in this row: hoisted to the top, the 149 values spill)
+    float val[NT + 1];
+    asm volatile("" ::: "memory");                  // (this row's LDS reads stay behind the previous row's)
 #pragma unroll
-    for (int dx = -E; dx + 1 <= E; dx += 2) {
-        const v2f v = {row[dx], row[dx + 1]};
-        const v2f space2 = {(float)(dx * dx + DY * DY), (float)((dx + 1) * (dx + 1) + DY * DY)};
-        const v2f dv = v - c2;
-        const v2f w = exp_neg_spec2(space2 * ss + (dv * dv) * sc);
-        const v2f wv = w * v;
-        sum1 = sum1 + wv.x; sum2 = sum2 + w.x;      // the first tap, then the second: the definition's order
-        sum1 = sum1 + wv.y; sum2 = sum2 + w.y;
-    }
-    {                                               // 2 E + 1 taps: the last one on its own
-        const float v = row[E];
-        const float dvs = v - center;
-        const float w = exp_neg_spec((float)(E * E + DY * DY) * ss + (dvs * dvs) * sc);
-        sum1 = sum1 + w * v; sum2 = sum2 + w;
+    for (int i = 0; i < NT; i++) val[i] = row[i - E];
+    val[NT] = val[NT - 1];                          // (the last tap goes through the pair's code too, its second half unused: exp_neg_spec's
+                                                    // early exit is a branch, and fifteen branches cut the kernel into blocks across which
+                                                    // the compiler kept 149 tile values alive)
+    // Order, said with data dependences -- a scheduling barrier alone did not keep the compiler from computing every weight of the
+    // kernel first --: the sums and the NEXT group's operands pass through one empty asm statement at the end of each group.
+    constexpr int NP = (NT + 1) / 2;                // pairs of the row (the last one: one tap)
+#ifndef SSF_BIL_GROUP
+#define SSF_BIL_GROUP 2                             // pairs per group: independent chains the scheduler can interleave
+#endif
+#pragma unroll
+    for (int g = 0; g < NP; g += SSF_BIL_GROUP) {
+#pragma unroll
+        for (int q = g; q < g + SSF_BIL_GROUP && q < NP; q++) asm volatile("" : "+v"(sum1), "+v"(sum2), "+v"(val[2 * q]), "+v"(val[2 * q + 1]));
+        v2f w[SSF_BIL_GROUP], wv[SSF_BIL_GROUP];
+#pragma unroll
+        for (int q = g; q < g + SSF_BIL_GROUP && q < NP; q++) {
+            const v2f v = {val[2 * q], val[2 * q + 1]};
+            w[q - g] = bilateral_pair_w<DY>(v, c2, 2 * q - E, ss, sc);
+            wv[q - g] = w[q - g] * v;
+        }
+#pragma unroll
+        for (int q = g; q < g + SSF_BIL_GROUP && q < NP; q++) {            // tap by tap: the definition's order
+            sum1 = sum1 + wv[q - g].x; sum2 = sum2 + w[q - g].x;
+            if (2 * q + 1 < NT) { sum1 = sum1 + wv[q - g].y; sum2 = sum2 + w[q - g].y; }
+        }
     }
 }
 template <int WAVES>
