@@ -396,7 +396,7 @@ def main():
     n_local = len(model_local["confidences"])
     cap = n_local + 65536
     if a.extract_batch is None:
-        a.extract_batch = 4 if a.config == 3 else 8        # measured optima
+        a.extract_batch = 4 if a.config == 3 else (12 if a.config == 5 else 8)        # measured optima (12 with the pre-filter in the frame: the extract stage bounds the replay then)
     if a.cpu_frames is None:
         a.cpu_frames = 12 if a.config == 3 else 80
     depth, batch = a.pipeline_depth, a.extract_batch
@@ -681,19 +681,20 @@ def main():
         if os.environ.get("BENCH_EXTRAS_AGAIN"):
             variants += [("host_frames_pageable_again", dict(), False, depth), ("host_frames_and_depth_prefilter_again", dict(prefilter=1), False, depth)]
         for key, kw, on_dev, dpt in variants:
-            fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, dpt, batch, **kw))
+            bx = 12 if (kw.get("prefilter") and batch == 8) else batch           # (the optimum with the pre-filter in the frame, as for config 5)
+            fx = binding.Fusion(lib, make_cfg(lib, cap, 0, 1, None, a.force_icp, dpt, bx, **kw))
             fx.set_model(model_local, nvis_local, 30)
             def seq(first, count):
                 if on_dev:
                     return fx.prepare_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)], [d_depth[i].data_ptr() for i in range(first, first + count)])
                 return fx.prepare_sequence([hsweep[i][0].ctypes.data for i in range(first, first + count)], [hsweep[i][1].ctypes.data for i in range(first, first + count)])
-            fx.process_prepared(seq(0, a.warmup + 3 * batch), on_device=on_dev)
-            prep = seq(a.warmup + 3 * batch, nx)
+            fx.process_prepared(seq(0, a.warmup + 3 * bx), on_device=on_dev)
+            prep = seq(a.warmup + 3 * bx, nx)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             fx.process_prepared(prep, on_device=on_dev)
             torch.cuda.synchronize(dev)
-            extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt)
+            extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt, extract_batch=bx)
             fx.close()
         extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
         # ---- the other single-GPU BASELINE configurations beside the headline: config 3 (1280x960, 1 M rows in view, 10 forced

@@ -132,7 +132,7 @@ struct FrameMaps {
 // The extract kernels take the batch index from the grid (blockIdx.z, or .y for 1-D kernels): one
 // launch relabels the tiles of all frames of the batch.  srgb_lut is shared.
 #ifndef SSF_MAX_BATCH
-#define SSF_MAX_BATCH 8
+#define SSF_MAX_BATCH 16        // (= SSF_MAX_EXTRACT_BATCH of include/ssf.h)
 #endif
 // (byte arithmetic on a char pointer, not on an integer: a pointer that went through an integer loses its address
 // space, and every access through it becomes a FLAT instruction -- which also ties LDS waits to outstanding loads)

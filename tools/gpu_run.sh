@@ -29,7 +29,7 @@ lastline() { [ -s "$1" ] && tail -n 1 "$1" | python -c "import json,sys; d=json.
 for step in "$@"; do
   case $step in
     prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; TAG="_config3";;
-    prof5) PROF="python $R/bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (TUM-shaped frames, pre-filter in the frame, pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; TAG="_config5";;
+    prof5) PROF="python $R/bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (TUM-shaped frames, pre-filter in the frame, pipelined 2 x 12)"; export PMC_EXTRACT_BATCH=12; TAG="_config5";;
     prof2) PROF="python $R/bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; TAG="";;
     driver)
       timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err; lastline $O/bench_driver_command.json driver_command;;
