@@ -197,7 +197,7 @@ def test_full_size_determinism_and_partition_properties(product_lib):
     assert set(np.unique(new)) <= {30, 31}
 
 
-@pytest.mark.parametrize("depth_ahead,batch", [(1, 1), (2, 1), (3, 1), (0, 3), (1, 2), (2, 4), (1, 8)])
+@pytest.mark.parametrize("depth_ahead,batch", [(1, 1), (2, 1), (3, 1), (0, 3), (1, 2), (2, 4), (1, 8), (1, 12), (0, 16)])
 def test_pipelined_equals_sequential_bit_exact(depth_ahead, batch, oracle_lib, product_lib):
     """ssf_submit_frame / ssf_process_submitted with extract running ahead on its own streams and
     `batch` frames per launch chain: every per-frame result and the final map equal the oracle's
@@ -718,3 +718,22 @@ def test_a_later_handle_runs_on_the_streams_of_an_earlier_one(oracle_lib, produc
     alive = run()
     assert alive <= after_first - 4, (alive, after_first)   # the second handle took them
     assert L.ssf_dbg_pooled_streams() >= after_first        # ... and gave them back
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [12, 16])
+def test_sequences_with_twelve_and_sixteen_frames_per_extract_launch(batch, oracle_lib, product_lib):
+    """SSF_MAX_EXTRACT_BATCH is 16 since round 4 (12 frames per launch is the optimum once the depth pre-filter is in the frame): a
+    sequence of host frames with the pre-filter on, pipelined 2 x batch -- leading batches of 3/8 and 5/8, full ones, a partial last
+    one -- equals the oracle's frame-by-frame run."""
+    W, H, nf = 160, 128, 41
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, depth_prefilter=1))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, depth_prefilter=1, pipeline_depth=2, extract_batch=batch))
+    assert fh.pipeline_capacity() == 3 * batch
+    frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
+    frames = [(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in frames]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
