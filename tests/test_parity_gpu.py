@@ -737,3 +737,24 @@ def test_sequences_with_twelve_and_sixteen_frames_per_extract_launch(batch, orac
     for a, b in zip(want, got):
         util.same_result(a, b)
     util.compare_state(fo, fh)
+
+
+@pytest.mark.gpu
+def test_a_long_sequence_of_host_frames_wraps_the_upload_ring(oracle_lib, product_lib):
+    """Host frames of a sequence are staged and copied ahead by worker threads into a ring of (contexts + 3) x batch + 2 slots; a slot is
+    reused once the frame that held it has been tracked.  130 frames through a ring of 26: five laps, every frame the oracle's."""
+    W, H, nf = 160, 128, 130
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H))
+    fh = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=2, extract_batch=4))
+    base = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(26)]
+    order = [(i % 50) if (i % 50) < 26 else 50 - (i % 50) for i in range(nf)]          # the orbit forth and back
+    frames = [(np.ascontiguousarray(base[k][0]), np.ascontiguousarray(base[k][1])) for k in order]
+    want = [fo.process_frame(r, d) for r, d in frames]
+    got = fh.process_sequence([r.ctypes.data for r, _ in frames], [d.ctypes.data for _, d in frames], on_device=False)
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(fo, fh)
+    import ctypes as C
+    st = (C.c_double * 6)()
+    product_lib.lib.ssf_dbg_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    assert product_lib.lib.ssf_dbg_upload_stats(fh.h, st) == 0 and int(st[1]) == nf, list(st)
