@@ -423,8 +423,9 @@ struct StreamPool {
     std::mutex mu;
     std::map<std::pair<int, int>, std::vector<hipStream_t>> idle;         // (device, priority) -> streams
     static const int CAPTURE = 1 << 20;                                    // "priority" of the capture-only streams
-    hipStream_t take(int prio) {
-        int dev = 0; (void)hipGetDevice(&dev);
+    // (dev: the handle's device, cfg.device_id -- not the calling thread's current one: a handle may be destroyed from a thread whose
+    // current device is another GPU of the node)
+    hipStream_t take(int dev, int prio) {
         {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = idle[std::make_pair(dev, prio)];
@@ -434,9 +435,8 @@ struct StreamPool {
         const hipError_t e = prio == CAPTURE ? hipStreamCreateWithFlags(&st, hipStreamNonBlocking) : hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
         return e == hipSuccess ? st : nullptr;
     }
-    void give(hipStream_t st, int prio) {
+    void give(hipStream_t st, int dev, int prio) {
         if (!st) return;
-        int dev = 0; (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(mu);
         idle[std::make_pair(dev, prio)].push_back(st);
     }
@@ -736,7 +736,7 @@ static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
             static const bool unlocked = SSF_ENV_SET("CAPTURE_UNLOCKED");          // (control runs of that probe)
             std::unique_lock<std::mutex> capture_lock(capture_mutex, std::defer_lock);
             if (!unlocked) capture_lock.lock();
-            bool ok = (h->capture_stream || (h->capture_stream = stream_pool().take(StreamPool::CAPTURE)) != nullptr) &&
+            bool ok = (h->capture_stream || (h->capture_stream = stream_pool().take(h->cfg.device_id, StreamPool::CAPTURE)) != nullptr) &&
                       hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 enqueue_segmentation(h, c, h->capture_stream);
@@ -1588,16 +1588,16 @@ void ssf_destroy(ssf_handle* h) {
         for (int n = 0; n <= SSF_MAX_BATCH; n++) { if (c.exec[n]) (void)hipGraphExecDestroy(c.exec[n]); if (c.graph[n]) (void)hipGraphDestroy(c.graph[n]); }
         hipEvent_t evs[4] = {c.ev_done, c.ev_consumed, c.ev_t0, c.ev_t1};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        if (c.own_stream && c.stream) stream_pool().give(c.stream, c.stream_prio);          // (synchronised above)
+        if (c.own_stream && c.stream) stream_pool().give(c.stream, h->cfg.device_id, c.stream_prio);          // (synchronised above)
     }
-    if (h->capture_stream) stream_pool().give(h->capture_stream, StreamPool::CAPTURE);
+    if (h->capture_stream) stream_pool().give(h->capture_stream, h->cfg.device_id, StreamPool::CAPTURE);
     if (!h->guarded.empty() && !SSF_ENV_SET("GUARD_ONLY")) check_guards(h);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->ev_resident) (void)hipEventDestroy(h->ev_resident);
     for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_pool().give(h->stream, h->stream_prio); }
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_pool().give(h->stream, h->cfg.device_id, h->stream_prio); }
     delete h;
 }
 
@@ -1634,7 +1634,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const int prio = SSF_ENV_INT("TRACK_PRIORITY", greatest);
-        h->stream = stream_pool().take(prio);
+        h->stream = stream_pool().take(cfg->device_id, prio);
         if (!h->stream) { delete h; g_create_err = "hipStreamCreate failed"; return SSF_ERR_DEVICE; }
         h->own_stream = true; h->stream_prio = prio;
     }
@@ -1702,7 +1702,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             static const bool ctx0_up = SSF_ENV_INT("CTX0_PRIORITY", 1) != 0;
             const int prio = (ci == 0 && ctx0_up && least - greatest >= 2) ? least - 1 : least;
-            c.stream = stream_pool().take(prio); ok = c.stream != nullptr; c.own_stream = ok; c.stream_prio = prio;
+            c.stream = stream_pool().take(h->cfg.device_id, prio); ok = c.stream != nullptr; c.own_stream = ok; c.stream_prio = prio;
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&
