@@ -701,7 +701,7 @@ def main():
         # iterations: the HBM-bound stress) and config 5 (TUM-shaped input, pre-filter in the frame, one deformation), each as
         # this same script in a process of its own, outside every timed region of this one (>= 64 / >= 240 frames) -----------------
         if a.config == 2:
-            for cfg_n, nsteps in ((3, 128), (5, 720)):
+            for cfg_n, nsteps in ((3, 64), (5, 720)):
                 extras["config%d" % cfg_n] = other_config(cfg_n, nsteps, a.pin)
 
     # ---- CPU baseline: the reference has no CPU implementation of this path, so the baseline
