@@ -711,7 +711,7 @@ def main():
     # allocated afterwards -- the extras above -- were staged out of whatever the allocator recycled: the first extra ran at 4700
     # instead of 8200 frames/s behind it, round 4)
     cpu = None
-    if rank == 0 and a.cpu_frames > 0:
+    if rank == 0 and world == 1 and a.cpu_frames > 0:            # (the contract: the CPU baseline on rank 0 at N = 1 only)
         import subprocess
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         mk = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp", "native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
