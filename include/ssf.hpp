@@ -24,10 +24,16 @@
  * floats x, y, z), any other gets the plain struct below.  SSF_NO_MATRIX_TYPES: the includer brings its own
  * matrix_types.h. */
 #ifndef SSF_NO_MATRIX_TYPES
+/* Include order: a translation unit that uses HIP's / CUDA's vector types includes THEIR header before this one (then
+ * float3 / float2 / int2 below are theirs).  The other order is a compile error (redefinition of float3 in the vendor
+ * header), never a silent mismatch: the three fallbacks have the vendor types' size and field order, asserted below. */
 #if !defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H) && !defined(__VECTOR_TYPES_H__) && !defined(SSF_HAVE_FLOAT3)
 #define SSF_HAVE_FLOAT3
 struct float3 { float x, y, z; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
 #endif
+static_assert(sizeof(float3) == 12 && sizeof(float2) == 8 && sizeof(int2) == 8, "ssf.hpp: float3 / float2 / int2 must be the packed vendor layouts");
 #ifndef MATRIX_TYPES_HPP            /* the reference header's own guard: both may be included, in either order */
 #define MATRIX_TYPES_HPP
 struct Cov3 { float xx, xy, xz, yy, yz, zz; };                          /* matrix_types.h:26-31 */
@@ -90,16 +96,26 @@ struct HostSupersurfels {
 #include <thrust/host_vector.h>
 #include <thrust/copy.h>
 namespace supersurfel_fusion {
+#endif
+/* DATA LAYOUT IS UNCONDITIONAL: DeviceArray<T> is a pointer and a count whether or not thrust is there -- only its
+ * thrust-typed accessors depend on the include order -- and SupersurfelFusion always holds its two views, so
+ * sizeof(SupersurfelFusion) is the same in every translation unit of a node (a .hip file with thrust and a main.cpp
+ * without may share one object).  What DOES differ between the two forms is the return type of getModel() / getFrame();
+ * the class therefore lives in an inline namespace named after the form (`thrust_view` / `host_copy`): code never spells
+ * it, but a function that passes a SupersurfelFusion between translation units of different forms fails to LINK instead
+ * of calling the wrong getModel(). */
 template <typename T> struct DeviceArray {
-    typedef thrust::device_ptr<T> iterator;
-    typedef thrust::device_ptr<T> const_iterator;
     T* ptr = nullptr; size_t n = 0;
-    iterator begin() const { return thrust::device_pointer_cast(ptr); }
-    iterator end() const { return thrust::device_pointer_cast(ptr) + n; }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
     T* data() const { return ptr; }
+#ifdef SSF_THRUST_VIEW
+    typedef thrust::device_ptr<T> iterator;
+    typedef thrust::device_ptr<T> const_iterator;
+    iterator begin() const { return thrust::device_pointer_cast(ptr); }
+    iterator end() const { return thrust::device_pointer_cast(ptr) + n; }
     operator thrust::host_vector<T>() const { thrust::host_vector<T> v(n); thrust::copy(begin(), end(), v.begin()); return v; }
+#endif
 };
 struct Supersurfels {                                                    /* supersurfels.hpp:32-40, as views */
     DeviceArray<float3> positions, colors;
@@ -115,6 +131,13 @@ struct Supersurfels {                                                    /* supe
         positions.n = colors.n = stamps.n = orientations.n = shapes.n = dims.n = confidences.n = n;
     }
 };
+static_assert(sizeof(DeviceArray<float3>) == sizeof(void*) + sizeof(size_t) && sizeof(Supersurfels) == 7 * sizeof(DeviceArray<float>),
+              "ssf.hpp: the device views are (pointer, count) pairs in every translation unit");
+
+#ifdef SSF_THRUST_VIEW
+inline namespace thrust_view {
+#else
+inline namespace host_copy {
 #endif
 
 class SupersurfelFusion {
@@ -260,6 +283,19 @@ public:
     HostSupersurfels getModel() { return getModelHost(); }
     HostSupersurfels getFrame() { return getFrameHost(); }
 #endif
+    /* the device views under a name of their own, in both forms (data() / size() only without thrust) */
+    const Supersurfels& getModelView() {
+        ssf_surfels v; int n = 0;
+        check(ssf_get_model_device(need(), &v, &n));
+        model_view_.bind(v, (size_t)n);
+        return model_view_;
+    }
+    const Supersurfels& getFrameView() {
+        ssf_surfels v; int n = 0;
+        check(ssf_get_frame_device(need(), &v, &n));
+        frame_view_.bind(v, (size_t)n);
+        return frame_view_;
+    }
     /* getModel() as the reference returns it: device-resident arrays in the reference's layout (orientations =
      * packed Mat33), n rows, valid until the next call (supersurfel_fusion.hpp:87; the node copies
      * [0, nbSupersurfels) out array by array, supersurfel_fusion_node.cpp:306-310) */
@@ -280,12 +316,11 @@ private:
     ssf_handle* h_ = nullptr;
     ssf_frame_result last_{};
     mutable Transform3 pose_{};
-#ifdef SSF_THRUST_VIEW
-    Supersurfels model_view_, frame_view_;
-#endif
+    Supersurfels model_view_, frame_view_;        /* always there (layout does not depend on the include order); bound by the thrust form's getModel() / getFrame() and by getModelView() / getFrameView() */
     int width_ = 0, height_ = 0;
     int pipeline_depth_ = 0, extract_batch_ = 1; bool depth_prefilter_ = true;
 };
 
+}  /* inline namespace thrust_view / host_copy */
 }  /* namespace supersurfel_fusion */
 #endif

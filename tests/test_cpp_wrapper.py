@@ -240,6 +240,28 @@ def test_the_reference_nodes_model_copy_lines_on_the_hip_library(product_lib, tm
     assert lines[1] == "model_whole_array_form 1" and lines[2].startswith("frame_whole_array_form 1 valid="), r.stdout
 
 
+def test_ssf_hpp_layout_does_not_depend_on_the_include_order(tmp_path):
+    """tests/cpp/layout_probe.cpp built twice (hipcc + rocThrust first / plain g++): the same sizeof(SupersurfelFusion), views and
+    pose types in both translation units (advisor, round 4: the view members used to exist only behind THRUST_VERSION -- two
+    files of one node disagreed about the object's size), and a different inline-namespace tag, so mixing the forms cannot link."""
+    if not (os.path.exists(HIPCC) and os.path.exists("/opt/rocm/include/thrust/host_vector.h")):
+        pytest.skip("no hipcc / rocThrust on this box")
+    src = os.path.join(ROOT, "tests", "cpp", "layout_probe.cpp")
+    out = {}
+    for form, cmd in (("thrust", [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O1", "-DLAYOUT_WITH_THRUST"]),
+                      ("plain", ["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-Werror"])):
+        exe = tmp_path / ("layout_" + form)
+        r = subprocess.run(cmd + ["-I", os.path.join(ROOT, "include"), src, "-o", str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-4000:]
+        r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)       # (prints sizes only: no device, no library call)
+        assert r.returncode == 0, r.stdout
+        out[form] = dict(t.split("=") for t in r.stdout.split())
+    assert out["thrust"]["form"] == "1" and out["plain"]["form"] == "0"
+    for k in ("fusion", "views", "array", "transform", "float3"):
+        assert out["thrust"][k] == out["plain"][k], (k, out)
+    assert out["plain"]["float3"] == "12" and out["plain"]["transform"] == "48"
+
+
 def test_model_device_view_has_the_reference_layout(oracle_lib):
     """ssf_get_model_device: packed Mat33 orientations (9 floats per row), rows [visible | out of view]"""
     import ctypes as C
