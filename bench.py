@@ -522,14 +522,14 @@ def main():
             # where a short timed region goes: completion time of every frame inside ssf_process_sequence (the library's
             # own clock, from its entry), the call's return and the end of the closing barrier, all in microseconds
             tt_ = np.zeros(64)
-            lib.lib.ssf_dbg_sequence_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-            lib.lib.ssf_dbg_sequence_times(f.h, tt_.ctypes.data_as(ctypes.c_void_p))
+            lib.lib.ssf_sequence_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            lib.lib.ssf_sequence_times(f.h, tt_.ctypes.data_as(ctypes.c_void_p))
             fill = dict(frame_done_us=[round(float(v), 1) for v in tt_[:K]], call_returned_us=round(1e6 * (t_ret - t0), 1),
                         region_us=round(1e6 * dt, 1), icp_iters=[int(r["icp_iters"]) for r in results])
-            if hasattr(lib.lib, "ssf_dbg_sequence_marks"):
+            if hasattr(lib.lib, "ssf_sequence_marks"):
                 mk = np.zeros(320)
-                lib.lib.ssf_dbg_sequence_marks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-                lib.lib.ssf_dbg_sequence_marks(f.h, mk.ctypes.data_as(ctypes.c_void_p))
+                lib.lib.ssf_sequence_marks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+                lib.lib.ssf_sequence_marks(f.h, mk.ctypes.data_as(ctypes.c_void_p))
                 for j, name in enumerate(("track_entered_us", "first_icp_record_us", "icp_done_us")):
                     fill[name] = [round(float(v), 1) for v in mk[64 * j:64 * j + K]]
                 fill["extract_batches_launched"] = [dict(at_us=round(float(mk[256 + 2 * i]), 1), frames=int(mk[257 + 2 * i]), host_us=round(1e4 * (mk[257 + 2 * i] % 1.0), 1)) for i in range(32) if mk[256 + 2 * i] >= 0]
@@ -628,10 +628,10 @@ def main():
     # ... and by a plain 16-bytes-per-lane copy kernel of the library's own (the form MI355X_MICROARCH.md quotes at 6.29 TB/s):
     # torch's copy kernel reaches ~15 % less on the same box, which is why hbm_peak_measured_GBs read 5.3 TB/s in round 3
     hbm_float4 = None
-    if rank == 0 and a.extras and hasattr(lib.lib, "ssf_dbg_stream_copy_GBs"):
-        lib.lib.ssf_dbg_stream_copy_GBs.restype = ctypes.c_double
-        lib.lib.ssf_dbg_stream_copy_GBs.argtypes = [ctypes.c_int, ctypes.c_int]
-        v = lib.lib.ssf_dbg_stream_copy_GBs(1024, 10)
+    if rank == 0 and a.extras and hasattr(lib.lib, "ssf_stream_copy_rate"):
+        lib.lib.ssf_stream_copy_rate.restype = ctypes.c_double
+        lib.lib.ssf_stream_copy_rate.argtypes = [ctypes.c_int, ctypes.c_int]
+        v = lib.lib.ssf_stream_copy_rate(1024, 10)
         hbm_float4 = v if v > 0 else None
     if roofline is not None and (hbm_measured or hbm_float4):
         best_copy = max(hbm_measured or 0.0, hbm_float4 or 0.0)

@@ -60,6 +60,8 @@ typedef enum ssf_status {
     SSF_ERR_STATE = -5,        /* stage called out of order */
     SSF_ERR_IO = -6
 } ssf_status;
+/* Errors are NEGATIVE.  One entry point also returns positive values that are not errors: ssf_rehome_end's return is the
+ * number of arrivals a full shard had to turn away (0 = none) -- test `rc < 0` there, not `rc != SSF_OK`. */
 
 /* Number of values in one ICP normal-equation record: JtJ upper triangle (21, row-major order
  * 00,01,..,05,11,..,55), Jtr (6), sum r2^2 (1), inlier count (1).  Mirrors MotionTrackingData
@@ -459,6 +461,26 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
 int ssf_reset_kernel_times(ssf_handle* h);
 /* Change cfg.profile at run time (0, 1 or 2). */
 int ssf_set_profile(ssf_handle* h, int enable);
+/* Where the last ssf_process_sequence went (the library's own clock, microseconds from the call's entry; the first 64 frames):
+ *   ssf_sequence_times  out64[k] = frame k's results complete
+ *   ssf_sequence_marks  out320: [0..63] track loop entered, [64..127] first ICP record back, [128..191] ICP loop done,
+ *                       [192..255] counters back; then 32 x (launch time of an extract batch, frames + host microseconds / 1e4)
+ * bench.py's `pipeline_fill` is these.  The CPU checker returns zeros. */
+int ssf_sequence_times(ssf_handle* h, double* out64);
+int ssf_sequence_marks(ssf_handle* h, double* out320);
+/* What a plain 16-bytes-per-lane stream copy sustains on this box, GB/s (mib MiB read + the same written, best of reps;
+ * non-temporal, unrolled): the "measured-achievable" HBM figure beside the 8 TB/s spec.  < 0: n/a. */
+double ssf_stream_copy_rate(int mib, int reps);
+/* Counters of the host-side machinery (tests and tools/ read them; none is on the frame path):
+ *   ssf_upload_stats          out6: [0] upload workers, [1] host frames uploaded, microseconds summed over the workers [2] waiting
+ *                             for a ring slot, [3] in the staging memcpy, [4] in the copy enqueues, [5] the caller's wait for uploads
+ *   ssf_pooled_streams        streams of destroyed handles waiting in the process-wide pool for the next handle
+ *   ssf_waiter_matches        frames whose association ran inside an ICP launch that was waiting for the host's word
+ *   ssf_waiter_match_repairs  ... and the ones re-run as a launch because that word came too late to be trusted */
+int ssf_upload_stats(ssf_handle* h, double* out6);
+int ssf_pooled_streams(void);
+long long ssf_waiter_matches(ssf_handle* h);
+long long ssf_waiter_match_repairs(ssf_handle* h);
 
 #ifdef __cplusplus
 }

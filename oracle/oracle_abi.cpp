@@ -420,6 +420,14 @@ int ssf_get_kernel_times(ssf_handle* h, const char** names, double* ms, int64_t*
 }
 int ssf_reset_kernel_times(ssf_handle* h) { (void)h; return SSF_OK; }
 int ssf_set_profile(ssf_handle* h, int enable) { (void)h; (void)enable; return SSF_OK; }
+// the product's measurement counters (include/ssf.h "measurement"): the checker has no pipeline, no streams, no uploads
+int ssf_sequence_times(ssf_handle* h, double* out64) { if (!h || !out64) return SSF_ERR_INVALID_ARG; for (int i = 0; i < 64; i++) out64[i] = 0.0; return SSF_OK; }
+int ssf_sequence_marks(ssf_handle* h, double* out320) { if (!h || !out320) return SSF_ERR_INVALID_ARG; for (int i = 0; i < 320; i++) out320[i] = i >= 256 && !(i & 1) ? -1.0 : 0.0; return SSF_OK; }
+double ssf_stream_copy_rate(int mib, int reps) { (void)mib; (void)reps; return -1.0; }
+int ssf_upload_stats(ssf_handle* h, double* out6) { if (!h || !out6) return SSF_ERR_INVALID_ARG; for (int i = 0; i < 6; i++) out6[i] = 0.0; return SSF_OK; }
+int ssf_pooled_streams(void) { return 0; }
+long long ssf_waiter_matches(ssf_handle* h) { return h ? 0 : -1; }
+long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? 0 : -1; }
 
 // OpenMP build only (the timed CPU baseline): number of threads of the parallel loops; returns the number in effect
 // (1 for the single-threaded checker).  Not part of ssf.h.

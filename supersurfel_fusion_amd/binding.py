@@ -67,6 +67,7 @@ ABI_SYMBOLS = [
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
     "ssf_comm_unique_id", "ssf_comm_attach", "ssf_comm_info", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_rehome_begin", "ssf_rehome_end", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
+    "ssf_sequence_times", "ssf_sequence_marks", "ssf_stream_copy_rate", "ssf_upload_stats", "ssf_pooled_streams", "ssf_waiter_matches", "ssf_waiter_match_repairs",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),

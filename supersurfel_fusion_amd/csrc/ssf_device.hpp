@@ -32,7 +32,12 @@ static inline int ssf_env_int_(const char* name, int dflt) { const char* e = get
 #define SSF_ENV_INT(name, dflt) ssf_env_int_("SSF_" name, dflt)
 #define SSF_ENV_SET(name) (getenv("SSF_" name) != nullptr)
 #define SSF_ENV_STR(name) getenv("SSF_" name)
+// a probe bit of a kernel's `dbg` argument (ablation switches of tools/pass_probe.py, tools/icp_probe.py: loads only / no energy /
+// no accumulation ...): a run-time test in the lab build, the constant `false` in the product -- the branch and its scalar
+// register are compiled out of kernels that are bound by instruction issue and sensitive to their scalar-register count
+#define SSF_PROBE(dbg, bits) ((((dbg)) & (bits)) != 0)
 #else
+#define SSF_PROBE(dbg, bits) (false)
 #define SSF_ENV_INT(name, dflt) (dflt)
 #define SSF_ENV_SET(name) (false)
 #define SSF_ENV_STR(name) ((const char*)nullptr)
@@ -247,7 +252,10 @@ void launch_preview(hipStream_t st, int W, int H, const int32_t* label, const ui
 // and fences once (one PCIe write of the whole line), and the sixteen lanes that POLL the slot fetch all of it with every poll --
 // the transform needs no trip of its own behind the word (it used to: ~1 us at the head of every chained iteration).  Should the
 // line ever arrive in pieces, the flag word says so: bits 0-31 the low half of go_seq, bits 32-61 a checksum of the other
-// fourteen words (icp_go_word_weight), bit 62 "associate", bit 63 "leave" (no checksum: nothing else of the line is read then).
+// fourteen words (icp_go_word_weight), bit 62 "associate", bit 63 "leave".  "Leave" is self-validating too: its bits 32-61 are a
+// hash of go_seq (icp_go_abort_check), so a poll that sees the NEW low half next to a stale high half -- the slot's previous use
+// may have ended in "leave" -- keeps polling instead of leaving a launch the host has just told to associate (the flag is read
+// as two 32-bit halves of the sixteen-lane line fetch, not as one 64-bit atomic).
 struct alignas(64) IcpGo { float T[12]; unsigned long long flag; unsigned long long x; };
 static_assert(sizeof(IcpGo) == 64, "one line");
 #define SSF_ICP_GO_ABORT (1ull << 63)
@@ -256,6 +264,7 @@ static_assert(sizeof(IcpGo) == 64, "one line");
 SSF_HD unsigned int icp_go_word_weight(unsigned int dword) {      // dword 0..11: the transform; 14, 15: x; 12, 13 (the flag itself): 0
     return dword < 12u ? (2u * dword + 1u) * 0x9E3779B1u : (dword == 14u ? 0x85EBCA6Bu : (dword == 15u ? 0xC2B2AE35u : 0u));
 }
+SSF_HD unsigned int icp_go_abort_check(unsigned int want) { return ((want * 0x9E3779B1u) >> 2) & SSF_ICP_GO_CHECK_MASK; }
 #define SSF_ICP_GO_SLOTS 4
 struct MatchArgs { float zmin, zmax; long long id_offset; unsigned long long* best; uint8_t* matched; int32_t* cand; };    // launch_match's arguments
 int icp_variant_mode();              // 0: the product's k_icp; other values: measurement arms that cannot take SSF_ICP_GO_MATCH

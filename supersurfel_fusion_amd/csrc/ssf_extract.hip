@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     constexpr unsigned int QPR_MAGIC = 65536u / QPR + 1u;          // e / QPR == (e * QPR_MAGIC) >> 16 for e < 1024
     static_assert(NQ <= 1024 && TILE_LOADS * 4 <= 32, "quad index / outside mask");
     uint4 tile_reg[TILE_LOADS]; unsigned int outside = 0u;
-    const bool no_tile = (dbg & 32) != 0;                      // (probe: every element reads as outside the image)
+    const bool no_tile = SSF_PROBE(dbg, 32);                     // (probe: every element reads as outside the image)
     const bool interior = X0 >= 1 && X0 - 1 + TWP <= p.W && Y0 >= 1 && Y0 + TILE < p.H;
     if (interior) {
         typedef uint32_t Quad __attribute__((ext_vector_type(4), aligned(4)));     // ONE load of four labels, 4-byte aligned
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #ifdef SSF_EXPERIMENTS
             if (may_skip && inside && threadIdx.x < 64) stamp_max = max(stamp_max, ld_off<int>(sr.r, (unsigned int)(k * (int)sizeof(SumRec) + (int)offsetof(SumRec, stamp))));
 #endif
-            if (inside && !(dbg & 1)) {
+            if (inside && !SSF_PROBE(dbg, 1)) {
                 if (threadIdx.x < 64) {
                     SpRow row = zero_row;
                     row_means_from_sums(sr, k, row);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     if (threadIdx.x == 0) s_nlog = 0;
 #ifdef SSF_EXPERIMENTS
     if (threadIdx.x < 64) {                        // (wave 0 holds all the stamps: one ballot -- lab/pass_skip.inc "clean tiles")
-        const bool clean = may_skip && window_ok && n_prev == 0u && __ballot(stamp_max > pass - 5) == 0ull && !(dbg & 64);
+        const bool clean = may_skip && window_ok && n_prev == 0u && __ballot(stamp_max > pass - 5) == 0ull && !SSF_PROBE(dbg, 64);
         if (threadIdx.x == 0) { s_far = 0; s_clean = clean ? 1 : 0; }
     }
 #endif
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             }
         }
     };
-    if (dbg & 2) return;
+    if (SSF_PROBE(dbg, 2)) return;
 #if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_JUNK)
     // measurement only: SSF_PASS_JUNK extra vector instructions per wave (is the pass bound by instruction issue?)
     {
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         int new_index = index;
         const int nl[4] = {t[-TWP], t[-1], t[1], t[TWP]};                           // N, W, E, S
         const int bounds = (nl[0] != index) + (nl[1] != index) + (nl[2] != index) + (nl[3] != index);
-        bool eligible = in_image[s] && bounds != 0 && !(dbg & 4);
+        bool eligible = in_image[s] && bounds != 0 && !SSF_PROBE(dbg, 4);
         if (eligible) {
             // connectivity guard isUnchangeable (TPS_RGBD_kernels.cuh:178-233): ring NW,N,NE,E,SE,S,SW,W; the label changes
             // more than twice along the ring = the pixel is a bridge.  Bit k of `ring`: ring pixel k carries the pixel's label
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
     }
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
-    if (!(dbg & 8)) {
+    if (!SSF_PROBE(dbg, 8)) {
 #pragma unroll
         for (int s = 0; s < NPX; s++)
             if (threadIdx.x + 256u * s < n_prev)

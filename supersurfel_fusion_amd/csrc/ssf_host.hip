@@ -332,6 +332,9 @@ static inline int seq_batch_of(int i, int batch) {
 }
 // (a longer ramp -- 2, 4, 4, 6 before the batches of 8 -- was measured in round 2: 6100-6150 against 5960-6260 frames/s over
 // 20 timed frames, i.e. nothing)
+#ifndef SSF_UPLOAD_RING_BYTES
+#define SSF_UPLOAD_RING_BYTES (256ull << 20)          // cap of the upload ring's device buffers (and, again, of its page-locked staging)
+#endif
 struct Uploader {
     // several workers, frames dealt to them in turn: a pageable hipMemcpyAsync is a host memcpy into a staging buffer, and one
     // thread sustains 6-10 GB/s of it (box to box) = 3000-5000 frames/s at 2.1 MB per frame, less than the pipeline consumes.
@@ -358,7 +361,7 @@ struct Uploader {
     // the runtime a truly asynchronous DMA; left to the runtime, pageable copies of several threads serialise inside it
     std::vector<uint8_t*> p_rgb; std::vector<float*> p_depth;
     bool ready(int i) const { return done[i % NTH].load(std::memory_order_acquire) > i; }
-    // where the workers' time went, microseconds summed over the workers since the handle was created (ssf_dbg_upload_stats):
+    // where the workers' time went, microseconds summed over the workers since the handle was created (ssf_upload_stats):
     // waiting for a free ring slot | the staging memcpy | the two hipMemcpyAsync calls; frames
     std::atomic<long long> us_ring{0}, us_memcpy{0}, us_enqueue{0}, frames_done{0};
     void run(int t) {
@@ -425,20 +428,32 @@ struct StreamPool {
     static const int CAPTURE = 1 << 20;                                    // "priority" of the capture-only streams
     // (dev: the handle's device, cfg.device_id -- not the calling thread's current one: a handle may be destroyed from a thread whose
     // current device is another GPU of the node)
+    // A stream is created ON the handle's device (the calling thread's current device is put back afterwards: the capture stream is
+    // taken lazily, from whatever thread first runs a segmentation).  The idle list of a key is bounded: a process that has run many
+    // handles SIDE BY SIDE and destroyed them keeps at most MAX_IDLE streams per (device, priority) -- what a later handle can take --
+    // and destroys the surplus instead of holding every hardware queue for good.
+    static const size_t MAX_IDLE = 8;
     hipStream_t take(int dev, int prio) {
         {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = idle[std::make_pair(dev, prio)];
             if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
         }
+        int cur = -1;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
         hipStream_t st = nullptr;
         const hipError_t e = prio == CAPTURE ? hipStreamCreateWithFlags(&st, hipStreamNonBlocking) : hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
+        if (switched) (void)hipSetDevice(cur);
         return e == hipSuccess ? st : nullptr;
     }
     void give(hipStream_t st, int dev, int prio) {
         if (!st) return;
-        std::lock_guard<std::mutex> lk(mu);
-        idle[std::make_pair(dev, prio)].push_back(st);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = idle[std::make_pair(dev, prio)];
+            if (v.size() < MAX_IDLE) { v.push_back(st); return; }
+        }
+        (void)hipStreamDestroy(st);                 // (the caller has synchronised it)
     }
 };
 static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }      // (never destroyed: the runtime may be gone by then)
@@ -494,7 +509,7 @@ struct ssf_handle {
     long long n_waiter_matches = 0;           // frames whose association ran in a waiting ICP launch (debug)
     int seq_k = 0;                            // frame of the sequence the track loop is working on (debug marks)
     int seq_batches = 0;                      // batches launched by the running ssf_process_sequence (see seq_batch_size)
-    double us_wait_upload = 0.0;                          // the submitting thread's wait for uploads (ssf_dbg_upload_stats)
+    double us_wait_upload = 0.0;                          // the submitting thread's wait for uploads (ssf_upload_stats)
     Uploader* up = nullptr; bool seq_upload = false;   // host frames of a sequence are copied ahead by a worker thread
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
@@ -536,7 +551,7 @@ struct ssf_handle {
     // fused (do_fuse): valid for exactly that frame, that pose and that model; anything else drops it
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
     double wait_launched_us = 0.0; long long n_waiter_match_repairs = 0; long long dbg_stall_before_match_us = 0;     // see process_oldest: SSF_ICP_GO_MATCH has no acknowledgement
-    bool icp_ahead = true;
+    bool icp_ahead = true; int icp_ahead_mode = 1;         // 1: when the next frame's extract has finished (the product); 2 (lab): always, the track stream waits for it
     // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
@@ -1178,10 +1193,17 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
             ExtractCtx& nc = h->ctx[h->pending.front().first];
             const int nslot = h->pending.front().second;
             const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
-            // (not finished yet: the track stream waits here instead of at the start of the next frame; the host
-            // does not, it continues on the counters the fuse launch has published before the move)
-            if (nc.launched) {
-                if (multi && !nc.waited) { HCK(hipStreamWaitEvent(h->stream, nc.ev_done, 0)); nc.waited = true; }
+            // Only when that frame's extract HAS finished (round 5).  Frames of the batch being consumed are ready by construction;
+            // at a batch boundary the next context's event is asked.  Until round 4 the track stream was made to wait for it here --
+            // in a sequence's fill phase that parked the row moves behind a batch that was still 100-200 us from done, and the
+            // driver's 20-frame form ran 4 % slower with the fusion than without (7680-7730 against 8030-8060 frames/s, same box,
+            // alternated twice: profiles/track_chain_r05.txt); in the steady state the next batch is ready and nothing changes.
+            bool ready = nc.launched && (!multi || nc.waited);
+            if (nc.launched && !ready && (h->icp_ahead_mode == 2 || hipEventQuery(nc.ev_done) == hipSuccess)) {
+                HCK(hipStreamWaitEvent(h->stream, nc.ev_done, 0)); nc.waited = true; ready = true;
+            }
+            (void)hipGetLastError();                      // (hipErrorNotReady of the query is not an error)
+            if (ready) {
                 const FrameMaps nm = batch_slot(nc.maps, nslot);
                 IcpLoop first;
                 icp_start_from(first, h->pose);
@@ -1362,7 +1384,7 @@ static void icp_release_waiting(IcpGo* slot, unsigned long long go_seq, const Rt
         for (int i = 0; i < 12; i++) s->T[i] = v[i];
         s->x = p2p_seq;
         s->flag = want | ((unsigned long long)((sum >> 2) & SSF_ICP_GO_CHECK_MASK) << 32) | (match ? SSF_ICP_GO_MATCH : 0ull);
-    } else s->flag = want | SSF_ICP_GO_ABORT;
+    } else s->flag = want | ((unsigned long long)icp_go_abort_check((unsigned int)want) << 32) | SSF_ICP_GO_ABORT;
     store_fence();
 }
 
@@ -1472,7 +1494,9 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     bool matched_by_waiter = false;
     if (waiting && !timing && icp_waiter_can_match(h)) {
         icp_end(h, &valid);
-        if (h->dbg_stall_before_match_us > 0) usleep((useconds_t)h->dbg_stall_before_match_us);      // (test hook: a stalled host thread)
+#ifdef SSF_EXPERIMENTS
+        if (h->dbg_stall_before_match_us > 0) usleep((useconds_t)h->dbg_stall_before_match_us);      // (test hook of the lab build: a stalled host thread)
+#endif
         icp_release_waiting(wait_slot, wait_go_seq, &h->pose, 0, true);
         matched_by_waiter = true;
         // The word has no acknowledgement.  A waiting workgroup gives up after SSF_ICP_GO_WAIT_TICKS (0.25 s) and tells the rest
@@ -1624,7 +1648,8 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
 #define SSF_MOVE_TOTALS_DEFAULT 1
 #endif
     h->move_totals_on = SSF_ENV_INT("MOVE_TOTALS", SSF_MOVE_TOTALS_DEFAULT) != 0;      // (-DSSF_MOVE_TOTALS_DEFAULT=0: a product build that keeps the fuse launch's tail, for the A/B)
-    h->icp_ahead = SSF_ENV_INT("ICP_AHEAD", 1) != 0;      // (lab: measurement switches, tools/)
+    h->icp_ahead_mode = SSF_ENV_INT("ICP_AHEAD", 1);      // (lab: measurement switches, tools/)
+    h->icp_ahead = h->icp_ahead_mode != 0;
     h->icp_chain = SSF_ENV_INT("ICP_CHAIN", 1) != 0;
     if (SSF_ENV_SET("NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -1815,9 +1840,15 @@ int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* cons
             // the one that drives the track chain -- waited 18 us per frame for uploads and the replay ran at 6100-6300 frames/s on hosts
             // with a slower memcpy (8800-10 000 on faster ones) against 11 400 with frames in HBM: tools/host_buffer_probe.py.  Two
             // more batches of slack.
-            u->ring = ((int)h->ctx.size() + 3) * h->batch + 2;
+            // The ring is capped by BYTES as well (advisor, round 4: at depth 3 x 16 frames per launch the formula asks for 98 slots =
+            // 0.85 GB of HBM and as much page-locked host memory at 1280x960, held until ssf_destroy): never more than
+            // SSF_UPLOAD_RING_BYTES of device buffers (and the same again page-locked), never fewer than the window the submitting
+            // thread can run ahead by + 2 (below that the workers could not keep up at all).  INTEGRATION.md section 2b has the footprint.
+            const int window = ((int)h->ctx.size() + 1) * h->batch + 2;
+            const int by_bytes = (int)(SSF_UPLOAD_RING_BYTES / (7 * P));
+            u->ring = std::max(window, std::min(((int)h->ctx.size() + 3) * h->batch + 2, by_bytes));
             u->rgb_bytes = 3 * P; u->depth_bytes = 4 * P;
-            (void)hipGetDevice(&u->device);
+            u->device = h->cfg.device_id;
             bool ok = true;
             u->d_rgb.assign(u->ring, nullptr); u->d_depth.assign(u->ring, nullptr);
             for (int i = 0; i < u->ring && ok; i++) ok = dalloc(h, &u->d_rgb[i], 3 * P) && dalloc(h, &u->d_depth[i], P);
@@ -2560,6 +2591,7 @@ int ssf_set_profile(ssf_handle* h, int enable) {
 }
 
 // completion times (us since the call started) of the first 64 frames of the last ssf_process_sequence (tools/startup_probe.py)
+#ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
 // the record of the last ICP iteration the host fetched (after the exchange of a sharded map: the SUM over the ranks)
 int ssf_dbg_last_icp_record(ssf_handle* h, int64_t* out29) {
     if (!h || !out29) return SSF_ERR_INVALID_ARG;
@@ -2573,25 +2605,29 @@ int ssf_dbg_device_icp_records(ssf_handle* h, int64_t* out64) {
     HCK(hipMemcpy(out64, h->d_icp, 64 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return SSF_OK;
 }
+#endif
 // per frame of the last sequence (first 64): entry of the track loop, first ICP record back, ICP loop done, counters
 // back [us from the call's entry]; then 32 x (time, frames) of the extract batches launched
-int ssf_dbg_sequence_marks(ssf_handle* h, double* out320) {
+int ssf_sequence_marks(ssf_handle* h, double* out320) {
     if (!h || !out320) return SSF_ERR_INVALID_ARG;
     for (int m = 0; m < 4; m++) for (int i = 0; i < 64; i++) out320[m * 64 + i] = h->seq_mark_us[m][i];
     for (int i = 0; i < 32; i++) { out320[256 + 2 * i] = i < h->seq_launches ? h->seq_launch_us[i] : -1.0; out320[257 + 2 * i] = i < h->seq_launches ? h->seq_launch_n[i] + h->seq_launch_host_us[i] / 1e4 : 0; }
     return SSF_OK;
 }
 // frames whose association ran inside a waiting ICP launch (SSF_ICP_GO_MATCH) since the handle was created
-long long ssf_dbg_waiter_matches(ssf_handle* h) { return h ? h->n_waiter_matches : -1; }
+long long ssf_waiter_matches(ssf_handle* h) { return h ? h->n_waiter_matches : -1; }
 // ... and the frames whose association was run again as a launch of its own because the host's word to the waiting launch came
 // too late to be trusted; the test hook that makes it late (a stall of the calling thread in front of the word)
-long long ssf_dbg_waiter_match_repairs(ssf_handle* h) { return h ? h->n_waiter_match_repairs : -1; }
-void ssf_dbg_stall_before_match_us(ssf_handle* h, long long us) { if (h) h->dbg_stall_before_match_us = us; }
-int ssf_dbg_sequence_times(ssf_handle* h, double* out64) {
+long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? h->n_waiter_match_repairs : -1; }
+#ifdef SSF_EXPERIMENTS
+void ssf_dbg_stall_before_match_us(ssf_handle* h, long long us) { if (h) h->dbg_stall_before_match_us = us; }      // (fault injection: lab build only)
+#endif
+int ssf_sequence_times(ssf_handle* h, double* out64) {
     if (!h || !out64) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 64; i++) out64[i] = h->seq_done_us[i];
     return SSF_OK;
 }
+#ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
 // host-side time split of the pipelined loop (tools/pipeline_probe.py); reset on read
 int ssf_dbg_host_times(ssf_handle* h, double* out8) {
     if (!h || !out8) return SSF_ERR_INVALID_ARG;
@@ -2620,6 +2656,7 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
     return (now_us() - t0) / (double)(n - n / 4);
 }
 
+#endif
 
 // What a plain stream copy reaches on THIS box (nominal AND measured-achievable peak): 16 bytes per lane,
 // grid-stride, `mib` MiB read + the same written, best of `reps` -- the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s (79 % of
@@ -2632,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ 
         out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
     }
 }
-double ssf_dbg_stream_copy_GBs(int mib, int reps) {
+double ssf_stream_copy_rate(int mib, int reps) {
     if (mib < 16 || reps < 1) return -1.0;
     const size_t bytes = (size_t)mib << 20, n = bytes / sizeof(float4);
     float4 *a = nullptr, *b = nullptr;
@@ -2652,6 +2689,7 @@ double ssf_dbg_stream_copy_GBs(int mib, int reps) {
     return best;
 }
 
+#ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
 // ablation timer for the ICP kernel (tools/icp_probe.py): `reps` back-to-back launches in mode `dbg`
 // (bit0: skip the per-surfel math, bit1: skip the LDS accumulation, bit2: skip arrival counting + tail)
 double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
@@ -2671,11 +2709,12 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     return 1000.0 * ms / reps;
 }
 
+#endif
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
 // lab build: tiles of the last extracted frame (slot 0 of the active context) that proved themselves clean, per pass
 // (FrameMaps::epoch[1 + pass], counted by k_update_pass under SSF_EXPERIMENTS; tools/skip_probe.py)
 // streams waiting in the process-wide pool for the next handle (StreamPool)
-int ssf_dbg_pooled_streams(void) {
+int ssf_pooled_streams(void) {
     StreamPool& sp = stream_pool();
     std::lock_guard<std::mutex> lk(sp.mu);
     int n = 0;
@@ -2684,7 +2723,7 @@ int ssf_dbg_pooled_streams(void) {
 }
 // host frames of sequences: [0] workers, [1] frames uploaded, microseconds summed over the workers [2] waiting for a ring slot,
 // [3] in the staging memcpy, [4] in the two hipMemcpyAsync calls, [5] the submitting thread's wait for uploads (tools/host_buffer_probe.py)
-int ssf_dbg_upload_stats(ssf_handle* h, double* out6) {
+int ssf_upload_stats(ssf_handle* h, double* out6) {
     if (!h || !out6) return SSF_ERR_INVALID_ARG;
     for (int i = 0; i < 6; i++) out6[i] = 0.0;
     if (h->up) {
@@ -2694,6 +2733,7 @@ int ssf_dbg_upload_stats(ssf_handle* h, double* out6) {
     out6[5] = h->us_wait_upload;
     return SSF_OK;
 }
+#ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
 int ssf_dbg_pass_skips(ssf_handle* h, uint32_t* out64) {
     if (!h || !h->active.ctx || !out64) return SSF_ERR_INVALID_ARG;
     HCK(hipStreamSynchronize(h->active.ctx->stream));
@@ -2716,6 +2756,7 @@ double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg, int nb) {
     return 1000.0 * ms / reps;
 }
 
+#endif
 // ---- test hooks (include/ssf_testing.h): the host solvers, so they can be pinned on a CPU box ----------
 int ssf_dbg_ldlt_solve6(const double* A, const double* b, double* x) { sym6_ldlt_solve(A, b, x); return 0; }
 int ssf_dbg_lu_inverse6(const double* A, double* Ainv) { mat6_inverse_lu(A, Ainv); return 0; }

@@ -67,15 +67,15 @@ __device__ __forceinline__ void icp_row_terms_(const Cam& cam, const uint2* __re
                                                const M3& R, const V3& t, const V3& mpos, const V3& mlab, const V3& mnrm, int dbg, Emit emit,
                                                bool live = true) {
     const V3 ps = add(m3_mulv(R, mpos), t);
-    if (dbg & 1) { if (ps.z > 1e30f) emit(28, 1ll); return; }
+    if (SSF_PROBE(dbg, 1)) { if (ps.z > 1e30f) emit(28, 1ll); return; }
     const int u = pixel_round(ps.x * cam.fx / ps.z + cam.cx);
     const int v = pixel_round(ps.y * cam.fy / ps.z + cam.cy);
     bool ok = live && u >= 0 && u < cam.W && v >= 0 && v < cam.H;
     if (!UNIFORM && !ok) return;
     size_t q = ok ? (size_t)v * cam.W + u : 0;
-    if (dbg & 16) q = (blockIdx.x * blockDim.x + threadIdx.x) & 0x7ffffu;          // probe: the lanes of a wave gather ADJACENT pixels (the first 2^19 of the table)
+    if (SSF_PROBE(dbg, 16)) q = (blockIdx.x * blockDim.x + threadIdx.x) & 0x7ffffu;          // probe: the lanes of a wave gather ADJACENT pixels (the first 2^19 of the table)
     const uint2 pl = pix2[q];                                    // (label, plane depth) of the pixel: one 8-byte gather
-    const int tid = (dbg & 8) ? (int)(q & 1023) : (int)pl.x;     // probe (8): the frame supersurfel does not depend on the pixel's word -- two trips instead of three
+    const int tid = SSF_PROBE(dbg, 8) ? (int)(q & 1023) : (int)pl.x;     // probe (8): the frame supersurfel does not depend on the pixel's word -- two trips instead of three
     const float zt = __uint_as_float(pl.y);
     float4 f0 = fpack[4 * tid], f1 = fpack[4 * tid + 1];         // (conf, lab) (normal) of the frame supersurfel: one 32-byte gather
     // (keeps the gather whole: left alone, the compiler fetches the confidence first, tests it, and only then the
@@ -93,7 +93,7 @@ __device__ __forceinline__ void icp_row_terms_(const Cam& cam, const uint2* __re
     const float dn1 = dot3(d, ns), dn2 = dot3(d, nt);
     const float x1[6] = {c1.x, c1.y, c1.z, ns.x, ns.y, ns.z};
     const float x2[6] = {c2.x, c2.y, c2.z, nt.x, nt.y, nt.z};
-    if (dbg & 2) { if (x1[0] * x2[0] > 1e30f) emit(0, 1ll); return; }
+    if (SSF_PROBE(dbg, 2)) { if (x1[0] * x2[0] > 1e30f) emit(0, 1ll); return; }
     // (UNIFORM: a lane that is no inlier carries zeros -- every term of it is then exactly 0, whatever the lane had computed)
     const float m10 = (UNIFORM && !ok) ? 0.0f : 1024.0f, m14 = (UNIFORM && !ok) ? 0.0f : 16384.0f;
     float X1[6], X2[6];
@@ -452,14 +452,17 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
                 w = l < 16u ? __hip_atomic_load(&gw[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
                 const unsigned int flo = (unsigned int)__builtin_amdgcn_readlane((int)w, 12), fhi = (unsigned int)__builtin_amdgcn_readlane((int)w, 13);
                 if (flo == want) {
-                    if (fhi & 0x80000000u) { told = 1; break; }                                  // SSF_ICP_GO_ABORT
-                    unsigned int sum = w * weight;                                               // (lanes >= 16: 0)
+                    if (fhi & 0x80000000u) {                                                     // SSF_ICP_GO_ABORT, valid only with this go_seq's hash beside it
+                        if ((fhi & SSF_ICP_GO_CHECK_MASK) == icp_go_abort_check(want)) { told = 1; break; }      // (else: a stale high half -- keep polling)
+                    } else {
+                        unsigned int sum = w * weight;                                           // (lanes >= 16: 0)
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-                    sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
-                    if (((sum >> 2) & SSF_ICP_GO_CHECK_MASK) == (fhi & SSF_ICP_GO_CHECK_MASK)) {
-                        ok = (fhi & 0x40000000u) ? 2 : 1; told = 1;                              // SSF_ICP_GO_MATCH: the loop is over, associate under the pose in the line
-                        break;
+                        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                        sum = (unsigned int)__builtin_amdgcn_readfirstlane((int)sum);
+                        if (((sum >> 2) & SSF_ICP_GO_CHECK_MASK) == (fhi & SSF_ICP_GO_CHECK_MASK)) {
+                            ok = (fhi & 0x40000000u) ? 2 : 1; told = 1;                          // SSF_ICP_GO_MATCH: the loop is over, associate under the pose in the line
+                            break;
+                        }
                     }
                 }
                 if ((spin & 63u) == 63u && wall_clock64() - t0 > SSF_ICP_GO_WAIT_TICKS) break;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
             // dispatched later must not find a word that arrives after all and start accumulating into a record nobody
             // completes.  (Only then: the normal "leave" word is the host's, and hundreds of workgroups echoing it
             // through the BAR cost the launch behind this one 3 us per frame.)
-            if (!told && l == 0u) __hip_atomic_store(&go->flag, (unsigned long long)want | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!told && l == 0u) __hip_atomic_store(&go->flag, (unsigned long long)want | ((unsigned long long)icp_go_abort_check(want) << 32) | SSF_ICP_GO_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (ok) {
                 if (l < 12u) s_T[l] = __uint_as_float(w);
                 // (a launch made ahead learns the number of its peer exchange with its transform: a dismissed launch must
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void k_icp(Cam cam, SurfelSoA model, int n_vis
         }
     __syncthreads();
     __shared__ int s_last;
-    if (dbg & 4) {                              // probe: fold only
+    if (SSF_PROBE(dbg, 4)) {                    // probe: fold only
         icp_fold(red, replicas);
         return;
     }

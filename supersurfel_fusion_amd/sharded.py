@@ -39,27 +39,46 @@ import torch.distributed as dist
 COUNT_KEYS = ("n_model", "n_visible", "n_removed", "n_inserted", "n_updated")
 
 
-def rehome_over(fusion, world, group=None, device=None):
+class RehomeReport(int):
+    """what rehome_over returns: the number of rows that changed rank (an int, as before) with `.turned_away` = the arrivals
+    full shards had to turn away, summed over the ranks (those rows are lost to the map: ssf_rehome_end's positive return)"""
+    turned_away = 0
+
+
+def rehome_over(fusion, world, group=None, device=None, on_loss="warn"):
     """the re-homing sweep of ONE rank's handle over torch.distributed (any backend): also for handles that run their
-    frames through the native exchanges (ssf_comm_attach / ssf_p2p_attach)"""
+    frames through the native exchanges (ssf_comm_attach / ssf_p2p_attach).  ssf_rehome_end returns the POSITIVE number of
+    arrivals a full shard turned away; those rows have already left their source shards, so the count is summed over the
+    ranks and reported on every rank: on_loss = "warn" (default; warnings.warn), "raise" (RuntimeError) or "ignore"."""
     if world <= 1:
-        return 0
+        return RehomeReport(0)
     mine = fusion.rehome_begin()
     dev = device if device is not None else torch.device("cpu")
     n_all = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(n_all, torch.tensor([len(mine)], dtype=torch.int64, device=dev), group=group)
     n_all = [int(v) for v in n_all.cpu()]
     cap = max(n_all)
-    if cap == 0:
-        return 0
-    pad = torch.zeros((cap, mine.shape[1]), dtype=torch.int32, device=dev)
-    if len(mine):
-        pad[:len(mine)] = torch.from_numpy(mine).to(dev)
-    got = torch.zeros((world * cap, mine.shape[1]), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(got, pad, group=group)
-    got = got.cpu().numpy().reshape(world, cap, -1)
-    fusion.rehome_end(np.concatenate([got[r, :n_all[r]] for r in range(world)]))
-    return sum(n_all)
+    turned = 0
+    if cap > 0:
+        pad = torch.zeros((cap, mine.shape[1]), dtype=torch.int32, device=dev)
+        if len(mine):
+            pad[:len(mine)] = torch.from_numpy(mine).to(dev)
+        got = torch.zeros((world * cap, mine.shape[1]), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(got, pad, group=group)
+        got = got.cpu().numpy().reshape(world, cap, -1)
+        turned = int(fusion.rehome_end(np.concatenate([got[r, :n_all[r]] for r in range(world)])))
+        lost = torch.tensor([turned], dtype=torch.int64, device=dev)
+        dist.all_reduce(lost, op=dist.ReduceOp.SUM, group=group)          # (every rank makes this call: cap is the same everywhere)
+        turned = int(lost.cpu()[0])
+    rep = RehomeReport(sum(n_all))
+    rep.turned_away = turned
+    if turned > 0 and on_loss != "ignore":
+        msg = "re-homing sweep: %d row(s) turned away by full shards and lost to the map (raise nb_supersurfels_max per rank)" % turned
+        if on_loss == "raise":
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+    return rep
 
 
 class ShardedFusion:

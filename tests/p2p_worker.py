@@ -109,7 +109,8 @@ def main():
         f.apply_deformation(*util.deformation_for(f.get_model(), cfg.get("nodes", 12), angle=cfg.get("angle", 0.01), shift=cfg.get("shift", 0.004)))
         tables = trade(d, "t", rank, world, f.rehome_begin())
         moved = len(tables[rank])
-        f.rehome_end(np.concatenate(tables))
+        turned = f.rehome_end(np.concatenate(tables))
+        assert turned == 0, "rank %d turned %d arrival(s) away" % (rank, turned)
         m = f.get_model()
         home = bool((synthetic.tile_owner(m["positions"][m["confidences"] > 0], world, cfg.get("tile", 0.25)) == rank).all())
         np.save(os.path.join(d, "home%d.npy" % rank), np.array([home, moved]))

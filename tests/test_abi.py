@@ -86,6 +86,24 @@ def test_the_product_library_reads_no_environment_variable(product_lib):
         assert "getenv(" not in body, src
 
 
+def test_the_product_exports_no_probe_entry_points(product_lib):
+    """round 5: the ablation timers, fault injection and record dumps (ssf_dbg_time_pass / _time_icp / _extract_only /
+    _stall_before_match_us / ...) exist only in the lab build; what the product exports under ssf_dbg_ is exactly the
+    documented test hooks of include/ssf_testing.h (host arithmetic, no device code), and every kernel probe bit
+    (SSF_PROBE) is the constant false there"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", product_lib.path], stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(set(re.findall(r"\b(ssf_dbg_[a-z0-9_]+)\b", out)))
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ssf_testing.h")).read(), flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(ssf_dbg_[a-z0-9_]+)\s*\(", txt)))
+    assert exported == hooks, sorted(set(exported) ^ set(hooks))
+    dev = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", "ssf_device.hpp")).read()
+    assert "#define SSF_PROBE(dbg, bits) (false)" in dev
+    for src in ("ssf_extract.hip", "ssf_track_fuse.hip"):
+        body = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", src)).read()
+        assert not re.search(r"\bdbg\s*&\s*\d", body), src          # a probe bit tested outside SSF_PROBE
+
+
 def test_comm_info_without_an_exchange(oracle_lib):
     f = binding.Fusion(oracle_lib, oracle_lib.default_config(width=160, height=128, fx=131.25, fy=131.25, cx=79.5, cy=63.5, nb_supersurfels_max=2048))
     assert f.comm_info() == dict(backend="none", ranks=1, rank=0)

@@ -604,9 +604,9 @@ def test_association_inside_the_waiting_icp_launch(oracle_lib, product_lib):
     for a, b in zip(want, got):
         util.same_result(a, b)
     util.compare_state(fo, fh)
-    product_lib.lib.ssf_dbg_waiter_matches.restype = C.c_longlong
-    product_lib.lib.ssf_dbg_waiter_matches.argtypes = [C.c_void_p]
-    n = product_lib.lib.ssf_dbg_waiter_matches(fh.h)
+    product_lib.lib.ssf_waiter_matches.restype = C.c_longlong
+    product_lib.lib.ssf_waiter_matches.argtypes = [C.c_void_p]
+    n = product_lib.lib.ssf_waiter_matches(fh.h)
     iters = [r["icp_iters"] for r in got]
     assert n >= 1, ("no frame's association ran in a waiting launch", iters)
     assert n == sum(1 for r in got if r["icp_iters"] > 0), (n, iters)
@@ -626,31 +626,32 @@ def test_a_loop_that_ends_at_the_iteration_cap_associates_in_a_waiting_launch_to
     for a, b in zip(want, got):
         util.same_result(a, b)
     util.compare_state(fo, fh)
-    product_lib.lib.ssf_dbg_waiter_matches.restype = C.c_longlong
-    product_lib.lib.ssf_dbg_waiter_matches.argtypes = [C.c_void_p]
+    product_lib.lib.ssf_waiter_matches.restype = C.c_longlong
+    product_lib.lib.ssf_waiter_matches.argtypes = [C.c_void_p]
     iters = [r["icp_iters"] for r in got]
     assert all(i == 10 for i in iters), iters
-    assert product_lib.lib.ssf_dbg_waiter_matches(fh.h) == len(got), (product_lib.lib.ssf_dbg_waiter_matches(fh.h), iters)
+    assert product_lib.lib.ssf_waiter_matches(fh.h) == len(got), (product_lib.lib.ssf_waiter_matches(fh.h), iters)
 
 
-def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, product_lib):
+def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, lab_lib):
     """The host's word SSF_ICP_GO_MATCH has no acknowledgement: a calling thread stalled for longer than the waiting launch's
     0.25 s bound (descheduled, debugger, SIGSTOP -- here a test hook sleeps 0.35 s in front of the word) posts it after the
     resident workgroups have given up, and only the late-dispatched part of the grid would associate.  The host bounds the
     device's wait with its own clock and runs the association again as a launch of its own: results stay the oracle's."""
     import ctypes as C
+    product_lib = lab_lib            # (the stall is a fault-injection hook: it exists in the lab build of the same sources only)
     fo, nv = seeded(oracle_lib, 50000, 640, 480)
     fh, _ = seeded(product_lib, 50000, 640, 480)
     L = product_lib.lib
     L.ssf_dbg_stall_before_match_us.argtypes = [C.c_void_p, C.c_longlong]; L.ssf_dbg_stall_before_match_us.restype = None
-    L.ssf_dbg_waiter_match_repairs.argtypes = [C.c_void_p]; L.ssf_dbg_waiter_match_repairs.restype = C.c_longlong
+    L.ssf_waiter_match_repairs.argtypes = [C.c_void_p]; L.ssf_waiter_match_repairs.restype = C.c_longlong
     L.ssf_dbg_stall_before_match_us(fh.h, 350000)
     for k in range(4):
         rgb, depth = util.frame(k, 640, 480, noise=True, holes=0.02)
         ro, rh = fo.process_frame(rgb, depth), fh.process_frame(rgb, depth)
         util.same_result(ro, rh)
     util.compare_state(fo, fh)
-    assert L.ssf_dbg_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
+    assert L.ssf_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
 
 
 @pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_SKIP=1"])
@@ -701,23 +702,23 @@ def test_a_later_handle_runs_on_the_streams_of_an_earlier_one(oracle_lib, produc
     ran the same sequence at 6400 instead of 11 300 frames/s (round 4).  A destroyed handle leaves its streams in a pool and the
     next one takes them; results are the oracle's on both."""
     L = product_lib.lib
-    L.ssf_dbg_pooled_streams.restype = __import__("ctypes").c_int
+    L.ssf_pooled_streams.restype = __import__("ctypes").c_int
     frames = [util.frame(k, 160, 128) for k in range(3)]
     def run():
         fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, 160, 128))
         fh = binding.Fusion(product_lib, util.make_cfg(product_lib, 160, 128, pipeline_depth=2, extract_batch=2))
-        idle_while_alive = L.ssf_dbg_pooled_streams()
+        idle_while_alive = L.ssf_pooled_streams()
         for rgb, depth in frames:
             util.same_result(fo.process_frame(rgb, depth), fh.process_frame(rgb, depth))
         util.compare_state(fo, fh)
         fh.close(); fo.close()
         return idle_while_alive
     run()
-    after_first = L.ssf_dbg_pooled_streams()
+    after_first = L.ssf_pooled_streams()
     assert after_first >= 4, after_first                    # track stream + three extract contexts (+ the capture stream)
     alive = run()
     assert alive <= after_first - 4, (alive, after_first)   # the second handle took them
-    assert L.ssf_dbg_pooled_streams() >= after_first        # ... and gave them back
+    assert L.ssf_pooled_streams() >= after_first        # ... and gave them back
 
 
 @pytest.mark.gpu
@@ -756,5 +757,5 @@ def test_a_long_sequence_of_host_frames_wraps_the_upload_ring(oracle_lib, produc
     util.compare_state(fo, fh)
     import ctypes as C
     st = (C.c_double * 6)()
-    product_lib.lib.ssf_dbg_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-    assert product_lib.lib.ssf_dbg_upload_stats(fh.h, st) == 0 and int(st[1]) == nf, list(st)
+    product_lib.lib.ssf_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    assert product_lib.lib.ssf_upload_stats(fh.h, st) == 0 and int(st[1]) == nf, list(st)

@@ -183,6 +183,52 @@ def test_rehoming_into_a_full_shard_turns_the_surplus_away(oracle_lib):
     assert rehoming_into_a_full_shard(oracle_lib) > 0
 
 
+def _full_shard_worker(rank, world, port, outdir):
+    """the set-up of rehoming_into_a_full_shard over gloo: rank 1 holds the whole map, rank 0 has room for five arrivals"""
+    import warnings
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = binding.Library(ORACLE_LIB)
+    whole = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096))
+    whole.process_frame(*util.frame(0, W, H))
+    m = whole.get_model()
+    ok = m["confidences"] > 0
+    S = ((W + 15) // 16) * ((H + 15) // 16)
+    n0, room = S + 11, 5
+    if rank == 1:
+        f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=1, nranks=world, shard_tile=0.25))
+        f.set_model(m, whole.counts()["n_visible"], 1)
+    else:
+        f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=n0 + room, rank=0, nranks=world, shard_tile=0.25))
+        from supersurfel_fusion_amd import synthetic
+        mine = np.flatnonzero(ok & (synthetic.tile_owner(m["positions"], world, 0.25) == 0))      # rows that stay: no room is freed
+        pick = mine[np.arange(n0) % len(mine)]
+        f.set_model({k: v[pick] for k, v in m.items()}, n0 // 2, 1)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        rep = sharded.rehome_over(f, world)
+    raised = False
+    try:
+        sharded.rehome_over(f, world, on_loss="raise")             # (second sweep: nothing left to move, nothing lost)
+    except RuntimeError:
+        raised = True
+    np.save(os.path.join(outdir, "lost%d.npy" % rank), np.array([int(rep), rep.turned_away, len(caught), int(raised)]))
+    dist.destroy_process_group()
+
+
+def test_rows_lost_in_a_rehoming_sweep_are_reported_on_every_rank(tmp_path):
+    """ssf_rehome_end's positive return (arrivals a full shard turned away) used to be dropped by sharded.rehome_over: rows
+    that had already left their source shard vanished from the global map without a signal (advisor, round 4).  Now the
+    count is summed over the ranks, every rank's report carries it and warns."""
+    world = 2
+    mp.spawn(_full_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "lost%d.npy" % r)) for r in range(world)]
+    assert got[0][0] == got[1][0] > 5                       # rows that changed rank
+    assert got[0][1] == got[1][1] == got[0][0] - 5          # all but the five that fitted: the same number on BOTH ranks
+    assert got[0][2] >= 1 and got[1][2] >= 1                # both warned
+    assert got[0][3] == 0 and got[1][3] == 0                # the clean second sweep does not raise
+
+
 def _rehome_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -168,7 +168,8 @@ def rehome_in_process(ranks):
     tables = [f.rehome_begin() for f in ranks]
     allt = np.concatenate(tables) if sum(len(t) for t in tables) else np.zeros((0, binding.MIGRANT_WORDS), np.int32)
     for f in ranks:
-        f.rehome_end(allt)
+        turned = f.rehome_end(allt)
+        assert turned == 0, "a shard turned %d arrival(s) away: they are lost to the map" % turned
     return [len(t) for t in tables]
 
 

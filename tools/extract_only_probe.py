@@ -13,7 +13,7 @@ import bench  # noqa: E402
 from supersurfel_fusion_amd import binding  # noqa: E402
 
 dev = torch.device("cuda", 0)
-lib = binding.load_product()
+lib = binding.load_lab()          # (the probe entry points live in the lab build: -DSSF_EXPERIMENTS)
 fn = lib.lib.ssf_dbg_extract_only
 fn.restype = C.c_double
 fn.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from supersurfel_fusion_amd import binding, synthetic
-lib = binding.load_product()
+lib = binding.load_lab()          # (the probe entry points live in the lab build: -DSSF_EXPERIMENTS)
 nf = 24 + int(os.environ.get('PROBE_NF', '1200'))
 frames = bench.render_frames(64)
 model, nvis = synthetic.seed_model_cam0(bench.N_MODEL, bench.W, bench.H, stamp=30)
@@ -37,10 +37,10 @@ for kind in os.environ.get("PROBE_KINDS", "device,pageable,pinned").split(","):
     nfh = max(ht[3], 1.0)
     print("          host thread, per frame: submit %.1f us | ICP loop %.1f us (until its first record %.1f) | association + fuse %.1f us; extract ready at activation %.0f %%"
           % (ht[0] / nfh, ht[1] / nfh, ht[5] / nfh, ht[2] / nfh, 100.0 * ht[4] / nfh))
-    if kind != "device" and hasattr(lib.lib, "ssf_dbg_upload_stats"):
+    if kind != "device" and hasattr(lib.lib, "ssf_upload_stats"):
         st = (C.c_double * 6)()
-        lib.lib.ssf_dbg_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-        lib.lib.ssf_dbg_upload_stats(f.h, st)
+        lib.lib.ssf_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.lib.ssf_upload_stats(f.h, st)
         nfr = max(st[1], 1.0)
         print("          upload: %d workers, %d frames; per frame and worker-thread: ring wait %.0f us, staging memcpy %.0f us, two hipMemcpyAsync %.0f us; "
               "submitting thread waited %.0f us per frame for uploads" % (st[0], st[1], st[2] / nfr, st[3] / nfr, st[4] / nfr, st[5] / nfr))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import util
 from supersurfel_fusion_amd import binding, synthetic
 # (the measurement arms and their switches live in the lab build of the sources)
-lib = binding.load_lab() if (os.environ.get("SSF_ICP_WRED") or os.environ.get("SSF_ICP_PER_LANE")) else binding.load_product()
+lib = binding.load_lab()          # (ssf_dbg_time_icp and the probe bits: lab build)
 lib.lib.ssf_dbg_time_icp.restype = C.c_double
 lib.lib.ssf_dbg_time_icp.argtypes = [C.c_void_p, C.c_int, C.c_int]
 W, H = (1280, 960) if "--config3" in sys.argv else (640, 480)

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--independent", action="store_true", help="the handles are NOT shards: each holds the whole map (no exchange), "
                                                                "all run side by side -- is it the exchange, or handles running concurrently?")
     a = ap.parse_args()
-    lib = binding.load_product()
+    lib = binding.load_lab()          # (ssf_dbg_last_icp_record / _device_icp_records: lab build)
     lib.lib.ssf_dbg_last_icp_record.argtypes = [C.c_void_p, C.c_void_p]
     lib.lib.ssf_dbg_device_icp_records.argtypes = [C.c_void_p, C.c_void_p]
     dev = torch.device("cuda", 0)

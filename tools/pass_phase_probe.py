@@ -29,7 +29,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--read":
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import util
 from supersurfel_fusion_amd import binding
-lib = binding.load_product()
+lib = binding.load_lab()          # (the probe entry points live in the lab build: -DSSF_EXPERIMENTS)
 lib.lib.ssf_dbg_time_pass.restype = C.c_double
 lib.lib.ssf_dbg_time_pass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
 f = binding.Fusion(lib, util.make_cfg(lib, 640, 480, nb_supersurfels_max=50000, extract_batch=8))

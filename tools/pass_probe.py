@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import util
 from supersurfel_fusion_amd import binding
-lib = binding.load_product()
+lib = binding.load_lab()          # (the probe entry points live in the lab build: -DSSF_EXPERIMENTS)
 lib.lib.ssf_dbg_time_pass.restype = C.c_double
 lib.lib.ssf_dbg_time_pass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 480)

@@ -17,7 +17,7 @@ from supersurfel_fusion_amd import binding, synthetic  # noqa: E402
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda", 0)
-lib = binding.load_product()
+lib = binding.load_lab()          # (the probe entry points live in the lab build: -DSSF_EXPERIMENTS)
 nf = 100
 frames = bench.render_frames(nf)
 d_rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]

@@ -15,11 +15,11 @@ f.set_model(model, nvis, 30)
 idx = lambda j: j % 60
 seq = lambda n, o=0: f.prepare_sequence([d_rgb[idx(o + j)].data_ptr() for j in range(n)], [d_depth[idx(o + j)].data_ptr() for j in range(n)])
 f.process_prepared(seq(40)); f.process_prepared(seq(20, 40))            # graphs of every batch size built
-lib.lib.ssf_dbg_sequence_times.argtypes = [C.c_void_p, C.c_void_p]
+lib.lib.ssf_sequence_times.argtypes = [C.c_void_p, C.c_void_p]
 for rep in range(3):
     prep = seq(20, 60 + 20 * rep)
     torch.cuda.synchronize(); t0 = time.perf_counter(); f.process_prepared(prep); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    t = np.zeros(64); lib.lib.ssf_dbg_sequence_times(f.h, t.ctypes.data_as(C.c_void_p))
+    t = np.zeros(64); lib.lib.ssf_sequence_times(f.h, t.ctypes.data_as(C.c_void_p))
     print("20 frames: %.0f us in all (%.0f frames/s); frame k done at [us]: %s" % (1e6 * dt, 20 / dt, " ".join("%d" % v for v in t[:20])))
     print("   per-frame increments: %s" % " ".join("%d" % v for v in np.diff(np.concatenate([[0], t[:20]]))))
 prep = seq(600, 120)
