@@ -631,12 +631,12 @@ def main():
     if rank == 0 and a.extras and hasattr(lib.lib, "ssf_stream_copy_rate"):
         lib.lib.ssf_stream_copy_rate.restype = ctypes.c_double
         lib.lib.ssf_stream_copy_rate.argtypes = [ctypes.c_int, ctypes.c_int]
-        v = lib.lib.ssf_stream_copy_rate(1024, 10)
+        v = lib.lib.ssf_stream_copy_rate(1024, 6)          # (best of six forms of the copy: unrolled 4 / 8, plain / non-temporal, grid-stride / one pass)
         hbm_float4 = v if v > 0 else None
     if roofline is not None and (hbm_measured or hbm_float4):
         best_copy = max(hbm_measured or 0.0, hbm_float4 or 0.0)
         roofline["peak_measured"] = best_copy; roofline["frac_of_measured"] = roofline["achieved"] / best_copy
-        roofline["peak_measured_note"] = "best of torch's copy kernel (%s GB/s) and the library's float4 stream copy (%s GB/s), 1 GiB read + 1 GiB written" % (
+        roofline["peak_measured_note"] = "best of torch's copy kernel (%s GB/s) and the library's float4 stream copy (%s GB/s: best of six forms, unrolled / non-temporal / one pass), 1 GiB read + 1 GiB written" % (
             "%.0f" % hbm_measured if hbm_measured else "n/a", "%.0f" % hbm_float4 if hbm_float4 else "n/a")
 
     # ---- the same workload handed over differently (N = 1): host-resident frames (what the reference's caller has: cv::Mat,
@@ -710,20 +710,26 @@ def main():
     # (LAST of everything this process measures: its OpenMP teams fault memory in on every NUMA node of the host, and host frames
     # allocated afterwards -- the extras above -- were staged out of whatever the allocator recycled: the first extra ran at 4700
     # instead of 8200 frames/s behind it, round 4)
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and a.cpu_frames > 0:            # (the contract: the CPU baseline on rank 0 at N = 1 only)
         import subprocess
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         mk = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "omp", "native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         legs, omp_probe = {}, {}
 
-        def time_oracle(olib, nfr, first=1):
+        PARITY_KEYS = ("icp_valid", "icp_iters", "n_model", "n_visible", "n_removed", "n_inserted", "n_updated")
+
+        def time_oracle(olib, nfr, first=1, keep=None):
+            """keep: a list that receives (pose, counters) of every timed frame -- the parity leg below replays the same frames on
+            the product"""
             fo = binding.Fusion(olib, make_cfg(olib, N_MODEL + 65536, 0, 1, None, a.force_icp, prefilter=1 if a.config == 5 else 0))
             fo.set_model(model, nvis, 30)
             fo.process_frame(*h_frames[0])                    # warm-up frame
             t1 = time.perf_counter()
             for i in range(first, first + nfr):
-                fo.process_frame(*h_frames[i])
+                r = fo.process_frame(*h_frames[i])
+                if keep is not None:
+                    keep.append((np.array(r["pose"], np.float32), [int(r[k]) for k in PARITY_KEYS]))
             dt_ = time.perf_counter() - t1
             fo.close()
             return nfr / dt_, nfr, dt_
@@ -742,13 +748,38 @@ def main():
                     break
             omp_threads = max(omp_probe, key=omp_probe.get)
             olib.lib.ssf_oracle_set_threads(omp_threads)
-            legs["openmp"] = time_oracle(olib, a.cpu_frames)
+            oracle_frames = []
+            legs["openmp"] = time_oracle(olib, a.cpu_frames, keep=oracle_frames)
+            # ---- parity inside the driver's record (north_star: "pose error vs reference <= 1e-4"): the frames the CPU oracle
+            # has just been timed on, replayed on a product handle (the same call: one process_frame per host frame, one frame in
+            # flight).  Checker only: nothing here is timed or shipped. ------------------------------------------------------------
+            try:
+                fp = binding.Fusion(lib, make_cfg(lib, N_MODEL + 65536, 0, 1, None, a.force_icp, 0, 1, prefilter=1 if a.config == 5 else 0))
+                fp.set_model(model, nvis, 30)
+                fp.process_frame(*h_frames[0])
+                worst, equal, counters_equal = 0.0, 0, 0
+                for j, (pose_o, cnt_o) in enumerate(oracle_frames):
+                    r = fp.process_frame(*h_frames[1 + j])
+                    pose_p = np.array(r["pose"], np.float32)
+                    worst = max(worst, float(np.abs(pose_p.astype(np.float64) - pose_o.astype(np.float64)).max()))
+                    same_cnt = [int(r[k]) for k in PARITY_KEYS] == cnt_o
+                    counters_equal += 1 if same_cnt else 0
+                    equal += 1 if (same_cnt and np.array_equal(pose_p.view(np.uint32), pose_o.view(np.uint32))) else 0
+                fp.close()
+                parity = dict(frames=len(oracle_frames), frames_bit_equal=equal, frames_counters_equal=counters_equal, max_abs_pose_diff=worst,
+                              tolerance=1e-4, within_tolerance=bool(worst <= 1e-4),
+                              checked="pose (12 floats, bit patterns) and %s of every frame: HIP product (one frame in flight, host frames) against "
+                                      "the CPU oracle (OpenMP build; its bits equal the single-threaded checker's, tests/test_oracle.py) on the "
+                                      "cpu_baseline sample of this workload" % ", ".join(PARITY_KEYS))
+            except Exception as e:               # the parity leg must never take the headline line with it
+                parity = dict(error=repr(e))
         if legs:
             best = "openmp" if "openmp" in legs else "single_thread"
             cpu = dict(value=legs[best][0], unit="frames/s", cores=omp_threads if best == "openmp" else 1, kind="port", host_cores=ncpu,
                        single_thread_frames_per_sec=legs.get("single_thread", (None,))[0],
                        openmp_frames_per_sec=legs.get("openmp", (None,))[0], openmp_threads=omp_threads,
                        openmp_probe_frames_per_sec_by_threads={str(k): v for k, v in omp_probe.items()},
+                       parity=parity,            # (inside this object as well: the driver's record keeps config / roofline / cpu_baseline whole)
                        sample="the same %dx%d / ~%d-supersurfel workload on the CPU oracle (the build's restatement of the reference "
                               "algorithm; the reference has no CPU path), g++ -O3 -march=native: %s" %
                               (W, H, N_MODEL, "; ".join("%s %d frames in %.1f s" % (k, v[1], v[2]) for k, v in legs.items())))
@@ -762,6 +793,13 @@ def main():
                           peak=HBM_PEAK_GBS, unit="GB/s", frac=fbytes / (dt / K) / 1e9 / HBM_PEAK_GBS,
                           note="extract 180 B/pixel, ICP 36 B/visible supersurfel/iteration + frame tables, fuse: association 40 B/visible, "
                                "classify 28 B/row, row moves 2 B/slot + 208 B/visible row (the reference's full reorder would be 212 B/row)")
+    node_call = max([(extras or {}).get(k, {}).get("frames_per_sec") or 0.0 for k in ("host_frames_and_depth_prefilter", "host_frames_and_depth_prefilter_depth1")]) or None
+    if roofline is not None:
+        # the whole-frame view inside the object the driver keeps: algorithmic bytes of one frame over the frame time of the timed
+        # region, and over the steady-state frame time (720 further frames) when that was measured
+        roofline["frame_frac"] = frame_roofline["frac"]; roofline["frame_algo_bytes"] = fbytes; roofline["frame_achieved"] = frame_roofline["achieved"]
+        if steady:
+            roofline["frame_frac_steady"] = fbytes * steady["frames_per_sec"] / 1e9 / HBM_PEAK_GBS
     gcounts = gcounts_early if drv is None else dict(n_model=last["global_n_model"], n_visible=last["global_n_visible"])
     if rank == 0:
         gn, gv = gcounts["n_model"], gcounts["n_visible"]
@@ -780,6 +818,10 @@ def main():
                        "exchange_note": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        # what the attached exchange itself reports (ncclCommCount / opened regions): must equal n_gpus
                        "exchange_ranks_reported": comm_info["ranks"], "exchange_backend_attached": comm_info["backend"],
+                       # (the figures the README leads with, inside the object the driver's record keeps whole)
+                       "pipeline_depth": depth, "extract_batch": batch, "extract": "replicated" if world > 1 else "single rank",
+                       "steady_state_frames_per_sec": steady["frames_per_sec"] if steady else None,
+                       "node_call_frames_per_sec": node_call, "sequential_ms_per_frame": seq_ms,
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "
                                       "ahead of ICP/fusion on its own HIP streams, %d per extract launch" % (world, cap_frames if (depth or batch > 1) else 0, batch)},
             "pipeline_depth": depth, "extract_batch": batch, "warmup_extra_frames": Wm - a.warmup, "sequential_ms_per_frame": seq_ms,
@@ -789,8 +831,8 @@ def main():
             "hbm_peak_measured_GBs": max(hbm_measured or 0.0, hbm_float4 or 0.0) or None, "hbm_peak_torch_copy_GBs": hbm_measured, "hbm_peak_float4_copy_GBs": hbm_float4,
             # the reference node's real call (host images in, depth pre-filter inside the frame), beside the headline
             # whose frames are HBM-resident and already filtered
-            "as_the_reference_node_calls_it_frames_per_sec": max([(extras or {}).get(k, {}).get("frames_per_sec") or 0.0 for k in
-                                                                  ("host_frames_and_depth_prefilter", "host_frames_and_depth_prefilter_depth1")]) or None,
+            "as_the_reference_node_calls_it_frames_per_sec": node_call,
+            "parity": parity,
             "roofline": roofline, "frame_roofline": frame_roofline, "cpu_baseline": cpu, "extras": extras, "kernel_source_sha": kernel_source_sha(), "host_affinity": affinity,
             "per_kernel": per_kernel,
         }

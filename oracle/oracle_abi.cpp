@@ -18,6 +18,7 @@
 #endif
 
 using namespace orc;
+namespace orc { int g_oracle_rsqrt_ulp = 0; }       // (test hook of oracle_math.h normalize(): see ssf_oracle_set_rsqrt_ulp below)
 
 struct PendingFrame { std::vector<uint8_t> rgb; std::vector<float> depth; std::vector<uint8_t> mask; bool has_mask; };
 struct ssf_handle { State s; std::deque<PendingFrame> pending; bool fusing = false; };
@@ -428,6 +429,10 @@ int ssf_upload_stats(ssf_handle* h, double* out6) { if (!h || !out6) return SSF_
 int ssf_pooled_streams(void) { return 0; }
 long long ssf_waiter_matches(ssf_handle* h) { return h ? 0 : -1; }
 long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? 0 : -1; }
+
+// test hook (oracle only, see oracle_math.h normalize()): 0 = the specification, -2 .. 2 = every reciprocal square root moved
+// by that many ulp, 3 = by a pseudo-random number of ulp in [-2, 2]
+int ssf_oracle_set_rsqrt_ulp(int mode) { orc::g_oracle_rsqrt_ulp = (mode >= -2 && mode <= 3) ? mode : 0; return orc::g_oracle_rsqrt_ulp; }
 
 // OpenMP build only (the timed CPU baseline): number of threads of the parallel loops; returns the number in effect
 // (1 for the single-threaded checker).  Not part of ssf.h.

@@ -39,7 +39,25 @@ static inline f3 cross(f3 a, f3 b) {
 // vector_math.cuh:241-244
 static inline float length(f3 v) { return sqrtf(dot(v, v)); }
 // vector_math.cuh:247-252 (rsqrtf -> exact 1/sqrt, see header)
-static inline f3 normalize(f3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
+// TEST HOOK (oracle only; tests/test_oracle.py::test_a_2_ulp_reciprocal_square_root_flips_no_integer_decision): CUDA's rsqrtf is an
+// approximation within 2 ulp that cannot be observed here; g_oracle_rsqrt_ulp != 0 moves every reciprocal square root of a
+// normalize() by that many ulp (-2 .. 2), 3 = by a pseudo-random number of ulp in [-2, 2] keyed by the operand's bits -- so that
+// the integer decisions downstream (the 0.8 normal gates of ICP / association, counts, iteration numbers) can be shown not to
+// hang on the stand-in.  0 (the default) is this build's specification: the correctly rounded 1 / sqrt.
+extern int g_oracle_rsqrt_ulp;
+static inline float oracle_rsqrt(float x) {
+    float inv = 1.0f / sqrtf(x);
+    const int mode = g_oracle_rsqrt_ulp;
+    if (mode != 0 && inv > 0.f && inv < 3.0e38f) {
+        uint32_t bits; memcpy(&bits, &x, 4);
+        const int k = mode == 3 ? (int)((bits * 2654435761u) >> 16) % 5 - 2 : mode;
+        uint32_t ib; memcpy(&ib, &inv, 4);
+        ib = (uint32_t)((int32_t)ib + k);              // (positive finite floats: consecutive bit patterns are consecutive values)
+        memcpy(&inv, &ib, 4);
+    }
+    return inv;
+}
+static inline f3 normalize(f3 v) { float inv = oracle_rsqrt(dot(v, v)); return v * inv; }
 
 // ---- Cov3 / Mat33 (matrix_math.cuh) --------------------------------------------------------
 static inline Cov3 mkcov(float xx, float xy, float xz, float yy, float yz, float zz) {

@@ -1208,6 +1208,222 @@ __global__ __launch_bounds__(1024) void k_plane_filter(SegParams p, FrameMaps m,
     }
 }
 
+// The same filter for grids whose 44 B / node do not fit the 64 KB a launch gets without asking (S = 4800 at 1280x960: 211 KB).
+// What the sweeps EXCHANGE, and the centroids every node reads of its neighbours, live in LDS: 32 B / node (154 KB at S = 4800:
+// gfx950 has 160 KB per CU and a single workgroup may declare all of it); the one thing a node alone reads -- its data term Z --
+// stays in its thread's registers (NPT = nodes per thread = ceil(S / 1024) <= 5).  Same operations on the same values in the same
+// order as k_plane_filter: bit-identical.  (Round 4's fall-back kept the eleven floats in a global scratch and ran every sweep
+// through __threadfence_block: 148 us per 4-frame launch at 1280x960, 6.6 % of BASELINE config 3's GPU time for a 4800-node stencil.)
+template <int NPT>
+__global__ __launch_bounds__(1024) void k_plane_filter_regs(SegParams p, FrameMaps m, int true_buf) {
+    m = batch_slot(m, blockIdx.x);
+    const int S = p.S;
+    float* Xa = filt_lds; float* Xb = Xa + 3 * S; float* px = Xb + 3 * S; float* py = px + S;
+    const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
+    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    V3 Z[NPT];
+    // the final merge of every node (one node's sums and plane solve in registers at a time: no interleaving across nodes)
+#pragma unroll
+    for (int k = 0; k < NPT; k++) {
+        const int i = threadIdx.x + 1024 * k;
+        Z[k] = v3(0.f, 0.f, 0.f);
+        if (i < S) {
+            const SpRow sp = row_from_sums(sm, i, true, zero_row);
+            m.sp[i] = sp;
+#pragma unroll
+            for (int j = 0; j < 13; j++) m.moments[(size_t)i * 13 + j] = 0;
+            const float d0 = (sp.cx * sp.ta + sp.cy * sp.tb) + sp.tc;
+            Xa[3 * i] = d0; Xa[3 * i + 1] = sp.ta; Xa[3 * i + 2] = sp.tb;
+            Z[k] = v3(d0, sp.ta, sp.tb);
+            px[i] = sp.cx; py[i] = sp.cy;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    const float alpha = p.filter_alpha, beta = p.filter_beta, thr = p.filter_threshold;
+    for (int it = 0; it < p.filter_iter; it++) {
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            const int idx = threadIdx.x + 1024 * k;
+            if (idx < S) {
+                const int x = idx % p.gx, y = idx / p.gx;
+                Sym3 A = sym3(alpha, 0.f, 0.f, alpha, 0.f, alpha);
+                const V3 Xi = v3(Xa[3 * idx], Xa[3 * idx + 1], Xa[3 * idx + 2]);
+                V3 R = scale(alpha, Z[k]);
+                const int v[4] = {-1, 0, 0, 1}, u[4] = {0, -1, 1, 0};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int yy = y + v[j], xx = x + u[j];
+                    if (yy >= 0 && yy < p.gy && xx >= 0 && x < p.gx) {
+                        const int nidx = yy * p.gx + xx;
+                        if (nidx >= S) continue;
+                        const V3 Xj = v3(Xa[3 * nidx], Xa[3 * nidx + 1], Xa[3 * nidx + 2]);
+                        const float dx = px[idx] - px[nidx], dy = py[idx] - py[nidx];
+                        const float dz = Xi.x - Xj.x;
+                        if (isfinite(dz) && dz * dz < thr * thr) {
+                            A.xx += beta * 2.f;
+                            A.xy += -beta * dx;
+                            A.xz += -beta * dy;
+                            A.yy += beta * (2.f + dx * dx);
+                            A.yz += beta * (dx * dy);
+                            A.zz += beta * (2.f + dy * dy);
+                            R.x += beta * ((2.f * Xj.x + dx * Xj.y) + dy * Xj.z);
+                            R.y += beta * (-dx * Xj.x + 2.f * Xj.y);
+                            R.z += beta * (-dy * Xj.x + 2.f * Xj.z);
+                        }
+                    }
+                }
+                Sym3 A1;
+                V3 Xn = Xi;
+                if (sym_inverse(A, A1)) Xn = sym_mul(A1, R);
+                Xb[3 * idx] = Xn.x; Xb[3 * idx + 1] = Xn.y; Xb[3 * idx + 2] = Xn.z;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        float* t = Xa; Xa = Xb; Xb = t;
+    }
+#pragma unroll 1
+    for (int i = threadIdx.x; i < S; i += 1024) {
+        SpRow sp = m.sp[i];
+        const float X = Xa[3 * i], Y = Xa[3 * i + 1], Zz = Xa[3 * i + 2];
+        sp.ta = Y; sp.tb = Zz;
+        sp.tc = (X - sp.cx * Y) - sp.cy * Zz;
+        m.sp[i] = sp;
+    }
+}
+
+// The filter on MANY workgroups per frame, without any exchange between them (round 5).  F Jacobi sweeps make a node's final
+// state a function of the nodes within graph distance F of it, so a workgroup that owns a CORE tile of PF_TX x PF_TY nodes
+// computes everything within F of the core redundantly (the merge of those nodes included) and nobody waits for anybody: after
+// sweep s the nodes at distance > F - s from the core hold values that differ from the global iteration's -- they miss a
+// neighbour outside the window -- and by construction none of them is read on the way to the core.  The graph is the
+// reference's, typo included (TPS_RGBD_kernels.cu:583: `x<gridSizeX` where `xx<gridSizeX` was meant): the right-hand
+// neighbour of a node in the LAST column is the FIRST node of the next row.  A window that touches the last column therefore
+// takes a second rectangle along the first columns (W2: columns [0, F), one row down), whose nodes are at distance >= 1 + column
+// from the core; nothing in the first columns reads the last one, so the closure ends there.  One node per thread, 32 B per
+// node in LDS (two states, the centroid), the data term in a register; same operations on the same values as
+// k_plane_filter: bit-identical (tests/test_parity_gpu.py::test_plane_filter_at_every_grid_size).
+// Single-workgroup forms: 26.6 us per 8-frame launch at 640x480 (1200 nodes), 148 us (global scratch) / 93 us (160 KB of LDS)
+// per 4-frame launch at 1280x960 (4800 nodes) -- the merge's IEEE divisions and plane solves of a whole frame on ONE compute unit.
+#define PF_TX 16
+#define PF_TY 12
+struct PfWindow {
+    int x0, y0, w, h;              // W1: core +- F, clipped to the grid
+    int x2n, y2, h2;               // W2: columns [0, x2n) x rows [y2, y2 + h2) (x2n = 0: none)
+    int n1, n2;
+    __device__ __forceinline__ int slot(int x, int y) const {
+        const unsigned int lx = (unsigned int)(x - x0), ly = (unsigned int)(y - y0);
+        if (lx < (unsigned int)w && ly < (unsigned int)h) return (int)ly * w + (int)lx;
+        const unsigned int l2 = (unsigned int)(y - y2);
+        if ((unsigned int)x < (unsigned int)x2n && l2 < (unsigned int)h2) return n1 + (int)l2 * x2n + x;
+        return -1;
+    }
+};
+__host__ __device__ __forceinline__ PfWindow pf_window(int gx, int gy, int tx, int ty, int F) {
+    PfWindow wd;
+    const int cx0 = tx * PF_TX, cy0 = ty * PF_TY, cx1 = min(cx0 + PF_TX, gx) - 1, cy1 = min(cy0 + PF_TY, gy) - 1;
+    wd.x0 = max(cx0 - F, 0); wd.y0 = max(cy0 - F, 0);
+    const int x1 = min(cx1 + F, gx - 1), y1 = min(cy1 + F, gy - 1);
+    wd.w = x1 - wd.x0 + 1; wd.h = y1 - wd.y0 + 1; wd.n1 = wd.w * wd.h;
+    wd.x2n = 0; wd.y2 = 0; wd.h2 = 0;
+    if (x1 == gx - 1 && wd.x0 > 0 && F > 0) {                // touches the last column without holding the first
+        wd.x2n = min(F, wd.x0); wd.y2 = wd.y0 + 1;
+        wd.h2 = min(y1 + 1, gy - 1) - wd.y2 + 1;
+        if (wd.h2 <= 0) { wd.x2n = 0; wd.h2 = 0; }
+    }
+    wd.n2 = wd.x2n * wd.h2;
+    return wd;
+}
+__global__ __launch_bounds__(1024) void k_plane_filter_tiled(SegParams p, FrameMaps m, int true_buf) {
+    m = batch_slot(m, blockIdx.z);
+    const int S = p.S, F = p.filter_iter;
+    const PfWindow wd = pf_window(p.gx, p.gy, (int)blockIdx.x, (int)blockIdx.y, F);
+    const int nn = wd.n1 + wd.n2;                              // <= blockDim.x (launch_plane_filter)
+    float* Xa = filt_lds; float* Xb = Xa + 3 * nn; float* px = Xb + 3 * nn; float* py = px + nn;
+    const SpSums sm = true_buf ? m.sums[1] : m.sums[0];
+    const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int t = threadIdx.x;
+    const bool have = t < nn;
+    int x = 0, y = 0;
+    if (have) {
+        if (t < wd.n1) { const int ly = t / wd.w; x = wd.x0 + (t - ly * wd.w); y = wd.y0 + ly; }
+        else { const int q = t - wd.n1, ly = q / wd.x2n; x = q - ly * wd.x2n; y = wd.y2 + ly; }
+    }
+    const int idx = y * p.gx + x;
+    const int cx0 = (int)blockIdx.x * PF_TX, cy0 = (int)blockIdx.y * PF_TY;
+    const bool core = have && x >= cx0 && x < cx0 + PF_TX && y >= cy0 && y < cy0 + PF_TY;
+    V3 Z = v3(0.f, 0.f, 0.f);
+    SpRow sp = zero_row;
+    if (have) {
+        sp = row_from_sums(sm, idx, true, zero_row);           // the final merge (mergeTPSRGBDCoeffs_kernel) of this node
+        const float d0 = (sp.cx * sp.ta + sp.cy * sp.tb) + sp.tc;
+        Xa[3 * t] = d0; Xa[3 * t + 1] = sp.ta; Xa[3 * t + 2] = sp.tb;
+        Z = v3(d0, sp.ta, sp.tb);
+        px[t] = sp.cx; py[t] = sp.cy;
+        if (core) {
+#pragma unroll
+            for (int j = 0; j < 13; j++) m.moments[(size_t)idx * 13 + j] = 0;     // accumulators of k_render_moments
+        }
+    }
+    __syncthreads();
+    const float alpha = p.filter_alpha, beta = p.filter_beta, thr = p.filter_threshold;
+    // the neighbours' slots (-1: no such node in the reference's graph, or outside the window -- then this node is at distance F
+    // from the core and nobody reads what it computes)
+    int ns[4] = {-1, -1, -1, -1};
+    if (have) {
+        const int v[4] = {-1, 0, 0, 1}, u[4] = {0, -1, 1, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int yy = y + v[j], xx = x + u[j];
+            if (yy >= 0 && yy < p.gy && xx >= 0 && x < p.gx) {
+                const int nidx = yy * p.gx + xx;
+                if (nidx >= S) continue;
+                const int ny = nidx / p.gx, nx = nidx - ny * p.gx;          // (xx == gx: the first node of the next row)
+                ns[j] = wd.slot(nx, ny);
+            }
+        }
+    }
+    for (int it = 0; it < F; it++) {
+        if (have) {
+            Sym3 A = sym3(alpha, 0.f, 0.f, alpha, 0.f, alpha);
+            const V3 Xi = v3(Xa[3 * t], Xa[3 * t + 1], Xa[3 * t + 2]);
+            V3 R = scale(alpha, Z);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n = ns[j];
+                if (n < 0) continue;
+                const V3 Xj = v3(Xa[3 * n], Xa[3 * n + 1], Xa[3 * n + 2]);
+                const float dx = px[t] - px[n], dy = py[t] - py[n];
+                const float dz = Xi.x - Xj.x;
+                if (isfinite(dz) && dz * dz < thr * thr) {
+                    A.xx += beta * 2.f;
+                    A.xy += -beta * dx;
+                    A.xz += -beta * dy;
+                    A.yy += beta * (2.f + dx * dx);
+                    A.yz += beta * (dx * dy);
+                    A.zz += beta * (2.f + dy * dy);
+                    R.x += beta * ((2.f * Xj.x + dx * Xj.y) + dy * Xj.z);
+                    R.y += beta * (-dx * Xj.x + 2.f * Xj.y);
+                    R.z += beta * (-dy * Xj.x + 2.f * Xj.z);
+                }
+            }
+            Sym3 A1;
+            V3 Xn = Xi;
+            if (sym_inverse(A, A1)) Xn = sym_mul(A1, R);
+            Xb[3 * t] = Xn.x; Xb[3 * t + 1] = Xn.y; Xb[3 * t + 2] = Xn.z;
+        }
+        __syncthreads();
+        float* q = Xa; Xa = Xb; Xb = q;
+    }
+    if (core) {
+        const float X = Xa[3 * t], Y = Xa[3 * t + 1], Zz = Xa[3 * t + 2];
+        sp.ta = Y; sp.tb = Zz;
+        sp.tc = (X - sp.cx * Y) - sp.cy * Zz;
+        m.sp[idx] = sp;
+    }
+}
+
 // ---- plane depth + supersurfel moments -----------------------------------------------------------
 // renderDepthImage_kernel (TPS_RGBD_kernels.cu:469-508) fused with computeSupersurfelCoeffs
 // (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
@@ -1694,10 +1910,36 @@ void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, 
 }
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("plane_filter", st);
+    // many workgroups per frame (core tiles + everything within filter_iter of them), when the largest window fits a workgroup
+    {
+        const int ntx = (p.gx + PF_TX - 1) / PF_TX, nty = (p.gy + PF_TY - 1) / PF_TY;
+        int worst = 0;
+        for (int ty = 0; ty < nty; ty++)
+            for (int tx = 0; tx < ntx; tx++) { const PfWindow wd = pf_window(p.gx, p.gy, tx, ty, p.filter_iter); worst = std::max(worst, wd.n1 + wd.n2); }
+        if (worst <= 1024 && ntx * nty > 1) {
+            const int threads = ((worst + 63) / 64) * 64;
+            hipLaunchKernelGGL(k_plane_filter_tiled, dim3(ntx, nty, nb), dim3(threads), (size_t)worst * 8 * sizeof(float), st, p, m, true_buf);
+            return;
+        }
+    }
     const size_t lds = (size_t)p.S * 11 * sizeof(float);
     const int threads = p.S >= 1024 ? 1024 : ((p.S + 63) / 64) * 64;
-    if (lds <= 60 * 1024) hipLaunchKernelGGL(k_plane_filter<true>, dim3(nb), dim3(threads), lds, st, p, m, true_buf);
-    else hipLaunchKernelGGL(k_plane_filter<false>, dim3(nb), dim3(1024), 0, st, p, m, true_buf);
+    if (lds <= 60 * 1024) { hipLaunchKernelGGL(k_plane_filter<true>, dim3(nb), dim3(threads), lds, st, p, m, true_buf); return; }
+    // larger grids: states and centroids in LDS (32 B / node, up to 160 KB per workgroup), the data term in registers
+    const size_t lds2 = (size_t)p.S * 8 * sizeof(float);
+    const int npt = (p.S + 1023) / 1024;
+    static const bool big_lds = [] {                    // (once per process: these instantiations ask for more than 64 KB)
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
+        (void)hipGetLastError();
+        return ok;
+    }();
+    if (big_lds && lds2 <= 160 * 1024 && npt <= 5) {
+        if (npt <= 3) hipLaunchKernelGGL(k_plane_filter_regs<3>, dim3(nb), dim3(1024), lds2, st, p, m, true_buf);
+        else hipLaunchKernelGGL(k_plane_filter_regs<5>, dim3(nb), dim3(1024), lds2, st, p, m, true_buf);
+        return;
+    }
+    hipLaunchKernelGGL(k_plane_filter<false>, dim3(nb), dim3(1024), 0, st, p, m, true_buf);
 }
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb) {
     ScopedKernel sk("render_moments", st);

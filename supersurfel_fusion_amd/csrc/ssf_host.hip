@@ -1574,6 +1574,23 @@ struct DevTemps {
 };
 
 // ---- C ABI ----------------------------------------------------------------------------------------------
+// (kernels of ssf_stream_copy_rate, further down)
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int U, bool NT, bool ONE_PASS>
+__global__ __launch_bounds__(256) void k_stream_copy(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n) {
+    // (n is a multiple of U x the grid's threads: see the caller)
+    const size_t stride = ONE_PASS ? (size_t)256 : (size_t)gridDim.x * 256;
+    size_t i = ONE_PASS ? (size_t)blockIdx.x * 256 * U + threadIdx.x : (size_t)blockIdx.x * 256 + threadIdx.x;
+    do {
+        f4v v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(&in[i + k * stride]) : in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) { if (NT) __builtin_nontemporal_store(v[k], &out[i + k * stride]); else out[i + k * stride] = v[k]; }
+        i += U * stride;
+    } while (!ONE_PASS && i + (U - 1) * stride < n);
+}
+
 extern "C" {
 
 int ssf_abi_version(void) { return SSF_ABI_VERSION; }
@@ -2658,33 +2675,40 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
 
 #endif
 
-// What a plain stream copy reaches on THIS box (nominal AND measured-achievable peak): 16 bytes per lane,
-// grid-stride, `mib` MiB read + the same written, best of `reps` -- the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s (79 % of
-// the 8 TB/s spec).  bench.py reports it beside torch's own copy kernel, which reaches ~15 % less (`hbm_peak_measured_GBs`).
-__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
-    // four independent 16-byte loads per lane in flight, then four stores (n is a multiple of 4 x the grid's threads: see the caller)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
-        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
-        out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
-    }
-}
+// What a stream copy reaches on THIS box (nominal AND measured-achievable peak): 16 bytes per lane, `mib` MiB
+// read + the same written, best of `reps` over four forms of the same copy -- MI355X_MICROARCH.md quotes 6.29 TB/s (79 % of the
+// 8 TB/s spec) for a float4 copy; round 4's single grid-stride form reached 4.7-4.8 TB/s on these boxes and torch's own copy kernel
+// 5.2, neither tuned.  Forms: U independent 16-byte loads per lane in flight before the first store (4 or 8), plain or
+// non-temporal (`nt`: streamed data is not kept in L2 / MALL, which a copy of 2 GiB only thrashes), grid-stride over 8192
+// workgroups or one pass of exactly-sized workgroups.  The best form's rate is returned.
 double ssf_stream_copy_rate(int mib, int reps) {
     if (mib < 16 || reps < 1) return -1.0;
-    const size_t bytes = (size_t)mib << 20, n = bytes / sizeof(float4);
-    float4 *a = nullptr, *b = nullptr;
+    const size_t bytes = ((size_t)mib << 20) & ~(size_t)((1u << 25) - 1u), n = bytes / sizeof(f4v);       // a multiple of 32 MiB = 8 x 2^21 threads x 16 B... (2^21 float4)
+    if (bytes == 0) return -1.0;
+    f4v *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(a); return -1.0; }
     (void)hipMemset(a, 1, bytes); (void)hipMemset(b, 0, bytes);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     double best = 0.0;
-    for (int r = 0; r < reps + 2; r++) {
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 32), dim3(256), 0, 0, a, b, n);        // (2^26 float4 per GiB: a multiple of 4 x 2^21 threads)
-        (void)hipEventRecord(e1, 0);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (r >= 2 && ms > 0.f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+    for (int form = 0; form < 6; form++) {
+        for (int r = 0; r < reps + 2; r++) {
+            (void)hipEventRecord(e0, 0);
+            const dim3 grid_stride(256 * 32), blk(256);
+            switch (form) {
+                case 0: hipLaunchKernelGGL((k_stream_copy<4, false, false>), grid_stride, blk, 0, 0, a, b, n); break;
+                case 1: hipLaunchKernelGGL((k_stream_copy<4, true, false>), grid_stride, blk, 0, 0, a, b, n); break;
+                case 2: hipLaunchKernelGGL((k_stream_copy<8, true, false>), grid_stride, blk, 0, 0, a, b, n); break;
+                case 3: hipLaunchKernelGGL((k_stream_copy<4, true, true>), dim3((unsigned int)(n / (256 * 4))), blk, 0, 0, a, b, n); break;
+                case 4: hipLaunchKernelGGL((k_stream_copy<8, true, true>), dim3((unsigned int)(n / (256 * 8))), blk, 0, 0, a, b, n); break;
+                default: hipLaunchKernelGGL((k_stream_copy<8, false, true>), dim3((unsigned int)(n / (256 * 8))), blk, 0, 0, a, b, n); break;
+            }
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r >= 2 && ms > 0.f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+        }
     }
+    (void)hipGetLastError();
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
     return best;
 }

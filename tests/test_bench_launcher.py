@@ -102,3 +102,12 @@ def test_the_bench_line_keeps_the_drivers_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and 0.5 < cb["value"] < d["value"] and "sample" in cb
     assert d["frame_roofline"]["frac"] < 1.0 and d["kernel_source_sha"]
+    # round 5: what the README leads with sits INSIDE the objects the driver's record keeps whole, and the record carries a parity
+    # block -- the cpu_baseline sample's frames replayed on the product, poses and counters against the oracle's
+    assert abs(rf["frame_frac"] - d["frame_roofline"]["frac"]) < 1e-12
+    for key in ("steady_state_frames_per_sec", "node_call_frames_per_sec", "sequential_ms_per_frame", "pipeline_depth", "extract_batch", "extract"):
+        assert key in c, key
+    assert c["sequential_ms_per_frame"] > 0.05 and c["extract"] == "single rank"
+    par = cb["parity"]
+    assert par == d["parity"] and "error" not in par, par
+    assert par["frames"] == 4 and par["frames_bit_equal"] == 4 and par["frames_counters_equal"] == 4 and par["max_abs_pose_diff"] == 0.0 and par["within_tolerance"] is True

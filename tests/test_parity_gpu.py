@@ -309,6 +309,29 @@ def test_segmentation_parameter_space(kw, oracle_lib, product_lib):
         util.compare_state(fo, fh)
 
 
+@pytest.mark.parametrize("size,cell,filter_iter", [((640, 480), 12, 3), ((640, 480), 12, 7), ((1280, 960), 16, 3), ((1280, 960), 16, 0), ((640, 480), 8, 3), ((960, 720), 8, 4),
+                                                   ((320, 240), 16, 1), ((330, 250), 16, 5), ((640, 480), 16, 12), ((640, 480), 12, 12), ((1280, 960), 16, 12), ((960, 720), 8, 12)],
+                         ids=lambda v: "x".join(str(t) for t in v) if isinstance(v, tuple) else str(v))
+def test_plane_filter_at_every_grid_size(size, cell, filter_iter, oracle_lib, product_lib):
+    """TPS_RGBD::filter by the size of the superpixel grid and the number of sweeps.  Up to filter_iter 9 every grid larger than one
+    16 x 12 tile takes the round-5 form (k_plane_filter_tiled): many workgroups per frame, each computing its core tile and
+    everything within filter_iter of it -- including, for windows that touch the last column, the first columns one row down
+    (the reference's `x<gridSizeX` typo makes those neighbours).  More sweeps than a 1024-thread window holds fall back to one
+    workgroup per frame: all eleven floats per node in LDS up to 1396 nodes (k_plane_filter<true>), states + centroids in up to
+    160 KB of LDS with the data term in registers up to 5120 nodes (k_plane_filter_regs<3> / <5>: 2160 and 4800 nodes here), the
+    global scratch beyond (10 800 nodes).  Planes and everything rendered from them must be the oracle's, bit for bit."""
+    W, H = size
+    fo, fh = pair(oracle_lib, product_lib, W, H, nb_supersurfels_max=40000, cell_size=cell, filter_iter=filter_iter)
+    rgb, depth = util.frame(1, W, H, noise=True, holes=0.03)
+    fo.stage_extract(rgb, depth); fh.stage_extract(rgb, depth)
+    util.assert_same_bits(fo.superpixels(), fh.superpixels(), "superpixel planes after the filter")
+    util.assert_same_bits(fo.plane_depth(), fh.plane_depth(), "plane-rendered depth")
+    util.assert_same_bits(fo.index_map(), fh.index_map(), "labels")
+    a, b = fo.get_frame(), fh.get_frame()
+    for name in a:
+        util.assert_same_bits(a[name], b[name], "frame." + name)
+
+
 def test_segmentation_parameter_space_batched(oracle_lib, product_lib):
     """The same fallbacks through the batched / pipelined extract (cell 8 at 150x100: partial cells and tiles)."""
     W, H, nf = 150, 100, 7
