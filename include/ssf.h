@@ -211,6 +211,19 @@ int ssf_process_frame_device(ssf_handle* h, const void* d_rgb, const void* d_dep
 int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth_m, int on_device,
                      const uint8_t* dynamic_mask);
 int ssf_process_submitted(ssf_handle* h, const float* prior_pose, ssf_frame_result* out);
+/* The NEXT frame, extracted ELSEWHERE (multi-GPU: the extract stage dealt over the ranks, SURVEY.md section 8e -- "compute on
+ * GPU 0 and broadcast index map + plane depth + frame SoA"): takes the place of ssf_submit_frame for a frame whose extract
+ * stage another rank has run.  What the track chain reads of an extracted frame, in the reference's own terms:
+ *   label        H x W int32   TPS_RGBD::getIndexImage (TPS_RGBD.hpp:77): ssf_get_index_map of the rank that extracted it
+ *   plane_depth  H x W float   the plane-rendered depth (TPS_RGBD::computeDepthImage, TPS_RGBD.cu:507-525): ssf_get_plane_depth
+ *   frame        S rows        the frame supersurfels (generateSupersurfels, supersurfel_fusion.cu:551-593): ssf_get_frame
+ * (2.5 MB at 640 x 480).  The library rebuilds its private tables from them (bit-identical to a local extract: they are pure
+ * functions of these three) and queues the frame like a submitted one; the handle's frame counter / RANSAC epoch advance as
+ * if it had extracted the frame itself, so local and foreign frames may alternate freely.  ssf_process_submitted,
+ * ssf_stage_begin_submitted, ssf_pending_frames, ssf_can_submit treat it like any submitted frame.  A frame submitted this
+ * way forms a batch of its own.  The per-pixel getters other than the two above (inlier map, superpixel table, preview)
+ * are not defined for such a frame.  on_device = 1: device pointers. */
+int ssf_submit_frame_tables(ssf_handle* h, const int32_t* label, const float* plane_depth, const ssf_surfels* frame, int on_device);
 int ssf_pending_frames(const ssf_handle* h);
 /* Frames that can be pending at once: (pipeline_depth + 1) * extract_batch. */
 int ssf_pipeline_capacity(const ssf_handle* h);
@@ -340,6 +353,16 @@ int ssf_fern_codes(ssf_handle* h, const uint8_t* rgb, const float* depth, int wi
  * torch.distributed backend through the stage seams). */
 int ssf_comm_unique_id(uint8_t* id128);
 int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
+/* The extract stage DEALT over the ranks instead of replicated: with mode 1, batch j of
+ * the frame stream is extracted by rank j % nranks alone, which broadcasts each frame's label map + plane depth + frame
+ * supersurfels (ssf_submit_frame_tables' three quantities, 2.5 MB per 640 x 480 frame) to the others over a communicator of
+ * the batch context (ncclCommSplit of the attached one; ncclBroadcast on the context's own stream, behind its extract chain
+ * and ahead of the track chain: off the critical path).  Each rank then runs 1 / nranks of the extract work; results are
+ * bit-identical.  Collective: every rank calls it after ssf_comm_attach, with an empty pipeline; every rank must then
+ * be handed the same frame stream in the same batches (the images of a batch another rank extracts are not read).  mode 0
+ * = replicated again; mode 2 = as 1, and the extracting rank rebuilds its own tables from what it ships (a self-check).
+ * RCCL backend only.  Like the rest of the native N > 1 path it has run on ONE rank only on this build's hardware. */
+int ssf_comm_deal_extract(ssf_handle* h, int mode);
 /* what is attached: *backend = 0 none, 1 RCCL, 2 peer-to-peer regions; *ranks = the number of ranks the exchange
  * itself reports (ncclCommCount of the communicator; the number of opened regions + 1), 1 when nothing is attached;
  * *my_rank likewise (ncclCommUserRank).  A launcher prints these next to cfg.nranks: they must agree. */
@@ -476,8 +499,12 @@ double ssf_stream_copy_rate(int mib, int reps);
  *                             for a ring slot, [3] in the staging memcpy, [4] in the copy enqueues, [5] the caller's wait for uploads
  *   ssf_pooled_streams        streams of destroyed handles waiting in the process-wide pool for the next handle
  *   ssf_waiter_matches        frames whose association ran inside an ICP launch that was waiting for the host's word
- *   ssf_waiter_match_repairs  ... and the ones re-run as a launch because that word came too late to be trusted */
+ *   ssf_waiter_match_repairs  ... and the ones re-run as a launch because that word came too late to be trusted
+ *   ssf_tuner_state           out4: [0] 1 when the next frame's first ICP iteration is being accumulated by the row-move kernel
+ *                             (0: by a launch of its own) -- the library measures which is faster on the running workload,
+ *                             results are identical --, [1] pipelined frames seen, [2] / [3] the two forms' last measured means */
 int ssf_upload_stats(ssf_handle* h, double* out6);
+int ssf_tuner_state(ssf_handle* h, double* out4);
 int ssf_pooled_streams(void);
 long long ssf_waiter_matches(ssf_handle* h);
 long long ssf_waiter_match_repairs(ssf_handle* h);

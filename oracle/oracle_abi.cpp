@@ -20,7 +20,11 @@
 using namespace orc;
 namespace orc { int g_oracle_rsqrt_ulp = 0; }       // (test hook of oracle_math.h normalize(): see ssf_oracle_set_rsqrt_ulp below)
 
-struct PendingFrame { std::vector<uint8_t> rgb; std::vector<float> depth; std::vector<uint8_t> mask; bool has_mask; };
+struct PendingFrame {
+    std::vector<uint8_t> rgb; std::vector<float> depth; std::vector<uint8_t> mask; bool has_mask = false;
+    // a frame extracted elsewhere (ssf_submit_frame_tables): label map, plane depth, the S frame supersurfels
+    bool tables = false; std::vector<int32_t> label; std::vector<float> plane_depth; Surfels frame;
+};
 struct ssf_handle { State s; std::deque<PendingFrame> pending; bool fusing = false; };
 static std::string g_create_err;
 
@@ -81,6 +85,7 @@ const char* ssf_last_error(const ssf_handle* h) { return h ? h->s.err.c_str() : 
 static void frame_lab_refresh(State& s) {
     for (int k = 0; k < s.S; k++) s.frame_lab[k] = rgbToLab(s.frame.col[k]);
 }
+static void install_frame_tables(State& s, PendingFrame& f);
 
 int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth, int on_device, const uint8_t* mask) {
     (void)on_device;
@@ -161,6 +166,7 @@ int ssf_comm_info(ssf_handle* h, int* backend, int* ranks, int* my_rank) {
     if (my_rank) *my_rank = 0;
     return SSF_OK;
 }
+int ssf_comm_deal_extract(ssf_handle* h, int mode) { (void)mode; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_export(ssf_handle* h, uint8_t* handle64) { (void)handle64; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_attach(ssf_handle* h, const uint8_t* handles) { (void)handles; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
 int ssf_p2p_region(ssf_handle* h, void** region, size_t* bytes) { (void)region; (void)bytes; if (h) h->s.err = "the CPU checker has no peers"; return SSF_ERR_DEVICE; }
@@ -177,6 +183,7 @@ int ssf_stage_begin_submitted(ssf_handle* h) {
     if (h->pending.empty()) return SSF_ERR_STATE;
     PendingFrame f = std::move(h->pending.front());
     h->pending.pop_front();
+    if (f.tables) { install_frame_tables(h->s, f); frame_lab_refresh(h->s); return SSF_OK; }
     return ssf_stage_extract(h, f.rgb.data(), f.depth.data(), 0, f.has_mask ? f.mask.data() : nullptr);
 }
 int ssf_stage_icp_accumulate_device(ssf_handle* h, int64_t* d_sums) { return ssf_stage_icp_accumulate(h, d_sums); }
@@ -201,13 +208,20 @@ int ssf_stage_fuse_device(ssf_handle* h, const uint64_t* d_best, const uint8_t* 
     return ssf_stage_fuse(h, d_best, d_matched, out);
 }
 
-int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, const float* prior,
-                      const uint8_t* mask, ssf_frame_result* out) {
-    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+// a frame extracted by another rank becomes the current frame: what extract() leaves behind for ICP / association / fusion
+static void install_frame_tables(State& s, PendingFrame& f) {
+    s.label = f.label; s.plane_depth = f.plane_depth;
+    for (int k = 0; k < s.S; k++) s.frame.copy_row((size_t)k, f.frame, (size_t)k);
+    s.extract_ordinal++;                       // (extract()'s epoch guard: the next locally extracted frame draws the next counters)
+    s.have_frame = true;
+}
+static int process_current_or(ssf_handle* h, PendingFrame* tables, const uint8_t* rgb, const float* depth, const float* prior,
+                              const uint8_t* mask, ssf_frame_result* out) {
     State& s = h->s;
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    extract(s, rgb, depth, mask);
+    if (tables) install_frame_tables(s, *tables);
+    else extract(s, rgb, depth, mask);
     frame_lab_refresh(s);
     auto t1 = clk::now();
     icp_begin(s, prior);
@@ -226,6 +240,11 @@ int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, con
     r.stage_ms[2] = std::chrono::duration<float, std::milli>(t3 - t2).count();
     if (out) *out = r;
     return SSF_OK;
+}
+int ssf_process_frame(ssf_handle* h, const uint8_t* rgb, const float* depth, const float* prior,
+                      const uint8_t* mask, ssf_frame_result* out) {
+    if (!h || !rgb || !depth) return SSF_ERR_INVALID_ARG;
+    return process_current_or(h, nullptr, rgb, depth, prior, mask, out);
 }
 int ssf_pipeline_capacity(const ssf_handle* h) {
     if (!h) return 0;
@@ -247,11 +266,33 @@ int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int /*on
     h->pending.push_back(std::move(f));
     return SSF_OK;
 }
+int ssf_submit_frame_tables(ssf_handle* h, const int32_t* label, const float* plane_depth, const ssf_surfels* in, int /*on_device*/) {
+    if (!h || !label || !plane_depth || !in) return SSF_ERR_INVALID_ARG;
+    if (!in->positions || !in->colors || !in->stamps || !in->orientations || !in->shapes || !in->dims || !in->confidences) return SSF_ERR_INVALID_ARG;
+    if ((int)h->pending.size() >= ssf_pipeline_capacity(h)) return SSF_ERR_STATE;
+    const size_t P = (size_t)h->s.W * h->s.H; const int S = h->s.S;
+    PendingFrame f;
+    f.tables = true;
+    f.label.assign(label, label + P); f.plane_depth.assign(plane_depth, plane_depth + P);
+    f.frame.resize((size_t)S);
+    for (int i = 0; i < S; i++) {
+        f.frame.pos[i] = mk3(in->positions[3 * i], in->positions[3 * i + 1], in->positions[3 * i + 2]);
+        f.frame.col[i] = mk3(in->colors[3 * i], in->colors[3 * i + 1], in->colors[3 * i + 2]);
+        f.frame.stamps[2 * i] = in->stamps[2 * i]; f.frame.stamps[2 * i + 1] = in->stamps[2 * i + 1];
+        for (int r = 0; r < 3; r++) f.frame.orient[i].r[r] = mk3(in->orientations[9 * i + 3 * r], in->orientations[9 * i + 3 * r + 1], in->orientations[9 * i + 3 * r + 2]);
+        const float* c = &in->shapes[6 * i]; f.frame.shape[i] = mkcov(c[0], c[1], c[2], c[3], c[4], c[5]);
+        f.frame.dims[2 * i] = in->dims[2 * i]; f.frame.dims[2 * i + 1] = in->dims[2 * i + 1];
+        f.frame.conf[i] = in->confidences[i];
+    }
+    h->pending.push_back(std::move(f));
+    return SSF_OK;
+}
 int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* out) {
     if (!h) return SSF_ERR_INVALID_ARG;
     if (h->pending.empty()) return SSF_ERR_STATE;
     PendingFrame f = std::move(h->pending.front());
     h->pending.pop_front();
+    if (f.tables) return process_current_or(h, &f, nullptr, nullptr, prior, nullptr, out);
     return ssf_process_frame(h, f.rgb.data(), f.depth.data(), prior, f.has_mask ? f.mask.data() : nullptr, out);
 }
 int ssf_process_sequence(ssf_handle* h, const void* const* rgb, const void* const* depth, int n, int /*on_device*/, ssf_frame_result* out) {
@@ -427,6 +468,7 @@ int ssf_sequence_marks(ssf_handle* h, double* out320) { if (!h || !out320) retur
 double ssf_stream_copy_rate(int mib, int reps) { (void)mib; (void)reps; return -1.0; }
 int ssf_upload_stats(ssf_handle* h, double* out6) { if (!h || !out6) return SSF_ERR_INVALID_ARG; for (int i = 0; i < 6; i++) out6[i] = 0.0; return SSF_OK; }
 int ssf_pooled_streams(void) { return 0; }
+int ssf_tuner_state(ssf_handle* h, double* out4) { if (!h || !out4) return SSF_ERR_INVALID_ARG; for (int i = 0; i < 4; i++) out4[i] = 0.0; return SSF_OK; }
 long long ssf_waiter_matches(ssf_handle* h) { return h ? 0 : -1; }
 long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? 0 : -1; }
 

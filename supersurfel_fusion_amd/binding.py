@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "ssf_process_submitted", "ssf_pending_frames", "ssf_pipeline_capacity", "ssf_can_submit", "ssf_stage_begin_submitted",
     "ssf_stage_icp_accumulate_device", "ssf_stage_icp_fetch", "ssf_stage_match_device", "ssf_stage_fuse_device",
     "ssf_comm_unique_id", "ssf_comm_attach", "ssf_comm_info", "ssf_p2p_export", "ssf_p2p_attach", "ssf_p2p_region", "ssf_p2p_attach_local", "ssf_p2p_configure", "ssf_rehome_begin", "ssf_rehome_end", "ssf_get_global_counts", "ssf_align", "ssf_fern_codes", "ssf_process_sequence", "ssf_debug_recentre", "ssf_debug_recentre_count", "ssf_get_preview_image", "ssf_stage_fuse_begin", "ssf_stage_fuse_end", "ssf_stage_fuse_begin_device", "ssf_stage_fuse_end_device",
-    "ssf_sequence_times", "ssf_sequence_marks", "ssf_stream_copy_rate", "ssf_upload_stats", "ssf_pooled_streams", "ssf_waiter_matches", "ssf_waiter_match_repairs",
+    "ssf_sequence_times", "ssf_sequence_marks", "ssf_stream_copy_rate", "ssf_upload_stats", "ssf_pooled_streams", "ssf_waiter_matches", "ssf_waiter_match_repairs", "ssf_tuner_state", "ssf_submit_frame_tables", "ssf_comm_deal_extract",
 ]
 
 SURFEL_FIELDS = (("positions", 3, np.float32), ("colors", 3, np.float32), ("stamps", 2, np.int32),
@@ -262,6 +262,15 @@ class Fusion:
         self._ck(self.L.lib.ssf_submit_frame(self.h, rp, dp, 1 if on_device else 0, _ptr(mask)), "ssf_submit_frame")
         self._held.append((rgb, depth, mask))
 
+    def submit_frame_tables(self, label, plane_depth, frame):
+        """The next frame, extracted by ANOTHER rank (ssf_submit_frame_tables): its label map (H x W int32), plane-rendered depth
+        (H x W float32) and frame supersurfels (the dict get_frame() returns) take the place of submit_frame's images."""
+        label = np.ascontiguousarray(label, np.int32); plane_depth = np.ascontiguousarray(plane_depth, np.float32)
+        assert label.shape == (self.H, self.W) and plane_depth.shape == (self.H, self.W) and len(frame["confidences"]) == self.S
+        keep = [np.ascontiguousarray(frame[name], dt) for name, _, dt in SURFEL_FIELDS]
+        st = SsfSurfels(*[a.ctypes.data_as(C.c_void_p) for a in keep])
+        self._ck(self.L.lib.ssf_submit_frame_tables(self.h, _ptr(label), _ptr(plane_depth), C.byref(st), 0), "ssf_submit_frame_tables")
+
     def prepare_sequence(self, rgb_ptrs, depth_ptrs):
         """ctypes argument arrays of a sequence (built ahead, e.g. outside a timed region): (rgb, depth, results, n)"""
         n = len(rgb_ptrs)
@@ -409,6 +418,11 @@ class Fusion:
         return codes
 
     # ---- multi-GPU, native RCCL ------------------------------------------------------------------
+    def comm_deal_extract(self, mode=1):
+        """After comm_attach, on every rank: batch j of the frame stream is extracted by rank j % nranks alone, which broadcasts
+        its frames' tables (ssf_comm_deal_extract; mode 2 additionally re-imports on the extracting rank: a self-check)"""
+        self._ck(self.L.lib.ssf_comm_deal_extract(self.h, int(mode)), "ssf_comm_deal_extract")
+
     def comm_attach(self, group=None):
         """Attach an RCCL communicator over the ranks of a torch.distributed group (which is only used
         to ship rank 0's unique id); afterwards process_frame / process_submitted exchange natively."""

@@ -226,6 +226,9 @@ void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb);
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac);
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);   // includes the final merge
+// a frame extracted by another rank (ssf_submit_frame_tables): m.label / m.plane_depth hold its maps, wire its 26 S words
+void launch_import_frame(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, const float* wire, unsigned long long* best, uint8_t* matched);
+void launch_export_rows(hipStream_t st, const SegParams& p, const FrameMaps& m, int nb, SurfelSoA frame, float* wire);      // the nb slots' supersurfels -> their wire buffers
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb);
 // frame k of the batch gets stamp stamp0 + k; bit k of mask_bits: dynamic_mask slot k is valid
 void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, float zmin,

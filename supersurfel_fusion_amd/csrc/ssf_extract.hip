@@ -1328,8 +1328,12 @@ __host__ __device__ __forceinline__ PfWindow pf_window(int gx, int gy, int tx, i
     wd.w = x1 - wd.x0 + 1; wd.h = y1 - wd.y0 + 1; wd.n1 = wd.w * wd.h;
     wd.x2n = 0; wd.y2 = 0; wd.h2 = 0;
     if (x1 == gx - 1 && wd.x0 > 0 && F > 0) {                // touches the last column without holding the first
-        wd.x2n = min(F, wd.x0); wd.y2 = wd.y0 + 1;
-        wd.h2 = min(y1 + 1, gy - 1) - wd.y2 + 1;
+        // rows: a node of the last column at distance d from the core has its wrap neighbour (0, y + 1) at distance d + 1, whose
+        // column neighbours matter up to F - d - 1 rows away: rows [cy0 - F + 2, cy1 + F] whatever d (one more row on top kept);
+        // NOT "the window's rows + 1": a window clipped by the top of the grid still needs row 0 (found by the test with
+        // filter_threshold 1.0, where no neighbour is gated away)
+        wd.x2n = min(F, wd.x0); wd.y2 = max(cy0 - F + 1, 0);
+        wd.h2 = min(cy1 + F + 1, gy - 1) - wd.y2 + 1;
         if (wd.h2 <= 0) { wd.x2n = 0; wd.h2 = 0; }
     }
     wd.n2 = wd.x2n * wd.h2;
@@ -1598,6 +1602,66 @@ __global__ __launch_bounds__(256) void k_finalize_surfels(SegParams p, FrameMaps
     m.fpack[4 * k + 2] = make_float4(pos.x, pos.y, pos.z, 0.f);
 }
 
+// ---- a frame extracted elsewhere (ssf_submit_frame_tables: the extract stage dealt over the ranks of a sharded map) -------------
+// What the track chain reads of a frame -- the supersurfel SoA with its Lab cache, the 64-byte lines of ICP / association (fpack),
+// the packed (label, plane depth) table (pix2), the association tables' initial state -- rebuilt from the three things another
+// rank ships: label map and plane depth (already in this slot's maps) and the S frame supersurfels in the reference's layout
+// (`wire`: positions 3S | colours 3S | stamps 2S | orientations 9S | shapes 6S | dims 2S | confidences S).  Every value is a
+// copy or a pure function of those (lab = rgb_to_lab(colour), as k_finalize_surfels computes it): bit-identical to a local extract.
+__global__ __launch_bounds__(256) void k_import_frame(int P, int S, FrameMaps m, SurfelSoA f, const float* __restrict__ wire,
+                                                      unsigned long long* __restrict__ best, uint8_t* __restrict__ matched) {
+    {                                                                   // slot blockIdx.y of the batch context
+        const size_t off = (size_t)blockIdx.y * m.slab;
+        m = batch_slot(m, blockIdx.y); f = batch_slot(f, off); wire = slab_shift(wire, off);
+        best = slab_shift(best, off); matched = slab_shift(matched, off);
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) m.pix2[i] = make_uint2((uint32_t)m.label[i], __float_as_uint(m.plane_depth[i]));
+    if (i >= S) return;
+    const int k = i;
+    const float* wpos = wire; const float* wcol = wpos + 3 * (size_t)S; const int32_t* wst = reinterpret_cast<const int32_t*>(wcol + 3 * (size_t)S);
+    const float* wori = reinterpret_cast<const float*>(wst + 2 * (size_t)S); const float* wsh = wori + 9 * (size_t)S;
+    const float* wd = wsh + 6 * (size_t)S; const float* wc = wd + 2 * (size_t)S;
+    const V3 pos = v3(wpos[3 * k], wpos[3 * k + 1], wpos[3 * k + 2]), col = v3(wcol[3 * k], wcol[3 * k + 1], wcol[3 * k + 2]);
+    const V3 lab = rgb_to_lab(col);
+    const V3 r2 = v3(wori[9 * k + 6], wori[9 * k + 7], wori[9 * k + 8]);
+    const float conf = wc[k];
+    f.pos[3 * k] = pos.x; f.pos[3 * k + 1] = pos.y; f.pos[3 * k + 2] = pos.z;
+    f.col[3 * k] = col.x; f.col[3 * k + 1] = col.y; f.col[3 * k + 2] = col.z;
+    f.lab[3 * k] = lab.x; f.lab[3 * k + 1] = lab.y; f.lab[3 * k + 2] = lab.z;
+    f.stamps[2 * k] = wst[2 * k]; f.stamps[2 * k + 1] = wst[2 * k + 1];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { f.r0[3 * k + j] = wori[9 * k + j]; f.r1[3 * k + j] = wori[9 * k + 3 + j]; f.r2[3 * k + j] = wori[9 * k + 6 + j]; }
+#pragma unroll
+    for (int j = 0; j < 6; j++) f.shape[6 * k + j] = wsh[6 * k + j];
+    f.dims[2 * k] = wd[2 * k]; f.dims[2 * k + 1] = wd[2 * k + 1];
+    f.conf[k] = conf;
+    m.fpack[4 * k] = make_float4(conf, lab.x, lab.y, lab.z);
+    m.fpack[4 * k + 1] = make_float4(r2.x, r2.y, r2.z, 0.f);
+    m.fpack[4 * k + 2] = make_float4(pos.x, pos.y, pos.z, 0.f);
+    best[k] = SSF_NO_MATCH; matched[k] = 0;
+}
+
+// the S frame supersurfels of slot blockIdx.y in the wire layout of k_import_frame (what the rank that extracted a batch ships)
+__global__ __launch_bounds__(256) void k_export_rows(int S, SurfelSoA f, float* __restrict__ wire, size_t slab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    const size_t off = (size_t)blockIdx.y * slab;
+    f = batch_slot(f, off); wire = slab_shift(wire, off);
+    float* wpos = wire; float* wcol = wpos + 3 * (size_t)S; int32_t* wst = reinterpret_cast<int32_t*>(wcol + 3 * (size_t)S);
+    float* wori = reinterpret_cast<float*>(wst + 2 * (size_t)S); float* wsh = wori + 9 * (size_t)S;
+    float* wd = wsh + 6 * (size_t)S; float* wc = wd + 2 * (size_t)S;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        wpos[3 * k + j] = f.pos[3 * k + j]; wcol[3 * k + j] = f.col[3 * k + j];
+        wori[9 * k + j] = f.r0[3 * k + j]; wori[9 * k + 3 + j] = f.r1[3 * k + j]; wori[9 * k + 6 + j] = f.r2[3 * k + j];
+    }
+    wst[2 * k] = f.stamps[2 * k]; wst[2 * k + 1] = f.stamps[2 * k + 1];
+#pragma unroll
+    for (int j = 0; j < 6; j++) wsh[6 * k + j] = f.shape[6 * k + j];
+    wd[2 * k] = f.dims[2 * k]; wd[2 * k + 1] = f.dims[2 * k + 1];
+    wc[k] = f.conf[k];
+}
 __global__ __launch_bounds__(256) void k_boundary_map(SegParams p, const int32_t* __restrict__ label, int32_t* __restrict__ out) {
     __shared__ int tile[TW * TW];
     const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
@@ -1944,6 +2008,15 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb) {
     ScopedKernel sk("render_moments", st);
     hipLaunchKernelGGL(k_render_moments, batch_tile_grid(p, nb), dim3(256), 0, st, p, cam, m);
+}
+void launch_import_frame(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, const float* wire, unsigned long long* best, uint8_t* matched) {
+    ScopedKernel sk("import_frame", st);
+    const int P = p.W * p.H, n = std::max(P, p.S);
+    hipLaunchKernelGGL(k_import_frame, dim3((n + 255) / 256, nb), dim3(256), 0, st, P, p.S, m, frame, wire, best, matched);
+}
+void launch_export_rows(hipStream_t st, const SegParams& p, const FrameMaps& m, int nb, SurfelSoA frame, float* wire) {
+    ScopedKernel sk("export_rows", st);
+    hipLaunchKernelGGL(k_export_rows, dim3((p.S + 255) / 256, nb), dim3(256), 0, st, p.S, frame, wire, m.slab);
 }
 void launch_finalize_surfels(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, float zmin,
                              float zmax, int stamp0, const uint8_t* dynamic_mask, unsigned mask_bits,

@@ -265,6 +265,10 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;           // the three below: only the dealt extract stage needs them (ssf_comm_deal_extract)
+    decltype(&ncclCommSplit) CommSplit = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     std::string err;
 };
 static RcclApi* rccl_api() {
@@ -284,6 +288,10 @@ static RcclApi* rccl_api() {
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
     api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
+    api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+    api.CommSplit = (decltype(api.CommSplit))dlsym(api.lib, "ncclCommSplit");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) {
         api.err = "librccl lacks a required symbol"; api.lib = nullptr; return nullptr;
     }
@@ -458,6 +466,37 @@ struct StreamPool {
 };
 static StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }      // (never destroyed: the runtime may be gone by then)
 
+// ---- the first ICP iteration of the next frame: inside the row-move kernel, or as a launch of its own? ------------------------
+// Both forms give the same record bit for bit (exact integer sums).  Which one is FASTER depends on what else the part is doing,
+// and flipped sign between measurements of round 5 (profiles/track_chain_r05.txt): alone on the part the fused form saves a launch
+// and a trip (first record 11 us after the frame's entry against 15); next to the extract launches of a filling pipeline its
+// 3900-workgroup launch finishes late (36 us against 27) -- the driver's 20-frame form ran 4-7 % faster WITHOUT the fusion, a
+// 1200-frame steady state 3-5 % faster WITH it.  So the handle measures: the period between consecutive frame completions of a
+// pipelined sequence is attributed to the form that was in effect, the two forms take turns of PROBE frames, and the better mean
+// holds for HOLD frames before the next probe.  A handle starts WITHOUT the fusion (short sequences are fill-bound and never leave
+// that phase).  Results do not depend on any of it.
+struct AheadTuner {
+    static const int START = 48, PROBE = 16, ROUNDS = 3, HOLD = 1024, SKIP = 2;
+    int forced = -1;                 // lab: SSF_ICP_AHEAD = 0 / 1 / 2 pins the form (2: fused and the track stream waits for the next batch)
+    int mode = 0, frames = 0, left = START, round = 0, since_switch = 0;
+    bool probing = false;
+    double sum[2] = {0, 0}; int n[2] = {0, 0};
+    double last_done_us = -1.0; int last_mode = 0;
+    int current() const { return forced >= 0 ? (forced ? 1 : 0) : mode; }
+    void sequence_break() { last_done_us = -1.0; }                       // (the period across a drained pipeline says nothing)
+    void frame_done(double t_us, int iters) {
+        if (forced >= 0) return;
+        if (last_done_us >= 0.0 && since_switch >= SKIP && probing && iters > 0) { sum[last_mode] += (t_us - last_done_us) / (double)(iters + 4); n[last_mode]++; }   // (per unit of chain work: iterations + the fixed part)
+        last_done_us = t_us; last_mode = mode; frames++; since_switch++;
+        if (--left > 0) return;
+        if (!probing) { probing = true; round = 0; sum[0] = sum[1] = 0; n[0] = n[1] = 0; mode ^= 1; left = PROBE; since_switch = 0; return; }
+        if (++round < 2 * ROUNDS) { mode ^= 1; left = PROBE; since_switch = 0; return; }
+        probing = false;
+        if (n[0] > 0 && n[1] > 0) mode = (sum[1] / n[1] < sum[0] / n[0]) ? 1 : 0;
+        left = HOLD; since_switch = 0;
+    }
+};
+
 // ---- handle -----------------------------------------------------------------------------------------
 struct IcpLoop {
     bool active = false, valid = true, done = true;
@@ -477,6 +516,9 @@ struct ExtractCtx {
     SurfelSoA frame;
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
+    float* d_wire = nullptr;                      // 26 S words: the frame supersurfels of a frame extracted elsewhere (ssf_submit_frame_tables)
+    ncclComm_t deal_comm = nullptr;               // dealt extract stage: this context's own communicator (a collective per batch on ITS stream)
+    bool mine = true; long long deal_batch = 0;   // ... whether the open batch is this rank's to extract, and its number in the frame stream
     hipStream_t stream = nullptr; bool own_stream = false; int stream_prio = 0;
     hipEvent_t ev_done = nullptr, ev_consumed = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool consumed_valid = false, timed = false;
@@ -514,6 +556,7 @@ struct ssf_handle {
     // multi-GPU: RCCL communicator over the ranks of cfg.nranks (ssf_comm_attach); the shard sizes of all ranks
     // are all-gathered at the end of every frame and read lazily at the start of the next one
     ncclComm_t comm = nullptr; int* d_all5 = nullptr;
+    int deal = 0; long long deal_batches = 0;     // ssf_comm_deal_extract: 0 replicated, 1 dealt, 2 dealt + the extracting rank re-imports its own tables (self-check)
     // ... or the peer-to-peer exchange region of ssf_p2p_* (one node; no collective launches): own region, the peers'
     // regions as mapped into this process, and one sequence number per exchange kind (identical on every rank)
     struct P2P {
@@ -552,6 +595,7 @@ struct ssf_handle {
     struct { bool valid = false; unsigned long long seq = 0; ExtractCtx* ctx = nullptr; int slot = 0; int stamp = 0; Rt pose; } ahead;
     double wait_launched_us = 0.0; long long n_waiter_match_repairs = 0; long long dbg_stall_before_match_us = 0;     // see process_oldest: SSF_ICP_GO_MATCH has no acknowledgement
     bool icp_ahead = true; int icp_ahead_mode = 1;         // 1: when the next frame's extract has finished (the product); 2 (lab): always, the track stream waits for it
+    AheadTuner ahead_tuner;
     // chained ICP launches: iteration i + 1 is launched while iteration i runs and waits on the device for the host's
     // word (launch_icp, IcpGo): slots in fine-grained device memory the host stores into directly
     IcpGo* go = nullptr; bool icp_chain = true; unsigned long long go_count = 0;
@@ -777,15 +821,40 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
     c.timed = h->cfg.profile != 0;
     if (c.timed) HCK(hipEventRecord(c.ev_t0, st));
-    if (h->cfg.depth_prefilter) {                                          // supersurfel_fusion.cu:180 -- the batch's frames in one launch
-        launch_bilateral_batch(st, c.in, c.d_depth_filt, c.maps.slab, nb, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
-        for (int b = 0; b < nb; b++) c.in.depth[b] = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
+    // The extract stage DEALT over the ranks of a sharded map (ssf_comm_deal_extract): batch j of the frame
+    // stream is extracted by rank j % nranks alone, which broadcasts every frame's label map, plane depth and supersurfels (2.5 MB
+    // at 640 x 480) on THIS context's communicator and stream; the other ranks receive them into the same slots and rebuild their
+    // private tables (k_import_frame).  Every rank launches the same batches in the same order (same frames, same configuration),
+    // so the collectives of a context's communicator are issued in the same order everywhere.
+    const bool dealt = h->deal != 0 && h->comm != nullptr;
+    const bool mine = !dealt || c.mine;
+    if (mine) {
+        if (h->cfg.depth_prefilter) {                                      // supersurfel_fusion.cu:180 -- the batch's frames in one launch
+            launch_bilateral_batch(st, c.in, c.d_depth_filt, c.maps.slab, nb, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
+            for (int b = 0; b < nb; b++) c.in.depth[b] = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
+        }
+        launch_ingest(st, h->seg, c.in, c.maps, nb, c.epoch0);
+        int rc = run_segmentation(h, c);
+        if (rc) return rc;
+        launch_finalize_surfels(st, h->seg, c.maps, nb, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp0, c.d_mask, c.mask_bits,
+                                c.d_best, c.d_matched);
     }
-    launch_ingest(st, h->seg, c.in, c.maps, nb, c.epoch0);
-    int rc = run_segmentation(h, c);
-    if (rc) return rc;
-    launch_finalize_surfels(st, h->seg, c.maps, nb, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp0, c.d_mask, c.mask_bits,
-                            c.d_best, c.d_matched);
+    if (dealt) {
+        RcclApi* api = rccl_api();
+        const int root = (int)(c.deal_batch % (long long)h->cfg.nranks);
+        const size_t P = (size_t)h->cfg.width * h->cfg.height;
+        if (mine) launch_export_rows(st, h->seg, c.maps, nb, c.frame, c.d_wire);
+        NCK(api->GroupStart());
+        for (int b = 0; b < nb; b++) {
+            const size_t off = (size_t)b * c.maps.slab;
+            int32_t* lab = slab_shift(c.maps.label, off); float* pd = slab_shift(c.maps.plane_depth, off); float* w = slab_shift(c.d_wire, off);
+            NCK(api->Broadcast(lab, lab, P, ncclInt32, root, c.deal_comm, st));
+            NCK(api->Broadcast(pd, pd, P, ncclFloat32, root, c.deal_comm, st));
+            NCK(api->Broadcast(w, w, 26 * (size_t)h->S, ncclFloat32, root, c.deal_comm, st));
+        }
+        NCK(api->GroupEnd());
+        if (!mine || h->deal == 2) launch_import_frame(st, h->seg, c.maps, nb, c.frame, c.d_wire, c.d_best, c.d_matched);
+    }
     HCK(hipGetLastError());
     if (c.timed) HCK(hipEventRecord(c.ev_t1, st));
     if (multi) HCK(hipEventRecord(c.ev_done, st));
@@ -804,21 +873,59 @@ static int submit_extract(ssf_handle* h, const void* rgb, const void* depth, int
     const int b = c.count;
     if (b == 0) {
         c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal;
+        if (h->deal && h->comm) { c.deal_batch = h->deal_batches++; c.mine = (int)(c.deal_batch % (long long)h->cfg.nranks) == h->cfg.rank; }
+        else c.mine = true;
     }
     h->extract_ordinal++;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, off = (size_t)b * c.maps.slab;
     c.in.rgb[b] = (const uint8_t*)rgb; c.in.depth[b] = (const float*)depth;
-    if (!on_device) {
+    if (!on_device && c.mine) {            // (a batch another rank extracts: its images are never looked at here)
         uint8_t* drgb = slab_shift(c.d_rgb_in, off); float* ddep = slab_shift(c.d_depth_in, off);
         HCK(hipMemcpyAsync(drgb, rgb, 3 * P, hipMemcpyHostToDevice, c.stream));
         HCK(hipMemcpyAsync(ddep, depth, 4 * P, hipMemcpyHostToDevice, c.stream));
         c.in.rgb[b] = drgb; c.in.depth[b] = ddep;
     }
-    if (mask) { HCK(hipMemcpyAsync(slab_shift(c.d_mask, off), mask, h->S, hipMemcpyHostToDevice, c.stream)); c.mask_bits |= 1u << b; }
+    if (mask && c.mine) { HCK(hipMemcpyAsync(slab_shift(c.d_mask, off), mask, h->S, hipMemcpyHostToDevice, c.stream)); c.mask_bits |= 1u << b; }
     c.count = b + 1;
     h->pending.push_back(std::make_pair(h->open_ctx, b));
     // (inside ssf_process_sequence the first two batches are smaller: seq_batch_size)
     if (c.count == (h->seq_n > 0 ? seq_batch_size(h->seq_batches, h->batch) : h->batch)) return launch_batch(h, c);
+    return SSF_OK;
+}
+// A frame extracted elsewhere takes a batch context of its own: its maps and rows are copied into slot 0 and the private tables
+// rebuilt (k_import_frame) on the context's stream, where a local batch would run its extract chain.
+static int submit_tables(ssf_handle* h, const int32_t* label, const float* plane_depth, const ssf_surfels* fr, int on_device) {
+    if (h->ctx[h->open_ctx].count > 0 && !h->ctx[h->open_ctx].launched) {        // an open local batch: it goes first (frame order)
+        int rc = launch_batch(h, h->ctx[h->open_ctx]);
+        if (rc) return rc;
+    }
+    ExtractCtx& c = h->ctx[h->open_ctx];
+    if (c.launched) { h->err = "extract pipeline is full: process a submitted frame first"; return SSF_ERR_STATE; }
+    hipStream_t st = c.stream;
+    const bool multi = h->ctx.size() > 1;
+    if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
+    c.stamp0 = h->stamp + h->stamp_bias + (int)h->pending.size(); c.mask_bits = 0; c.epoch0 = h->extract_ordinal;
+    h->extract_ordinal++;                          // (the RANSAC epoch advances as if the frame had been extracted here)
+    const size_t P = (size_t)h->cfg.width * h->cfg.height, S = (size_t)h->S;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    c.timed = false;
+    HCK(hipMemcpyAsync(c.maps.label, label, 4 * P, kind, st));
+    HCK(hipMemcpyAsync(c.maps.plane_depth, plane_depth, 4 * P, kind, st));
+    float* w = c.d_wire;
+    HCK(hipMemcpyAsync(w, fr->positions, 12 * S, kind, st)); w += 3 * S;
+    HCK(hipMemcpyAsync(w, fr->colors, 12 * S, kind, st)); w += 3 * S;
+    HCK(hipMemcpyAsync(w, fr->stamps, 8 * S, kind, st)); w += 2 * S;
+    HCK(hipMemcpyAsync(w, fr->orientations, 36 * S, kind, st)); w += 9 * S;
+    HCK(hipMemcpyAsync(w, fr->shapes, 24 * S, kind, st)); w += 6 * S;
+    HCK(hipMemcpyAsync(w, fr->dims, 8 * S, kind, st)); w += 2 * S;
+    HCK(hipMemcpyAsync(w, fr->confidences, 4 * S, kind, st));
+    if (!on_device) HCK(hipStreamSynchronize(st));             // (pageable host buffers: the caller may reuse them on return)
+    launch_import_frame(st, h->seg, c.maps, 1, c.frame, c.d_wire, c.d_best, c.d_matched);
+    HCK(hipGetLastError());
+    if (multi) HCK(hipEventRecord(c.ev_done, st));
+    c.count = 1; c.launched = true; c.waited = false; c.inflight = 1; c.nb_launched = 1;
+    h->pending.push_back(std::make_pair(h->open_ctx, 0));
+    h->open_ctx = (int)((&c - h->ctx.data() + 1) % (ptrdiff_t)h->ctx.size());
     return SSF_OK;
 }
 // the frame held by h->active will not be fused (or has been): its slot is free again
@@ -1189,7 +1296,7 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
         NextFrameIcp next{};
         P2PView next_pv{};
         bool have_next = false;
-        if (h->icp_ahead && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.icp_iter > 0 && !h->pending.empty()) {
+        if (h->icp_ahead && (h->p2p.on || h->ahead_tuner.current() == 1) && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.icp_iter > 0 && !h->pending.empty()) {
             ExtractCtx& nc = h->ctx[h->pending.front().first];
             const int nslot = h->pending.front().second;
             const bool multi = h->ctx.size() > 1;         // one context: extract ran on the track stream itself
@@ -1540,6 +1647,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     } else
         rc = do_fuse(h, &r);
     if (rc) return rc;
+    if (h->pending.empty()) h->ahead_tuner.sequence_break(); else h->ahead_tuner.frame_done(now_us(), r.icp_iters);
     h->host_us[1] += t_b - t_a; h->host_us[2] += now_us() - t_b; h->host_us[3] += 1;
     if (timing) {
         HCK(hipEventRecord(h->ev[3], h->stream));
@@ -1622,6 +1730,7 @@ void ssf_destroy(ssf_handle* h) {
     }
     for (auto& c : h->ctx) if (c.stream) (void)hipStreamSynchronize(c.stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& c : h->ctx) if (c.deal_comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(c.deal_comm); c.deal_comm = nullptr; }
     if (h->comm) { RcclApi* api = rccl_api(); if (api) (void)api->CommDestroy(h->comm); h->comm = nullptr; }
     for (void* q : h->p2p.opened) (void)hipIpcCloseMemHandle(q);
     if (h->p2p.region) (void)hipFree(h->p2p.region);
@@ -1667,6 +1776,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     h->move_totals_on = SSF_ENV_INT("MOVE_TOTALS", SSF_MOVE_TOTALS_DEFAULT) != 0;      // (-DSSF_MOVE_TOTALS_DEFAULT=0: a product build that keeps the fuse launch's tail, for the A/B)
     h->icp_ahead_mode = SSF_ENV_INT("ICP_AHEAD", 1);      // (lab: measurement switches, tools/)
     h->icp_ahead = h->icp_ahead_mode != 0;
+    h->ahead_tuner.forced = SSF_ENV_INT("ICP_AHEAD", -1);  // (lab: 0 / 1 / 2 pin the form; the product measures, see AheadTuner)
     h->icp_chain = SSF_ENV_INT("ICP_CHAIN", 1) != 0;
     if (SSF_ENV_SET("NO_GRAPH")) h->graph_failed = true;                             // extract chain launched eagerly
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -1718,6 +1828,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         take(f.pos, 3 * S); take(f.col, 3 * S); take(f.lab, 3 * S); take(f.stamps, 2 * S); take(f.r0, 3 * S); take(f.r1, 3 * S);
         take(f.r2, 3 * S); take(f.shape, 6 * S); take(f.dims, 2 * S); take(f.conf, S);
         take(c.d_best, S); take(c.d_matched, S); take(c.d_rgb_in, 3 * P); take(c.d_depth_in, P); take(c.d_depth_filt, P); take(c.d_mask, S);
+        take(c.d_wire, 26 * S);
         return (off + 255) & ~(size_t)255;
     };
     size_t slab_bytes = 0;
@@ -1828,6 +1939,12 @@ int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int on_d
     int rc = submit_extract(h, rgb, depth, on_device, mask);
     h->host_us[0] += now_us() - t0;
     return rc;
+}
+int ssf_submit_frame_tables(ssf_handle* h, const int32_t* label, const float* plane_depth, const ssf_surfels* frame, int on_device) {
+    if (!h || !label || !plane_depth || !frame) return SSF_ERR_INVALID_ARG;
+    if (!frame->positions || !frame->colors || !frame->stamps || !frame->orientations || !frame->shapes || !frame->dims || !frame->confidences) return SSF_ERR_INVALID_ARG;
+    TimerScope ts(h);
+    return submit_tables(h, label, plane_depth, frame, on_device);
 }
 int ssf_process_submitted(ssf_handle* h, const float* prior, ssf_frame_result* out) {
     if (!h) return SSF_ERR_INVALID_ARG;
@@ -2042,6 +2159,22 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128) {
     std::memcpy(&id, id128, 128);
     NCK(api->CommInitRank(&h->comm, h->cfg.nranks, id, h->cfg.rank));
     h->all_valid = false; h->all_pending = false;
+    return SSF_OK;
+}
+// The extract stage dealt over the ranks (see launch_batch): one communicator per batch context, split off the attached one --
+// a collective call, made by every rank after ssf_comm_attach and with an empty pipeline.  mode 0: back to the replicated form.
+int ssf_comm_deal_extract(ssf_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return SSF_ERR_INVALID_ARG;
+    if (!h->comm) { h->err = "ssf_comm_deal_extract: attach an RCCL communicator first (the peer-to-peer backend keeps the extract stage replicated)"; return SSF_ERR_STATE; }
+    if (!h->pending.empty()) { h->err = "frames are pending in the extract pipeline"; return SSF_ERR_STATE; }
+    for (auto& c : h->ctx) if (c.count > 0 || c.launched) { h->err = "a batch is open in the extract pipeline"; return SSF_ERR_STATE; }
+    RcclApi* api = rccl_api();
+    if (!api || !api->Broadcast || !api->CommSplit || !api->GroupStart || !api->GroupEnd) { h->err = "this RCCL has no ncclCommSplit / ncclBroadcast"; return SSF_ERR_DEVICE; }
+    HCK(hipSetDevice(h->cfg.device_id));
+    if (mode != 0)
+        for (auto& c : h->ctx)
+            if (!c.deal_comm) NCK(api->CommSplit(h->comm, 0, h->cfg.rank, &c.deal_comm, nullptr));
+    h->deal = mode; h->deal_batches = 0;
     return SSF_OK;
 }
 int ssf_comm_info(ssf_handle* h, int* backend, int* ranks, int* my_rank) {
@@ -2633,6 +2766,14 @@ int ssf_sequence_marks(ssf_handle* h, double* out320) {
 }
 // frames whose association ran inside a waiting ICP launch (SSF_ICP_GO_MATCH) since the handle was created
 long long ssf_waiter_matches(ssf_handle* h) { return h ? h->n_waiter_matches : -1; }
+// the self-tuned choice of AheadTuner: [0] form in effect (1: first ICP iteration inside the row-move kernel), [1] pipelined frames
+// seen, [2] / [3] mean chain period per unit of work measured in the last probe without / with the fusion (0: not probed yet)
+int ssf_tuner_state(ssf_handle* h, double* out4) {
+    if (!h || !out4) return SSF_ERR_INVALID_ARG;
+    const AheadTuner& t = h->ahead_tuner;
+    out4[0] = t.current(); out4[1] = t.frames; out4[2] = t.n[0] ? t.sum[0] / t.n[0] : 0.0; out4[3] = t.n[1] ? t.sum[1] / t.n[1] : 0.0;
+    return SSF_OK;
+}
 // ... and the frames whose association was run again as a launch of its own because the host's word to the waiting launch came
 // too late to be trusted; the test hook that makes it late (a stall of the calling thread in front of the word)
 long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? h->n_waiter_match_repairs : -1; }

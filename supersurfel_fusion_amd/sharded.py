@@ -81,8 +81,45 @@ def rehome_over(fusion, world, group=None, device=None, on_loss="warn"):
     return rep
 
 
+def pack_frame_tables(fusion):
+    """the current frame of `fusion` as ONE int32 array -- what a rank that ran the extract stage ships to the others
+    ("index map + plane depth + frame SoA", 2.5 MB at 640 x 480): label map | plane depth | the seven
+    arrays of the S frame supersurfels, bit patterns throughout"""
+    from .binding import SURFEL_FIELDS
+    fr = fusion.get_frame()
+    parts = [fusion.index_map().reshape(-1).view(np.int32), fusion.plane_depth().reshape(-1).view(np.int32)]
+    parts += [np.ascontiguousarray(fr[name], dt).reshape(-1).view(np.int32) for name, _, dt in SURFEL_FIELDS]
+    return np.concatenate(parts)
+
+
+def frame_tables_words(fusion):
+    return 2 * fusion.W * fusion.H + 26 * fusion.S
+
+
+def unpack_frame_tables(fusion, words):
+    """-> (label, plane_depth, frame dict) for Fusion.submit_frame_tables"""
+    from .binding import SURFEL_FIELDS
+    P, S = fusion.W * fusion.H, fusion.S
+    words = np.ascontiguousarray(words, np.int32)
+    label = words[:P].reshape(fusion.H, fusion.W)
+    depth = words[P:2 * P].view(np.float32).reshape(fusion.H, fusion.W)
+    off, frame = 2 * P, {}
+    for name, width, dt in SURFEL_FIELDS:
+        a = words[off:off + width * S].view(dt)
+        frame[name] = a.reshape(S, width) if width > 1 else a.reshape(S)
+        off += width * S
+    return label, depth, frame
+
+
 class ShardedFusion:
-    def __init__(self, fusion, device=None, group=None, stream=None, always_reduce=False):
+    def __init__(self, fusion, device=None, group=None, stream=None, always_reduce=False, extract="replicated"):
+        """extract = "replicated": every rank runs the extract stage of every frame (deterministic: identical tables, nothing is
+        shipped).  "dealt": frame k is extracted by rank k % world only, which broadcasts its tables (pack_frame_tables) to the
+        others -- 1 / world of the extract work per rank for one broadcast of 2.5 MB per frame; results are bit-identical
+        (tests/test_sharded.py::test_dealt_extract_*).  Frames go one at a time in this driver (process_frame)."""
+        assert extract in ("replicated", "dealt")
+        self.extract = extract
+        self._frame_no = 0
         self.f = fusion
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -127,10 +164,11 @@ class ShardedFusion:
     def pending_frames(self):
         return self.f.pending_frames()
 
-    def process_submitted(self, prior_pose=None):
+    def process_submitted(self, prior_pose=None, _begun=False):
         f = self.f
         t0 = time.perf_counter()
-        f.begin_submitted()
+        if not _begun:
+            f.begin_submitted()
         if self._counts is None:                  # first frame (or after set_model): exchange the shard sizes
             c = f.counts()
             self._counts = self._gather_counts([c["n_model"], c["n_visible"], 0, 0, 0])[:, :2]
@@ -172,6 +210,24 @@ class ShardedFusion:
 
     def process_frame(self, rgb, depth, prior_pose=None, dynamic_mask=None, on_device=False):
         assert self.f.pending_frames() == 0, "frames are pending: use process_submitted"
+        k = self._frame_no
+        self._frame_no += 1
+        if self.extract == "dealt" and self.world > 1:
+            owner = k % self.world
+            n = frame_tables_words(self.f)
+            if owner == self.rank:                    # this rank's turn: extract, make the frame current, ship its tables
+                self.f.submit_frame(rgb, depth, dynamic_mask, on_device=on_device)
+                self.f.begin_submitted()
+                buf = torch.from_numpy(pack_frame_tables(self.f)).to(self.device)
+            else:
+                buf = torch.empty(n, dtype=torch.int32, device=self.device)
+            src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+            dist.broadcast(buf, src=src, group=self.group)
+            if owner != self.rank:
+                self.f.submit_frame_tables(*unpack_frame_tables(self.f, buf.cpu().numpy()))
+            res = self.process_submitted(prior_pose, _begun=(owner == self.rank))
+            res["extracted_here"] = owner == self.rank
+            return res
         self.f.submit_frame(rgb, depth, dynamic_mask, on_device=on_device)
         return self.process_submitted(prior_pose)
 

@@ -53,3 +53,27 @@ def test_one_rank_communicator_equals_plain_run(depth_ahead, batch, one_rank_gro
     g = comm.global_counts()
     assert g["n_model"] == want[-1]["n_model"] and g["n_visible"] == want[-1]["n_visible"]
     assert g["n_inserted"] == want[-1]["n_inserted"] and g["n_updated"] == want[-1]["n_updated"]
+
+
+@pytest.mark.parametrize("depth_ahead,batch,mode", [(0, 1, 2), (2, 4, 2), (2, 4, 1)])
+def test_dealt_extract_on_a_one_rank_communicator(depth_ahead, batch, mode, one_rank_group, product_lib):
+    """ssf_comm_deal_extract on a one-rank communicator: every batch is this rank's, the broadcasts of its frames' tables run (on the
+    batch context's own communicator and stream, ncclCommSplit) as self-broadcasts, and in mode 2 the rank REBUILDS its private
+    tables (k_import_frame) from the wire buffers it has just shipped (k_export_rows) -- what a receiving rank does -- before the
+    track chain reads them: results and state must equal the plain run's bit for bit.  (Two ranks of one RCCL communicator cannot
+    share this box's one GPU; the receive path across libraries and emulated ranks is test_parity_gpu.py's.)"""
+    W, H, nf = 320, 240, 9
+    plain = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H))
+    comm = binding.Fusion(product_lib, util.make_cfg(product_lib, W, H, pipeline_depth=depth_ahead, extract_batch=batch))
+    comm.comm_attach()
+    comm.comm_deal_extract(mode)
+    frames = [util.frame(k, W, H, noise=True, holes=0.02) for k in range(nf)]
+    want = [plain.process_frame(*fr) for fr in frames]
+    got, nsub = [], 0
+    for k in range(nf):
+        while nsub < nf and comm.can_submit():
+            comm.submit_frame(*frames[nsub]); nsub += 1
+        got.append(comm.process_submitted().as_dict())
+    for a, b in zip(want, got):
+        util.same_result(a, b)
+    util.compare_state(plain, comm)

@@ -430,17 +430,29 @@ def test_soak_600_frames_pipelined(oracle_lib, product_lib):
     assert want[-1]["n_model"] > 100
 
 
-def _emulated_ranks(lib, world, W, H, nframes, cap=4096):
+def _emulated_ranks(lib, world, W, H, nframes, cap=4096, extract="replicated"):
     """`world` handles of one library acting as the ranks of a sharded map in ONE process: the exchanges (ICP record
-    SUM, association MIN / MAX, migrant table SUM, shard sizes) are done on the host between the stage calls."""
+    SUM, association MIN / MAX, migrant table SUM, shard sizes) are done on the host between the stage calls.
+    extract = "dealt": rank k % world alone extracts frame k; the others get its label map + plane depth + frame supersurfels
+    (sharded.pack_frame_tables -> ssf_submit_frame_tables) and never see the images."""
+    from supersurfel_fusion_amd import sharded
     fs = [binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=cap, rank=r, nranks=world, shard_tile=0.25))
           for r in range(world)]
     counts = np.zeros((world, 2), np.int64)
     out = []
     for k in range(nframes):
         rgb, depth = util.frame(k, W, H)
-        for f in fs:
-            f.stage_extract(rgb, depth)
+        if extract == "dealt":
+            owner = k % world
+            fs[owner].stage_extract(rgb, depth)
+            words = sharded.pack_frame_tables(fs[owner])
+            for r, f in enumerate(fs):
+                if r != owner:
+                    f.submit_frame_tables(*sharded.unpack_frame_tables(f, words))
+                    f.begin_submitted()
+        else:
+            for f in fs:
+                f.stage_extract(rgb, depth)
         g_model, g_vis = int(counts[:, 0].sum()), int(counts[:, 1].sum())
         for r, f in enumerate(fs):
             f.set_shard(int(counts[:r, 1].sum()), g_model, g_vis)
@@ -484,6 +496,42 @@ def test_emulated_ranks_bit_exact(world, oracle_lib, product_lib):
         mh, mo = fh[r].get_model(), fo[r].get_model()
         for name in mh:
             assert np.array_equal(mh[name].view(np.uint32), mo[name].view(np.uint32)), (name, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_dealt_extract_emulated_ranks_bit_exact(world, oracle_lib, product_lib):
+    """The extract stage dealt over the ranks (round 5): rank k % world extracts frame k, the others rebuild
+    their private tables from its label map + plane depth + frame supersurfels (k_import_frame).  Every rank's poses, counters
+    and shard equal the REPLICATED run's on the oracle -- which the gloo tests tie to the unsharded oracle -- bit for bit."""
+    W, H, NF = 320, 240, 6
+    fh, oh = _emulated_ranks(product_lib, world, W, H, NF, extract="dealt")
+    fo, oo = _emulated_ranks(oracle_lib, world, W, H, NF)
+    for k in range(NF):
+        for r in range(world):
+            assert np.array_equal(oh[k][0][r].view(np.uint32), oo[k][0][r].view(np.uint32)), ("pose", k, r)
+        assert np.array_equal(oh[k][1], oo[k][1]), ("counts", k, oh[k][1], oo[k][1])
+        assert oh[k][2] == oo[k][2], ("frame counters", k)
+    for r in range(world):
+        mh, mo = fh[r].get_model(), fo[r].get_model()
+        for name in mh:
+            assert np.array_equal(mh[name].view(np.uint32), mo[name].view(np.uint32)), (name, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", ["oracle_extracts", "product_extracts", "product_pipelined"])
+def test_a_frame_extracted_elsewhere_on_the_hip_library(direction, oracle_lib, product_lib):
+    """ssf_submit_frame_tables across the two libraries: the product tracks and fuses from tables the ORACLE extracted, and the
+    oracle from tables the PRODUCT extracted (the tables are the reference's own quantities, not a private format); with a
+    pipelined product handle a foreign frame takes a batch context of its own between local batches."""
+    import test_sharded
+    if direction == "oracle_extracts":
+        fb, fr = test_sharded.frames_through_tables(oracle_lib, product_lib, 320, 240)
+    elif direction == "product_extracts":
+        fb, fr = test_sharded.frames_through_tables(product_lib, oracle_lib, 320, 240)
+    else:
+        fb, fr = test_sharded.frames_through_tables(product_lib, product_lib, 320, 240, pipeline_depth=2, extract_batch=2)
+    util.compare_state(fb, fr, maps=False)
 
 
 @pytest.mark.gpu

@@ -23,17 +23,22 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, extract="replicated"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = binding.Library(ORACLE_LIB)
     f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=rank, nranks=world, shard_tile=0.25))
-    drv = sharded.ShardedFusion(f)
-    poses, glob = [], []
+    drv = sharded.ShardedFusion(f, extract=extract)
+    poses, glob, here = [], [], 0
     for k in range(NF):
         rgb, depth = util.frame(k, W, H)
+        if extract == "dealt" and k % world != rank:
+            rgb, depth = np.zeros_like(rgb), np.zeros_like(depth)       # a rank that is not this frame's extractor never looks at the images
         r = drv.process_frame(rgb, depth)
+        here += 1 if r.get("extracted_here", True) else 0
         poses.append(r["pose"]); glob.append([r["global_n_model"], r["global_n_visible"], r["icp_valid"], r["icp_iters"]])
+    if extract == "dealt":
+        assert here == len(range(rank, NF, world)), (rank, here)        # 1 / world of the extract work
     m = f.get_model()
     from supersurfel_fusion_amd import synthetic
     at_home = bool((synthetic.tile_owner(m["positions"][m["confidences"] > 0], world, 0.25) == rank).all())     # migration keeps rows with their tile's owner
@@ -49,10 +54,13 @@ def _rows(m):
     return rows[np.lexsort(rows.T[::-1])]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_map_equals_single_rank_map(world, oracle_lib, tmp_path):
+@pytest.mark.parametrize("world,extract", [(2, "replicated"), (3, "replicated"), (2, "dealt"), (3, "dealt")])
+def test_sharded_map_equals_single_rank_map(world, extract, oracle_lib, tmp_path):
+    """extract = "dealt" (round 5): frame k is extracted by rank k % world only, which broadcasts label map + plane depth + frame
+    supersurfels; the other ranks are handed BLACK images for that frame, so a rank that looked at its own
+    input would diverge at once.  Poses, counters and the union of the shards stay the single-rank run's, bit for bit."""
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), extract), nprocs=world, join=True)
     # single rank reference through the same driver
     f = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
     drv = sharded.ShardedFusion(f)
@@ -72,6 +80,44 @@ def test_sharded_map_equals_single_rank_map(world, oracle_lib, tmp_path):
     assert np.array_equal(_rows(merged), _rows(single)), "union of shards != single-rank map"
     sizes = [len(r["confidences"]) for r in ranks]
     assert min(sizes) > 0, sizes   # the tile hash spreads the map over every rank
+
+
+def frames_through_tables(lib_extract, lib_track, W_=W, H_=H, nf=5, **kw):
+    """Handle A (library lib_extract) runs every frame and hands out what its extract stage produced; handle B (lib_track) is
+    fed A's label map + plane depth + frame supersurfels through ssf_submit_frame_tables for every other frame (and the images
+    for the rest) and tracks / fuses from them.  A third
+    handle (lib_track, plain process_frame) is the reference.  Returns (B, reference) after comparing every frame's result."""
+    fa = binding.Fusion(lib_extract, util.make_cfg(lib_extract, W_, H_, nb_supersurfels_max=4096, **kw))
+    fb = binding.Fusion(lib_track, util.make_cfg(lib_track, W_, H_, nb_supersurfels_max=4096, **kw))
+    fr = binding.Fusion(lib_track, util.make_cfg(lib_track, W_, H_, nb_supersurfels_max=4096))
+    for k in range(nf):
+        rgb, depth = util.frame(k, W_, H_, noise=True, holes=0.03)
+        want = fr.process_frame(rgb, depth)
+        fa.process_frame(rgb, depth)                                   # (A is a rank in step with the others: its frame carries the frame's stamp)
+        words = sharded.pack_frame_tables(fa)
+        assert len(words) == sharded.frame_tables_words(fa)
+        if k % 2 == 0:                                                 # foreign and local frames may alternate freely
+            fb.submit_frame_tables(*sharded.unpack_frame_tables(fb, words))
+        else:
+            fb.submit_frame(rgb, depth)
+        assert fb.pending_frames() == 1
+        got = fb.process_submitted()
+        got = got if isinstance(got, dict) else got.as_dict()
+        util.same_result(want, got)
+        util.assert_same_bits(fb.index_map(), fr.index_map(), "label map of frame %d" % k)
+        util.assert_same_bits(fb.plane_depth(), fr.plane_depth(), "plane depth of frame %d" % k)
+        a, b = fb.get_frame(), fr.get_frame()
+        for name in a:
+            util.assert_same_bits(a[name], b[name], "frame.%s of frame %d" % (name, k))
+    return fb, fr
+
+
+def test_a_frame_extracted_elsewhere_tracks_like_a_local_one(oracle_lib):
+    """ssf_submit_frame_tables on the checker: the map after five frames, three of them handed over as tables, equals the plain run's"""
+    fb, fr = frames_through_tables(oracle_lib, oracle_lib)
+    util.compare_state(fb, fr, maps=False)
+    fb2, fr2 = frames_through_tables(oracle_lib, oracle_lib, pipeline_depth=1, extract_batch=2)       # (a pipelined handle: a foreign frame is a batch of its own)
+    util.compare_state(fb2, fr2, maps=False)
 
 
 def test_sharded_driver_equals_process_frame(oracle_lib):
