@@ -315,6 +315,10 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "p2p"], default="rccl",
                     help="native exchange backend at N > 1 (or with --force-sharded): RCCL collectives on the track stream, or the "
                          "peer-to-peer exchange regions of ssf_p2p_* (one node, no collective launches)")
+    ap.add_argument("--extract", choices=["replicated", "dealt"], default="replicated",
+                    help="N > 1 (or --force-sharded) with the RCCL backend: 'dealt' = batch j of the frame stream is extracted by rank j %% N alone, "
+                         "which broadcasts its frames' tables (ssf_comm_deal_extract): 1 / N of the extract work per rank.  Default "
+                         "'replicated' (every rank extracts every frame, nothing is shipped): the dealt form has run on ONE rank only")
     ap.add_argument("--py-driver", action="store_true",
                     help="N > 1 through supersurfel_fusion_amd/sharded.py (torch.distributed collectives) instead of native RCCL")
     a = ap.parse_args()
@@ -433,6 +437,8 @@ def main():
                 fus.p2p_attach()                   # IPC handles of the exchange regions, all-gathered over torch.distributed
             else:
                 fus.comm_attach()
+                if a.extract == "dealt":
+                    fus.comm_deal_extract(1)
         return fus, None
 
     native_ok = 1
@@ -819,7 +825,7 @@ def main():
                        # what the attached exchange itself reports (ncclCommCount / opened regions): must equal n_gpus
                        "exchange_ranks_reported": comm_info["ranks"], "exchange_backend_attached": comm_info["backend"],
                        # (the figures the README leads with, inside the object the driver's record keeps whole)
-                       "pipeline_depth": depth, "extract_batch": batch, "extract": "replicated" if world > 1 else "single rank",
+                       "pipeline_depth": depth, "extract_batch": batch, "extract": ("dealt" if (a.extract == "dealt" and a.comm == "rccl" and native_ok and drv is None) else "replicated") if exchange else "single rank",
                        "steady_state_frames_per_sec": steady["frames_per_sec"] if steady else None,
                        "node_call_frames_per_sec": node_call, "sequential_ms_per_frame": seq_ms,
                        "parallelism": "map sharded by world tile over %d rank(s); extract of up to %d frame(s) runs "

@@ -37,7 +37,8 @@ for step in "$@"; do
       timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_gpus2.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$? $(cat $O/bench_gpus2.json)" >> $O/summary.txt;;
     sharded1)
       timeout 400 python bench.py --force-sharded --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err; lastline $O/bench_one_rank_rccl.json one_rank_rccl
-      timeout 400 python bench.py --force-sharded --comm p2p --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_p2p.json 2> $O/bench_one_rank_p2p.err; lastline $O/bench_one_rank_p2p.json one_rank_p2p;;
+      timeout 400 python bench.py --force-sharded --comm p2p --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_p2p.json 2> $O/bench_one_rank_p2p.err; lastline $O/bench_one_rank_p2p.json one_rank_p2p
+      timeout 400 python bench.py --force-sharded --extract dealt --extras 0 --cpu-frames 0 --steps 240 > $O/bench_one_rank_rccl_dealt.json 2> $O/bench_one_rank_rccl_dealt.err; lastline $O/bench_one_rank_rccl_dealt.json one_rank_rccl_dealt;;
     env:*) export "${step#env:}"; case "${step#env:}" in SSF_*) export SSF_PRODUCT_VARIANT=${SSF_PRODUCT_VARIANT:-lab};; esac;    # (the switches live in the lab build)
             TAG="${TAG}_$(echo ${step#env:} | tr -c 'A-Za-z0-9=\n' '_')";;
     suite)
