@@ -99,7 +99,14 @@ struct SegParams {
     uint64_t seed;
     float inv_gx;         // 1.0f / (float)gx (one IEEE division, made on the host)
     uint32_t cell_magic;  // ceil(2^32 / cell) (0 when cell == 1): x / cell == mulhi(x, cell_magic) for 0 <= x < 65536
+    // per tile of the relabelling passes' grid, [OX = 0 | OX = 1]: the window of grid cells around the tile and whether the tile
+    // lies inside the image (pass_geometry_table: built once per handle on the host; k_update_pass fetches one 8-byte entry
+    // instead of working the same ~60 scalar instructions out in every wave of every pass)
+    const uint2* pass_geom; int pass_ntile;
 };
+// entry: x = (wcx0 & 0xFFFF) | (wcy0 << 16) (first window cell, may be negative), y = nwx | nwy << 8 | interior << 16 (nwx = nwy = 0: no window)
+int pass_geometry_entries(int W, int H);                                  // 2 x tiles of the shifted 32-wide grid
+void pass_geometry_table(const SegParams& p, uint2* host_out);
 
 // One relabelled pixel of a pass, replayed by the next pass into the lagging sums buffer.
 // flags: 1 = label moved (from -> to), 2 = add the disparity terms to `to`, 4 = remove them from `from`

@@ -365,8 +365,20 @@ static inline TileOrder tile_order(dim3 grid) {
 #else
 #define SSF_SKIP_STAMP(rec) ((void)0)
 #endif
+// What a pass touches of a frame's working set, chosen on the HOST (round 5): the read / write sums buffer by the pass' parity, the
+// previous / current log by pass mod 3.  Selected in the kernel -- from FrameMaps, after shifting all of its ~30 pointers to the
+// batch slot -- it was ~50 scalar instructions of every wave's prologue (s_cselect chains + 64-bit adds); the counters put the
+// prologue at 205 of the RGB-D wave's 321 scalar instructions, and 150 extra scalar instructions per wave cost the 8-frame
+// launch 1.8 us (profiles/pass_issue_r05.txt): ONE scalar unit serves the four SIMDs of a compute unit, and this kernel is as
+// close to its issue limit as to the vector pipes'.
+struct PassArgs {
+    const SumRec* sr; SumRec* sw;                                      // sums[k & 1] (read), sums[(k + 1) & 1] (written)
+    const int4* pent; const float* pdis; const unsigned int* pcnt;     // log of pass k - 1
+    int4* cent; float* cdis; unsigned int* ccnt;                       // log of pass k
+    const uint2* geom;                                                 // window geometry per tile of this pass' grid (PassGeomEntry), or null
+};
 template <bool RGBD, int NPX, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
@@ -385,10 +397,15 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         const unsigned int r = t - bz * ord.ntile;
         by = __umulhi(r, ord.magic_ntx); bx = r - by * ord.ntx;
     }
-    m = batch_slot(m, bz);
-    const bool odd = (pass & 1) != 0;
-    const SpSums sr = odd ? m.sums[1] : m.sums[0];           // read buffer (selects, no dynamic kernarg indexing)
-    const SpSums sw = odd ? m.sums[0] : m.sums[1];           // write buffer
+    const size_t slot_off = (size_t)bz * m.slab;                 // this frame's slot of the batch context
+#ifdef SSF_EXPERIMENTS
+    m = batch_slot(m, bz);                                       // (the lab arms read other members)
+#else
+    m.rgba = slab_shift(m.rgba, slot_off); m.disp = slab_shift(m.disp, slot_off); m.label = slab_shift(m.label, slot_off);
+    m.inlier = slab_shift(m.inlier, slot_off);
+#endif
+    SpSums sr, sw;
+    sr.r = const_cast<SumRec*>(slab_shift(pa.sr, slot_off)); sw.r = slab_shift(pa.sw, slot_off);
     const int X0 = __builtin_amdgcn_readfirstlane((int)bx * TWX - (OX ? 0 : TWX - 2)), Y0 = __builtin_amdgcn_readfirstlane((int)by * TILE);  // OX = 0: tiles start at 2 (mod 4)
     int32_t* __restrict__ lab = m.label;
     // this thread's pass pixels: local columns 4j+1, 4j+2 of pass rows; pixel s of the thread is element threadIdx.x + 256 s
@@ -403,8 +420,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         q[s] = in_image[s] ? __umul24((unsigned int)y[s], (unsigned int)p.W) + (unsigned int)x[s] : 0u;      // (W, H < 2^16)
     }
     const int tile_id = (int)(by * ord.ntx + bx);
-    const int lp = (pass + 2) % 3, lc = pass % 3;
-    const unsigned int* __restrict__ pcnt = lp == 0 ? m.log.count[0] : (lp == 1 ? m.log.count[1] : m.log.count[2]);
+    const unsigned int* __restrict__ pcnt = slab_shift(pa.pcnt, slot_off);
     // The previous pass' entry count of this tile (uniform, needed only further down).  Behind `pass > 0` the compiler waits
     // for the word inside the branch -- a dependent trip to memory before the first vector load is issued.  Form 1 requests it
     // unconditionally (at pass 0 the word is a stale count of an earlier frame and is ignored), form 2 as a VECTOR load of
@@ -447,7 +463,12 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     static_assert(NQ <= 1024 && TILE_LOADS * 4 <= 32, "quad index / outside mask");
     uint4 tile_reg[TILE_LOADS]; unsigned int outside = 0u;
     const bool no_tile = SSF_PROBE(dbg, 32);                     // (probe: every element reads as outside the image)
-    const bool interior = X0 >= 1 && X0 - 1 + TWP <= p.W && Y0 >= 1 && Y0 + TILE < p.H;
+    // (window geometry and the interior test: one 8-byte table entry per tile for the product's 32-wide tiles, fetched by a scalar
+    // load that travels with the kernel arguments; worked out here for the lab's 64-wide tiles)
+    uint2 geom = make_uint2(0u, 0u);
+    constexpr bool have_geom = NPX == 1;                      // (launch_update_pass always supplies the table for 32-wide tiles)
+    if (have_geom) geom = pa.geom[by * ord.ntx + bx];
+    const bool interior = have_geom ? ((geom.y >> 16) & 1u) != 0u : (X0 >= 1 && X0 - 1 + TWP <= p.W && Y0 >= 1 && Y0 + TILE < p.H);
     if (interior) {
         typedef uint32_t Quad __attribute__((ext_vector_type(4), aligned(4)));     // ONE load of four labels, 4-byte aligned
         const unsigned int base_off = (unsigned int)((Y0 - 1) * p.W + (X0 - 1));
@@ -484,17 +505,26 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     }
     if (no_tile) outside = 0xFFFFFFFFu;
     // window of grid cells around the tile whose superpixel rows are cached in LDS
-    int margin = 2;
-    const int tcx0 = div_cell(p, max(X0, 0)), tcy0 = div_cell(p, Y0);
-    const int tcx1 = div_cell(p, min(X0 + TWX - 1, p.W - 1)), tcy1 = div_cell(p, min(Y0 + TILE - 1, p.H - 1));
-    while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
-    // (uniform values, said so: without the readfirstlane the RGB-D variant computed the whole window geometry -- two
-    // mul_hi, four quarter-rate mul_lo, the margin loop -- in vector registers, ~45 issue slots per wave)
-    margin = __builtin_amdgcn_readfirstlane(margin);
-    const int wcx0 = __builtin_amdgcn_readfirstlane(tcx0 - margin), wcy0 = __builtin_amdgcn_readfirstlane(tcy0 - margin);
-    const int nwx_ = tcx1 - tcx0 + 1 + 2 * margin, nwy_ = tcy1 - tcy0 + 1 + 2 * margin;
-    const bool window_ok = nwx_ * nwy_ <= WIN_MAX;
-    const int nwx = __builtin_amdgcn_readfirstlane(window_ok ? nwx_ : 0), nwy = __builtin_amdgcn_readfirstlane(window_ok ? nwy_ : 0), nslots = nwx * nwy;   // no window: every label takes the exact path
+    int wcx0, wcy0, nwx, nwy;
+    bool window_ok;
+    if (have_geom) {
+        wcx0 = __builtin_amdgcn_readfirstlane((int)(short)(geom.x & 0xFFFFu)); wcy0 = __builtin_amdgcn_readfirstlane((int)(short)(geom.x >> 16));
+        nwx = __builtin_amdgcn_readfirstlane((int)(geom.y & 255u)); nwy = __builtin_amdgcn_readfirstlane((int)((geom.y >> 8) & 255u));
+        window_ok = nwx != 0;
+    } else {
+        int margin = 2;
+        const int tcx0 = div_cell(p, max(X0, 0)), tcy0 = div_cell(p, Y0);
+        const int tcx1 = div_cell(p, min(X0 + TWX - 1, p.W - 1)), tcy1 = div_cell(p, min(Y0 + TILE - 1, p.H - 1));
+        while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
+        // (uniform values, said so: without the readfirstlane the RGB-D variant computed the whole window geometry -- two
+        // mul_hi, four quarter-rate mul_lo, the margin loop -- in vector registers, ~45 issue slots per wave)
+        margin = __builtin_amdgcn_readfirstlane(margin);
+        wcx0 = __builtin_amdgcn_readfirstlane(tcx0 - margin); wcy0 = __builtin_amdgcn_readfirstlane(tcy0 - margin);
+        const int nwx_ = tcx1 - tcx0 + 1 + 2 * margin, nwy_ = tcy1 - tcy0 + 1 + 2 * margin;
+        window_ok = nwx_ * nwy_ <= WIN_MAX;
+        nwx = __builtin_amdgcn_readfirstlane(window_ok ? nwx_ : 0); nwy = __builtin_amdgcn_readfirstlane(window_ok ? nwy_ : 0);   // no window: every label takes the exact path
+    }
+    const int nslots = nwx * nwy;
     const SpRow zero_row = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (window <= 64 cells: wave 0 builds the means of cell `lane`, wave 1 -- RGB-D passes -- its plane, side by side)
     if (threadIdx.x < (RGBD ? 128 : 64)) {
@@ -527,8 +557,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     // this tile's log of the previous pass is replayed at the very end.  Only the valid entries are fetched (an unconditional
     // fetch of the whole region cost 5 B per pixel of HBM): the other lanes read entry 0 again -- one address, and no branch
     // around the load (behind a branch the compiler waits for the entry at once)
-    const int4* __restrict__ pent = lp == 0 ? m.log.ent[0] : (lp == 1 ? m.log.ent[1] : m.log.ent[2]);
-    const float* __restrict__ pdis = lp == 0 ? m.log.disp[0] : (lp == 1 ? m.log.disp[1] : m.log.disp[2]);
+    const int4* __restrict__ pent = slab_shift(pa.pent, slot_off);
+    const float* __restrict__ pdis = slab_shift(pa.pdis, slot_off);
     int4 prev_ent[NPX]; float prev_disp[NPX];
     const unsigned int n_prev = pass > 0 ? n_prev_word : 0u;
 #pragma unroll
@@ -569,7 +599,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #ifdef SSF_EXPERIMENTS
     if (s_clean) {
         if (threadIdx.x == 0) {
-            unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+            unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
             ccnt[tile_id] = 0u;
             atomicAdd(&m.epoch[1 + (pass & 31)], 1u);          // (ssf_dbg_pass_skips)
         }
@@ -638,6 +668,16 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
     };
     if (SSF_PROBE(dbg, 2)) return;
+#if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_SJUNK)
+    // measurement only: SSF_PASS_SJUNK extra SCALAR instructions per wave (one scalar unit serves the four SIMDs of a compute unit:
+    // is the pass bound by scalar issue -- its waves execute ~310 scalar instructions beside ~420 vector ones?)
+    {
+        int sj = __builtin_amdgcn_readfirstlane((int)blockIdx.x | 3);
+#pragma unroll
+        for (int i = 0; i < SSF_PASS_SJUNK; i++) asm volatile("s_mul_i32 %0, %0, %0" : "+s"(sj));
+        if (sj == 0x12345677) s_nlog = 1;
+    }
+#endif
 #if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_JUNK)
     // measurement only: SSF_PASS_JUNK extra vector instructions per wave (is the pass bound by instruction issue?)
     {
@@ -647,8 +687,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         if (junk == 12345.678f) s_nlog = 1;
     }
 #endif
-    int4* __restrict__ cent = lc == 0 ? m.log.ent[0] : (lc == 1 ? m.log.ent[1] : m.log.ent[2]);
-    float* __restrict__ cdis = lc == 0 ? m.log.disp[0] : (lc == 1 ? m.log.disp[1] : m.log.disp[2]);
+    int4* __restrict__ cent = slab_shift(pa.cent, slot_off);
+    float* __restrict__ cdis = slab_shift(pa.cdis, slot_off);
 #pragma unroll
     for (int s = 0; s < NPX; s++) {
         const int lx = lxh[s], ly = lyh[s];
@@ -763,7 +803,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     // A tile that logged nothing and replayed nothing has nothing to flush (most tiles of the later passes): no scan.
     if (s_nlog == 0u && n_prev == 0u) {
         if (threadIdx.x == 0) {
-            unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+            unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
             ccnt[tile_id] = 0u;
         }
         return;
@@ -789,7 +829,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
     }
     if (threadIdx.x == 0) {
-        unsigned int* __restrict__ ccnt = lc == 0 ? m.log.count[0] : (lc == 1 ? m.log.count[1] : m.log.count[2]);
+        unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
         ccnt[tile_id] = s_nlog;
     }
 }
@@ -1913,6 +1953,29 @@ int pass_tile_npx(int nb) {
                     // the algorithmic bytes but not its time -- the kernel is bound by instruction issue, not by memory or by
                     // how many workgroups are resident -- and cost a single-frame launch 50 % more (8 -> 12 us)
 }
+// the table behind SegParams::pass_geom: exactly what k_update_pass<., 1, .> works out for a tile (same formulas, host integers)
+int pass_geometry_entries(int W, int H) { return 2 * ((W + (TILE - 2) + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+void pass_geometry_table(const SegParams& p, uint2* out) {
+    const int ntx = (p.W + (TILE - 2) + TILE - 1) / TILE, nty = (p.H + TILE - 1) / TILE;
+    auto cell_of = [&](int x) { return p.cell_magic ? (int)(((uint64_t)(uint32_t)x * p.cell_magic) >> 32) : x; };
+    for (int ox = 0; ox < 2; ox++)
+        for (int by = 0; by < nty; by++)
+            for (int bx = 0; bx < ntx; bx++) {
+                const int X0 = bx * TILE - (ox ? 0 : TILE - 2), Y0 = by * TILE;
+                const int TWP1 = TILE + 4;
+                const bool interior = X0 >= 1 && X0 - 1 + TWP1 <= p.W && Y0 >= 1 && Y0 + TILE < p.H;
+                int margin = 2;
+                const int tcx0 = cell_of(std::max(X0, 0)), tcy0 = cell_of(Y0);
+                const int tcx1 = cell_of(std::min(X0 + TILE - 1, p.W - 1)), tcy1 = cell_of(std::min(Y0 + TILE - 1, p.H - 1));
+                while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
+                const int nwx = tcx1 - tcx0 + 1 + 2 * margin, nwy = tcy1 - tcy0 + 1 + 2 * margin;
+                const bool ok = nwx * nwy <= WIN_MAX && nwx < 256 && nwy < 256;
+                uint2 e;
+                e.x = ((uint32_t)(tcx0 - margin) & 0xFFFFu) | ((uint32_t)(tcy0 - margin) << 16);
+                e.y = (ok ? (uint32_t)nwx | ((uint32_t)nwy << 8) : 0u) | (interior ? 1u << 16 : 0u);
+                out[(size_t)ox * ntx * nty + (size_t)by * ntx + bx] = e;
+            }
+}
 void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg, int skip_from) {
 #ifdef SSF_EXPERIMENTS
     static const char* per_pass_names[64] = {nullptr};
@@ -1937,6 +2000,14 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     grid.x = (p.W + (twx - 2) + twx - 1) / twx;
     grid.z = nb;
     const TileOrder ord = tile_order(grid);
+    PassArgs pa;
+    {
+        const int lp = (k + 2) % 3, lc = k % 3, odd = k & 1;
+        pa.sr = m.sums[odd].r; pa.sw = m.sums[odd ^ 1].r;
+        pa.pent = m.log.ent[lp]; pa.pdis = m.log.disp[lp]; pa.pcnt = m.log.count[lp];
+        pa.cent = m.log.ent[lc]; pa.cdis = m.log.disp[lc]; pa.ccnt = m.log.count[lc];
+        pa.geom = npx == 1 ? p.pass_geom + (size_t)(ox ? p.pass_ntile : 0) : nullptr;        // (pass_geometry_table: this grid, by construction)
+    }
     // occupancy target of the RGB-D variant: 6 waves per SIMD (73 registers, no spills).  Forcing 8 (64 registers, 9 spilled
     // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
     static const int waves_env = SSF_ENV_INT("PASS_WAVES", 6);
@@ -1948,15 +2019,15 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
 #ifdef SSF_EXPERIMENTS
     // the instantiations that lost their A/B: 64-wide tiles (two pass pixels per thread), 7 / 8 waves per SIMD for the RGB-D pass
     if (npx == 2) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
-        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
+        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
+        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
         return;
     }
-    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from); return; }
-    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from); return; }
+    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
+    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
 #endif
-    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
-    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, k, ox, oy, dbg, ord, skip_from);
+    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
+    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

@@ -1809,6 +1809,15 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
     bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 512);
+    {   // window geometry of the relabelling tiles (SegParams::pass_geom)
+        const int ne = pass_geometry_entries(W, H);
+        std::vector<uint2> tab((size_t)ne);
+        p.pass_geom = nullptr; p.pass_ntile = ne / 2;
+        pass_geometry_table(p, tab.data());
+        uint2* d_geom = nullptr;
+        ok = ok && dalloc(h, &d_geom, (size_t)ne) && hipMemcpy(d_geom, tab.data(), (size_t)ne * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) p.pass_geom = d_geom;
+    }
     // working set of one frame, carved out of a slab (256 B aligned pieces); a context owns `batch` slabs
     auto carve = [&](ExtractCtx& c, char* base) -> size_t {
         size_t off = 0;
