@@ -332,8 +332,9 @@ template <typename T> __device__ __forceinline__ void st_off(void* __restrict__ 
 // of a tile) are those of the logical tile, the same in every pass.
 struct TileOrder { unsigned int ntx, ntile, magic_ntx, magic_ntile, total; int xcd; };
 __device__ __forceinline__ unsigned int xcd_share(unsigned int b, unsigned int nb) {
+    // x (q + 1) for x < r, r (q + 1) + (x - r) q otherwise == x q + min(x, r): no branch (this runs in every wave's prologue)
     const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+    return x * q + min(x, r) + (b >> 3);
 }
 static inline TileOrder tile_order(dim3 grid) {
     TileOrder o;
@@ -390,7 +391,11 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #endif
     // this workgroup's (frame, tile row, tile column): see TileOrder
     unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (ord.xcd) {
+#ifdef SSF_EXPERIMENTS
+    if (ord.xcd) {              // (lab: SSF_PASS_XCD=0 = tiles in grid order)
+#else
+    {
+#endif
         const unsigned int lin = blockIdx.x + ord.ntx * blockIdx.y + ord.ntile * blockIdx.z;
         const unsigned int t = xcd_share(lin, ord.total);
         bz = __umulhi(t, ord.magic_ntile);
