@@ -503,11 +503,13 @@ def main():
     # sequence starts with batches of batch/4 and batch/2 frames, continues with full ones and ends with what is left
     # (ssf_process_sequence): one short untimed sequence with exactly those sizes builds the graphs before the timing
     if batch > 1 and not (depth == 0 and batch == 1):
-        ramp = [max(1, batch // 4), max(1, batch // 2)]
-        if os.environ.get("SSF_SEQ_RAMP"):          # (experiments: the library reads the same variable)
+        ramp = [max(1, (3 * batch + 4) // 8), max(1, (5 * batch + 4) // 8)]      # the library's leading batches: 3/8 and 5/8 of a batch (seq_batch_size)
+        if os.environ.get("SSF_SEQ_RAMP"):          # (experiments: the lab build reads the same variable)
             ramp = [min(batch, max(1, int(v))) for v in os.environ["SSF_SEQ_RAMP"].split(",") if v]
         tail = (K - sum(ramp)) % batch if K > sum(ramp) else 0
-        extra = sum(ramp) + batch + tail
+        # graphs are per (context, batch size): a warm-up sequence of the SAME length builds exactly the graphs a short timed
+        # sequence uses; a long one needs every context to have seen a full batch (ramp + one full batch per context + tail)
+        extra = K if K <= 64 else sum(ramp) + (depth + 1) * batch + tail
         run(Wm, extra)
         Wm += extra                                 # (reported as warmup_extra_frames)
     native_seq = not (depth == 0 and batch == 1) and drv is None

@@ -1386,7 +1386,7 @@ __host__ __device__ __forceinline__ PfWindow pf_window(int gx, int gy, int tx, i
 }
 __global__ __launch_bounds__(1024) void k_plane_filter_tiled(SegParams p, FrameMaps m, int true_buf) {
     m = batch_slot(m, blockIdx.z);
-    const int S = p.S, F = p.filter_iter;
+    const int S = p.S, F = max(p.filter_iter, 0);
     const PfWindow wd = pf_window(p.gx, p.gy, (int)blockIdx.x, (int)blockIdx.y, F);
     const int nn = wd.n1 + wd.n2;                              // <= blockDim.x (launch_plane_filter)
     float* Xa = filt_lds; float* Xb = Xa + 3 * nn; float* px = Xb + 3 * nn; float* py = px + nn;
@@ -2055,7 +2055,7 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int n
         const int ntx = (p.gx + PF_TX - 1) / PF_TX, nty = (p.gy + PF_TY - 1) / PF_TY;
         int worst = 0;
         for (int ty = 0; ty < nty; ty++)
-            for (int tx = 0; tx < ntx; tx++) { const PfWindow wd = pf_window(p.gx, p.gy, tx, ty, p.filter_iter); worst = std::max(worst, wd.n1 + wd.n2); }
+            for (int tx = 0; tx < ntx; tx++) { const PfWindow wd = pf_window(p.gx, p.gy, tx, ty, std::max(p.filter_iter, 0)); worst = std::max(worst, wd.n1 + wd.n2); }
         if (worst <= 1024 && ntx * nty > 1) {
             const int threads = ((worst + 63) / 64) * 64;
             hipLaunchKernelGGL(k_plane_filter_tiled, dim3(ntx, nty, nb), dim3(threads), (size_t)worst * 8 * sizeof(float), st, p, m, true_buf);
