@@ -932,6 +932,19 @@ __global__ __launch_bounds__(256) void k_init_samples(SegParams p, FrameMaps m, 
 #define ACC_REP 8
 #define EVAL_NS 16
 #define EVAL_REP 8
+#ifndef SSF_PASS_RGBD_WAVES
+#define SSF_PASS_RGBD_WAVES 6          // waves per SIMD the RGB-D pass is compiled for (launch bounds)
+#endif
+// unused dynamic LDS of the two accumulator-heavy tile kernels: caps their workgroups per compute unit (an occupancy knob for A/Bs)
+#ifndef SSF_INITDISP_DYN_LDS
+#define SSF_INITDISP_DYN_LDS 0
+#endif
+#ifndef SSF_RENDER_DYN_LDS
+#define SSF_RENDER_DYN_LDS 0
+#endif
+#ifndef SSF_EVAL_PLANE_STRIDE
+#define SSF_EVAL_PLANE_STRIDE 17
+#endif
 // FAST = the reference's sixteen samples (every launch file): per pixel all planes of its superpixel are read from LDS first,
 // the sixteen tests follow, and the votes go out as LDS atomics nobody waits for -- TWO samples per 32-bit counter (16-bit
 // fields: a tile has 1024 pixels), in the layout [pair][window cell][replica]: eight atomics per pixel instead of sixteen,
@@ -940,7 +953,13 @@ __global__ __launch_bounds__(256) void k_init_samples(SegParams p, FrameMaps m, 
 // per CU instead of three).
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
-    __shared__ float4 w_plane[EVAL_WIN * EVAL_NS];
+    // (FAST: the sixteen planes of a window cell 17 float4 apart, not 16: the lanes of a wave read plane sk of a handful of DIFFERENT
+    // cells in one ds_read_b128, and with a stride of 64 dwords every cell's plane sk sits on the same four banks -- the counters
+    // put 53 % of this kernel's LDS cycles down to bank conflicts.  Round 5, same box, alternated: 33.2-34.4 us per 8-frame launch
+    // at a stride of 16, 26.0-26.9 at 17, 32.5-32.8 at 24 (cells two apart collide again; three workgroups per compute unit instead
+    // of four).)
+    constexpr int PLANE_STRIDE = FAST ? SSF_EVAL_PLANE_STRIDE : EVAL_NS;
+    __shared__ float4 w_plane[EVAL_WIN * (FAST ? SSF_EVAL_PLANE_STRIDE : EVAL_NS)];
     // EVAL_REP replicas of every counter (lane & 7): the 64 pixels of a wave sit in a handful of superpixels, and
     // same-address LDS atomics serialise (SQ_LDS_BANK_CONFLICT was 80 % of the LDS cycles with one replica)
     __shared__ __attribute__((aligned(16))) int w_cnt[EVAL_WIN * (FAST ? EVAL_NS / 2 : EVAL_NS) * EVAL_REP];
@@ -980,7 +999,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
 #pragma unroll
     for (int k = 0; k < PLANE_ROUNDS; k++) {
         const int i = threadIdx.x + 256 * k;
-        if (i < n_planes) w_plane[i] = wp_ok[k] ? wp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_planes) w_plane[FAST ? (i / EVAL_NS) * PLANE_STRIDE + (i % EVAL_NS) : i] = wp_ok[k] ? wp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     // The reference's sample count (16 in every launch file) has a path of its own: per pixel, ALL planes of its superpixel
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
             const float d = pd[k];
             const int ws = win.slot(l);
             if (ws >= 0) {
-                const float4* __restrict__ plane = &w_plane[ws * EVAL_NS];
+                const float4* __restrict__ plane = &w_plane[ws * PLANE_STRIDE];
                 unsigned int votes = 0u;
 #pragma unroll
                 for (int sk = 0; sk < EVAL_NS; sk++) {
@@ -2031,7 +2050,7 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
     if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
 #endif
-    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
+    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, SSF_PASS_RGBD_WAVES>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
     else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
@@ -2046,7 +2065,7 @@ void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac) {
     ScopedKernel sk("init_disp", st);
-    hipLaunchKernelGGL(k_init_disp, batch_tile_grid(p, nb), dim3(256), 0, st, p, m, ransac ? 1 : 0);
+    hipLaunchKernelGGL(k_init_disp, batch_tile_grid(p, nb), dim3(256), SSF_INITDISP_DYN_LDS, st, p, m, ransac ? 1 : 0);
 }
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("plane_filter", st);
@@ -2083,7 +2102,7 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 }
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb) {
     ScopedKernel sk("render_moments", st);
-    hipLaunchKernelGGL(k_render_moments, batch_tile_grid(p, nb), dim3(256), 0, st, p, cam, m);
+    hipLaunchKernelGGL(k_render_moments, batch_tile_grid(p, nb), dim3(256), SSF_RENDER_DYN_LDS, st, p, cam, m);
 }
 void launch_import_frame(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, const float* wire, unsigned long long* best, uint8_t* matched) {
     ScopedKernel sk("import_frame", st);
