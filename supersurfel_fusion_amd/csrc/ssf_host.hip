@@ -2883,6 +2883,40 @@ double ssf_dbg_time_icp(ssf_handle* h, int reps, int dbg) {
     return 1000.0 * ms / reps;
 }
 
+// ablation timer for the fuse launch (tools/fuse_probe.py; lab build; leaves model and partition sums garbage): `reps` back-to-back
+// k_update_insert launches on the current frame.  mode bit 0: without the out-of-view arm, bit 1: without update + insert,
+// bit 2: without the classification of the visible rows (and then without the update, which needs them)
+double ssf_dbg_time_fuse(ssf_handle* h, int reps, int mode, long long* blocks2 /* out-of-view blocks of 256 slots | those with rows that move; may be null */) {
+    if (!h || !h->have_frame || !h->cc) return -1.0;
+    SurfelSoA& M = h->model[h->mcur];
+    PartitionWs ws;
+    uint32_t* set = h->d_part + (size_t)h->part_set * h->part_words;
+    ws.sup_vis = set; ws.sup_oov = set + h->part_sup_vis; ws.tot = ws.sup_oov + h->part_sup_oov;
+    ws.ticket = h->d_part_ticket; ws.other = h->d_part + (size_t)(h->part_set ^ 1) * h->part_words; ws.words = h->part_words;
+    const int S = (mode & 2) ? 0 : h->S, nvis = (mode & 4) ? 0 : h->n_visible, span = (mode & 1) ? 0 : h->oov_tail - h->oov_head;
+    auto launch = [&] {
+        launch_fuse(h->stream, M, h->cc->frame, h->pose, h->stamp, h->id_offset, nvis, h->cc->d_best, h->cc->d_matched, h->d_cand,
+                    S, (nvis > 0 && S > 0) ? 1 : 0, h->cfg.nb_supersurfels_max, 0, 1, h->cfg.shard_tile, h->d_cnt,
+                    h->cam, h->oov[h->ocur], span, h->cc->maps.plane_depth, h->cfg.delta_t,
+                    h->cfg.conf_thresh, h->cfg.range_min, h->cfg.range_max, h->d_state, h->d_state_oov, h->d_bc_oov, ws, 0, 1);
+    };
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3 && reps > 0; i++) launch();              // (reps <= 0: only the block census of the last real frame)
+    (void)hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps; i++) launch();
+    (void)hipEventRecord(e1, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (blocks2) {
+        const int nb = (span + 255) / 256;
+        std::vector<uint32_t> bc((size_t)std::max(nb, 1));
+        if (nb > 0) (void)hipMemcpy(bc.data(), h->d_bc_oov, (size_t)nb * 4, hipMemcpyDeviceToHost);
+        blocks2[0] = nb; blocks2[1] = 0;
+        for (int i = 0; i < nb; i++) blocks2[1] += bc[i] != 0u;
+    }
+    return reps > 0 ? 1000.0 * ms / reps : 0.0;
+}
 #endif
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
 // lab build: tiles of the last extracted frame (slot 0 of the active context) that proved themselves clean, per pass

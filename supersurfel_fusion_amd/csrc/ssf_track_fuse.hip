@@ -818,7 +818,12 @@ __device__ __forceinline__ int classify_row(const Cam& cam, const SurfelSoA& M, 
     if (st == 2) M.conf[idx] = -1.0f;
     return st;
 }
-#define OOV_PER_WG 8
+// (4 since round 5: the launch no longer ends in an arrival count -- the move kernel works the counters out --, so fewer, longer
+//  workgroups buy nothing; 8 -> 4 takes the arm alone from 8.6 to 7.2 us and the whole launch from 12.5 to 11.0 at 870 k slots,
+//  +1.0 % frames/s in place, alternated three times; 2 is no better: profiles/track_chain_r05.txt item 6)
+#ifndef OOV_PER_WG
+#define OOV_PER_WG 4
+#endif
 // 256 slots of the out-of-view span (class B; dead slots are skipped).  These rows are touched by neither the
 // update nor the insertion of the frame, so their blocks ride along in the update/insert launch (whose duration is
 // set by the long serial chain of the updated rows) instead of lengthening the classify launch.  Of the three
@@ -829,7 +834,7 @@ __device__ __forceinline__ void classify_oov_block(const Cam& cam, const OovStor
                                                    int stamp, int delta_t, float conf_thresh, float zmin, float zmax,
                                                    uint8_t* __restrict__ state_oov, uint32_t* __restrict__ bc_oov, PartitionWs ws,
                                                    const Counters* __restrict__ cnt, int wg, int nb_oov) {
-    // OOV_PER_WG blocks of 256 slots per workgroup (fewer arrivals at the end of the launch)
+    // OOV_PER_WG blocks of 256 slots per workgroup: their loads are in flight together
     __shared__ int h2[OOV_PER_WG][4][2];
     const int wv = threadIdx.x >> 6;
     const long long head = cnt->oov_head, tail = cnt->oov_tail;
