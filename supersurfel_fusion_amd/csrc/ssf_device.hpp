@@ -315,6 +315,9 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
                  int tail_in_move = 0 /* the launch ends without turning the class totals into counters: launch_move_rows(totals) does */);
 // launch_move_rows(totals != nullptr): the fuse launch ended without its tail; every block of the move kernel takes the old
 // counts from here (the host mirrors them) and the class totals from the partition's replicas, block 0 finalises the counters
+#ifdef SSF_EXPERIMENTS
+void set_fuse_trace(unsigned long long* device_words /* 3 per workgroup of the fuse launch; nullptr: off */);      // (lab: tools/fuse_probe.py)
+#endif
 struct MoveTotals { int from_tot, nv /* visible rows before the frame */, head_old, tail_old /* out-of-view span before the frame */; };
 // Multi-GPU migration (ssf_stage_fuse_begin / _end in ssf.h).  launch_fuse(migrate = 1) marks an updated row whose new
 // position belongs to another rank's world tile as leaving (partition class "dropped", confidence kept);

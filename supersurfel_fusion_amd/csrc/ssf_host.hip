@@ -2917,6 +2917,29 @@ double ssf_dbg_time_fuse(ssf_handle* h, int reps, int mode, long long* blocks2 /
     }
     return reps > 0 ? 1000.0 * ms / reps : 0.0;
 }
+// one fuse launch on the current frame with every workgroup leaving its three ticks (g_fuse_trace in ssf_track_fuse.hip): out =
+// 3 x workgroups words, arms4 = workgroups of update | insertion | visible rows | out-of-view span.  Returns the workgroups, < 0: n/a.
+int ssf_dbg_trace_fuse(ssf_handle* h, unsigned long long* out, int cap_wgs, int* arms4, int mode /* as ssf_dbg_time_fuse */) {
+    if (!h || !h->have_frame || !h->cc || !out || !arms4) return -1;
+    arms4[0] = (mode & 2) ? 0 : (h->S + 31) / 32; arms4[1] = (mode & 2) ? 0 : (h->S + 255) / 256; arms4[2] = (mode & 4) ? 0 : (h->n_visible + 255) / 256;
+    long long b2[2];
+    unsigned long long* d = nullptr;
+    const size_t words = (size_t)3 * 65536;
+    if (hipMalloc((void**)&d, words * 8) != hipSuccess) return -2;
+    (void)hipMemset(d, 0, words * 8);
+    set_fuse_trace(d);
+    (void)ssf_dbg_time_fuse(h, 1, mode, b2);         // (3 warm launches with the trace on, then the one whose ticks stay)
+    set_fuse_trace(nullptr);
+    std::vector<unsigned long long> all(words);
+    (void)hipMemcpy(all.data(), d, words * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    int n = 0;
+    for (int i = 0; i < 65536; i++) if (all[3 * (size_t)i]) n = i + 1;
+    arms4[3] = n - arms4[0] - arms4[1] - arms4[2];
+    const int m = n < cap_wgs ? n : cap_wgs;
+    std::memcpy(out, all.data(), (size_t)m * 24);
+    return m;
+}
 #endif
 // ablation timer for the relabelling pass (tools/pass_probe.py); leaves the segmentation state garbage
 // lab build: tiles of the last extracted frame (slot 0 of the active context) that proved themselves clean, per pass

@@ -1126,6 +1126,12 @@ __device__ __forceinline__ Counters frame_counters(const Counters& c_in, const u
     c.oov_live = (c_in.oov_live - b0 - b2) + a1 + c1;
     return c;
 }
+#ifdef SSF_EXPERIMENTS
+// lab: when set, every workgroup of the fuse launch leaves three ticks of the 100 MHz wall clock -- entry, end of its arm, its
+// memory operations acknowledged (tools/fuse_probe.py: which arm is late, and is it late to start or slow to run?)
+__device__ unsigned long long* g_fuse_trace = nullptr;
+void set_fuse_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_trace), &p, sizeof(p)); }
+#endif
 __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F, Rt pose, int stamp, long long id_offset,
                                                        int n_visible, const unsigned long long* __restrict__ best,
                                                        const uint8_t* __restrict__ matched, const int32_t* __restrict__ cand, int S,
@@ -1139,6 +1145,10 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
     __shared__ int s_last;
     __shared__ uint32_t tot[8];
     const int b = blockIdx.x;
+#ifdef SSF_EXPERIMENTS
+    unsigned long long* const trace = g_fuse_trace;
+    if (trace && threadIdx.x == 0) trace[3 * (size_t)b] = wall_clock64();
+#endif
     if (b >= nupd + nchunks + nb_vis)
         classify_oov_block(ca.cam, O, pose, ca.plane_depth, stamp, ca.delta_t, ca.conf_thresh, ca.zmin, ca.zmax, state_oov, bc_oov,
                            ws, cnt, b - nupd - nchunks - nb_vis, nb_oov);
@@ -1178,6 +1188,15 @@ __global__ __launch_bounds__(256) void k_update_insert(SurfelSoA M, SurfelSoA F,
     // into the frame's counters before the row moves; the kernel boundary in front of k_move_rows completes every atomic of this
     // launch for free, every block of the move kernel sums the eight replicas of the totals it needs itself (64 words), and its
     // block 0 finalises and publishes the counters (move_totals / the head of k_move_rows).
+#ifdef SSF_EXPERIMENTS
+    if (trace) {
+        __syncthreads();
+        if (threadIdx.x == 0) trace[3 * (size_t)b + 1] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) trace[3 * (size_t)b + 2] = wall_clock64();
+    }
+#endif
     if (tail_in_move) return;
     // the atomics above (and cnt->n_updated / n_inserted) are device-scope, complete (vmcnt(0) + barrier) before this
     // block counts its arrival; the last block reads them back with device-scope atomic loads (same protocol as the

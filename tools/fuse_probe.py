@@ -31,3 +31,22 @@ print("   first launch on the frame: %.2f us;" % lib.lib.ssf_dbg_time_fuse(f.h, 
 for mode in (0, 1, 2, 3, 6, 7, 0):
     t = lib.lib.ssf_dbg_time_fuse(f.h, 200, mode, b2)
     print("   %-45s %.2f us   (out-of-view blocks %d, with rows that move %d)" % (names[mode], t, b2[0], b2[1]))
+
+# where the time goes inside ONE launch: every workgroup's entry | end of its arm | memory acknowledged (100 MHz wall clock)
+import numpy as np
+lib.lib.ssf_dbg_trace_fuse.restype = C.c_int
+lib.lib.ssf_dbg_trace_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+buf = np.zeros((65536, 3), np.uint64); arms = (C.c_int * 4)()
+for mode in (0, 1, 6, 3):
+    n = lib.lib.ssf_dbg_trace_fuse(f.h, buf.ctypes.data, 65536, arms, mode)
+    if n <= 0:
+        continue
+    t = buf[:n].astype(np.int64); t0 = t[:, 0].min(); us = (t - t0) / 100.0
+    print("one launch (%s), %d workgroups; microseconds after the first workgroup's entry:" % (names[mode], n))
+    lo = 0
+    for name, k in zip(("update", "insertion", "visible rows", "out-of-view span"), arms):
+        a = us[lo:lo + k]; lo += k
+        if len(a):
+            d = a[:, 2] - a[:, 0]
+            print("   %-17s %5d workgroups  entry %.2f .. %.2f   arm done median %.2f max %.2f   memory acknowledged median %.2f max %.2f   inside the workgroup: min %.2f median %.2f max %.2f"
+                  % (name, len(a), a[:, 0].min(), a[:, 0].max(), np.median(a[:, 1]), a[:, 1].max(), np.median(a[:, 2]), a[:, 2].max(), d.min(), np.median(d), d.max()))
