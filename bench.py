@@ -52,6 +52,9 @@ ALGO_BYTES = {
     "match": lambda c: 44.0 * c["n_visible"],
     "update_pass_rgb": lambda c: c["batch"] * 9.0 * P,
     "update_pass_rgbd": lambda c: c["batch"] * 14.0 * P,
+    # the passes of a phase in one launch (k_passes_team): the same bytes per pass and frame, c["passes"] passes per launch
+    "passes_team_rgb": lambda c: c["batch"] * 9.0 * P * c["passes"],
+    "passes_team_rgbd": lambda c: c["batch"] * 14.0 * P * c["passes"],
     "ingest": lambda c: c["batch"] * 23.0 * P,
     "init_disp": lambda c: c["batch"] * 9.0 * P,
     "eval_samples": lambda c: c["batch"] * 8.0 * P,
@@ -62,7 +65,7 @@ ALGO_BYTES = {
 }
 
 
-EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
+EXTRACT_KERNELS = ("update_pass_rgb", "update_pass_rgbd", "passes_team_rgb", "passes_team_rgbd", "ingest", "init_disp", "eval_samples", "render_moments")
 
 
 def strip_comments(src):
@@ -588,7 +591,7 @@ def main():
         torch.cuda.synchronize(dev)
     kt = f.kernel_times()
     f.set_profile(0)
-    counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S, batch=batch)
+    counts = dict(n_model=cnt_before["n_model"], n_visible=cnt_before["n_visible"], S=f.S, batch=batch, passes=2 * int(PARAMS["seg_iter"]))      # (4 passes per iteration, half of the iterations per phase)
     per_kernel = {}
     for name, (ms, calls) in kt.items():
         avg_us = 1000.0 * ms / max(calls, 1)
@@ -600,7 +603,7 @@ def main():
         per_kernel[name] = ent
     # The dominant KERNEL: k_update_pass is one kernel with two instantiations (RGB / RGB-D passes, timed under two names);
     # its share is their sum.  The roofline is reported for the instantiation with the larger share of the two.
-    fam = lambda n: "update_pass" if n.startswith("update_pass") else n
+    fam = lambda n: "update_pass" if (n.startswith("update_pass") or n.startswith("passes_team")) else n
     fam_ms = {}
     for n, e in per_kernel.items():
         fam_ms[fam(n)] = fam_ms.get(fam(n), 0.0) + e["total_ms_per_frame"]

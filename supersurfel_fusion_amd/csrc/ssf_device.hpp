@@ -229,6 +229,14 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
 // abort_flag: host-visible word set (never cleared) when the launch's workgroups could not all become resident and gave up.
 bool launch_update_passes(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k0, int k1, bool rgbd, unsigned int* abort_flag);
 bool update_passes_resident(const SegParams& p, int nb);       // would launch_update_passes take this geometry?
+// The passes k0 .. k1 - 1 of a batch in ONE launch whose workgroups stay, a frame per XCD, meeting inside their XCD between passes
+// (k_passes_team in ssf_extract.hip).  d_pas: the context's table of per-pass arguments (pass_args_table, pass_args_bytes(kmax) bytes
+// uploaded once); d_ws: pass_team_ws_bytes() of device memory ZEROED in stream order in front of every launch.
+size_t pass_team_ws_bytes();
+size_t pass_args_bytes(int kmax);
+void pass_args_table(const SegParams& p, const FrameMaps& m, int kmax, void* host_out);
+void launch_update_passes_team(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k0, int k1, bool rgbd, const void* d_pas, void* d_ws,
+                               unsigned int* abort_flag);
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf);
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb);
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac);

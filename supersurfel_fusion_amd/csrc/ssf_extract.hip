@@ -103,19 +103,38 @@ __device__ __forceinline__ SpRow ld_global_row(const SpRow* p) {
     r.size = c.x; r.pad0 = c.y; r.pad1 = c.z; r.pad2 = c.w;
     return r;
 }
+// A load that must see what ANOTHER compute unit of this XCD stored earlier in the same launch (k_passes_team: a pass reads what
+// the pass before wrote): past the compute unit's vector L1, served by the XCD's L2 (the sc1 bit; an L1 invalidate at workgroup
+// scope -- buffer_inv sc0 -- does nothing on this part and one at agent scope costs 8-15 us: tools/probe/xcd_team_barrier.hip).
+// COH = false: an ordinary load.  16-byte values travel as two 8-byte loads (4-byte alignment suffices for the hardware).
+template <bool COH, typename T> __device__ __forceinline__ T ld_coh(const T* p) {
+    if (!COH) return *p;
+    T out;
+    if (sizeof(T) == 1) { const unsigned char v = __hip_atomic_load(reinterpret_cast<const unsigned char*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_memcpy(&out, &v, 1); }
+    else if (sizeof(T) == 4) { const unsigned int v = __hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_memcpy(&out, &v, 4); }
+    else if (sizeof(T) == 8) { const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_memcpy(&out, &v, 8); }
+    else {
+        static_assert(sizeof(T) == 1 || sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "ld_coh: 1, 4, 8 or 16 bytes");
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long v[2] = {__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        __builtin_memcpy(&out, v, 16);
+    }
+    return out;
+}
+template <bool COH = false>
 __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with_planes, SpRow prev) {
     SpRow row = prev;
     // the record is read as whole 16-byte pieces (two cache lines per superpixel)
     const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
-    const int4 i0 = rec[0], i1 = rec[1];             // sx sy sr sg | sb n dx dy
+    const int4 i0 = ld_coh<COH>(rec), i1 = ld_coh<COH>(rec + 1);             // sx sy sr sg | sb n dx dy
     const float n = (float)i1.y;
     row.cx = (float)i0.x / n; row.cy = (float)i0.y / n;
     row.r = (float)i0.z / n; row.g = (float)i0.w / n; row.b = (float)i1.x / n;
     row.size = n;
     if (with_planes) {
-        int dn_i = s.r[k].dn;
+        int dn_i = ld_coh<COH>(&s.r[k].dn);
         const longlong2* __restrict__ q = reinterpret_cast<const longlong2*>(&s.r[k].dxx);
-        longlong2 q0 = q[0], q1 = q[1], q2 = q[2];         // dxx dyy | dxy dxd | dyd dd
+        longlong2 q0 = ld_coh<COH>(q), q1 = ld_coh<COH>(q + 1), q2 = ld_coh<COH>(q + 2);         // dxx dyy | dxy dxd | dyd dd
         // the whole record in ONE round trip: left alone, the compiler fetches dxd / dyd / dd only behind the first
         // test of the plane solve, a second dependent trip to memory in every RGB-D pass
         asm volatile("" : "+v"(dn_i), "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y));
@@ -134,20 +153,22 @@ __device__ __forceinline__ SpRow row_from_sums(const SpSums& s, int k, bool with
 }
 // the same in two independent halves, so that two waves of a workgroup can build a window row side by side (the plane
 // solve is a chain of three dependent IEEE divisions; the means are five independent ones): identical arithmetic
+template <bool COH = false>
 __device__ __forceinline__ void row_means_from_sums(const SpSums& s, int k, SpRow& row) {
     const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
-    const int4 i0 = rec[0], i1 = rec[1];             // sx sy sr sg | sb n dx dy
+    const int4 i0 = ld_coh<COH>(rec), i1 = ld_coh<COH>(rec + 1);             // sx sy sr sg | sb n dx dy
     const float n = (float)i1.y;
     row.cx = (float)i0.x / n; row.cy = (float)i0.y / n;
     row.r = (float)i0.z / n; row.g = (float)i0.w / n; row.b = (float)i1.x / n;
     row.size = n;
 }
+template <bool COH = false>
 __device__ __forceinline__ void row_plane_from_sums(const SpSums& s, int k, float& ta, float& tb, float& tc) {
     const int4* __restrict__ rec = reinterpret_cast<const int4*>(&s.r[k]);
-    int4 i1 = rec[1];
-    int dn_i = s.r[k].dn;
+    int4 i1 = ld_coh<COH>(rec + 1);
+    int dn_i = ld_coh<COH>(&s.r[k].dn);
     const longlong2* __restrict__ q = reinterpret_cast<const longlong2*>(&s.r[k].dxx);
-    longlong2 q0 = q[0], q1 = q[1], q2 = q[2];         // dxx dyy | dxy dxd | dyd dd
+    longlong2 q0 = ld_coh<COH>(q), q1 = ld_coh<COH>(q + 1), q2 = ld_coh<COH>(q + 2);         // dxx dyy | dxy dxd | dyd dd
     asm volatile("" : "+v"(i1.z), "+v"(i1.w), "+v"(dn_i), "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y));
     const double inv = 1.0 / SSF_DISP_SCALE;
     const float dx = (float)i1.z, dy = (float)i1.w, dn = (float)dn_i;
@@ -319,6 +340,9 @@ __device__ __forceinline__ void flush_field(const SpSums& s, int l, int field, l
 template <typename T> __device__ __forceinline__ T ld_off(const void* __restrict__ base, unsigned int byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+template <bool COH, typename T> __device__ __forceinline__ T ld_off_c(const void* __restrict__ base, unsigned int byte_off) {      // (see ld_coh)
+    return ld_coh<COH>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+}
 template <typename T> __device__ __forceinline__ void st_off(void* __restrict__ base, unsigned int byte_off, const T& v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
@@ -378,8 +402,12 @@ struct PassArgs {
     int4* cent; float* cdis; unsigned int* ccnt;                       // log of pass k
     const uint2* geom;                                                 // window geometry per tile of this pass' grid (PassGeomEntry), or null
 };
-template <bool RGBD, int NPX, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
+// One tile of one pass: the body of k_update_pass (one workgroup per tile and launch) and of k_passes_team (resident workgroups that
+// walk the tiles of a frame pass after pass).  bx, by, bz = the tile's column, row and frame slot.
+// COH: what other workgroups wrote in an earlier pass OF THIS LAUNCH -- labels, inlier bytes, sums, logs -- is read past the L1 (ld_coh).
+template <bool RGBD, int NPX, bool COH = false>
+__device__ __forceinline__ void update_pass_tile(const SegParams& p, FrameMaps m, const PassArgs& pa, int pass, int OX, int OY, int dbg,
+                                                 const TileOrder& ord, int skip_from, unsigned int bx, unsigned int by, unsigned int bz) {
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
@@ -389,19 +417,6 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #ifdef SSF_EXPERIMENTS
     __shared__ int s_clean, s_far;
 #endif
-    // this workgroup's (frame, tile row, tile column): see TileOrder
-    unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-#ifdef SSF_EXPERIMENTS
-    if (ord.xcd) {              // (lab: SSF_PASS_XCD=0 = tiles in grid order)
-#else
-    {
-#endif
-        const unsigned int lin = blockIdx.x + ord.ntx * blockIdx.y + ord.ntile * blockIdx.z;
-        const unsigned int t = xcd_share(lin, ord.total);
-        bz = __umulhi(t, ord.magic_ntile);
-        const unsigned int r = t - bz * ord.ntile;
-        by = __umulhi(r, ord.magic_ntx); bx = r - by * ord.ntx;
-    }
     const size_t slot_off = (size_t)bz * m.slab;                 // this frame's slot of the batch context
 #ifdef SSF_EXPERIMENTS
     m = batch_slot(m, bz);                                       // (the lab arms read other members)
@@ -434,7 +449,8 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     // pays is measured per variant (SSF_PASS_NPREV_RGBD / SSF_PASS_NPREV_RGB).
     constexpr int NPREV_FORM = RGBD ? SSF_PASS_NPREV_RGBD : SSF_PASS_NPREV_RGB;
     unsigned int n_prev_word = 0u;
-    if (NPREV_FORM == 0) { if (pass > 0) n_prev_word = pcnt[tile_id]; }
+    if (COH) n_prev_word = ld_coh<true>(&pcnt[tile_id]);      // (never through the scalar cache: the count was stored by a vector store of this launch)
+    else if (NPREV_FORM == 0) { if (pass > 0) n_prev_word = pcnt[tile_id]; }
     else if (NPREV_FORM == 1) n_prev_word = pcnt[tile_id];
     else { int lane_zero = 0; asm volatile("" : "+v"(lane_zero)); n_prev_word = pcnt[tile_id + lane_zero]; }
 #ifdef SSF_EXPERIMENTS
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     for (int s = 0; s < NPX; s++) {
         px[s] = ld_off<uint32_t>(m.rgba, 4u * q[s]);
         disp[s] = 0.f; prev_inlier[s] = 0;
-        if (RGBD) { disp[s] = ld_off<float>(m.disp, 4u * q[s]); prev_inlier[s] = ld_off<unsigned char>(m.inlier, q[s]); }
+        if (RGBD) { disp[s] = ld_off<float>(m.disp, 4u * q[s]); prev_inlier[s] = ld_off_c<COH, unsigned char>(m.inlier, q[s]); }
     }
     // the label tile + halo: requested into registers NOW (independent loads), stored to LDS after the superpixel rows
     // have been computed -- one memory round trip for tile, pixel operands, sums and log.
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
-            const Quad v = ld_off<Quad>(lab, tile_off[k]);
+            const Quad v = ld_off_c<COH, Quad>(lab, tile_off[k]);
             tile_reg[k] = make_uint4(v.x, v.y, v.z, v.w);
         }
     } else {
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         }
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++)
-            tile_reg[k] = make_uint4(ld_off<uint32_t>(lab, tile_off[k][0]), ld_off<uint32_t>(lab, tile_off[k][1]), ld_off<uint32_t>(lab, tile_off[k][2]), ld_off<uint32_t>(lab, tile_off[k][3]));
+            tile_reg[k] = make_uint4(ld_off_c<COH, uint32_t>(lab, tile_off[k][0]), ld_off_c<COH, uint32_t>(lab, tile_off[k][1]), ld_off_c<COH, uint32_t>(lab, tile_off[k][2]), ld_off_c<COH, uint32_t>(lab, tile_off[k][3]));
     }
     if (no_tile) outside = 0xFFFFFFFFu;
     // window of grid cells around the tile whose superpixel rows are cached in LDS
@@ -547,13 +563,13 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
             if (inside && !SSF_PROBE(dbg, 1)) {
                 if (threadIdx.x < 64) {
                     SpRow row = zero_row;
-                    row_means_from_sums(sr, k, row);
+                    row_means_from_sums<COH>(sr, k, row);
                     w_row[i].cx = row.cx; w_row[i].cy = row.cy; w_row[i].r = row.r; w_row[i].g = row.g; w_row[i].b = row.b; w_row[i].size = row.size;
                     w_row[i].pad0 = row.size / (row.size - 1.f);      // the pixel's own-energy scale n / (n - 1): one division per window cell instead of one per pass pixel
                     if (!RGBD) { w_row[i].ta = 0.f; w_row[i].tb = 0.f; w_row[i].tc = 0.f; }
                 } else {
                     float ta, tb, tc;
-                    row_plane_from_sums(sr, k, ta, tb, tc);
+                    row_plane_from_sums<COH>(sr, k, ta, tb, tc);
                     w_row[i].ta = ta; w_row[i].tb = tb; w_row[i].tc = tc;
                 }
             }
@@ -570,9 +586,9 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
     for (int s = 0; s < NPX; s++) {
         const unsigned int e = threadIdx.x + 256u * s;
         const unsigned int le = (unsigned int)tile_id * LOGN + (e < n_prev ? e : 0u);
-        prev_ent[s] = ld_off<int4>(pent, 16u * le);
+        prev_ent[s] = ld_off_c<COH, int4>(pent, 16u * le);
         prev_disp[s] = 0.f;
-        if (RGBD) prev_disp[s] = ld_off<float>(pdis, 4u * le);
+        if (RGBD) prev_disp[s] = ld_off_c<COH, float>(pdis, 4u * le);
     }
     if (threadIdx.x == 0) s_nlog = 0;
 #ifdef SSF_EXPERIMENTS
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 #ifdef SSF_EXPERIMENTS
         s_far = 1;                                            // (its sums are not among the stamps the clean-tile test reads)
 #endif
-        SpRow far = row_from_sums(sr, l, RGBD, zero_row);     // drifted out of the window: exact slow path
+        SpRow far = row_from_sums<COH>(sr, l, RGBD, zero_row);     // drifted out of the window: exact slow path
         far.pad0 = far.size / (far.size - 1.f);
         return far;
     };
@@ -838,6 +854,35 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
         ccnt[tile_id] = s_nlog;
     }
 }
+
+template <bool RGBD, int NPX, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
+    // this workgroup's (frame, tile row, tile column): see TileOrder
+    unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#ifdef SSF_EXPERIMENTS
+    if (ord.xcd) {              // (lab: SSF_PASS_XCD=0 = tiles in grid order)
+#else
+    {
+#endif
+        const unsigned int lin = blockIdx.x + ord.ntx * blockIdx.y + ord.ntile * blockIdx.z;
+        const unsigned int t = xcd_share(lin, ord.total);
+        bz = __umulhi(t, ord.magic_ntile);
+        const unsigned int r = t - bz * ord.ntile;
+        by = __umulhi(r, ord.magic_ntx); bx = r - by * ord.ntx;
+    }
+    update_pass_tile<RGBD, NPX>(p, m, pa, pass, OX, OY, dbg, ord, skip_from, bx, by, bz);
+}
+
+// ---- the passes of a phase in ONE launch, a frame per XCD (round 5): a measurement arm that lost its A/B (DESIGN.md section 7,
+// profiles/pass_team_r05.txt) -- lab/passes_team.inc, compiled only into the lab variant of the library
+#ifdef SSF_EXPERIMENTS
+#include "lab/passes_team.inc"
+#else
+size_t pass_team_ws_bytes() { return 0; }
+size_t pass_args_bytes(int) { return 0; }
+void pass_args_table(const SegParams&, const FrameMaps&, int, void*) {}
+void launch_update_passes_team(hipStream_t, const SegParams&, FrameMaps&, int, int, int, bool, const void*, void*, unsigned int*) {}
+#endif
 
 // ---- resident relabelling (all passes of a phase in one launch): a measurement arm that lost its A/B (DESIGN.md section
 // 4.1.1) -- lab/passes_resident.inc, compiled only into the lab variant of the library

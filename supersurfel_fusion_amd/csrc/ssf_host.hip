@@ -517,6 +517,7 @@ struct ExtractCtx {
     unsigned long long* d_best = nullptr; uint8_t* d_matched = nullptr;
     uint8_t* d_rgb_in = nullptr; float* d_depth_in = nullptr; float* d_depth_filt = nullptr; uint8_t* d_mask = nullptr;
     float* d_wire = nullptr;                      // 26 S words: the frame supersurfels of a frame extracted elsewhere (ssf_submit_frame_tables)
+    char* d_pas = nullptr; char* d_team_ws = nullptr;      // relabelling passes in one launch per phase (k_passes_team): per-pass arguments, team workspace
     ncclComm_t deal_comm = nullptr;               // dealt extract stage: this context's own communicator (a collective per batch on ITS stream)
     bool mine = true; long long deal_batch = 0;   // ... whether the open batch is this rank's to extract, and its number in the frame stream
     hipStream_t stream = nullptr; bool own_stream = false; int stream_prio = 0;
@@ -605,6 +606,10 @@ struct ssf_handle {
     SurfelSoA bins{}; int32_t* d_bin_idx = nullptr; uint32_t* d_bin_count = nullptr; uint32_t* d_bin_cursor = nullptr;
     bool bins_valid = false; int bin_min_rows = -1;      // OFF: measured a loss at BASELINE config 3 (k_icp is bound by its LDS atomics, not by the gathers; sorted rows pile k_match's atomicMin onto the same words)
     hipEvent_t ev_resident = nullptr; bool ev_resident_valid = false;     // resident relabelling launches take turns (resident_turn_begin)
+    // pass_team: the relabelling passes of a phase as ONE launch with a frame per XCD (k_passes_team) instead of a launch per pass.
+    // Its workgroups must all be on the chip at once, so whole batches take turns across the contexts (launch_batch: a batch's
+    // chain waits for the previous batch's ev_done).
+    bool pass_team = false; ExtractCtx* team_prev = nullptr;
     long long h_icp_local[SSF_ICP_RECORD];
     long long* h_icp = nullptr; Counters* h_cnt = nullptr;
     int n_model = 0, n_visible = 0, stamp = 0, max_passes = 0;
@@ -754,10 +759,14 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, b
     // k_passes in ssf_extract.hip; per-pass launches when the geometry does not qualify or SSF_RESIDENT_PASSES=0)
     unsigned int* abort_flag = &h->mb_dev->extract_abort;
     const bool multi = h->ctx.size() > 1;
+    const bool team = h->pass_team && c.d_pas && c.d_team_ws && !resident && h->max_passes == 0;
     if (resident) {
         if (multi) resident_turn_begin(h, st);
         (void)launch_update_passes(st, p, c.maps, nb, 0, k1, false, abort_flag);
         if (multi) resident_turn_end(h, st);
+    } else if (team) {
+        (void)hipMemsetAsync(c.d_team_ws, 0, pass_team_ws_bytes(), st);
+        launch_update_passes_team(st, p, c.maps, nb, 0, k1, false, c.d_pas, c.d_team_ws, abort_flag);
     } else
         for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false, 0, 4);
     // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
@@ -771,6 +780,10 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, b
         if (multi) resident_turn_begin(h, st);
         (void)launch_update_passes(st, p, c.maps, nb, k1, k2, true, abort_flag);
         if (multi) resident_turn_end(h, st);
+        k = std::max(k1, k2);
+    } else if (team) {
+        (void)hipMemsetAsync(c.d_team_ws, 0, pass_team_ws_bytes(), st);
+        launch_update_passes_team(st, p, c.maps, nb, k1, k2, true, c.d_pas, c.d_team_ws, abort_flag);
         k = std::max(k1, k2);
     } else
         for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true, 0, k1 + 4);
@@ -819,6 +832,7 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     const int nb = c.count;
     // the track/fuse chain must be done with the frames this context held before they are overwritten
     if (multi && c.consumed_valid) HCK(hipStreamWaitEvent(st, c.ev_consumed, 0));
+    if (multi && h->pass_team && h->team_prev && h->team_prev != &c) HCK(hipStreamWaitEvent(st, h->team_prev->ev_done, 0));      // (see pass_team)
     c.timed = h->cfg.profile != 0;
     if (c.timed) HCK(hipEventRecord(c.ev_t0, st));
     // The extract stage DEALT over the ranks of a sharded map (ssf_comm_deal_extract): batch j of the frame
@@ -858,6 +872,7 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     HCK(hipGetLastError());
     if (c.timed) HCK(hipEventRecord(c.ev_t1, st));
     if (multi) HCK(hipEventRecord(c.ev_done, st));
+    if (multi && h->pass_team) h->team_prev = &c;
     c.launched = true; c.waited = false; c.inflight = nb; c.nb_launched = nb;
     h->open_ctx = (int)((&c - h->ctx.data() + 1) % (ptrdiff_t)h->ctx.size());
     if (h->seq_n > 0) {
@@ -1808,6 +1823,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     const int nctx = std::max(0, std::min(cfg->pipeline_depth, SSF_MAX_PIPELINE_DEPTH)) + 1;
     h->batch = std::max(1, std::min(cfg->extract_batch, SSF_MAX_BATCH));
     h->ctx.resize(nctx);
+    h->pass_team = SSF_ENV_INT("PASS_TEAM", 0) != 0;              // (lab arm, lab/passes_team.inc: the product never takes it)
     bool ok = dalloc(h, &h->d_srgb_lut, 256) && dalloc(h, &h->d_tickets, 512);
     {   // window geometry of the relabelling tiles (SegParams::pass_geom)
         const int ne = pass_geometry_entries(W, H);
@@ -1865,6 +1881,13 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
             static const bool ctx0_up = SSF_ENV_INT("CTX0_PRIORITY", 1) != 0;
             const int prio = (ci == 0 && ctx0_up && least - greatest >= 2) ? least - 1 : least;
             c.stream = stream_pool().take(h->cfg.device_id, prio); ok = c.stream != nullptr; c.own_stream = ok; c.stream_prio = prio;
+        }
+        if (ok && h->pass_team) {
+            const int kmax = 4 * std::max(cfg->seg_iter, 0);
+            std::vector<char> tab(pass_args_bytes(std::max(kmax, 1)));
+            pass_args_table(p, c.maps, kmax, tab.data());
+            ok = dalloc(h, &c.d_pas, tab.size()) && dalloc(h, &c.d_team_ws, pass_team_ws_bytes()) &&
+                 hipMemcpy(c.d_pas, tab.data(), tab.size(), hipMemcpyHostToDevice) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c.ev_consumed, hipEventDisableTiming) == hipSuccess &&

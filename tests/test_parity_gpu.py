@@ -725,14 +725,17 @@ def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, l
     assert L.ssf_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
 
 
-@pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_SKIP=1"])
+@pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_SKIP=1", "SSF_PASS_TEAM=1"])
 def test_relabelling_passes_bit_exact_under_the_lab_switches(switch):
     """Two arms of the relabelling pass that only exist in the LAB build of the sources (the product reads no environment variable),
     each in a process of its own (the switches are read once per process):
       SSF_PASS_XCD=0   tiles in plain grid order instead of the XCD-aware order (DESIGN.md section 4.1.3): only speed may differ;
       SSF_PASS_SKIP=1  clean-tile skipping (lab/pass_skip.inc, section 4.1.5): a tile that can prove that nothing it depends on has
                        changed for four passes leaves after its loads -- exact by construction, measured useless.
-    The per-pass comparison against the oracle (drift-out-of-window parameter sets included) must hold under both."""
+      SSF_PASS_TEAM=1  the passes of a phase in ONE launch whose workgroups stay, a frame per XCD, meeting inside their XCD between
+                       passes and reading the previous pass' output past the L1 (lab/passes_team.inc): built in
+                       round 5, exact, slower (profiles/pass_team_r05.txt).  Whole frames, batches and pipelined sequences.
+    The comparison against the oracle (drift-out-of-window parameter sets included) must hold under all of them."""
     import os
     import subprocess
     import sys
@@ -740,7 +743,9 @@ def test_relabelling_passes_bit_exact_under_the_lab_switches(switch):
     name, value = switch.split("=")
     env = dict(os.environ, SSF_PRODUCT_VARIANT="lab", **{name: value})
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-q", "-m", "gpu", "-x",
-                        "-k", "test_every_relabelling_pass_bit_exact or test_segmentation_parameter_space_batched"], cwd=root, env=env,
+                        "-k", ("test_segmentation_parameter_space_batched or test_golden_vectors or test_seeded_model_50k_bit_exact or "
+                               "test_pipelined_equals_sequential_bit_exact") if name == "SSF_PASS_TEAM" else
+                        "test_every_relabelling_pass_bit_exact or test_segmentation_parameter_space_batched"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-1000:]

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_meet(Shared* sh, unsigned int* flags /*
     unsigned int stale = 0, failed = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 1; r <= rounds && !failed; r++) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE >= 3) {
             if (threadIdx.x < 64) my_payload[idx * 64 + threadIdx.x] = (unsigned int)r * 1000u + threadIdx.x;      // plain stores
             __builtin_amdgcn_s_waitcnt(0);                                                                          // ... acknowledged by the L2
             __syncthreads();
@@ -63,9 +63,14 @@ __global__ __launch_bounds__(256) void k_meet(Shared* sh, unsigned int* flags /*
                 }
             }
             __syncthreads();
+            if (MODE == 3) asm volatile("buffer_inv sc0\n\ts_dcache_inv" ::: "memory");        // workgroup scope
+            if (MODE == 5) asm volatile("buffer_inv sc1\n\ts_dcache_inv" ::: "memory");        // agent scope: the CU's vector L1 (and what of the L2?)
+            if (MODE == 6) asm volatile("buffer_inv sc0 sc1\n\ts_dcache_inv" ::: "memory");    // system scope
             if (threadIdx.x < 64) {                                   // the next member's payload, through the L2
                 const unsigned int n = (idx + 1) % team;
-                const unsigned int v = ld_sc1(&my_payload[n * 64 + threadIdx.x]);
+                const unsigned int* q = &my_payload[n * 64 + threadIdx.x];
+                asm volatile("" : "+v"(q));                           // (3 / 4: a PLAIN load -- no cache-policy bits -- that the compiler cannot hoist; `volatile` would make it sc0 sc1)
+                const unsigned int v = MODE == 0 ? ld_sc1(q) : *q;
                 if (v != (unsigned int)r * 1000u + threadIdx.x) stale++;
             }
         } else {
@@ -91,20 +96,26 @@ int main() {
     hipMalloc(&sh, sizeof(Shared)); hipMalloc(&flags, 8 * MAX_TEAM * 4); hipMalloc(&payload, (size_t)8 * MAX_TEAM * 64 * 4); hipMalloc(&cyc, 1024 * 8);
     const int rounds = 2000;
     for (int wgs : {256, 512}) {
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 7; mode++) {
             hipMemset(sh, 0, sizeof(Shared)); hipMemset(flags, 0, 8 * MAX_TEAM * 4); hipMemset(payload, 0, (size_t)8 * MAX_TEAM * 64 * 4);
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
             hipEventRecord(a, 0);
             if (mode == 0) hipLaunchKernelGGL(k_meet<0>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
             else if (mode == 1) hipLaunchKernelGGL(k_meet<1>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
-            else hipLaunchKernelGGL(k_meet<2>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
+            else if (mode == 2) hipLaunchKernelGGL(k_meet<2>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
+            else if (mode == 3) hipLaunchKernelGGL(k_meet<3>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
+            else if (mode == 4) hipLaunchKernelGGL(k_meet<4>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
+            else if (mode == 5) hipLaunchKernelGGL(k_meet<5>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
+            else hipLaunchKernelGGL(k_meet<6>, dim3(wgs), dim3(256), 0, 0, sh, flags, payload, rounds, cyc);
             hipEventRecord(b, 0); hipEventSynchronize(b);
             float ms = 0; hipEventElapsedTime(&ms, a, b);
             Shared h; hipMemcpy(&h, sh, sizeof(Shared), hipMemcpyDeviceToHost);
-            const char* name[3] = {"A flags + sc1 polls (team = XCD) ", "B team counter (agent atomics)     ", "C one device-wide counter          "};
+            const char* name[7] = {"A flags + sc1 polls (team = XCD) ", "B team counter (agent atomics)     ", "C one device-wide counter          ",
+                                   "A + buffer_inv sc0, PLAIN loads   ", "A, PLAIN loads, NO invalidate     ", "A + buffer_inv sc1, PLAIN loads   ",
+                                   "A + buffer_inv sc0 sc1, PLAIN     "};
             printf("%4d workgroups  %s  %.3f us per meeting  (teams %u %u %u %u %u %u %u %u; failures %u, stale payload words %u of %llu)\n", wgs, name[mode],
                    1000.0 * ms / rounds, h.census[0], h.census[1], h.census[2], h.census[3], h.census[4], h.census[5], h.census[6], h.census[7], h.failures,
-                   h.stale, mode == 0 ? (unsigned long long)wgs * 64ull * rounds : 0ull);
+                   h.stale, (mode == 0 || mode >= 3) ? (unsigned long long)wgs * 64ull * rounds : 0ull);
         }
     }
     return 0;
