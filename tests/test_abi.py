@@ -80,7 +80,7 @@ def test_the_product_library_reads_no_environment_variable(product_lib):
     import subprocess
     out = subprocess.run(["strings", product_lib.path], stdout=subprocess.PIPE, text=True).stdout.splitlines()
     assert [l for l in out if l.startswith("SSF_")] == []
-    for src in ("ssf_extract.hip", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
+    for src in ("ssf_extract.hip", "ssf_pass_tile.hpp", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
         txt = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", src)).read()
         body = txt.split("#ifdef SSF_EXPERIMENTS\n#include <stdlib.h>")[0] if src == "ssf_device.hpp" else txt
         assert "getenv(" not in body, src
