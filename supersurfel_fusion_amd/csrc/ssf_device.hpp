@@ -324,6 +324,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
 // launch_move_rows(totals != nullptr): the fuse launch ended without its tail; every block of the move kernel takes the old
 // counts from here (the host mirrors them) and the class totals from the partition's replicas, block 0 finalises the counters
 #ifdef SSF_EXPERIMENTS
+void set_pass_trace(unsigned long long* device_words /* 5 per workgroup of a relabelling pass launch; nullptr: off */);     // (lab: tools/pass_trace.py)
 void set_fuse_trace(unsigned long long* device_words /* 3 per workgroup of the fuse launch; nullptr: off */);      // (lab: tools/fuse_probe.py)
 #endif
 struct MoveTotals { int from_tot, nv /* visible rows before the frame */, head_old, tail_old /* out-of-view span before the frame */; };

@@ -402,6 +402,22 @@ struct PassArgs {
     int4* cent; float* cdis; unsigned int* ccnt;                       // log of pass k
     const uint2* geom;                                                 // window geometry per tile of this pass' grid (PassGeomEntry), or null
 };
+// lab: when g_pass_trace is set every workgroup of a pass launch leaves five ticks of the 100 MHz wall clock -- entry | everything it
+// requested up front has arrived | staged (first barrier) | decisions taken (second barrier) | end -- at 5 x its linear block index
+// (ssf_dbg_trace_pass, tools/pass_trace.py: where does a tile's 5-6 us go?).  Nothing of it in the product.
+#ifdef SSF_EXPERIMENTS
+__device__ unsigned long long* g_pass_trace = nullptr;
+void set_pass_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pass_trace), &p, sizeof(p)); }
+#define SSF_PASS_TICK_BEGIN() unsigned long long* const pass_trace = g_pass_trace; \
+    const size_t pass_wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z); \
+    if (pass_trace && threadIdx.x == 0) pass_trace[5 * pass_wg] = wall_clock64()
+#define SSF_PASS_TICK(i) do { if (pass_trace && threadIdx.x == 0) pass_trace[5 * pass_wg + (i)] = wall_clock64(); } while (0)
+#define SSF_PASS_TICK_LOADS() do { if (pass_trace) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); SSF_PASS_TICK(1); } } while (0)
+#else
+#define SSF_PASS_TICK_BEGIN() ((void)0)
+#define SSF_PASS_TICK(i) ((void)0)
+#define SSF_PASS_TICK_LOADS() ((void)0)
+#endif
 template <bool RGBD, int NPX, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
     constexpr bool COH = false;

@@ -3009,6 +3009,30 @@ double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg, int nb) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 1000.0 * ms / reps;
 }
+// one pass launch over nb frames of the active context with every workgroup leaving its five ticks (g_pass_trace, ssf_extract.hip);
+// `k` = the pass number (>= 20 with rgbd: the frames' state is that of a finished extract, a late pass' workload).  out: 5 words per
+// workgroup, grid3 = the launch's grid.  Returns the workgroups copied, < 0: n/a.  Leaves the segmentation state advanced by five passes.
+int ssf_dbg_trace_pass(ssf_handle* h, int rgbd, int nb, unsigned long long* out, int cap_wgs, int* grid3) {
+    if (!h || !h->active.ctx || !out || !grid3) return -1;
+    ExtractCtx& c = *h->active.ctx;
+    nb = std::max(1, std::min(nb, h->batch));
+    const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};
+    grid3[0] = (h->cfg.width + 30 + 31) / 32; grid3[1] = (h->cfg.height + 31) / 32; grid3[2] = nb;
+    const int n = grid3[0] * grid3[1] * grid3[2];
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)n * 40) != hipSuccess) return -2;
+    (void)hipMemset(d, 0, (size_t)n * 40);
+    for (int i = 0; i < 4; i++) launch_update_pass(h->stream, h->seg, c.maps, nb, 20 + i, ox[i & 3], oy[i & 3], rgbd != 0, 0);
+    (void)hipStreamSynchronize(h->stream);
+    set_pass_trace(d);
+    launch_update_pass(h->stream, h->seg, c.maps, nb, 24, ox[0], oy[0], rgbd != 0, 0);
+    (void)hipStreamSynchronize(h->stream);
+    set_pass_trace(nullptr);
+    const int m = std::min(n, cap_wgs);
+    (void)hipMemcpy(out, d, (size_t)m * 40, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return m;
+}
 
 #endif
 // ---- test hooks (include/ssf_testing.h): the host solvers, so they can be pinned on a CPU box ----------

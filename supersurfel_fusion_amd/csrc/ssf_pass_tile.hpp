@@ -6,6 +6,7 @@
 // an earlier pass of the same launch is read past the L1, ld_coh).  As a function called from the kernel the same text ran 1-1.5 %
 // slower in place (gpurun r13b, alternated three times), hence the include.
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
+    SSF_PASS_TICK_BEGIN();                        // (lab: five ticks of the wall clock per workgroup -- tools/pass_trace.py)
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
@@ -208,12 +209,14 @@
             if ((outside >> (4 * k + 3)) & 1u) tile_reg[k].w = 0xFFFFFFFFu;
         }
     }
+    SSF_PASS_TICK_LOADS();                        // (everything requested up front has arrived)
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) {
         const unsigned int e = 256 * (k + 1) <= NQ ? threadIdx.x + 256u * k : min(threadIdx.x + 256u * k, (unsigned int)(NQ - 1));
         reinterpret_cast<uint4*>(tile)[e] = tile_reg[k];
     }
     __syncthreads();
+    SSF_PASS_TICK(2);                             // (tile, window rows and accumulators staged)
 #ifdef SSF_EXPERIMENTS
     if (s_clean) {
         if (threadIdx.x == 0) {
@@ -411,6 +414,7 @@
                 add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
     __syncthreads();
+    SSF_PASS_TICK(3);                             // (decisions taken, deltas in LDS, log written)
 #ifdef SSF_EXPERIMENTS
     if (s_far && NPX == 1 && skip_from < (1 << 29)) skip_stamp_blocks<TWX>(m, p, X0, Y0, nbkx, pass);      // (a label from outside the window was met)
 #endif
@@ -424,6 +428,7 @@
             unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
             ccnt[tile_id] = 0u;
         }
+        SSF_PASS_TICK(4);
         return;
     }
     for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256) {
@@ -450,3 +455,4 @@
         unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
         ccnt[tile_id] = s_nlog;
     }
+    SSF_PASS_TICK(4);
