@@ -18,6 +18,10 @@
 #endif
 
 using namespace orc;
+#ifdef SSF_ORACLE_ARMS
+#include <xmmintrin.h>
+namespace orc { StudyArms g_arms = {0, 0, 0, 0, 0, 0}; }
+#endif
 namespace orc { int g_oracle_rsqrt_ulp = 0; }       // (test hook of oracle_math.h normalize(): see ssf_oracle_set_rsqrt_ulp below)
 
 struct PendingFrame {
@@ -474,6 +478,22 @@ long long ssf_waiter_match_repairs(ssf_handle* h) { return h ? 0 : -1; }
 
 // test hook (oracle only, see oracle_math.h normalize()): 0 = the specification, -2 .. 2 = every reciprocal square root moved
 // by that many ulp, 3 = by a pseudo-random number of ulp in [-2, 2]
+#ifdef SSF_ORACLE_ARMS
+// STUDY ARMS (oracle_math.h): exported only by libssf_oracle_arms*.so.  name: div_ulp | pow_ulp | schedule | tie | insert_rev |
+// filter_gs | ftz (flush-to-zero + denormals-are-zero in the calling thread's MXCSR: what --use_fast_math's -ftz=true does)
+int ssf_oracle_set_arm(const char* name, int value) {
+    const std::string n(name);
+    if (n == "div_ulp") orc::g_arms.div_ulp = value;
+    else if (n == "pow_ulp") orc::g_arms.pow_ulp = value;
+    else if (n == "schedule") orc::g_arms.schedule = value;
+    else if (n == "tie") orc::g_arms.tie = value;
+    else if (n == "insert_rev") orc::g_arms.insert_rev = value;
+    else if (n == "filter_gs") orc::g_arms.filter_gs = value;
+    else if (n == "ftz") { unsigned int csr = _mm_getcsr(); csr = value ? (csr | 0x8040u) : (csr & ~0x8040u); _mm_setcsr(csr); }
+    else return -1;
+    return 0;
+}
+#endif
 int ssf_oracle_set_rsqrt_ulp(int mode) { orc::g_oracle_rsqrt_ulp = (mode >= -2 && mode <= 3) ? mode : 0; return orc::g_oracle_rsqrt_ulp; }
 
 // OpenMP build only (the timed CPU baseline): number of threads of the parallel loops; returns the number in effect

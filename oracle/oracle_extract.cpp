@@ -85,8 +85,8 @@ static void merge_rgb(State& s) {
     for (int k = 0; k < s.S; k++) {
         const SpSums& c = s.sums[k]; Superpixel& sp = s.sp[k];
         float n = (float)c.n;
-        sp.cx = (float)c.sx / n; sp.cy = (float)c.sy / n;
-        sp.r = (float)c.sr / n; sp.g = (float)c.sg / n; sp.b = (float)c.sb / n;
+        sp.cx = fdiv((float)c.sx, n); sp.cy = fdiv((float)c.sy, n);
+        sp.r = fdiv((float)c.sr, n); sp.g = fdiv((float)c.sg, n); sp.b = fdiv((float)c.sb, n);
         sp.size = n;
     }
 }
@@ -110,6 +110,24 @@ static void merge_rgbd(State& s) {
     }
 }
 
+#ifdef SSF_ORACLE_ARMS
+static void update_pass_spec(State& s, int OX, int OY, bool rgbd);
+// STUDY ARM g_arms.schedule = 1 (oracle_math.h): the same pass under the OTHER extreme schedule the reference's kernel admits --
+// its 32 x 32-pixel blocks (16 x 16 threads, TPS_RGBD_kernels.cuh:264-292) run one after the other in raster order, each
+// snapshotting its 34 x 34 label tile AFTER every earlier block has stored its labels (the specification: before any block
+// stores).  Within a block all reads see the snapshot (the LDS tile), as on the GPU.  Sums, inlier bytes and the exact boundary
+// recount follow the labels exactly as in the specification.  Implemented by running the specification's pass restricted to one
+// block at a time on the evolving map.
+static int g_tile_x0 = 0, g_tile_y0 = 0, g_tile_on = 0;
+static void update_pass(State& s, int OX, int OY, bool rgbd) {
+    if (g_arms.schedule == 0) { g_tile_on = 0; update_pass_spec(s, OX, OY, rgbd); return; }
+    g_tile_on = 1;
+    for (int ty = 0; ty < s.H; ty += 32)
+        for (int tx = 0; tx < s.W; tx += 32) { g_tile_x0 = tx; g_tile_y0 = ty; update_pass_spec(s, OX, OY, rgbd); }
+    g_tile_on = 0;
+}
+#define update_pass update_pass_spec
+#endif
 // updateTPSRGB_kernel / updateTPSRGBD_kernel, TPS_RGBD_kernels.cuh:235-651, one pass (OX,OY).
 static void update_pass(State& s, int OX, int OY, bool rgbd) {
     const ssf_config& c = s.cfg;
@@ -117,21 +135,31 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
     const int min_size = (int)((float)(c.cell_size * c.cell_size) / 4.f);     // TPS_RGBD.cu:198 -> int param
     const std::vector<int32_t>& src = s.label;
     std::vector<int32_t>& dst = s.label_tmp;
+#ifdef SSF_ORACLE_ARMS
+    std::vector<std::pair<size_t, int32_t>> tile_changes;                       // (schedule arm: this block's stores, applied when it ends)
+    if (!g_tile_on)
+#endif
     dst = src;                                                                  // decision A1
     const int nx[4] = {0, -1, 1, 0}, ny[4] = {-1, 0, 0, 1};                    // neighbors[8], .cuh:350
     // Rows of a pass are independent (all reads are pre-pass values, decision A1) and the sums are exact integers, so
     // the OpenMP build (libssf_oracle_omp.so, the timed CPU baseline) splits the rows over threads, each with its own
     // delta table, and adds the tables up afterwards: bit-identical to the serial order.
-    const int n_rows = (H - OY + 1) / 2;
+    int n_rows = (H - OY + 1) / 2, row0 = 0, col0 = 0, col1 = (W + 1) / 2;
+#ifdef SSF_ORACLE_ARMS
+    if (g_tile_on) { row0 = g_tile_y0 / 2; n_rows = std::min(n_rows, g_tile_y0 / 2 + 16); col0 = g_tile_x0 / 2; col1 = std::min(col1, g_tile_x0 / 2 + 16); }
+#endif
 #pragma omp parallel
     {
     std::vector<SpSums> delta(s.S, SpSums{});
 #pragma omp for schedule(static)
-    for (int raw_y = 0; raw_y < n_rows; raw_y++) {
+    for (int raw_y = row0; raw_y < n_rows; raw_y++) {
         const int y = 2 * raw_y + OY;
-        for (int raw_x = 0; 2 * raw_x < W; raw_x++) {
+        for (int raw_x = col0; raw_x < col1; raw_x++) {
             const int x = 2 * raw_x + ((raw_x + OX) & 1);                       // .cuh:264
             if (x >= W) continue;
+#ifdef SSF_ORACLE_ARMS
+            if (g_tile_on && !(x >= g_tile_x0 && x < g_tile_x0 + 32 && y >= g_tile_y0 && y < g_tile_y0 + 32)) continue;
+#endif
             const size_t p = (size_t)y * W + x;
             const int index = src[p];
             int new_index = index;
@@ -155,7 +183,7 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
             if (bounds && !is_unchangeable(s, src, x, y)) {
                 const float posx = (float)x, posy = (float)y;
                 const float size = prev_sp.size;
-                const float sc = size / (size - 1.f);                           // .cuh:332
+                const float sc = fdiv(size, size - 1.f);                           // .cuh:332
                 const float dpx = sc * (posx - prev_sp.cx), dpy = sc * (posy - prev_sp.cy);
                 const f3 dcol = mk3(sc * (cr - prev_sp.r), sc * (cg - prev_sp.g), sc * (cb - prev_sp.b));
                 const float dsize = size - (float)min_size;
@@ -189,6 +217,9 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
                     if (e < best) { best = e; new_index = i_n; if (rgbd) inlier = n_inlier; }
                 }
                 if (new_index != index) {                                       // .cuh:400-440
+#ifdef SSF_ORACLE_ARMS
+                    if (g_tile_on) tile_changes.push_back(std::make_pair(p, (int32_t)new_index)); else
+#endif
                     dst[p] = new_index;
                     SpSums& a = delta[index]; SpSums& bsum = delta[new_index];
                     const int ir = (int)(px & 255u), ig = (int)((px >> 8) & 255u), ib = (int)((px >> 16) & 255u);
@@ -206,8 +237,14 @@ static void update_pass(State& s, int OX, int OY, bool rgbd) {
 #pragma omp critical
     for (int k = 0; k < s.S; k++) sums_add(s.sums[k], delta[k]);
     }
+#ifdef SSF_ORACLE_ARMS
+    if (g_tile_on) { for (const auto& ch : tile_changes) s.label[ch.first] = ch.second; return; }
+#endif
     s.label.swap(s.label_tmp);
 }
+#ifdef SSF_ORACLE_ARMS
+#undef update_pass
+#endif
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 // point-sampled clamp texture fetch with float coordinates (texture_impl.hpp:43-46)
@@ -343,6 +380,11 @@ static void plane_filter(State& s) {
     }
     const float alpha = s.cfg.filter_alpha, beta = s.cfg.filter_beta, thr = s.cfg.filter_threshold;
     const int v[4] = {-1, 0, 0, 1}, u[4] = {0, -1, 1, 0};
+#ifdef SSF_ORACLE_ARMS
+    const bool gauss_seidel = g_arms.filter_gs != 0;        // STUDY ARM: the reference updates data[idx].X in place (:585-612)
+#else
+    const bool gauss_seidel = false;
+#endif
     for (int it = 0; it < s.cfg.filter_iter; it++) {                            // iterateFilter_kernel
         Xn = X;
         for (int y = 0; y < gy; y++)
@@ -372,7 +414,7 @@ static void plane_filter(State& s) {
                     }
                 }
                 Cov3 A1;
-                if (inverse(A, A1)) Xn[idx] = A1 * R;
+                if (inverse(A, A1)) { Xn[idx] = A1 * R; if (gauss_seidel) X[idx] = Xn[idx]; }
             }
         X.swap(Xn);
     }
@@ -391,7 +433,7 @@ static void render_depth(State& s) {
             size_t p = (size_t)y * s.W + x;
             const Superpixel& sp = s.sp[s.label[p]];
             float disp = ((float)x * sp.ta + (float)y * sp.tb) + sp.tc;
-            s.plane_depth[p] = 1.f / disp;
+            s.plane_depth[p] = fdiv(1.f, disp);
         }
 }
 
@@ -414,7 +456,7 @@ static void generate_supersurfels(State& s) {
             int bound = boundary_at(s, s.label, x, y);
             float depth = s.plane_depth[p];
             if (std::isfinite(depth) && depth > 0.0f && bound == 0) {
-                f3 pos = mk3(((float)x - c.cx) * depth / c.fx, ((float)y - c.cy) * depth / c.fy, depth);
+                f3 pos = mk3(fdiv(((float)x - c.cx) * depth, c.fx), fdiv(((float)y - c.cy) * depth, c.fy), depth);
                 uint32_t px = s.rgba[p];
                 f3 lab = rgbToLab(mk3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)));
                 Cov3 cov = outer(pos);
@@ -440,17 +482,17 @@ static void generate_supersurfels(State& s) {
         f.col[k] = mk3(sum[3], sum[4], sum[5]);
         f.shape[k] = mkcov(sum[6], sum[7], sum[8], sum[9], sum[10], sum[11]);
         f.conf[k] = conf;
-        float z = f.pos[k].z / conf;
+        float z = fdiv(f.pos[k].z, conf);
         if (std::isfinite(z) && conf > 100.0f && z > c.range_min && z < c.range_max) {
-            f.pos[k] = mk3(f.pos[k].x / conf, f.pos[k].y / conf, z);
-            f.col[k] = labToRgb(mk3(f.col[k].x / conf, f.col[k].y / conf, f.col[k].z / conf));
+            f.pos[k] = mk3(fdiv(f.pos[k].x, conf), fdiv(f.pos[k].y, conf), z);
+            f.col[k] = labToRgb(mk3(fdiv(f.col[k].x, conf), fdiv(f.col[k].y, conf), fdiv(f.col[k].z, conf)));
             f.shape[k] = f.shape[k] / conf - outer(f.pos[k]);
             f3 vals; Mat33 vecs;
             eigenDecomposition(f.shape[k], vecs, vals, 10);
             f.orient[k] = vecs;
             f.dims[2 * k] = vals.x; f.dims[2 * k + 1] = vals.y;
             f.stamps[2 * k] = s.stamp; f.stamps[2 * k + 1] = s.stamp;
-            if (vals.x / vals.y > 50.0f) f.conf[k] = -1.0f;
+            if (fdiv(vals.x, vals.y) > 50.0f) f.conf[k] = -1.0f;
         } else
             f.conf[k] = -1.0f;
     }
@@ -487,7 +529,7 @@ void bilateral_filter(const float* in, float* out, int W, int H, float sigma_col
                     sum1 = sum1 + w * v;
                     sum2 = sum2 + w;
                 }
-            out[(size_t)y * W + x] = sum1 / sum2;
+            out[(size_t)y * W + x] = fdiv(sum1, sum2);
         }
 }
 
@@ -509,7 +551,7 @@ void extract(State& s, const uint8_t* rgb, const float* depth, const uint8_t* dy
             size_t p = (size_t)y * W + x;
             uint32_t r = rgb[3 * p], g = rgb[3 * p + 1], b = rgb[3 * p + 2];
             s.rgba[p] = r | (g << 8) | (b << 16) | (255u << 24);
-            s.disp[p] = 1.f / depth[p];
+            s.disp[p] = fdiv(1.f, depth[p]);
             int index = s.gx * (y / c.cell_size) + x / c.cell_size;
             s.label[p] = index;
             s.inlier[p] = 0;

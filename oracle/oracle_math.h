@@ -20,6 +20,44 @@
 
 namespace orc {
 
+// ---- STUDY ARMS (round 6; tools/cuda_tolerance_study.py, tests/test_replay.py) -------------------------------------------------
+// The reference is compiled --use_fast_math (cmake/UseCUDA.cmake:15: approximate division / sqrt / rsqrt / powf / cbrtf, FMA
+// contraction, flush-to-zero) and is racy by construction: "the CUDA path" is a FAMILY of executions, none of
+// which can be produced here.  To state how far that family lies from this build's specification, a second build of these sources
+// (-DSSF_ORACLE_ARMS -> oracle/_build/libssf_oracle_arms.so; and the same with -ffp-contract=fast -mfma -> ..._fma.so) routes every
+// device-side float division, square root and transcendental through the hooks below, and the schedule decisions of Appendix A
+// through g_arms; ssf_oracle_set_arm() (oracle_abi.cpp) switches them at run time.  In the DEFAULT build (the checker every parity
+// test uses) the hooks are the plain IEEE operation and g_arms does not exist: fdiv(a, b) IS a / b.
+#ifdef SSF_ORACLE_ARMS
+struct StudyArms {
+    int div_ulp;        // every device-side float division / sqrt result moved by this many ulp (any small integer; 3 = pseudo-random in [-2, 2])
+    int pow_ulp;        // the same for the results of powf / cbrtf (the Lab conversions)
+    int schedule;       // relabelling pass: 0 = every tile loads before any tile stores (the specification);
+                        //                   1 = the reference's 32 x 32 tiles one after the other in raster order, in place
+                        //                       ("every block loads after its predecessors stored": the other extreme valid CUDA outcome)
+    int tie;            // association arg-min: 0 = ties to the lowest model id, 1 = to the highest
+    int insert_rev;     // insertion: 0 = ascending frame id, 1 = descending (another atomic arrival order)
+    int filter_gs;      // plane filter: 0 = Jacobi sweeps (the specification), 1 = in place in node order (Gauss-Seidel: the in-place outcome)
+};
+extern StudyArms g_arms;
+static inline float nudge_ulp(float v, int mode, uint32_t key) {
+    if (mode == 0 || !(std::fabs(v) > 1.0e-37f) || !(std::fabs(v) < 3.0e38f)) return v;      // (zero, denormal, inf, NaN: untouched)
+    const int k = mode == 3 ? (int)(((key * 2654435761u) >> 16) % 5u) - 2 : mode;
+    uint32_t b; std::memcpy(&b, &v, 4);
+    b = (uint32_t)((int32_t)b + (v > 0.f ? k : -k) * 1);      // (sign-magnitude: + k ulp = towards larger magnitude for both signs)
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+static inline uint32_t fbits(float v) { uint32_t b; std::memcpy(&b, &v, 4); return b; }
+static inline float fdiv(float a, float b) { return nudge_ulp(a / b, g_arms.div_ulp, fbits(a) ^ (fbits(b) * 0x9E3779B9u)); }
+static inline float fsqrt(float a) { return nudge_ulp(sqrtf(a), g_arms.div_ulp, fbits(a)); }
+static inline float fpow_hook(float r, float x) { return nudge_ulp(r, g_arms.pow_ulp, fbits(x)); }
+#else
+static inline float fdiv(float a, float b) { return a / b; }
+static inline float fsqrt(float a) { return sqrtf(a); }
+static inline float fpow_hook(float r, float) { return r; }
+#endif
+
 struct f3 { float x, y, z; };
 struct Cov3 { float xx, xy, xz, yy, yz, zz; };          // matrix_types.h:26-31
 struct Mat33 { f3 r[3]; };                               // matrix_types.h:33-36 (rows)
@@ -37,7 +75,7 @@ static inline f3 cross(f3 a, f3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 // vector_math.cuh:241-244
-static inline float length(f3 v) { return sqrtf(dot(v, v)); }
+static inline float length(f3 v) { return fsqrt(dot(v, v)); }
 // vector_math.cuh:247-252 (rsqrtf -> exact 1/sqrt, see header)
 // TEST HOOK (oracle only; tests/test_oracle.py::test_a_2_ulp_reciprocal_square_root_flips_no_integer_decision): CUDA's rsqrtf is an
 // approximation within 2 ulp that cannot be observed here; g_oracle_rsqrt_ulp != 0 moves every reciprocal square root of a
@@ -46,7 +84,7 @@ static inline float length(f3 v) { return sqrtf(dot(v, v)); }
 // hang on the stand-in.  0 (the default) is this build's specification: the correctly rounded 1 / sqrt.
 extern int g_oracle_rsqrt_ulp;
 static inline float oracle_rsqrt(float x) {
-    float inv = 1.0f / sqrtf(x);
+    float inv = fdiv(1.0f, fsqrt(x));
     const int mode = g_oracle_rsqrt_ulp;
     if (mode != 0 && inv > 0.f && inv < 3.0e38f) {
         uint32_t bits; memcpy(&bits, &x, 4);
@@ -73,7 +111,7 @@ static inline Cov3 operator*(float b, const Cov3& a) {             // :120-130
     return mkcov(b * a.xx, b * a.xy, b * a.xz, b * a.yy, b * a.yz, b * a.zz);
 }
 static inline Cov3 operator/(const Cov3& a, float b) {             // :132-142
-    return mkcov(a.xx / b, a.xy / b, a.xz / b, a.yy / b, a.yz / b, a.zz / b);
+    return mkcov(fdiv(a.xx, b), fdiv(a.xy, b), fdiv(a.xz, b), fdiv(a.yy, b), fdiv(a.yz, b), fdiv(a.zz, b));
 }
 static inline f3 operator*(const Cov3& m, f3 b) {                  // :164-169
     return mk3((m.xx * b.x + m.xy * b.y) + m.xz * b.z,
@@ -102,7 +140,7 @@ static inline bool inverse(const Cov3& in, Cov3& out) {
     out.zz = in.xx * in.yy - in.xy * in.xy;
     float det = (in.xx * out.xx + in.xy * out.xy) + in.xz * out.xz;
     if (std::fabs((double)det) > 1e-9) {
-        out.xx /= det; out.xy /= det; out.xz /= det; out.yy /= det; out.yz /= det; out.zz /= det;
+        out.xx = fdiv(out.xx, det); out.xy = fdiv(out.xy, det); out.xz = fdiv(out.xz, det); out.yy = fdiv(out.yy, det); out.yz = fdiv(out.yz, det); out.zz = fdiv(out.zz, det);
         return true;
     }
     return false;
@@ -158,14 +196,14 @@ static inline double spec_root5(double a) {
 // x^2.4 = x^2 * (x^(1/5))^2 ; x^(1/2.4) = x^(5/12) = (cbrt(sqrt(sqrt(x))))^5, x > 0.
 static inline float spec_pow24(float x) {
     double a = (double)x, t = spec_root5(a);
-    return (float)((a * a) * (t * t));
+    return fpow_hook((float)((a * a) * (t * t)), x);
 }
 static inline float spec_pow_inv24(float x) {
     double t = spec_cbrt(std::sqrt(std::sqrt((double)x)));
     double t2 = t * t;
-    return (float)((t2 * t2) * t);
+    return fpow_hook((float)((t2 * t2) * t), x);
 }
-static inline float spec_cbrtf(float x) { return (float)spec_cbrt((double)x); }
+static inline float spec_cbrtf(float x) { return fpow_hook((float)spec_cbrt((double)x), x); }
 
 // exp(x) for x <= 0 as a specified sequence of IEEE single-precision operations (libm / OCML / CUDA exp are not
 // bit-reproducible across platforms, and this one gates nothing: it only weights the taps of the depth pre-filter):
@@ -193,13 +231,13 @@ static inline float spec_exp_neg(float x) {
 
 // vector_math.cuh:566-585
 static inline f3 rgbToLab(f3 c) {
-    float r = c.x / 255.0f, g = c.y / 255.0f, b = c.z / 255.0f;
-    r = (r > 0.04045f) ? spec_pow24((r + 0.055f) / 1.055f) : r / 12.92f;
-    g = (g > 0.04045f) ? spec_pow24((g + 0.055f) / 1.055f) : g / 12.92f;
-    b = (b > 0.04045f) ? spec_pow24((b + 0.055f) / 1.055f) : b / 12.92f;
-    float x = ((r * 0.4124f + g * 0.3575f) + b * 0.1805f) / 0.95047f;
+    float r = fdiv(c.x, 255.0f), g = fdiv(c.y, 255.0f), b = fdiv(c.z, 255.0f);
+    r = (r > 0.04045f) ? spec_pow24(fdiv(r + 0.055f, 1.055f)) : fdiv(r, 12.92f);
+    g = (g > 0.04045f) ? spec_pow24(fdiv(g + 0.055f, 1.055f)) : fdiv(g, 12.92f);
+    b = (b > 0.04045f) ? spec_pow24(fdiv(b + 0.055f, 1.055f)) : fdiv(b, 12.92f);
+    float x = fdiv((r * 0.4124f + g * 0.3575f) + b * 0.1805f, 0.95047f);
     float y = ((r * 0.2126f + g * 0.7152f) + b * 0.0722f);
-    float z = ((r * 0.0193f + g * 0.1192f) + b * 0.9505f) / 1.08883f;
+    float z = fdiv((r * 0.0193f + g * 0.1192f) + b * 0.9505f, 1.08883f);
     x = (x > 0.008856f) ? spec_cbrtf(x) : 7.787f * x + 16.0f / 116.0f;
     y = (y > 0.008856f) ? spec_cbrtf(y) : 7.787f * y + 16.0f / 116.0f;
     z = (z > 0.008856f) ? spec_cbrtf(z) : 7.787f * z + 16.0f / 116.0f;
@@ -208,13 +246,13 @@ static inline f3 rgbToLab(f3 c) {
 // vector_math.cuh:543-564.  The two double literals (1.8758, 1.0570) promote those sums to
 // double exactly as the C++ expression does.
 static inline f3 labToRgb(f3 c) {
-    float y = (c.x + 16.0f) / 116.0f;
-    float x = c.y / 500.0f + y;
-    float z = y - c.z / 200.0f;
+    float y = fdiv(c.x + 16.0f, 116.0f);
+    float x = fdiv(c.y, 500.0f) + y;
+    float z = y - fdiv(c.z, 200.0f);
     float x3 = (x * x) * x, y3 = (y * y) * y, z3 = (z * z) * z;
-    x = 0.95047f * ((x3 > 0.008856f) ? x3 : (x - 16.0f / 116.0f) / 7.787f);
-    y = 1.0f * ((y3 > 0.008856f) ? y3 : (y - 16.0f / 116.0f) / 7.787f);
-    z = 1.08883f * ((z3 > 0.008856f) ? z3 : (z - 16.0f / 116.0f) / 7.787f);
+    x = 0.95047f * ((x3 > 0.008856f) ? x3 : fdiv(x - 16.0f / 116.0f, 7.787f));
+    y = 1.0f * ((y3 > 0.008856f) ? y3 : fdiv(y - 16.0f / 116.0f, 7.787f));
+    z = 1.08883f * ((z3 > 0.008856f) ? z3 : fdiv(z - 16.0f / 116.0f, 7.787f));
     float r = (x * 3.2406f - y * 1.5372f) - z * 0.4986f;
     float g = (float)(((double)(-x * 0.9689f) + (double)y * 1.8758) + (double)(z * 0.0415f));
     float b = (float)((double)(x * 0.0557f - y * 0.2040f) + (double)z * 1.0570);
@@ -234,9 +272,9 @@ static inline f3 pick_axis(const Cov3& M) {
 }
 static inline float rayleigh(const Cov3& A, f3 v) {
     float emax = fmaxf(fmaxf(v.x, v.y), v.z);
-    if (v.x == emax) return ((A.xx * v.x + A.xy * v.y) + A.xz * v.z) / v.x;
-    if (v.y == emax) return ((A.xy * v.x + A.yy * v.y) + A.yz * v.z) / v.y;
-    return ((A.xz * v.x + A.yz * v.y) + A.zz * v.z) / v.z;
+    if (v.x == emax) return fdiv((A.xx * v.x + A.xy * v.y) + A.xz * v.z, v.x);
+    if (v.y == emax) return fdiv((A.xy * v.x + A.yy * v.y) + A.yz * v.z, v.y);
+    return fdiv((A.xz * v.x + A.yz * v.y) + A.zz * v.z, v.z);
 }
 static inline void eigenDecomposition(const Cov3& A, Mat33& vecs, f3& vals, int n) {
     Cov3 Ai = A / trace(A);
@@ -261,17 +299,17 @@ static inline bool solvePlaneEquations(float& tx, float& ty, float& tz,
     const float eps = 1e-20f;
     float denA = (x1 * z2 - x2 * z1) * (y2 * z3 - y3 * z2) - (x2 * z3 - x3 * z2) * (y1 * z2 - y2 * z1);
     if (!std::isfinite(denA) && denA < eps) return false;
-    tx = ((z2 * d1 - z1 * d2) * (y2 * z3 - y3 * z2) - (z3 * d2 - z2 * d3) * (y1 * z2 - y2 * z1)) / denA;
+    tx = fdiv((z2 * d1 - z1 * d2) * (y2 * z3 - y3 * z2) - (z3 * d2 - z2 * d3) * (y1 * z2 - y2 * z1), denA);
     float denB = y1 * z2 - y2 * z1;
     if (denB > eps) {
-        ty = ((z2 * d1 - z1 * d2) - tx * (x1 * z2 - x2 * z1)) / denB;
+        ty = fdiv((z2 * d1 - z1 * d2) - tx * (x1 * z2 - x2 * z1), denB);
     } else {
         denB = y2 * z3 - y3 * z2;
-        ty = ((z3 * d2 - z2 * d3) - tx * (x2 * z3 - x3 * z2)) / denB;
+        ty = fdiv((z3 * d2 - z2 * d3) - tx * (x2 * z3 - x3 * z2), denB);
     }
-    if (z1 > eps)      tz = ((d1 - tx * x1) - ty * y1) / z1;
-    else if (z2 > eps) tz = ((d2 - tx * x2) - ty * y2) / z2;
-    else               tz = ((d3 - tx * x3) - ty * y3) / z3;
+    if (z1 > eps)      tz = fdiv((d1 - tx * x1) - ty * y1, z1);
+    else if (z2 > eps) tz = fdiv((d2 - tx * x2) - ty * y2, z2);
+    else               tz = fdiv((d3 - tx * x3) - ty * y3, z3);
     return true;
 }
 

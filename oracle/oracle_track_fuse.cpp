@@ -12,6 +12,13 @@
 #include <cstring>
 #include <vector>
 #include "oracle.h"
+// ORC_HOST marks the functions that restate HOST code of the reference (Eigen solves, pose composition): --use_fast_math is a
+// device-code switch, so the FMA study arm (oracle/Makefile `arms`) must not contract them
+#if defined(SSF_ORACLE_ARMS) && defined(__FMA__)
+#define ORC_HOST __attribute__((optimize("fp-contract=off")))
+#else
+#define ORC_HOST
+#endif
 
 namespace orc {
 
@@ -22,7 +29,7 @@ static inline int project_round(float v) {
     return round_half_away(v);
 }
 
-static void mat4_mul(const double* a, const double* b, double* c) {
+ORC_HOST static void mat4_mul(const double* a, const double* b, double* c) {
     double r[16];
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)
@@ -37,7 +44,7 @@ static void refresh_inc(State& s) {                       // dense_registration.
     I.t_inc = mk3((float)I.tf_inc[3], (float)I.tf_inc[7], (float)I.tf_inc[11]);
 }
 
-void icp_begin(State& s, const float* prior) {
+ORC_HOST void icp_begin(State& s, const float* prior) {
     IcpState& I = s.icp;
     if (prior) {                                          // pose = vo->getPose(), supersurfel_fusion.cu:228
         for (int i = 0; i < 3; i++) s.pose.R.r[i] = mk3(prior[3 * i], prior[3 * i + 1], prior[3 * i + 2]);
@@ -75,15 +82,15 @@ void icp_accumulate(State& s, int64_t* sums) {
 #pragma omp for schedule(static)
     for (int id = 0; id < s.n_visible; id++) {
         f3 ps = R * s.model.pos[id] + t;
-        int u = project_round(ps.x * c.fx / ps.z + c.cx);
-        int v = project_round(ps.y * c.fy / ps.z + c.cy);
+        int u = project_round(fdiv(ps.x * c.fx, ps.z) + c.cx);
+        int v = project_round(fdiv(ps.y * c.fy, ps.z) + c.cy);
         if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
         const size_t p = (size_t)v * W + u;
         const int tid = s.label[p];
         const float zt = s.plane_depth[p];
         if (!(s.frame.conf[tid] > 0.0f && zt >= 0.2f && zt <= 5.0f)) continue;   // hard-coded range (:224)
         const float dist_color = length(s.model_lab[id] - s.frame_lab[tid]);
-        const f3 pt = mk3(zt * ((float)u - c.cx) / c.fx, zt * ((float)v - c.cy) / c.fy, zt);
+        const f3 pt = mk3(fdiv(zt * ((float)u - c.cx), c.fx), fdiv(zt * ((float)v - c.cy), c.fy), zt);
         const f3 nt = s.frame.orient[tid].r[2];
         const f3 ns = normalize(R * s.model.orient[id].r[2]);
         if (!(dist_color < 20.0f && length(ps - pt) < 0.1f && fabsf(dot(nt, ns)) > 0.8f)) continue;
@@ -113,7 +120,7 @@ void icp_accumulate(State& s, int64_t* sums) {
 }
 
 // host part of one iteration, dense_registration.cu:324-391
-void icp_update(State& s, const int64_t* sums, int* again) {
+ORC_HOST void icp_update(State& s, const int64_t* sums, int* again) {
     IcpState& I = s.icp;
     *again = 0;
     if (!I.active || I.done) return;
@@ -163,7 +170,7 @@ void icp_update(State& s, const int64_t* sums, int* again) {
 }
 
 // dense_registration.cu:394-421 and supersurfel_fusion.cu:313-328
-void icp_end(State& s, int* valid) {
+ORC_HOST void icp_end(State& s, int* valid) {
     IcpState& I = s.icp;
     *valid = 0;
     if (!I.active) return;
@@ -197,7 +204,7 @@ void icp_end(State& s, int* valid) {
 // iso_iter = T(target_centroid) * Rot * T(tran) * Rot * T(-source_centroid) (Eigen Isometry products, left to
 // right: linear = a.linear * b.linear, translation = a.linear * b.translation + a.translation), rotation block
 // re-normalised through a quaternion
-void align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf_iter) {
+ORC_HOST void align_increment(const double* JtJ, const double* Jtr, float scale, const float* cs, const float* ct, double* tf_iter) {
     double X[6];
     ldlt_solve6(JtJ, Jtr, X);                                                   // :186
     double tran[3] = {X[3], X[4], X[5]}, axis[3] = {X[0], X[1], X[2]};
@@ -232,7 +239,7 @@ static void for_each_pair(State& s, const f3* src_pos, const f3* src_lab, const 
     for (int id = 0; id < n; id++) {
         if (src_conf && !(src_conf[id] > 0.0f)) continue;
         const f3 pv = R * src_pos[id] + t;
-        const int u = project_round(pv.x * c.fx / pv.z + c.cx), v = project_round(pv.y * c.fy / pv.z + c.cy);
+        const int u = project_round(fdiv(pv.x * c.fx, pv.z) + c.cx), v = project_round(fdiv(pv.y * c.fy, pv.z) + c.cy);
         if (!(u >= 0 && u < s.W && v >= 0 && v < s.H)) continue;
         const size_t p = (size_t)v * s.W + u;
         const int tid = s.label[p];
@@ -243,7 +250,7 @@ static void for_each_pair(State& s, const f3* src_pos, const f3* src_lab, const 
         f3 sn = normalize(src_orient[id].r[2]);
         sn = normalize(R * sn);
         const f3 tn = normalize(s.frame.orient[tid].r[2]);
-        const f3 tp = mk3(td * ((float)u - c.cx) / c.fx, td * ((float)v - c.cy) / c.fy, td);
+        const f3 tp = mk3(fdiv(td * ((float)u - c.cx), c.fx), fdiv(td * ((float)v - c.cy), c.fy), td);
         if (!(dist_color < 20.0f && length(pv - tp) < 0.1f && fabsf(dot(sn, tn)) > 0.8f)) continue;
         visit(pv, sn, tp, tn);
     }
@@ -363,7 +370,7 @@ void match(State& s, uint64_t* best, uint8_t* matched) {
         const f3 mp = s.model.pos[id];
         const f3 pv = Rview * mp + tview;
         if (!(pv.z > c.range_min && pv.z < c.range_max)) continue;
-        int px = project_round(pv.x * c.fx / pv.z + c.cx), py = project_round(pv.y * c.fy / pv.z + c.cy);
+        int px = project_round(fdiv(pv.x * c.fx, pv.z) + c.cx), py = project_round(fdiv(pv.y * c.fy, pv.z) + c.cy);
         if (!(px >= 0 && px < s.W && py >= 0 && py < s.H)) continue;
         const int f = s.label[(size_t)py * s.W + px];
         lmatched[f] = 1;                                    // unconditional (:570)
@@ -378,6 +385,13 @@ void match(State& s, uint64_t* best, uint8_t* matched) {
         if (lab_dist < 15.0f && delta_norm > 0.8f && dist < 0.05f) {
             uint32_t bits; std::memcpy(&bits, &dist, 4);
             uint64_t key = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)(s.id_offset + id);
+#ifdef SSF_ORACLE_ARMS
+            // STUDY ARMS of the reference's torn arg-min (supersurfel_fusion_kernels.cu:590-594: a plain compare followed by two
+            // independent atomicExch): 1 = equal distances go to the HIGHEST id; 2 = every candidate saw the initial 0.05 and the
+            // last store (highest id) stays -- the worst valid outcome
+            if (g_arms.tie == 1 && lbest[f] != SSF_NO_MATCH && (uint32_t)(lbest[f] >> 32) == bits) { lbest[f] = key; continue; }
+            if (g_arms.tie == 2) { lbest[f] = key; continue; }
+#endif
             if (key < lbest[f]) lbest[f] = key;
         }
     }
@@ -407,7 +421,7 @@ static void update_one(State& s, int f, int m) {
     const Cov3 frame_shape = mult_ABAt(R, F.shape[f]);
     const f3 frame_lab = s.frame_lab[f], model_lab = s.model_lab[m];
     const float m_conf = M.conf[m], f_conf = F.conf[f];
-    const float ratio = 1.0f / (m_conf + f_conf);
+    const float ratio = fdiv(1.0f, m_conf + f_conf);
     M.stamps[2 * m + 1] = s.stamp;
     const f3 fused_color = labToRgb(ratio * (f_conf * frame_lab + m_conf * model_lab));
     Cov3 f1, m1, fused_shape, fused_1;
@@ -453,7 +467,7 @@ static int classify_row(const State& s, const Surfels& M, int i, const Mat33& Rv
     if ((time_diff > c.delta_t && M.conf[i] < c.conf_thresh && s.stamp > c.delta_t) || M.conf[i] <= 0.0f) return 2;
     const f3 p = Rview * M.pos[i] + tview;
     if (p.z > c.range_min && p.z < c.range_max) {
-        const float u = c.fx * p.x / p.z + c.cx, v = c.fy * p.y / p.z + c.cy;
+        const float u = fdiv(c.fx * p.x, p.z) + c.cx, v = fdiv(c.fy * p.y, p.z) + c.cy;
         if (u >= 0.0f && u < (float)s.W && v >= 0.0f && v < (float)s.H) {
             const float z = s.plane_depth[(size_t)((int)floorf(v)) * s.W + (int)floorf(u)];
             return (p.z < 0.8f * z) ? 2 : 0;
@@ -519,7 +533,12 @@ void fuse_begin(State& s, const uint64_t* best, const uint8_t* matched, int migr
         }
     // insertSupersurfels, supersurfel_fusion_kernels.cu:348-395 (decision A14)
     const Mat33 Rt = transpose(R);
-    for (int f = 0; f < s.S; f++) {
+    for (int f_ = 0; f_ < s.S; f_++) {
+#ifdef SSF_ORACLE_ARMS
+        const int f = g_arms.insert_rev ? s.S - 1 - f_ : f_;      // STUDY ARM: another atomic arrival order (:376)
+#else
+        const int f = f_;
+#endif
         if (!(s.frame.conf[f] > 0.0f) || matched[f]) continue;
         if (shard_owner(s, f, s.pose) != c.rank) continue;
         if (s.n_model >= c.nb_supersurfels_max) continue;
@@ -625,7 +644,7 @@ void fuse(State& s, const uint64_t* best, const uint8_t* matched, ssf_frame_resu
 }
 
 // rotMatToQuat matrix_math.cuh:529-618, quatToRotMat :512-527 (the wy = q.w*q.z quirk is kept)
-void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
+ORC_HOST void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
     float s, tr = (m.r[0].x + m.r[1].y) + m.r[2].z;
     if (tr > 0) {
         s = sqrtf(tr + 1);
@@ -650,7 +669,7 @@ void rot_to_quat(const Mat33& m, float* q /*x,y,z,w*/) {
         }
     }
 }
-Mat33 quat_to_rot(const float* q) {
+ORC_HOST Mat33 quat_to_rot(const float* q) {
     const float x2 = q[0] * q[0], y2 = q[1] * q[1], z2 = q[2] * q[2];
     const float xy = q[0] * q[1], xz = q[0] * q[2], yz = q[1] * q[2];
     const float wx = q[3] * q[0], wy = q[3] * q[2] /* sic */, wz = q[3] * q[2];
