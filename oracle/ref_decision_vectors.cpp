@@ -11,25 +11,37 @@
 // starts at the function's signature) and this file #includes them: what is evaluated below is the reference's text, compiled
 // by g++ against NVIDIA's CUDA runtime headers from the image (as ref_math_vectors.cpp) with -ffp-contract=off.
 //
-// ONE NAMED STAND-IN: eigenDecomposition normalises its vectors with the reference's normalize() = v * rsqrtf(dot(v, v))
-// (vector_math.cuh:247-252).  rsqrtf is a CUDA device intrinsic (approximate, <= 2 ulp) with no host definition; it is
-// defined HERE as 1.0f / sqrtf(x) -- the correctly rounded form this build specifies for both oracle and product
-// (oracle_math.h / ssf_math.hpp unit3).  Consequence, stated in tests/test_math.py: the eigen-frame vectors are bit-exact
-// against this generator, and what that does NOT pin is CUDA's own rsqrtf rounding (a relative 2^-22 on every component).
-// Everything else -- the guard, the plane solve (incl. its ineffective `!isfinite && < eps` test), branch selection and the
-// eigenvalue quotients of the frame -- involves no stand-in.
+// TWO BINARIES from this file (round 6), so that the one stand-in of the parity chain touches only what needs it:
+//   _ref/decision_vectors        (default)               isUnchangeable + solvePlaneEquations.  NO stand-in: rsqrtf is only DECLARED
+//                                                        (the reference's normalize() mentions it; nothing here calls it), exactly as in
+//                                                        ref_math_vectors.cpp -- these two helpers are the reference's text and nothing else.
+//   _ref/decision_eigen_vectors  (-DSSF_REF_EIGEN_ONLY)  eigenDecomposition alone, with ONE NAMED STAND-IN: it normalises its vectors
+//                                                        with the reference's normalize() = v * rsqrtf(dot(v, v)) (vector_math.cuh:247-252);
+//                                                        rsqrtf is a CUDA device intrinsic (approximate, <= 2 ulp) with no host definition and
+//                                                        is defined HERE as 1.0f / sqrtf(x) -- the correctly rounded form this build specifies
+//                                                        for both oracle and product (oracle_math.h / ssf_math.hpp unit3).  Consequence, stated
+//                                                        in tests/test_math.py: the eigen-frame vectors are bit-exact against this generator, and
+//                                                        what that does NOT pin is CUDA's own rsqrtf rounding (a relative 2^-22 on every component;
+//                                                        bounded by tools/cuda_tolerance_study.py, arm rsqrt~2: no integer decision moves).
 // Output: one JSON object, floats printed with %.9g (exact round trip for binary32).
 #include <cmath>
-extern "C" float rsqrtf(float x) { return 1.0f / sqrtf(x); }      // THE stand-in (see above)
+#ifdef SSF_REF_EIGEN_ONLY
+extern "C" float rsqrtf(float x) { return 1.0f / sqrtf(x); }      // THE stand-in (see above): this binary only
+#else
+extern "C" float rsqrtf(float x);                                  // declared, never defined, never called: no stand-in in this binary
+#endif
 #include <supersurfel_fusion/matrix_math.cuh>
 #include <cstdint>
 #include <cstdio>
 
 namespace ref {
 using std::isfinite;
+#ifdef SSF_REF_EIGEN_ONLY
+#include "_ref/decision_eigenDecomposition.inc"
+#else
 #include "_ref/decision_isUnchangeable.inc"
 #include "_ref/decision_solvePlaneEquations.inc"
-#include "_ref/decision_eigenDecomposition.inc"
+#endif
 }  // namespace ref
 
 static uint64_t st = 0x9E3779B97F4A7C15ULL;
@@ -52,6 +64,7 @@ static void close_arr() { std::printf("]"); }
 
 int main() {
     std::printf("{");
+#ifndef SSF_REF_EIGEN_ONLY
     // ---- the connectivity guard over ALL 2^8 ring patterns.  Bit k of the pattern: ring pixel k (NW, N, NE, E, SE, S, SW, W)
     // carries the centre's label.  Two label alphabets (the guard only compares for equality): foreign pixels all alike, and
     // foreign pixels all different.
@@ -112,9 +125,11 @@ int main() {
         open_arr("plane_ok"); for (int i = 0; i < N; i++) put((float)ok[i]); close_arr();
         open_arr("plane_theta"); for (int i = 0; i < N; i++) for (int k = 0; k < 3; k++) put(th[i][k]); close_arr();
     }
+#else
     // ---- the principal frame of 1024 SPD matrices at supersurfel scales (thin discs: two in-plane axes, a small normal
     // variance), n = 10 squarings as every caller passes (supersurfel_fusion_kernels.cu:209,334,673)
     {
+        st = 0xD1B54A32D192ED03ULL;                                   // (its own stream: the two binaries share no state)
         const int N = 1024;
         static Cov3 c[N]; static Mat33 V[N]; static float3 L[N];
         for (int i = 0; i < N; i++) {
@@ -136,10 +151,11 @@ int main() {
             V[i] = make_mat33(0, 0, 0, 0, 0, 0, 0, 0, 0); L[i] = make_float3(0, 0, 0);
             ref::eigenDecomposition(c[i], V[i], L[i], 10);
         }
-        open_arr("eig_cov"); for (int i = 0; i < N; i++) { put(c[i].xx); put(c[i].xy); put(c[i].xz); put(c[i].yy); put(c[i].yz); put(c[i].zz); } close_arr();
+        open_arr("eig_cov", true); for (int i = 0; i < N; i++) { put(c[i].xx); put(c[i].xy); put(c[i].xz); put(c[i].yy); put(c[i].yz); put(c[i].zz); } close_arr();
         open_arr("eig_vecs"); for (int i = 0; i < N; i++) for (int r = 0; r < 3; r++) { put(V[i].rows[r].x); put(V[i].rows[r].y); put(V[i].rows[r].z); } close_arr();
         open_arr("eig_vals"); for (int i = 0; i < N; i++) { put(L[i].x); put(L[i].y); put(L[i].z); } close_arr();
     }
+#endif
     std::printf("\n}\n");
     return 0;
 }

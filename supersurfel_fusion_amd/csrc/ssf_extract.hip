@@ -375,12 +375,6 @@ static inline TileOrder tile_order(dim3 grid) {
 #ifndef SSF_PASS_NPREV_RGB
 #define SSF_PASS_NPREV_RGB 1
 #endif
-#ifndef SSF_PASS_LDSDMA
-#define SSF_PASS_LDSDMA 0
-#endif
-#ifndef SSF_PASS_REPLAY_FIRST
-#define SSF_PASS_REPLAY_FIRST 0
-#endif
 #define PASS_F32 9                  // F_SX .. F_DN: 32-bit accumulators; F_DXX .. F_DD: 64-bit
 #define PASS_F64 (F_COUNT - PASS_F32)
 // accumulators of one window slot: 24 dwords = six 16-byte chunks -- the nine 32-bit sums (chunks 0-2, three dwords of padding),

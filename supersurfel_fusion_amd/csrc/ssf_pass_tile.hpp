@@ -7,12 +7,7 @@
 // slower in place (gpurun r13b, alternated three times), hence the include.
     constexpr int TWX = TILE * NPX, LOGN = 256 * NPX;
     SSF_PASS_TICK_BEGIN();                        // (lab: five ticks of the wall clock per workgroup -- tools/pass_trace.py)
-#if SSF_PASS_LDSDMA
-    // (direct-to-LDS tile loads: the last round's idle lanes land behind the tile -- room for whole rounds of 256 quads ... of 64 for the last)
-    __shared__ __attribute__((aligned(16))) int tile[((((TWX + 4) / 4) * TW + 63) / 64) * 64 * 4];
-#else
     __shared__ __attribute__((aligned(16))) int tile[(TWX + 4) * TW];      // rows of TWX + 4 labels: see the tile loads below
-#endif
     __shared__ SpRow w_row[WIN_MAX];
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
     __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
@@ -87,14 +82,12 @@
     static_assert(NQ <= 1024 && TILE_LOADS * 4 <= 32, "quad index / outside mask");
     uint4 tile_reg[TILE_LOADS]; unsigned int outside = 0u;
     const bool no_tile = SSF_PROBE(dbg, 32);                     // (probe: every element reads as outside the image)
-    const unsigned int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (window geometry and the interior test: one 8-byte table entry per tile for the product's 32-wide tiles, fetched by a scalar
     // load that travels with the kernel arguments; worked out here for the lab's 64-wide tiles)
     uint2 geom = make_uint2(0u, 0u);
     constexpr bool have_geom = NPX == 1;                      // (launch_update_pass always supplies the table for 32-wide tiles)
     if (have_geom) geom = pa.geom[by * ord.ntx + bx];
     const bool interior = have_geom ? ((geom.y >> 16) & 1u) != 0u : (X0 >= 1 && X0 - 1 + TWP <= p.W && Y0 >= 1 && Y0 + TILE < p.H);
-    const bool dma = SSF_PASS_LDSDMA >= 1 && !COH && interior && !no_tile;
     if (interior) {
         typedef uint32_t Quad __attribute__((ext_vector_type(4), aligned(4)));     // ONE load of four labels, 4-byte aligned
         const unsigned int base_off = (unsigned int)((Y0 - 1) * p.W + (X0 - 1));
@@ -105,41 +98,10 @@
             const unsigned int ly = __umul24(e, QPR_MAGIC) >> 16;      // quad (ly, e - ly * QPR): label offset ly * W + 4 (e - ly * QPR)
             tile_off[k] = 4u * (base_off + 4u * e + __umul24(ly, (unsigned int)(p.W - TWP)));   // bytes (24-bit multiplies are full rate)
         }
-        if (dma) {
-            // the tile's quads straight into LDS (global_load_lds_dwordx4: lane l of a wave lands at the wave's base + 16 l -- and quad
-            // e of the tile lies at LDS dword 4 e): no staging registers, no ds_write round.  Round k, wave w: quads 256 k + 64 w ...
-#pragma unroll
-            for (int k = 0; k < TILE_LOADS; k++) {
-                const unsigned int q0 = 256u * k + 64u * wave_id;
-                if (q0 < (unsigned int)NQ)                       // (wave-uniform; the idle lanes of the last wave land in the padding)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(lab) + tile_off[k]),
-                                                     (__attribute__((address_space(3))) void*)&tile[4u * q0], 16, 0, 0);
-            }
-        } else {
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
             const Quad v = ld_off_c<COH, Quad>(lab, tile_off[k]);
             tile_reg[k] = make_uint4(v.x, v.y, v.z, v.w);
-        }
-        }
-    } else if (SSF_PASS_LDSDMA >= 2 && !COH && !no_tile) {
-        // edge tiles, direct to LDS a LABEL at a time (global_load_lds_dword: lane l lands at the wave's base + 4 l) from offsets clamped
-        // into the image; the labels that are not in it are overwritten with -1 by the lane that fetched them, after the wave's own
-        // loads have landed (below)
-        constexpr int NE = TWP * TW, EDGE_LOADS = (NE + 255) / 256;
-        static_assert(EDGE_LOADS <= 32, "outside mask");
-#pragma unroll
-        for (int k = 0; k < EDGE_LOADS; k++) {
-            const unsigned int e = threadIdx.x + 256u * k;
-            const int ly = (int)(__umul24(e, 65536u / TWP + 1u) >> 16), lx = (int)e - ly * TWP;      // (e < 2048)
-            const int gy_ = Y0 - 1 + ly, cy_ = min(max(gy_, 0), p.H - 1);
-            const int gx_ = X0 - 1 + lx, cx_ = min(max(gx_, 0), p.W - 1);
-            if ((cx_ != gx_ || cy_ != gy_) && e < (unsigned int)NE) outside |= 1u << k;
-            const unsigned int off = 4u * (__umul24((unsigned int)cy_, (unsigned int)p.W) + (unsigned int)cx_);
-            const unsigned int e0 = 256u * k + 64u * wave_id;
-            if (e0 < (unsigned int)NE)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(lab) + off),
-                                                 (__attribute__((address_space(3))) void*)&tile[e0], 4, 0, 0);
         }
     } else {
         unsigned int tile_off[TILE_LOADS][4];
@@ -238,14 +200,7 @@
     for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256)
         reinterpret_cast<uint4*>(w_acc)[RGBD ? i : __mul24(i >> 1, 6) + (i & 1)] = make_uint4(0u, 0u, 0u, 0u);
     // (the idle lanes of the last round store the last quad once more: same value, same place -- no branch)
-    const bool dma_edge = SSF_PASS_LDSDMA >= 2 && !COH && !interior && !no_tile;
-    if (dma_edge) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (this wave's labels have landed: its lanes patch their own)
-        constexpr int EDGE_LOADS = (TWP * TW + 255) / 256;
-#pragma unroll
-        for (int k = 0; k < EDGE_LOADS; k++)
-            if ((outside >> k) & 1u) tile[threadIdx.x + 256u * k] = -1;
-    } else if (!interior || no_tile) {
+    if (!interior || no_tile) {
 #pragma unroll
         for (int k = 0; k < TILE_LOADS; k++) {
             if ((outside >> (4 * k)) & 1u) tile_reg[k].x = 0xFFFFFFFFu;
@@ -255,12 +210,10 @@
         }
     }
     SSF_PASS_TICK_LOADS();                        // (everything requested up front has arrived)
-    if (!dma && !dma_edge) {
 #pragma unroll
     for (int k = 0; k < TILE_LOADS; k++) {
         const unsigned int e = 256 * (k + 1) <= NQ ? threadIdx.x + 256u * k : min(threadIdx.x + 256u * k, (unsigned int)(NQ - 1));
         reinterpret_cast<uint4*>(tile)[e] = tile_reg[k];
-    }
     }
     __syncthreads();
     SSF_PASS_TICK(2);                             // (tile, window rows and accumulators staged)
@@ -353,15 +306,6 @@
 #pragma unroll
         for (int i = 0; i < SSF_PASS_JUNK; i++) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(junk));
         if (junk == 12345.678f) s_nlog = 1;
-    }
-#endif
-#if SSF_PASS_REPLAY_FIRST
-    // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
-    if (!SSF_PROBE(dbg, 8)) {
-#pragma unroll
-        for (int s = 0; s < NPX; s++)
-            if (threadIdx.x + 256u * s < n_prev)
-                add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
 #endif
     int4* __restrict__ cent = slab_shift(pa.cent, slot_off);
@@ -462,7 +406,6 @@
             if (RGBD) st_off<float>(cdis, 4u * ce, disp[s]);
         }
     }
-#if !SSF_PASS_REPLAY_FIRST
     // replay this tile's log of the previous pass into the buffer this pass writes (it lags by exactly that)
     if (!SSF_PROBE(dbg, 8)) {
 #pragma unroll
@@ -470,7 +413,6 @@
             if (threadIdx.x + 256u * s < n_prev)
                 add_delta(prev_ent[s].x, prev_ent[s].y, prev_ent[s].z & 0xFFFF, (prev_ent[s].z >> 16) & 0xFFFF, (uint32_t)prev_ent[s].w, prev_disp[s]);
     }
-#endif
     __syncthreads();
     SSF_PASS_TICK(3);                             // (decisions taken, deltas in LDS, log written)
 #ifdef SSF_EXPERIMENTS

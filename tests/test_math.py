@@ -190,6 +190,8 @@ def test_sym_inverse_threshold(oracle_lib):
 # (TPS_RGBD_kernels.cu:27-59) and eigenDecomposition (supersurfel_fusion_kernels.cu:48-111), cut out of the reference's files by
 # line range at build time and compiled as they stand (oracle/ref_decision_vectors.cpp, oracle/Makefile `decision`).  They gate
 # integer results (may a pixel change its label; which RANSAC sample / plane a superpixel gets; which axis is the normal).
+# Round 6: TWO generator binaries -- guard_* and plane_* come from one that only DECLARES rsqrtf (no stand-in anywhere in it, the
+# recipe checks with nm); eig_* alone comes from the binary that defines rsqrtf := 1 / sqrtf (the one named stand-in).
 DECISIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_decision_vectors.npz")
 
 

@@ -295,3 +295,54 @@ def test_a_2_ulp_reciprocal_square_root_flips_no_integer_decision(sequence, orac
     assert all(v[0] == 0 for v in report.values()), report
     assert all(v[2] < 1e-5 for v in report.values()), report          # (measured: <= 1.6e-6 over 8 real frames)
     assert any(v[2] > 0 for v in report.values()), "the hook did not reach the pose at all"
+
+
+# ---- the stated tolerance against the CUDA path (round 6) ------------------------------------------------------------------------
+# north_star: "match the reference CUDA path ... within a stated float tolerance (bit-exact for surfel indexing/assignment)".  The
+# product is bit-equal to the oracle (the specification); the reference itself is --use_fast_math and racy, i.e. a FAMILY of executions
+# none of which can be produced here.  tools/cuda_tolerance_study.py measures the width of that family around the specification with
+# the study build of the oracle (oracle/Makefile `arms`); profiles/cuda_tolerance_r06.txt is its full table (8 real + 6 synthetic
+# frames) and DESIGN.md section 2 states the tolerance.  Here: the quick form (4 + 3 frames), asserting the stated bounds.
+@pytest.fixture(scope="module")
+def tolerance_study():
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "arms"], stdout=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import cuda_tolerance_study as study
+    import io
+    return study.study(quick=True, out=io.StringIO())
+
+
+def test_stated_tolerance_arithmetic_arms(tolerance_study):
+    """--use_fast_math's arithmetic (FMA contraction, flush-to-zero, every division / sqrt / rsqrt / powf within its documented
+    error bound): at most 0.05 % of the labels and inlier flags of a frame move, no frame supersurfel's validity flips on the synthetic
+    frames, the pose stays within 5e-4 (m / rotation entry) of the specification's over the sequence; flush-to-zero, the tie rule of
+    the arg-min, the insertion order (as a multiset of rows) and powf / cbrtf within 8 ulp change NOTHING."""
+    r = tolerance_study
+    for seq in ("tum_fr1_xyz", "synthetic"):
+        for arm in ("fma", "div-2", "div+2", "div~2", "rsqrt~2", "pow-2", "pow+2", "pow~2", "pow+8", "ftz"):
+            d = r[(seq, arm)]
+            assert d["labels"] <= 5e-4 * d["px"] and d["inliers"] <= 5e-4 * d["px"], (seq, arm, d)
+            assert d["pose_t"] <= 5e-4 and d["pose_r"] <= 1e-3, (seq, arm, d)
+        for arm in ("ftz", "pow-2", "pow+2", "pow~2", "pow+8", "tie-high", "insert-rev"):
+            d = r[(seq, arm)]
+            assert d["labels"] == 0 and d["inliers"] == 0 and d["fvalid"] == 0 and d["icp"] == 0 and d["counters"] == 0 and d["row_diff"] == 0, (seq, arm, d)
+            assert d["pose_t"] == 0.0 and d["pose_r"] == 0.0, (seq, arm, d)
+        d = r[(seq, "rsqrt~2")]
+        assert d["labels"] == 0 and d["counters"] == 0 and d["row_diff"] == 0 and d["pose_t"] < 1e-5, (seq, d)
+    assert any(r[(s, a)]["labels"] > 0 for s in ("tum_fr1_xyz", "synthetic") for a in ("fma", "div~2")), "the arithmetic arms reached nothing"
+
+
+def test_stated_tolerance_schedule_arms(tolerance_study):
+    """The other extreme of each race the reference leaves open (blocks of a relabelling pass strictly in sequence; the plane filter in
+    place; the torn arg-min's worst outcome), and everything at once: at most 2 % of the labels, 0.5 % of the inlier flags, the pose
+    within 1e-2.  This -- not 1e-4 -- is how far two valid executions of the reference's own CUDA code can lie apart; the product's
+    1e-4 (in fact 0-bit) agreement is with the specification, one member of that family."""
+    r = tolerance_study
+    for seq in ("tum_fr1_xyz", "synthetic"):
+        for arm in ("schedule", "filter-gs", "argmin-torn", "all"):
+            d = r[(seq, arm)]
+            assert d["labels"] <= 0.02 * d["px"] and d["inliers"] <= 0.005 * d["px"], (seq, arm, d)
+            assert d["pose_t"] <= 1e-2 and d["pose_r"] <= 2e-2, (seq, arm, d)
+        assert r[(seq, "schedule")]["labels"] > 0 and r[(seq, "filter-gs")]["pose_t"] > 0 and r[(seq, "argmin-torn")]["row_diff"] > 0
