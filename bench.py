@@ -149,15 +149,21 @@ def next_kernel_times(lib, dev, model, nvis, cap):
     nrot = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (m, 1)); ntr = rng.uniform(-1e-3, 1e-3, (m, 3)).astype(np.float32)
     w4 = rng.dirichlet(np.ones(4), n).astype(np.float32); idx = rng.integers(0, m, (n, 4)).astype(np.int32)
     f.set_profile(1)
-    for rep in range(3):
-        if rep == 1:
-            f.reset_kernel_times()
-        f.apply_deformation(npos, nrot, ntr, w4, idx)
-    ms, calls = f.kernel_times().get("apply_deformation", (0.0, 0))
-    if calls:
-        us = 1000.0 * ms / calls
-        out["apply_deformation"] = dict(rows=n, nodes=m, avg_us=us, algo_bytes=176.0 * n, achieved_GBs=176.0 * n / (us * 1e-6) / 1e9,
-                                        frac_of_hbm_peak=176.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+    # two node assignments: uniformly random indices (the worst case for the node gathers; this key's meaning since round 2) and
+    # indices that follow the row order (a row's four nodes near row / 50: what a time-ordered deformation graph gives rows in
+    # arrival order -- the reference samples its nodes from the model and weights them sequentially, deformation_graph.cu:240-270)
+    idx_seq = np.clip((np.arange(n)[:, None] // 50) + rng.integers(-2, 3, (n, 4)), 0, m - 1).astype(np.int32)
+    for key, ix in (("apply_deformation", idx), ("apply_deformation_nodes_in_row_order", idx_seq)):
+        for rep in range(3):
+            if rep == 1:
+                f.reset_kernel_times()
+            f.apply_deformation(npos, nrot, ntr, w4, ix)
+        ms, calls = f.kernel_times().get("apply_deformation", (0.0, 0))
+        if calls:
+            us = 1000.0 * ms / calls
+            out[key] = dict(rows=n, nodes=m, avg_us=us, algo_bytes=176.0 * n, achieved_GBs=176.0 * n / (us * 1e-6) / 1e9,
+                            frac_of_hbm_peak=176.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            node_indices="uniformly random" if key == "apply_deformation" else "near row / 50 (rows in arrival order, time-ordered graph)")
     R, t = synthetic.orbit_pose(0)
     rgb, depth, _ = synthetic.render(R, t, W, H, noise=True, rng=np.random.default_rng(1000))
     d_in = torch.from_numpy(depth).to(dev); d_out = torch.empty_like(d_in)
@@ -173,6 +179,19 @@ def next_kernel_times(lib, dev, model, nvis, cap):
         out["bilateral_prefilter"] = dict(width=W, height=H, taps=149, avg_us=us, algo_bytes=8.0 * W * H, achieved_GBs=8.0 * W * H / (us * 1e-6) / 1e9,
                                           frac_of_hbm_peak=8.0 * W * H / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                           note="compute bound: 149 taps (circle of radius 7) x a specified (bit-reproducible) exp per pixel, two taps per packed fp32 instruction")
+        # "compute bound" as a number (round 6): vector instructions issued per launch (rocprofv3 --pmc SQ_INSTS_VALU) over the launch's
+        # duration in the kernel trace, against the part's vector issue peak (tools/pmc_issue.py -> profiles/pmc_rNN_config5_issue.json;
+        # used only when it was recorded at these kernel sources)
+        import glob
+        iss = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r[0-9][0-9]_config5_issue.json")))
+        if iss:
+            ij = json.load(open(iss[-1]))
+            ke = next((v for k, v in ij.get("kernels", {}).items() if k.startswith("k_bilateral_r7")), None)
+            if ke and ij.get("source_sha") == kernel_source_sha():
+                out["bilateral_prefilter"].update(valu_issue_frac=ke["valu_issue_frac"], valu_wave_insts_per_launch=ke["valu_wave_insts_per_launch"],
+                                                  valu_issue_note="profiles/%s: SQ_INSTS_VALU per launch / trace duration / (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles)" % os.path.basename(iss[-1]))
+            else:
+                out["bilateral_prefilter"]["valu_issue_note"] = "profiles/%s was recorded at other kernel sources" % os.path.basename(iss[-1])
     f.process_frame(rgb, depth)
     src = f.get_frame()
     f.reset_kernel_times()
@@ -634,6 +653,36 @@ def main():
                         traffic=traffic, traffic_note=traffic_note, avg_launch_us=per_kernel[dom]["avg_us"],
                         algo_bytes_per_launch=per_kernel[dom]["algo_bytes_per_launch"],
                         kernel_share_ms_per_frame={n: round(per_kernel[n]["total_ms_per_frame"], 5) for n in per_kernel if fam(n) == dom_fam})
+        # ---- what the PROFILE says beside it (round 6).  `kernel` above is the dominant kernel FAMILY's larger instantiation (one
+        # kernel, two template instances); by kernel NAME the largest single item of GPU time can be another one (k_icp at the
+        # metric's workload: profiles/rocprof_r05.txt) -- reported here with its own roofline figures, from the same hipEvent brackets:
+        tot_ms = sum(e["total_ms_per_frame"] for e in per_kernel.values()) or 1.0
+        topn = max(per_kernel, key=lambda n: per_kernel[n]["total_ms_per_frame"])
+        te = per_kernel[topn]
+        top_traffic = None
+        if pmcs and traffic is not None:
+            top_traffic = pmc["kernels"].get(topn, {}).get("hbm_bytes_per_launch")
+        roofline["top_kernel_by_name"] = dict(kernel=topn, share_of_kernel_time=te["total_ms_per_frame"] / tot_ms, avg_launch_us=te["avg_us"],
+                                              launches_per_frame=te["launches_per_frame"], achieved=te.get("achieved_GBs"),
+                                              frac=(te["achieved_GBs"] / HBM_PEAK_GBS) if te.get("achieved_GBs") else None,
+                                              algo_bytes_per_launch=te.get("algo_bytes_per_launch"), traffic=top_traffic,
+                                              traffic_over_algorithmic=(top_traffic / te["algo_bytes_per_launch"]) if (top_traffic and te.get("algo_bytes_per_launch")) else None)
+        roofline["traffic_over_algorithmic"] = (traffic / per_kernel[dom]["algo_bytes_per_launch"]) if traffic else None
+        # ... and the dominant kernel's fraction over the LAUNCH MIX of the committed rocprofv3 trace (leading batches of 3 and 5 frames
+        # included, where `frac` above is quoted at full batches): profiles/rocprof_rNN.json, written by tools/rocprof_summary.py from
+        # the trace's own durations and grid sizes, used only when it was taken at these kernel sources
+        rp = sorted(glob.glob(os.path.join(ROOT, "profiles", "rocprof_r[0-9][0-9]%s.json" % ("" if a.config == 2 else "_config%d" % a.config))))
+        roofline["frac_from_rocprof"], roofline["frac_from_rocprof_note"] = None, "no profiles/rocprof_rNN.json"
+        if rp:
+            rj = json.load(open(rp[-1])); rname = "profiles/" + os.path.basename(rp[-1])
+            mixk = (rj.get("relabelling_launch_mix") or {}).get(dom)
+            if rj.get("source_sha") != kernel_source_sha():
+                roofline["frac_from_rocprof_note"] = "%s was recorded at other kernel sources (%s)" % (rname, rj.get("source_sha"))
+            elif mixk:
+                roofline["frac_from_rocprof"] = mixk["frac_of_8TBs"]
+                roofline["frac_from_rocprof_note"] = ("%s: %d launches, %.2f frames per launch on average, %.2f us per launch (rocprofv3 --kernel-trace durations; "
+                                                      "algorithmic bytes of every launch by its own frame count)" % (rname, mixk["launches"], mixk["mean_frames_per_launch"], mixk["avg_us"]))
+                roofline["rocprof_top_kernels_by_name"] = [dict(kernel=t["kernel"], share=round(t["share"], 4), avg_us=round(t["avg_us"], 3)) for t in rj.get("top_kernels_by_name", [])[:4]]
     # nominal AND measured-achievable peak: a stream copy on this box, outside every timed region
     hbm_measured = measured_hbm_peak(dev) if (rank == 0 and a.extras) else None          # (--extras 0: profiling runs stay free of the copy kernels)
     # ... and by a plain 16-bytes-per-lane copy kernel of the library's own (the form MI355X_MICROARCH.md quotes at 6.29 TB/s):

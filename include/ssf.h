@@ -361,7 +361,10 @@ int ssf_comm_attach(ssf_handle* h, const uint8_t* id128);
  * bit-identical.  Collective: every rank calls it after ssf_comm_attach, with an empty pipeline; every rank must then
  * be handed the same frame stream in the same batches (the images of a batch another rank extracts are not read).  mode 0
  * = replicated again; mode 2 = as 1, and the extracting rank rebuilds its own tables from what it ships (a self-check).
- * RCCL backend only.  Like the rest of the native N > 1 path it has run on ONE rank only on this build's hardware. */
+ * RCCL backend only.  EXPERIMENTAL: like the rest of the native N > 1 path it has run on ONE rank only on this build's hardware
+ * (no test with two ranks exists).  While a handle deals, ssf_submit_frame_tables is refused (SSF_ERR_STATE): the two ways of
+ * receiving a frame extracted elsewhere do not mix.  A rank whose own extract launch fails still issues its broadcasts (the
+ * peers do not hang) and returns the error. */
 int ssf_comm_deal_extract(ssf_handle* h, int mode);
 /* what is attached: *backend = 0 none, 1 RCCL, 2 peer-to-peer regions; *ranks = the number of ranks the exchange
  * itself reports (ncclCommCount of the communicator; the number of opened regions + 1), 1 when nothing is attached;
@@ -492,7 +495,8 @@ int ssf_set_profile(ssf_handle* h, int enable);
 int ssf_sequence_times(ssf_handle* h, double* out64);
 int ssf_sequence_marks(ssf_handle* h, double* out320);
 /* What a plain 16-bytes-per-lane stream copy sustains on this box, GB/s (mib MiB read + the same written, best of reps;
- * non-temporal, unrolled): the "measured-achievable" HBM figure beside the 8 TB/s spec.  < 0: n/a. */
+ * non-temporal, unrolled): the "measured-achievable" HBM figure beside the 8 TB/s spec.  mib is rounded
+ * down to a multiple of 256 (every form of the copy moves whole rounds of 256 MiB); mib < 256 or reps < 1 returns -1.  < 0: n/a. */
 double ssf_stream_copy_rate(int mib, int reps);
 /* Counters of the host-side machinery (tests and tools/ read them; none is on the frame path):
  *   ssf_upload_stats          out6: [0] upload workers, [1] host frames uploaded, microseconds summed over the workers [2] waiting

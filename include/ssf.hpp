@@ -104,6 +104,14 @@ namespace supersurfel_fusion {
  * the class therefore lives in an inline namespace named after the form (`thrust_view` / `host_copy`): code never spells
  * it, but a function that passes a SupersurfelFusion between translation units of different forms fails to LINK instead
  * of calling the wrong getModel(). */
+/* (round 6: DeviceArray and Supersurfels live in the inline namespace too -- their member SETS differ between the forms, and two
+ * definitions of one class name in one namespace would be an ODR violation even where the layout agrees) */
+#ifdef SSF_THRUST_VIEW
+inline namespace thrust_view {
+#else
+inline namespace host_copy {
+#endif
+
 template <typename T> struct DeviceArray {
     T* ptr = nullptr; size_t n = 0;
     size_t size() const { return n; }
@@ -133,12 +141,6 @@ struct Supersurfels {                                                    /* supe
 };
 static_assert(sizeof(DeviceArray<float3>) == sizeof(void*) + sizeof(size_t) && sizeof(Supersurfels) == 7 * sizeof(DeviceArray<float>),
               "ssf.hpp: the device views are (pointer, count) pairs in every translation unit");
-
-#ifdef SSF_THRUST_VIEW
-inline namespace thrust_view {
-#else
-inline namespace host_copy {
-#endif
 
 class SupersurfelFusion {
 public:

@@ -417,9 +417,9 @@ void launch_publish_all_counts(hipStream_t st, const int* all5, int nranks, Mail
 void launch_publish_counts(hipStream_t st, Counters* cnt, int shrink_by_removed, Mailbox* mb, unsigned long long seq);
 void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n);
 void launch_pack_orient(hipStream_t st, SurfelSoA s, int n, float* out9);
-// m nodes; nodes24: scratch of 24 floats per node (the packed node records, see k_pack_nodes)
+// m nodes; nodes16: scratch of 16 floats per node (one 64-byte record) (the packed node records, see k_pack_nodes)
 void launch_deformation(hipStream_t st, SurfelSoA model, int n, int m, const float* npos, const float* nrot,
-                        const float* ntrans, float* nodes24, const float* w4, const int32_t* idx4);
+                        const float* ntrans, float* nodes16, const float* w4, const int32_t* idx4);
 
 // profiling hook: every launch_* brackets its kernels through these (ssf_host.hip)
 struct KernelTimer;

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include "ssf_device.hpp"
 
 namespace ssf {
@@ -1704,12 +1705,22 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int n
     // larger grids: states and centroids in LDS (32 B / node, up to 160 KB per workgroup), the data term in registers
     const size_t lds2 = (size_t)p.S * 8 * sizeof(float);
     const int npt = (p.S + 1023) / 1024;
-    static const bool big_lds = [] {                    // (once per process: these instantiations ask for more than 64 KB)
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
-        (void)hipGetLastError();
-        return ok;
-    }();
+    // (these instantiations ask for more than 64 KB; the attribute belongs to the function ON A DEVICE, and a process may hold handles
+    //  on several GPUs: asked once per device, not once per process)
+    static std::mutex big_lds_mutex;
+    static int big_lds_state[64] = {};                  // per device id: 0 = not asked, 1 = granted, 2 = refused
+    int dev = 0; (void)hipGetDevice(&dev);
+    bool big_lds = false;
+    if (dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(big_lds_mutex);
+        if (big_lds_state[dev] == 0) {
+            bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_filter_regs<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
+            (void)hipGetLastError();
+            big_lds_state[dev] = ok ? 1 : 2;
+        }
+        big_lds = big_lds_state[dev] == 1;
+    }
     if (big_lds && lds2 <= 160 * 1024 && npt <= 5) {
         if (npt <= 3) hipLaunchKernelGGL(k_plane_filter_regs<3>, dim3(nb), dim3(1024), lds2, st, p, m, true_buf);
         else hipLaunchKernelGGL(k_plane_filter_regs<5>, dim3(nb), dim3(1024), lds2, st, p, m, true_buf);

@@ -842,31 +842,37 @@ static int launch_batch(ssf_handle* h, ExtractCtx& c) {
     // so the collectives of a context's communicator are issued in the same order everywhere.
     const bool dealt = h->deal != 0 && h->comm != nullptr;
     const bool mine = !dealt || c.mine;
+    int extract_rc = SSF_OK;
     if (mine) {
         if (h->cfg.depth_prefilter) {                                      // supersurfel_fusion.cu:180 -- the batch's frames in one launch
             launch_bilateral_batch(st, c.in, c.d_depth_filt, c.maps.slab, nb, h->cfg.width, h->cfg.height, h->cfg.prefilter_sigma_color, h->cfg.prefilter_sigma_space);
             for (int b = 0; b < nb; b++) c.in.depth[b] = slab_shift(c.d_depth_filt, (size_t)b * c.maps.slab);
         }
         launch_ingest(st, h->seg, c.in, c.maps, nb, c.epoch0);
-        int rc = run_segmentation(h, c);
-        if (rc) return rc;
-        launch_finalize_surfels(st, h->seg, c.maps, nb, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp0, c.d_mask, c.mask_bits,
-                                c.d_best, c.d_matched);
+        extract_rc = run_segmentation(h, c);
+        if (extract_rc && !dealt) return extract_rc;
+        if (!extract_rc) launch_finalize_surfels(st, h->seg, c.maps, nb, c.frame, h->cfg.range_min, h->cfg.range_max, c.stamp0, c.d_mask, c.mask_bits,
+                                                 c.d_best, c.d_matched);
     }
     if (dealt) {
+        // (a local failure above must not leave the other ranks waiting in their broadcasts: the group is issued regardless -- what it
+        //  ships is then meaningless, and this rank reports the error -- and GroupStart is always paired with GroupEnd)
         RcclApi* api = rccl_api();
         const int root = (int)(c.deal_batch % (long long)h->cfg.nranks);
         const size_t P = (size_t)h->cfg.width * h->cfg.height;
-        if (mine) launch_export_rows(st, h->seg, c.maps, nb, c.frame, c.d_wire);
+        if (mine && !extract_rc) launch_export_rows(st, h->seg, c.maps, nb, c.frame, c.d_wire);
         NCK(api->GroupStart());
-        for (int b = 0; b < nb; b++) {
+        ncclResult_t bc_rc = ncclSuccess;
+        for (int b = 0; b < nb && bc_rc == ncclSuccess; b++) {
             const size_t off = (size_t)b * c.maps.slab;
             int32_t* lab = slab_shift(c.maps.label, off); float* pd = slab_shift(c.maps.plane_depth, off); float* w = slab_shift(c.d_wire, off);
-            NCK(api->Broadcast(lab, lab, P, ncclInt32, root, c.deal_comm, st));
-            NCK(api->Broadcast(pd, pd, P, ncclFloat32, root, c.deal_comm, st));
-            NCK(api->Broadcast(w, w, 26 * (size_t)h->S, ncclFloat32, root, c.deal_comm, st));
+            bc_rc = api->Broadcast(lab, lab, P, ncclInt32, root, c.deal_comm, st);
+            if (bc_rc == ncclSuccess) bc_rc = api->Broadcast(pd, pd, P, ncclFloat32, root, c.deal_comm, st);
+            if (bc_rc == ncclSuccess) bc_rc = api->Broadcast(w, w, 26 * (size_t)h->S, ncclFloat32, root, c.deal_comm, st);
         }
-        NCK(api->GroupEnd());
+        const ncclResult_t end_rc = api->GroupEnd();
+        if (extract_rc) return extract_rc;
+        NCK(bc_rc); NCK(end_rc);
         if (!mine || h->deal == 2) launch_import_frame(st, h->seg, c.maps, nb, c.frame, c.d_wire, c.d_best, c.d_matched);
     }
     HCK(hipGetLastError());
@@ -1321,7 +1327,9 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
             // driver's 20-frame form ran 4 % slower with the fusion than without (7680-7730 against 8030-8060 frames/s, same box,
             // alternated twice: profiles/track_chain_r05.txt); in the steady state the next batch is ready and nothing changes.
             bool ready = nc.launched && (!multi || nc.waited);
-            if (nc.launched && !ready && (h->icp_ahead_mode == 2 || hipEventQuery(nc.ev_done) == hipSuccess)) {
+            // (peer-to-peer shards: every rank must take the SAME form for a frame -- a rank that fused would spin in the exchange until
+            //  its peer's later launch publishes -- so there the decision stays host-deterministic: wait for the event, as until round 4)
+            if (nc.launched && !ready && (h->icp_ahead_mode == 2 || h->p2p.on || hipEventQuery(nc.ev_done) == hipSuccess)) {
                 HCK(hipStreamWaitEvent(h->stream, nc.ev_done, 0)); nc.waited = true; ready = true;
             }
             (void)hipGetLastError();                      // (hipErrorNotReady of the query is not an error)
@@ -1701,7 +1709,7 @@ struct DevTemps {
 typedef float f4v __attribute__((ext_vector_type(4)));
 template <int U, bool NT, bool ONE_PASS>
 __global__ __launch_bounds__(256) void k_stream_copy(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n) {
-    // (n is a multiple of U x the grid's threads: see the caller)
+    // (n is a multiple of U x the grid's threads -- ssf_stream_copy_rate rounds to 256 MiB and refuses less: the first round is unguarded)
     const size_t stride = ONE_PASS ? (size_t)256 : (size_t)gridDim.x * 256;
     size_t i = ONE_PASS ? (size_t)blockIdx.x * 256 * U + threadIdx.x : (size_t)blockIdx.x * 256 + threadIdx.x;
     do {
@@ -1975,6 +1983,9 @@ int ssf_submit_frame(ssf_handle* h, const void* rgb, const void* depth, int on_d
 int ssf_submit_frame_tables(ssf_handle* h, const int32_t* label, const float* plane_depth, const ssf_surfels* frame, int on_device) {
     if (!h || !label || !plane_depth || !frame) return SSF_ERR_INVALID_ARG;
     if (!frame->positions || !frame->colors || !frame->stamps || !frame->orientations || !frame->shapes || !frame->dims || !frame->confidences) return SSF_ERR_INVALID_ARG;
+    // (dealt extract counts batches to choose the broadcasting rank; a frame handed in here would not be counted and the ranks'
+    //  root choice would drift apart: the two ways of receiving a frame extracted elsewhere do not mix)
+    if (h->deal != 0) { h->err = "ssf_submit_frame_tables: the handle deals its extract stage (ssf_comm_deal_extract); submit frames, not tables"; return SSF_ERR_STATE; }
     TimerScope ts(h);
     return submit_tables(h, label, plane_depth, frame, on_device);
 }
@@ -2654,7 +2665,7 @@ int ssf_apply_deformation(ssf_handle* h, const float* np, const float* nr, const
     float *d_np, *d_nr, *d_nt, *d_w, *d_nodes; int32_t* d_i;
     DevTemps tmp;
     HCK(tmp.take(&d_np, 12 * (size_t)m)); HCK(tmp.take(&d_nr, 36 * (size_t)m)); HCK(tmp.take(&d_nt, 12 * (size_t)m));
-    HCK(tmp.take(&d_nodes, 96 * (size_t)m));
+    HCK(tmp.take(&d_nodes, 64 * (size_t)m));
     HCK(tmp.take(&d_w, 16 * n)); HCK(tmp.take(&d_i, 16 * n));
     hipStream_t st = h->stream;
     HCK(hipMemcpyAsync(d_np, np, 12 * (size_t)m, hipMemcpyHostToDevice, st));
@@ -2855,8 +2866,11 @@ double ssf_dbg_extract_only(ssf_handle* h, const void* const* rgb, const void* c
 // non-temporal (`nt`: streamed data is not kept in L2 / MALL, which a copy of 2 GiB only thrashes), grid-stride over 8192
 // workgroups or one pass of exactly-sized workgroups.  The best form's rate is returned.
 double ssf_stream_copy_rate(int mib, int reps) {
-    if (mib < 16 || reps < 1) return -1.0;
-    const size_t bytes = ((size_t)mib << 20) & ~(size_t)((1u << 25) - 1u), n = bytes / sizeof(f4v);       // a multiple of 32 MiB = 8 x 2^21 threads x 16 B... (2^21 float4)
+    // Every form moves WHOLE rounds: the grid-stride forms cover U x 2^21 threads x 16 B = 128 MiB (U = 4) or 256 MiB (U = 8) per
+    // round of their loop and their first round is unguarded (k_stream_copy), so the buffers are a multiple of 256 MiB and sizes
+    // below that are refused -- a smaller buffer would be overrun, a ragged one credited with bytes it did not move.
+    if (mib < 256 || reps < 1) return -1.0;
+    const size_t bytes = ((size_t)mib << 20) & ~(size_t)((1u << 28) - 1u), n = bytes / sizeof(f4v);
     if (bytes == 0) return -1.0;
     f4v *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(a); return -1.0; }

@@ -1816,21 +1816,24 @@ __global__ void k_lab_refresh(SurfelSoA s, int n) {
 
 // ---- deformation apply ("next" row) -----------------------------------------------------------------
 // rotMatToQuat matrix_math.cuh:529-618; quatToRotMat :512-527 (its wy = q.w*q.z is reproduced)
-// the nodes of the deformation graph as one 96-byte record each: (g.xyz, q.x) (t.xyz, q.y) (R row 0, q.z) (R row 1, q.w)
-// (R row 2, 0) (unused) -- the rotation -> quaternion conversion (rotMatToQuat, four branches, IEEE sqrt / divide) is done
-// once per node here instead of four times per supersurfel, and a supersurfel's four nodes are 4 x 5 whole 16-byte loads
+// The nodes of the deformation graph as ONE 64-BYTE RECORD each (round 6): (g.xyz, R00) (t.xyz, R01) (R02, R10, R11, R12) (R20, R21,
+// R22, 0) -- a supersurfel's four nodes are 4 x 4 whole 16-byte loads, each record one aligned 64-byte piece of a line, the table
+// 1.28 MB at 20 k nodes.  The node's quaternion (rotMatToQuat: four branches, an IEEE sqrt and a divide) is worked out per row and
+// node, as the reference does (deformation_graph_kernels.cu:44-52) -- the same operations on the same operands, so the same bits.
+// Measured (tools/deform_probe.py, profiles/deformation_r06.txt, 1 M rows, N / 50 nodes): rounds 2-5 kept a 96-byte record with the
+// quaternion precomputed (five gathers per node): 75 us with uniformly random node indices, of which 35 us were the gathers (nodes
+// 0 / 1 only: 40 us) -- this form: 60 us; records padded to 128 bytes: 85 (the table's footprint in L2 matters, not lines per
+// record); non-temporal row accesses: no change; one or two nodes per round at 8 / 5 waves per SIMD: 68-88.  With node indices that
+// follow the row order (what a time-ordered graph gives rows in arrival order) every form runs at 40-42 us = 0.52-0.55 of HBM peak.
 __global__ __launch_bounds__(256) void k_pack_nodes(int m, const float* __restrict__ npos, const float* __restrict__ nrot,
                                                     const float* __restrict__ ntrans, float4* __restrict__ nodes) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const V3 g = ld3(npos, k), t = ld3(ntrans, k);
-    const M3 R = m3(v3(nrot[9 * k], nrot[9 * k + 1], nrot[9 * k + 2]), v3(nrot[9 * k + 3], nrot[9 * k + 4], nrot[9 * k + 5]),
-                    v3(nrot[9 * k + 6], nrot[9 * k + 7], nrot[9 * k + 8]));
-    float q[4]; rot_to_quat(R, q);
-    float4* o = nodes + 6 * (size_t)k;
-    o[0] = make_float4(g.x, g.y, g.z, q[0]); o[1] = make_float4(t.x, t.y, t.z, q[1]);
-    o[2] = make_float4(R.r0.x, R.r0.y, R.r0.z, q[2]); o[3] = make_float4(R.r1.x, R.r1.y, R.r1.z, q[3]);
-    o[4] = make_float4(R.r2.x, R.r2.y, R.r2.z, 0.f); o[5] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* o = nodes + 4 * (size_t)k;
+    o[0] = make_float4(g.x, g.y, g.z, nrot[9 * k]); o[1] = make_float4(t.x, t.y, t.z, nrot[9 * k + 1]);
+    o[2] = make_float4(nrot[9 * k + 2], nrot[9 * k + 3], nrot[9 * k + 4], nrot[9 * k + 5]);
+    o[3] = make_float4(nrot[9 * k + 6], nrot[9 * k + 7], nrot[9 * k + 8], 0.f);
 }
 __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const float4* __restrict__ nodes,
                                                      const float* __restrict__ w4, const int32_t* __restrict__ idx4) {
@@ -1841,23 +1844,32 @@ __global__ __launch_bounds__(256) void k_deformation(SurfelSoA M, int n, const f
     const float4 w = reinterpret_cast<const float4*>(w4)[i];
     const int node[4] = {id.x, id.y, id.z, id.w};
     const float wv[4] = {w.x, w.y, w.z, w.w};
-    float4 rec[4][5];
+    float4 rec[4][4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int j = 0; j < 5; j++) rec[k][j] = nodes[6 * (size_t)node[k] + j];       // all twenty gathers in one round
+        for (int j = 0; j < 4; j++) rec[k][j] = nodes[4 * (size_t)node[k] + j];       // all sixteen gathers in one round
     V3 po = v3(0, 0, 0);
     float bq[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float wk = wv[k];
         const V3 gk = v3(rec[k][0].x, rec[k][0].y, rec[k][0].z), tk = v3(rec[k][1].x, rec[k][1].y, rec[k][1].z);
-        const M3 Rk = m3(v3(rec[k][2].x, rec[k][2].y, rec[k][2].z), v3(rec[k][3].x, rec[k][3].y, rec[k][3].z),
-                         v3(rec[k][4].x, rec[k][4].y, rec[k][4].z));
-        const float qk[4] = {rec[k][0].w, rec[k][1].w, rec[k][2].w, rec[k][3].w};
+        const M3 Rk = m3(v3(rec[k][0].w, rec[k][1].w, rec[k][2].x), v3(rec[k][2].y, rec[k][2].z, rec[k][2].w),
+                         v3(rec[k][3].x, rec[k][3].y, rec[k][3].z));
+        // rot_to_quat (ssf_math.hpp) with its result in named scalars: through the array the compiler kept it in scratch
+        float s_, qx, qy, qz, qw; const float tr = (Rk.r0.x + Rk.r1.y) + Rk.r2.z;
+        if (tr > 0) { s_ = sqrtf(tr + 1); qw = 0.5f * s_; s_ = 0.5f / s_; qx = (Rk.r2.y - Rk.r1.z) * s_; qy = (Rk.r0.z - Rk.r2.x) * s_; qz = (Rk.r1.x - Rk.r0.y) * s_; }
+        else {
+            int ii = 0;
+            if (Rk.r1.y > Rk.r0.x) ii = 1;
+            if (Rk.r2.z > Rk.r0.x || Rk.r2.z > Rk.r1.y) ii = 2;
+            if (ii == 0) { s_ = sqrtf(((1.0f + Rk.r0.x) - Rk.r1.y) - Rk.r2.z); qx = 0.5f * s_; s_ = 0.5f / s_; qw = (Rk.r2.y - Rk.r1.z) * s_; qy = (Rk.r0.y + Rk.r1.x) * s_; qz = (Rk.r0.z + Rk.r2.x) * s_; }
+            else if (ii == 1) { s_ = sqrtf(((1.0f + Rk.r1.y) - Rk.r0.x) - Rk.r2.z); qy = 0.5f * s_; s_ = 0.5f / s_; qw = (Rk.r0.z - Rk.r2.x) * s_; qx = (Rk.r0.y + Rk.r1.x) * s_; qz = (Rk.r1.z + Rk.r2.y) * s_; }
+            else { s_ = sqrtf(((1.0f + Rk.r2.z) - Rk.r0.x) - Rk.r1.y); qz = 0.5f * s_; s_ = 0.5f / s_; qw = (Rk.r1.x - Rk.r0.y) * s_; qx = (Rk.r0.z + Rk.r2.x) * s_; qy = (Rk.r1.z + Rk.r2.y) * s_; }
+        }
         po = add(po, scale(wk, add(add(m3_mulv(Rk, sub(pi, gk)), gk), tk)));
-#pragma unroll
-        for (int a = 0; a < 4; a++) bq[a] += wk * qk[a];
+        bq[0] += wk * qx; bq[1] += wk * qy; bq[2] += wk * qz; bq[3] += wk * qw;
     }
     const float len = sqrtf(((bq[0] * bq[0] + bq[1] * bq[1]) + bq[2] * bq[2]) + bq[3] * bq[3]);
     const float inv = 1.0f / len;
@@ -2191,11 +2203,11 @@ void launch_lab_refresh(hipStream_t st, SurfelSoA s, int n) {
     hipLaunchKernelGGL(k_lab_refresh, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
 void launch_deformation(hipStream_t st, SurfelSoA model, int n, int m, const float* npos, const float* nrot,
-                        const float* ntrans, float* nodes24, const float* w4, const int32_t* idx4) {
+                        const float* ntrans, float* nodes16, const float* w4, const int32_t* idx4) {
     if (n <= 0) return;
     ScopedKernel sk("apply_deformation", st);
-    hipLaunchKernelGGL(k_pack_nodes, dim3((m + 255) / 256), dim3(256), 0, st, m, npos, nrot, ntrans, reinterpret_cast<float4*>(nodes24));
-    hipLaunchKernelGGL(k_deformation, dim3((n + 255) / 256), dim3(256), 0, st, model, n, reinterpret_cast<const float4*>(nodes24), w4, idx4);
+    hipLaunchKernelGGL(k_pack_nodes, dim3((m + 255) / 256), dim3(256), 0, st, m, npos, nrot, ntrans, reinterpret_cast<float4*>(nodes16));
+    hipLaunchKernelGGL(k_deformation, dim3((n + 255) / 256), dim3(256), 0, st, model, n, reinterpret_cast<const float4*>(nodes16), w4, idx4);
 }
 
 }  // namespace ssf

@@ -59,7 +59,7 @@ for step in "$@"; do
     trace)
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace$TAG -o trace -- $PROF > $O/trace$TAG.log 2>&1 )
       DB=$(find $O/trace$TAG -name "*.db" | head -1)
-      [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/rocprof_summary$TAG.txt "$PROFNOTE" > /dev/null 2>&1
+      [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/rocprof_summary$TAG.txt "$PROFNOTE" $O/rocprof$TAG.json ${PROFPIX:-307200} > /dev/null 2>&1
       [ -n "$DB" ] && python tools/rocprof_dist.py $DB > $O/rocprof_distribution$TAG.txt 2>&1;;
     pmc)
       ( cd /tmp && export TMPDIR=/tmp
@@ -69,7 +69,9 @@ for step in "$@"; do
         timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/pmc_sq2$TAG -o p -- $PROF > $O/pmc_sq2$TAG.log 2>&1 )
       python tools/pmc_summary.py $O/pmc_fetch$TAG $O/pmc_write$TAG $O/pmc$TAG.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $PROF" > $O/pmc_summary$TAG.txt 2>&1
       python tools/pmc_counters.py $O/pmc_sq$TAG > $O/pmc_sq$TAG.txt 2>&1
-      python tools/pmc_counters.py $O/pmc_sq2$TAG > $O/pmc_sq2$TAG.txt 2>&1;;
+      python tools/pmc_counters.py $O/pmc_sq2$TAG > $O/pmc_sq2$TAG.txt 2>&1
+      DBT=$(find $O/trace$TAG -name "*.db" 2>/dev/null | head -1)         # (the `trace` step before `pmc`: durations come from the unperturbed run)
+      [ -n "$DBT" ] && python tools/pmc_issue.py $O/pmc_sq2$TAG $DBT $O/pmc_issue$TAG.json "$PROFNOTE" > $O/pmc_issue$TAG.txt 2>&1;;
     py:*)
       f=${step#py:}; timeout 900 python tools/$f > $O/${f%.py}$TAG.txt 2>&1;;
     sh:*)
