@@ -204,6 +204,123 @@ def next_kernel_times(lib, dev, model, nvis, cap):
     return out
 
 
+def drive_pipelined(eng, frame_at, first, count, on_device=True):
+    """The submit-ahead / process-in-order loop over frames [first, first + count) through an engine's own entry points (a
+    binding.Fusion, or the torch.distributed driver sharded.ShardedFusion of `--py-driver` / the fall-through at N > 1): as many
+    frames as the extract pipeline takes are submitted ahead, then the oldest one is tracked and fused.  frame_at(i) -> (rgb, depth)
+    of frame i (device addresses or host arrays).  Module level so that tests/test_sharded.py can run THIS loop at world size 2 over
+    gloo on the CPU checker -- the launcher path of an N > 1 run has then executed somewhere before it meets hardware."""
+    res, nsub = [], first
+    for i in range(first, first + count):
+        while nsub < first + count and eng.can_submit():
+            rgb, depth = frame_at(nsub)
+            eng.submit_frame(rgb, depth, on_device=on_device)
+            nsub += 1
+        r = eng.process_submitted()
+        res.append(r if isinstance(r, dict) else r.as_dict())
+    return res
+
+
+def real_frames_leg(lib, dev, model, nvis, cap):
+    """the path TIMED on real frames (every other timing of this script is the synthetic box room).  The 8
+    committed TUM fr1_xyz frames (tests/golden/tum_fr1_xyz_8frames.npz: cluttered desk, ~25 % depth holes, u16 depth at 5000 / m)
+    swept back and forth as the rendered ones are, resident in HBM, depth pre-filter ON, the benchmark node's launch parameters
+    (replay.BENCHMARK_LAUNCH; reference caller: node/supersurfel_fusion_rgbd_benchmark_node.cpp:573-744), pipelined 2 x 12 -- (a) on
+    the map the frames grow themselves and (b) against the seeded ~1 M-row map of the headline (whose walls the desk frames do not
+    show: the ICP is rejected and the map is only streamed -- what the kernels cost, not a trajectory).  Beside the rates: the stage
+    split, the dominant kernel's launch time, ICP iterations, and -- from the LAB build of the same sources, one frame in flight --
+    the relabelling statistics the box room could hide: log entries per tile and pass (the log region holds 256), and the share of
+    superpixel-row lookups whose label lay outside the tile's 7 x 7-cell LDS window (the exact global path)."""
+    from supersurfel_fusion_amd import replay
+    path = os.path.join(ROOT, "tests", "golden", "tum_fr1_xyz_8frames.npz")
+    if not os.path.exists(path):
+        return dict(error="tests/golden/tum_fr1_xyz_8frames.npz is missing")
+    fr = [(np.ascontiguousarray(rgb), np.ascontiguousarray(depth, np.float32)) for _, rgb, depth in replay.frames_from_npz(path)]
+    nr = len(fr)
+    t_rgb = [torch.from_numpy(a_).to(dev) for a_, _ in fr]; t_dep = [torch.from_numpy(b_).to(dev) for _, b_ in fr]
+    sweep = lambda i: (i % (2 * nr - 2)) if (i % (2 * nr - 2)) < nr else 2 * nr - 2 - (i % (2 * nr - 2))      # noqa: E731
+    out = dict(frames="8 x TUM fr1_xyz (640x480), swept back and forth, resident in HBM; depth pre-filter on; rgbd_benchmark launch parameters",
+               holes_share=float(np.mean([float((d_ == 0).mean()) for _, d_ in fr])))
+    bx, dpt, n_timed, n_warm = 12, 2, 480, 60
+
+    def cfg_for(L, cap_, depth_, batch_):
+        kw = dict(replay.BENCHMARK_LAUNCH, nb_supersurfels_max=cap_, pipeline_depth=depth_, extract_batch=batch_)
+        if L.backend.startswith("hip") and torch.cuda.is_available():
+            kw["device_id"] = torch.cuda.current_device()
+        return L.default_config(**kw)
+
+    for key, seeded in (("map_grown_by_the_frames", False), ("against_the_seeded_map", True)):
+        f = binding.Fusion(lib, cfg_for(lib, cap if seeded else 100000, dpt, bx))
+        if seeded:
+            f.set_model(model, nvis, 30)
+        seq = lambda a0, n_: f.prepare_sequence([t_rgb[sweep(i)].data_ptr() for i in range(a0, a0 + n_)], [t_dep[sweep(i)].data_ptr() for i in range(a0, a0 + n_)])      # noqa: E731
+        f.process_prepared(seq(0, n_warm), on_device=True)
+        prep = seq(n_warm, n_timed)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        res = [r.as_dict() for r in f.process_prepared(prep, on_device=True)]
+        torch.cuda.synchronize(dev)
+        dt_ = time.perf_counter() - t1
+        ent = dict(frames_per_sec=n_timed / dt_, frames=n_timed, pipeline_depth=dpt, extract_batch=bx,
+                   icp_iters_mean=float(np.mean([r["icp_iters"] for r in res])), icp_valid_share=float(np.mean([r["icp_valid"] for r in res])),
+                   n_model=int(res[-1]["n_model"]), n_visible=int(res[-1]["n_visible"]))
+        # stage split + per-kernel brackets, one batch at a time (as the headline's profile leg)
+        f.set_profile(2)
+        stage = np.zeros(3)
+        nsub, base_ = 0, n_warm + n_timed
+        rs = []
+        for i in range(bx):
+            while nsub < bx and f.can_submit():
+                f.submit_frame(t_rgb[sweep(base_ + nsub)].data_ptr(), t_dep[sweep(base_ + nsub)].data_ptr(), on_device=True); nsub += 1
+            rs.append(f.process_submitted().as_dict())
+        for r in rs:
+            stage += np.array(r["stage_ms"]) / bx
+        f.set_profile(1); f.reset_kernel_times()
+        for rep in range(2):
+            nsub = 0
+            for i in range(bx):
+                while nsub < bx and f.can_submit():
+                    f.submit_frame(t_rgb[sweep(base_ + bx * (rep + 1) + nsub)].data_ptr(), t_dep[sweep(base_ + bx * (rep + 1) + nsub)].data_ptr(), on_device=True); nsub += 1
+                f.process_submitted()
+            torch.cuda.synchronize(dev)
+        kt = f.kernel_times()
+        f.set_profile(0)
+        ent["stage_ms"] = dict(extract=stage[0], icp=stage[1], fuse=stage[2])
+        ent["kernel_avg_us"] = {k: round(1000.0 * ms / max(c, 1), 2) for k, (ms, c) in kt.items()
+                                if k in ("update_pass_rgbd", "update_pass_rgb", "bilateral_prefilter", "render_moments", "eval_samples", "init_disp", "icp_accumulate", "match", "update_insert", "reorder_move_icp", "reorder_move")}
+        ent["update_pass_rgbd_frames_per_launch"] = bx
+        f.close()
+        out[key] = ent
+    # relabelling statistics from the lab build (the product keeps no such counters): real frames, and the rendered room beside them
+    try:
+        lab = binding.load_lab()
+        lab.lib.ssf_dbg_pass_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+
+        def stats(frames_host, cfg_):
+            fl = binding.Fusion(lab, cfg_)
+            tot = np.zeros(64, np.uint64); mx = 0
+            for rgb_, dep_ in frames_host:
+                fl.process_frame(rgb_, dep_)
+                w = np.zeros(64, np.uint32)
+                if lab.lib.ssf_dbg_pass_stats(fl.h, w.ctypes.data_as(ctypes.c_void_p)) != 0:
+                    raise RuntimeError("ssf_dbg_pass_stats")
+                tot += w.astype(np.uint64); mx = max(mx, int(w[9]))
+            fl.close()
+            tiles = max(int(tot[10]), 1)
+            return dict(frames=len(frames_host), log_entries_per_tile_and_pass_mean=float(tot[8]) / tiles, log_entries_per_tile_and_pass_max=mx, log_capacity=256,
+                        row_lookups_outside_the_lds_window_share=float(tot[11]) / max(float(tot[12]), 1.0), row_lookups=int(tot[12]))
+        real16 = [fr[sweep(i)] for i in range(16)]
+        out["relabelling_statistics_real_frames"] = stats(real16, cfg_for(lab, 100000, 0, 1))
+        synth = render_frames(8, tum_shaped=False)
+        kw = dict(replay.BENCHMARK_LAUNCH, nb_supersurfels_max=100000, depth_prefilter=0)
+        if torch.cuda.is_available():
+            kw["device_id"] = torch.cuda.current_device()
+        out["relabelling_statistics_box_room"] = stats([(np.ascontiguousarray(a_), np.ascontiguousarray(b_)) for a_, b_ in synth], lab.default_config(**kw))
+    except Exception as e:           # (a box without the lab build: the timings above stand on their own)
+        out["relabelling_statistics_error"] = repr(e)
+    return out
+
+
 def pin_to_gpu_numa_node(local):
     """Run this process on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does): the track
     chain is a sequence of host <-> device round trips (mailbox polls, doorbells, BAR stores), and on a two-socket host a
@@ -434,7 +551,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
-    def make_engine(py_driver):
+    def make_engine(mode):
+        """mode: 'none' (one rank, no exchange) | 'rccl' | 'p2p' (native exchanges) | 'py' (torch.distributed through the stage seams)"""
+        py_driver = mode == "py"
         tstream, stream = None, None               # library-owned (high-priority) track stream
         if py_driver:
             tstream = torch.cuda.Stream(dev)       # the torch stream the collectives are ordered on
@@ -452,34 +571,50 @@ def main():
                 sharded.rehome_over(fus, world, device=dev)
         if py_driver:
             return fus, sharded.ShardedFusion(fus, device=dev, stream=tstream, always_reduce=a.force_sharded)
-        if exchange:
-            if a.comm == "p2p":
+        try:
+            if mode == "p2p":
                 # every rank on its own GPU (LOCAL_RANK): fine-grained regions; a forced one-rank run shares its GPU with itself
                 fus.p2p_configure(all_ranks_on_this_device=(world == 1))
                 fus.p2p_attach()                   # IPC handles of the exchange regions, all-gathered over torch.distributed
-            else:
+            elif mode == "rccl":
                 fus.comm_attach()
                 if a.extract == "dealt":
                     fus.comm_deal_extract(1)
+        except Exception:
+            fus.close()
+            raise
         return fus, None
 
+    # N > 1 (or --force-sharded): the native exchange asked for, then the other native one, then the torch.distributed driver --
+    # every rank must take the same path, so each attempt's outcome is agreed over the ranks (MIN), and every refusal is recorded
+    # in the line (`exchange_fallthrough`) instead of ending the run in a traceback
+    fallthrough = []
     native_ok = 1
-    if exchange and not a.py_driver:
-        # every rank must take the same path: agree on whether the native RCCL attach worked everywhere
-        try:
-            f, drv = make_engine(False)
-        except binding.SsfError as e:
-            sys.stderr.write("native RCCL attach failed on rank %d (%s): falling back to the torch.distributed driver\n" % (rank, e))
-            native_ok, f, drv = 0, None, None
-        flag = torch.tensor([native_ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native_ok = int(flag.item())
-        if not native_ok:
+    if exchange:
+        order = ["py"] if a.py_driver else ([a.comm] + [m_ for m_ in ("rccl", "p2p") if m_ != a.comm] + ["py"])
+        f = drv = None
+        for mode in order:
+            ok, why = 1, ""
+            try:
+                f, drv = make_engine(mode)
+            except Exception as e:          # binding.SsfError, a missing librccl, an IPC refusal ...
+                ok, why, f, drv = 0, "%s: %s" % (type(e).__name__, e), None, None
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                exchange_mode = mode
+                break
+            fallthrough.append(dict(tried=mode, rank=rank, reason=why or "another rank could not attach"))
+            sys.stderr.write("exchange '%s' refused on rank %d (%s): trying the next form\n" % (mode, rank, why or "another rank"))
             if f is not None:
-                f.close()
-            f, drv = make_engine(True)
+                f.close(); f = drv = None
+        if f is None:
+            raise RuntimeError("no exchange form could be attached: %s" % fallthrough)
+        native_ok = 0 if exchange_mode == "py" else 1
+        a.comm = exchange_mode if exchange_mode != "py" else a.comm
     else:
-        f, drv = make_engine(exchange and a.py_driver)
+        exchange_mode = "none"
+        f, drv = make_engine("none")
     eng = drv if drv is not None else f
     comm_info = f.comm_info()
     if exchange and drv is None and comm_info["ranks"] != world:
@@ -512,13 +647,7 @@ def main():
         if drv is None and native:                  # the submit-ahead / process-in-order loop, natively
             return f.process_sequence([d_rgb[i].data_ptr() for i in range(first, first + count)],
                                       [d_depth[i].data_ptr() for i in range(first, first + count)], on_device=True)
-        nsub = first
-        for i in range(first, first + count):
-            while nsub < first + count and eng.can_submit():
-                eng.submit_frame(d_rgb[nsub].data_ptr(), d_depth[nsub].data_ptr(), on_device=True)
-                nsub += 1
-            res.append(as_dict(eng.process_submitted()))
-        return res
+        return drive_pipelined(eng, lambda i: (d_rgb[i].data_ptr(), d_depth[i].data_ptr()), first, count, on_device=True)
 
     run(0, Wm)
     # the extract graph of every batch size the timed region will launch is built lazily on first use (like a JIT).  A
@@ -620,6 +749,8 @@ def main():
             ent["algo_bytes_per_launch"] = by
             ent["achieved_GBs"] = by / (avg_us * 1e-6) / 1e9
         per_kernel[name] = ent
+    exchange_by_kind = {n: round(1000.0 * e["total_ms_per_frame"], 3) for n, e in per_kernel.items() if n.startswith("exchange_") or n.startswith("p2p_")}
+    exchange_us = float(sum(exchange_by_kind.values()))
     # The dominant KERNEL: k_update_pass is one kernel with two instantiations (RGB / RGB-D passes, timed under two names);
     # its share is their sum.  The roofline is reported for the instantiation with the larger share of the two.
     fam = lambda n: "update_pass" if (n.startswith("update_pass") or n.startswith("passes_team")) else n
@@ -757,6 +888,11 @@ def main():
             extras[key] = dict(frames_per_sec=nx / (time.perf_counter() - t1), frames=nx, pipeline_depth=dpt, extract_batch=bx)
             fx.close()
         extras["next_kernels"] = next_kernel_times(lib, dev, model_local, nvis_local, cap)
+        if a.config == 2:
+            try:
+                extras["real_frames"] = real_frames_leg(lib, dev, model_local, nvis_local, cap)
+            except Exception as e:          # (never the headline's problem)
+                extras["real_frames"] = dict(error=repr(e))
         # ---- the other single-GPU BASELINE configurations beside the headline: config 3 (1280x960, 1 M rows in view, 10 forced
         # iterations: the HBM-bound stress) and config 5 (TUM-shaped input, pre-filter in the frame, one deformation), each as
         # this same script in a process of its own, outside every timed region of this one (>= 64 / >= 240 frames) -----------------
@@ -878,6 +1014,13 @@ def main():
                        "exchange_note": (("native peer-to-peer exchange regions (no collective launches)" if a.comm == "p2p" else "native RCCL on the track stream") if native_ok and drv is None else "torch.distributed driver") if exchange else "none (1 rank)",
                        # what the attached exchange itself reports (ncclCommCount / opened regions): must equal n_gpus
                        "exchange_ranks_reported": comm_info["ranks"], "exchange_backend_attached": comm_info["backend"],
+                       # (round 6) every exchange form that was tried and refused before the one that ran, with the reason
+                       "exchange_fallthrough": fallthrough,
+                       # time the track stream spends inside the exchanges per frame (RCCL collectives: hipEvent brackets around each call,
+                       # cfg.profile = 1; peer-to-peer: the p2p_* kernels), from the same profile leg as per_kernel.  0 on one rank without --force-sharded
+                       "exchange_us_per_frame": exchange_us, "exchange_us_per_frame_by_kind": exchange_by_kind,
+                       "multi_gpu_hardware_note": "no run of this build at N > 1 on real hardware exists (every box it has seen has one GPU): "
+                                                  "the N > 1 path is covered by gloo world-2 / world-3 tests on CPU and by emulated ranks / one-rank communicators on one GPU",
                        # (the figures the README leads with, inside the object the driver's record keeps whole)
                        "pipeline_depth": depth, "extract_batch": batch, "extract": ("dealt" if (a.extract == "dealt" and a.comm == "rccl" and native_ok and drv is None) else "replicated") if exchange else "single rank",
                        "steady_state_frames_per_sec": steady["frames_per_sec"] if steady else None,

@@ -62,7 +62,6 @@ struct alignas(64) SumRec {
 static_assert(offsetof(SumRec, dn) == 32 && offsetof(SumRec, stamp) == 36 && offsetof(SumRec, dxx) == 64 && offsetof(SumRec, dd) == 104 && sizeof(SumRec) == 128,
               "k_update_pass flushes its accumulators by field offset");
 #define SSF_STAMP_NEVER (-1000)           // "no pass has touched this yet" (stamps are compared with pass numbers 0 .. 4 seg_iter)
-#define SSF_CHANGE_BLOCK_LOG2 5           // labels / inlier flags: one "last changed in pass" stamp per 32 x 32 pixel block of the image
 struct SpSums { SumRec* r; };
 
 // device-side counters shared by the fuse kernels (no host round trip between them)
@@ -128,11 +127,6 @@ struct FrameMaps {
     // (pos.xyz, 0) (unused)
     uint2* pix2; float4* fpack;
     uint32_t* epoch;      // [0] = RNG epoch of the frame = number of frames extracted before it (written by ingest)
-    int32_t* bstamp;      // per 32 x 32 block of the image: the last relabelling pass that changed a label / inlier flag in it (ingest: never)
-    // resident relabelling (k_passes, launch_update_passes): second label map -- only the border pixels of the resident
-    // regions are ever valid in it -- and the frame's barrier words (one 64-bit word per phase: arrivals | abort << 32),
-    // zeroed by ingest
-    int32_t* label_alt; unsigned long long* pbar;
     long long* moments;   // 13 x i64 per superpixel
     float* filt;          // plane-filter scratch: X0[3S] X1[3S] Z[3S] px[S] py[S]
     const float* srgb_lut; // srgb_expand(c/255) for c = 0..255, built on the host with the same function
@@ -163,8 +157,7 @@ SSF_HD FrameMaps batch_slot(FrameMaps m, int b) {
     }
     m.sp = slab_shift(m.sp, o); m.samples = slab_shift(m.samples, o); m.sample_score = slab_shift(m.sample_score, o);
     m.moments = slab_shift(m.moments, o); m.filt = slab_shift(m.filt, o); m.epoch = slab_shift(m.epoch, o);
-    m.label_alt = slab_shift(m.label_alt, o); m.pbar = slab_shift(m.pbar, o);
-    m.bstamp = slab_shift(m.bstamp, o); m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
+    m.pix2 = slab_shift(m.pix2, o); m.fpack = slab_shift(m.fpack, o);
     return m;
 }
 SSF_HD SurfelSoA batch_slot(SurfelSoA s, size_t o) {
@@ -204,8 +197,8 @@ struct Mailbox {
     // peer-to-peer exchanges: set (never cleared) when a bounded wait for a peer ran out inside a kernel that has no record
     // of its own to withhold (association, migrant table); the host turns it into SSF_ERR_DEVICE at the end of the frame
     unsigned int p2p_timeout;
-    // resident relabelling: set (never cleared by the device) when a launch's workgroups could not all become resident
-    // within its bound and gave up (the frames of that batch are invalid; the host reports SSF_ERR_DEVICE)
+    // the team form of the relabelling passes (lab build): set (never cleared by the device) when a launch's workgroups could not
+    // all become resident within its bound and gave up (the frames of that batch are invalid; the host reports SSF_ERR_DEVICE)
     unsigned int extract_abort;
 };
 #ifndef SSF_ICP_REPLICAS
@@ -219,16 +212,8 @@ struct Mailbox {
 // frame k of the batch is frame number epoch0 + k of this handle (keys its RANSAC draws)
 void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameMaps& m, int nb, uint32_t epoch0);
 // pass number k (0-based over the whole frame) selects label/sums/log buffers: see FrameMaps
-int pass_tile_npx(int nb);     // 1: 32-wide relabelling tiles, 2: 64-wide (log regions of 512 entries per tile)
-// skip_from: the first pass of its phase whose tiles may prove themselves clean (phase start + 4: a tile compares with the pass of
-// the same pattern four passes back, which must have used the same energy)
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0, int skip_from = 1 << 30);
-// Passes [k0, k1) of one phase (all RGB or all RGB-D) in ONE launch whose workgroups keep their region of the label map
-// in LDS from pass to pass (k_passes in ssf_extract.hip); returns false -- nothing launched -- when the geometry does
-// not qualify (the caller then launches the passes one by one).  Both sums buffers are complete afterwards.
-// abort_flag: host-visible word set (never cleared) when the launch's workgroups could not all become resident and gave up.
-bool launch_update_passes(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k0, int k1, bool rgbd, unsigned int* abort_flag);
-bool update_passes_resident(const SegParams& p, int nb);       // would launch_update_passes take this geometry?
+int pass_tile_npx(int nb);     // pass pixels per thread: 1 (32-wide relabelling tiles; the 64-wide form was measured and removed)
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg = 0);
 // The passes k0 .. k1 - 1 of a batch in ONE launch whose workgroups stay, a frame per XCD, meeting inside their XCD between passes
 // (k_passes_team in ssf_extract.hip).  d_pas: the context's table of per-pass arguments (pass_args_table, pass_args_bytes(kmax) bytes
 // uploaded once); d_ws: pass_team_ws_bytes() of device memory ZEROED in stream order in front of every launch.

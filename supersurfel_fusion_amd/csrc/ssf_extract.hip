@@ -41,13 +41,8 @@ __global__ __launch_bounds__(256) void k_ingest(SegParams p, BatchIn in, FrameMa
     const int cell = blockIdx.x;
     if (cell == 0 && threadIdx.x == 0) m.epoch[0] = epoch0 + blockIdx.y;
 #ifdef SSF_EXPERIMENTS
-    if (cell == 0 && threadIdx.x >= 1 && threadIdx.x < 64) m.epoch[threadIdx.x] = 0u;       // clean-tile counters per pass (ssf_dbg_pass_skips)
+    if (cell == 0 && threadIdx.x >= 1 && threadIdx.x < 64) m.epoch[threadIdx.x] = 0u;       // the frame's relabelling statistics (SSF_PASS_STAT_*, ssf_dbg_pass_stats)
 #endif
-    if (cell == 0 && threadIdx.x < 16) m.pbar[threadIdx.x] = 0ull;          // barrier words of the resident relabelling launches
-    if (cell == 0) {                                                        // no block of the image has changed in any pass yet
-        const int nblk = ((p.W + 31) >> SSF_CHANGE_BLOCK_LOG2) * ((p.H + 31) >> SSF_CHANGE_BLOCK_LOG2);
-        for (int i = threadIdx.x; i < nblk; i += blockDim.x) m.bstamp[i] = SSF_STAMP_NEVER;
-    }
     const int cx0 = (cell % p.gx) * p.cell, cy0 = (cell / p.gx) * p.cell;
     const int w = min(p.cell, p.W - cx0), h = min(p.cell, p.H - cy0);
     int sx = 0, sy = 0, sr = 0, sg = 0, sb = 0, n = 0;
@@ -382,15 +377,6 @@ static inline TileOrder tile_order(dim3 grid) {
 // then the six 64-bit sums (chunks 3-5; RGB passes never touch them).  Zeroed and scanned a chunk at a time.
 #define PASS_ACC_DW 24
 #define PASS_ACC_WIDE_DW 12
-// clean-tile skipping: built in round 4, exact, and of no use -- on the bench's frames 3-28 % of the tiles of a pass can prove
-// themselves clean (profiles/clean_tiles_r04.txt): the 100-400 relabellings of a late pass are spread over the whole image.
-// A measurement arm of the lab build (lab/pass_skip.inc, SSF_PASS_SKIP=1); the product compiles none of it.
-#ifdef SSF_EXPERIMENTS
-#include "lab/pass_skip.inc"
-#define SSF_SKIP_STAMP(rec) do { if (skip_from < (1 << 29)) (rec).stamp = pass; } while (0)      /* (only when the arm is switched on: the lab build's default path stays the product's) */
-#else
-#define SSF_SKIP_STAMP(rec) ((void)0)
-#endif
 // What a pass touches of a frame's working set, chosen on the HOST (round 5): the read / write sums buffer by the pass' parity, the
 // previous / current log by pass mod 3.  Selected in the kernel -- from FrameMaps, after shifting all of its ~30 pointers to the
 // batch slot -- it was ~50 scalar instructions of every wave's prologue (s_cselect chains + 64-bit adds); the counters put the
@@ -414,13 +400,20 @@ void set_pass_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(
     if (pass_trace && threadIdx.x == 0) pass_trace[5 * pass_wg] = wall_clock64()
 #define SSF_PASS_TICK(i) do { if (pass_trace && threadIdx.x == 0) pass_trace[5 * pass_wg + (i)] = wall_clock64(); } while (0)
 #define SSF_PASS_TICK_LOADS() do { if (pass_trace) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); SSF_PASS_TICK(1); } } while (0)
+// lab: statistics of a frame's relabelling passes in FrameMaps::epoch[8 ..] (ssf_dbg_pass_stats; bench.py's real-frame leg, round 6):
+// [8] log entries written (sum over tiles and passes), [9] the largest log of a tile in a pass, [10] tiles x passes, [11] superpixel-row
+// lookups that found their label OUTSIDE the tile's LDS window (the exact global path), [12] all row lookups
+#define SSF_PASS_STAT_LOOKUP(far) do { atomicAdd(&m.epoch[12], 1u); if (far) atomicAdd(&m.epoch[11], 1u); } while (0)
+#define SSF_PASS_STAT_END(nlog) do { if (threadIdx.x == 0) { atomicAdd(&m.epoch[8], (nlog)); atomicMax(&m.epoch[9], (nlog)); atomicAdd(&m.epoch[10], 1u); } } while (0)
 #else
 #define SSF_PASS_TICK_BEGIN() ((void)0)
 #define SSF_PASS_TICK(i) ((void)0)
 #define SSF_PASS_TICK_LOADS() ((void)0)
+#define SSF_PASS_STAT_LOOKUP(far) ((void)0)
+#define SSF_PASS_STAT_END(nlog) ((void)0)
 #endif
 template <bool RGBD, int NPX, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord, int skip_from) {
+__global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMaps m, PassArgs pa, int pass, int OX, int OY, int dbg, TileOrder ord) {
     constexpr bool COH = false;
     // this workgroup's (frame, tile row, tile column): see TileOrder
     unsigned int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -441,7 +434,7 @@ __global__ __launch_bounds__(256, WAVES) void k_update_pass(SegParams p, FrameMa
 // the same body as a function of (tile column, row, frame slot): lab/passes_team.inc
 template <bool RGBD, int NPX, bool COH>
 __device__ __forceinline__ void update_pass_tile(const SegParams& p, FrameMaps m, const PassArgs& pa, int pass, int OX, int OY, int dbg,
-                                                 const TileOrder& ord, int skip_from, unsigned int bx, unsigned int by, unsigned int bz) {
+                                                 const TileOrder& ord, unsigned int bx, unsigned int by, unsigned int bz) {
 #include "ssf_pass_tile.hpp"
 }
 #endif
@@ -455,15 +448,6 @@ size_t pass_team_ws_bytes() { return 0; }
 size_t pass_args_bytes(int) { return 0; }
 void pass_args_table(const SegParams&, const FrameMaps&, int, void*) {}
 void launch_update_passes_team(hipStream_t, const SegParams&, FrameMaps&, int, int, int, bool, const void*, void*, unsigned int*) {}
-#endif
-
-// ---- resident relabelling (all passes of a phase in one launch): a measurement arm that lost its A/B (DESIGN.md section
-// 4.1.1) -- lab/passes_resident.inc, compiled only into the lab variant of the library
-#ifdef SSF_EXPERIMENTS
-#include "lab/passes_resident.inc"
-#else
-bool update_passes_resident(const SegParams&, int) { return false; }
-bool launch_update_passes(hipStream_t, const SegParams&, FrameMaps&, int, int, int, bool, unsigned int*) { return false; }
 #endif
 
 // ---- RANSAC plane initialisation ---------------------------------------------------------------
@@ -1588,8 +1572,6 @@ void launch_ingest(hipStream_t st, const SegParams& p, const BatchIn& in, FrameM
 }
 // pass pixels per thread (tile width / 32) for a launch over nb frames; SSF_PASS_NPX = 1 / 2 forces it (measurement)
 int pass_tile_npx(int nb) {
-    static const int forced = SSF_ENV_INT("PASS_NPX", 0);
-    if (forced == 1 || forced == 2) return forced;
     (void)nb;
     return 1;       // measured (profiles/bench_r02_npx*.json): the 64-wide tiles cut the pass's HBM traffic from 1.25x to 1.01x of
                     // the algorithmic bytes but not its time -- the kernel is bound by instruction issue, not by memory or by
@@ -1618,7 +1600,7 @@ void pass_geometry_table(const SegParams& p, uint2* out) {
                 out[(size_t)ox * ntx * nty + (size_t)by * ntx + bx] = e;
             }
 }
-void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg, int skip_from) {
+void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int k, int ox, int oy, bool rgbd, int dbg) {
 #ifdef SSF_EXPERIMENTS
     static const char* per_pass_names[64] = {nullptr};
     static int per_pass = -1;
@@ -1634,8 +1616,6 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
     // OX = 0: tiles shifted left by (tile width - 2): [-30,1], [2,33], ...  The same (larger) grid is used for OX = 1 so
     // that tile ids -- and with them the per-tile log regions replayed by the next pass -- coincide.  All passes of a
     // frame use the same tile width (the log layout depends on it): 64 when the launch covers several frames.
-    static const int skip_on = SSF_ENV_INT("PASS_SKIP", 0);          // (lab: 1 = tiles may prove themselves clean and leave, lab/pass_skip.inc)
-    if (!skip_on) skip_from = 1 << 30;
     const int npx = pass_tile_npx(nb);
     const int twx = TILE * npx;
     dim3 grid = tile_grid(p);
@@ -1650,26 +1630,13 @@ void launch_update_pass(hipStream_t st, const SegParams& p, FrameMaps& m, int nb
         pa.cent = m.log.ent[lc]; pa.cdis = m.log.disp[lc]; pa.ccnt = m.log.count[lc];
         pa.geom = npx == 1 ? p.pass_geom + (size_t)(ox ? p.pass_ntile : 0) : nullptr;        // (pass_geometry_table: this grid, by construction)
     }
-    // occupancy target of the RGB-D variant: 6 waves per SIMD (73 registers, no spills).  Forcing 8 (64 registers, 9 spilled
-    // dwords) measured slower: 20.8 vs 19.9 us per 8-frame launch, 7650-8200 vs 8730-8890 frames/s (SSF_PASS_WAVES=8 to repeat it)
-    static const int waves_env = SSF_ENV_INT("PASS_WAVES", 6);
-    const int waves = (waves_env == 7 || waves_env == 8) ? waves_env : 6; (void)waves;
-    // (Round 3 measured two more forms of this pass against the 256-thread kernel -- one wave per tile with the changeable
-    // pixels compacted: 22 / 31 us per 8-frame launch against 15 / 20; four waves that compact the changeable pixels into an
-    // LDS list and RELEASE the waves the list does not need: 17 / 22 us, same frame rate -- both bit-exact, both slower; they
-    // live in the history, not in the source.)
-#ifdef SSF_EXPERIMENTS
-    // the instantiations that lost their A/B: 64-wide tiles (two pass pixels per thread), 7 / 8 waves per SIMD for the RGB-D pass
-    if (npx == 2) {
-        if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 2, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
-        else hipLaunchKernelGGL((k_update_pass<false, 2, 6>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
-        return;
-    }
-    if (rgbd && waves == 8) { hipLaunchKernelGGL((k_update_pass<true, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
-    if (rgbd && waves == 7) { hipLaunchKernelGGL((k_update_pass<true, 1, 7>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from); return; }
-#endif
-    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, SSF_PASS_RGBD_WAVES>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
-    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord, skip_from);
+    // (Measured against this kernel and removed from the source, all bit-exact, all slower -- docs/HISTORY.md section 4.1.1 / 4.1.3:
+    // 64-wide tiles with two pass pixels per thread, the RGB-D variant forced to 7 / 8 waves per SIMD, one wave per tile with the
+    // changeable pixels compacted, four waves that release the ones the compacted list does not need, clean-tile skipping, all
+    // passes of a phase in one resident launch with the label regions in LDS.  Round 6: a 64-register body (the replay ahead of the
+    // decisions) and direct-to-LDS tile loads -- no gain, profiles/pass_ldsdma_r06.txt.)
+    if (rgbd) hipLaunchKernelGGL((k_update_pass<true, 1, SSF_PASS_RGBD_WAVES>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord);
+    else hipLaunchKernelGGL((k_update_pass<false, 1, 8>), grid, dim3(256), 0, st, p, m, pa, k, ox, oy, dbg, ord);
 }
 void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("init_samples", st);

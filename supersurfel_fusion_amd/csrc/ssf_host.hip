@@ -605,7 +605,6 @@ struct ssf_handle {
     // tracking when the visible set is large (bin_min_rows); valid for that frame only
     SurfelSoA bins{}; int32_t* d_bin_idx = nullptr; uint32_t* d_bin_count = nullptr; uint32_t* d_bin_cursor = nullptr;
     bool bins_valid = false; int bin_min_rows = -1;      // OFF: measured a loss at BASELINE config 3 (k_icp is bound by its LDS atomics, not by the gathers; sorted rows pile k_match's atomicMin onto the same words)
-    hipEvent_t ev_resident = nullptr; bool ev_resident_valid = false;     // resident relabelling launches take turns (resident_turn_begin)
     // pass_team: the relabelling passes of a phase as ONE launch with a frame per XCD (k_passes_team) instead of a launch per pass.
     // Its workgroups must all be on the chip at once, so whole batches take turns across the contexts (launch_batch: a batch's
     // chain waits for the previous batch's ev_done).
@@ -737,38 +736,19 @@ struct TimerScope {
 // Pass k reads label/sums buffer k&1 and writes the other; no merge launch between passes (the pass
 // kernel rebuilds the rows it needs from the quiescent sums buffer).  The global superpixel table is
 // only materialised where a later stage wants it: before the plane filter.
-// Resident relabelling launches (k_passes) need all their workgroups on the chip at once; two of them from different
-// extract contexts could each hold half of the slots and wait for the other half forever (bounded: they would give up and
-// the batch would be lost).  So they are serialised across the contexts of a handle: each one waits for the event recorded
-// behind the previous one.  (One host thread makes all these calls, in order: a single event suffices -- a wait refers to
-// the record that preceded it.)
-static void resident_turn_begin(ssf_handle* h, hipStream_t st) {
-    if (h->ev_resident_valid) (void)hipStreamWaitEvent(st, h->ev_resident, 0);
-}
-static void resident_turn_end(ssf_handle* h, hipStream_t st) {
-    if (!h->ev_resident && hipEventCreateWithFlags(&h->ev_resident, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h->ev_resident = nullptr; return; }
-    if (hipEventRecord(h->ev_resident, st) == hipSuccess) h->ev_resident_valid = true;
-}
-static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, bool resident = false) {
+static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st) {
     const SegParams& p = h->seg;
     const int nb = c.count;
     const int limit = h->max_passes > 0 ? h->max_passes : (1 << 30);
     const int ox[4] = {0, 1, 0, 1}, oy[4] = {0, 1, 1, 0};                 // pass order, TPS_RGBD.cu:190-268
     const int k1 = std::min(4 * (h->cfg.seg_iter / 2), limit), k2 = std::min(4 * h->cfg.seg_iter, std::max(limit, k1));
-    // (resident form: all passes of a phase in one launch whose workgroups keep their region of the label map in LDS,
-    // k_passes in ssf_extract.hip; per-pass launches when the geometry does not qualify or SSF_RESIDENT_PASSES=0)
     unsigned int* abort_flag = &h->mb_dev->extract_abort;
-    const bool multi = h->ctx.size() > 1;
-    const bool team = h->pass_team && c.d_pas && c.d_team_ws && !resident && h->max_passes == 0;
-    if (resident) {
-        if (multi) resident_turn_begin(h, st);
-        (void)launch_update_passes(st, p, c.maps, nb, 0, k1, false, abort_flag);
-        if (multi) resident_turn_end(h, st);
-    } else if (team) {
+    const bool team = h->pass_team && c.d_pas && c.d_team_ws && h->max_passes == 0;        // (lab: lab/passes_team.inc)
+    if (team) {
         (void)hipMemsetAsync(c.d_team_ws, 0, pass_team_ws_bytes(), st);
         launch_update_passes_team(st, p, c.maps, nb, 0, k1, false, c.d_pas, c.d_team_ws, abort_flag);
     } else
-        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false, 0, 4);
+        for (int k = 0; k < k1; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], false, 0);
     // sums[k1&1] holds the exact sums after k1 passes; RANSAC and the inlier initialisation read them directly
     if (h->cfg.seg_use_ransac) {
         launch_init_samples(st, p, c.maps, nb, k1 & 1);
@@ -776,25 +756,18 @@ static void enqueue_segmentation(ssf_handle* h, ExtractCtx& c, hipStream_t st, b
         launch_init_disp(st, p, c.maps, nb, true);
     } else launch_init_disp(st, p, c.maps, nb, false);
     int k = k1;
-    if (resident) {
-        if (multi) resident_turn_begin(h, st);
-        (void)launch_update_passes(st, p, c.maps, nb, k1, k2, true, abort_flag);
-        if (multi) resident_turn_end(h, st);
-        k = std::max(k1, k2);
-    } else if (team) {
+    if (team) {
         (void)hipMemsetAsync(c.d_team_ws, 0, pass_team_ws_bytes(), st);
         launch_update_passes_team(st, p, c.maps, nb, k1, k2, true, c.d_pas, c.d_team_ws, abort_flag);
         k = std::max(k1, k2);
     } else
-        for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true, 0, k1 + 4);
+        for (; k < k2; k++) launch_update_pass(st, p, c.maps, nb, k, ox[k & 3], oy[k & 3], true, 0);
     launch_plane_filter(st, p, c.maps, nb, k & 1);             // final merge (table + planes) + smoothing sweeps
     launch_render_moments(st, p, h->cam, c.maps, nb);
 }
 // ~45 short dependent kernels: replayed as one captured hipGraph (launch-bound inner loop), one graph per
 // batch size; eager when kernels are individually timed or the pass count is being bisected
 static int run_segmentation(ssf_handle* h, ExtractCtx& c) {
-    // the resident form is 8 launches instead of 45 and carries event waits between contexts: launched eagerly, no graph
-    if (update_passes_resident(h->seg, c.count)) { enqueue_segmentation(h, c, c.stream, true); return SSF_OK; }
     const bool use_graph = h->cfg.profile != 1 && h->max_passes == 0 && !h->graph_failed;
     if (use_graph) {
         hipGraphExec_t& ex = c.exec[c.count];
@@ -1388,8 +1361,8 @@ static int fuse_end(ssf_handle* h, const int32_t* d_table, ssf_frame_result* out
     h->oov_head = c.oov_head; h->oov_tail = c.oov_tail; h->oov_live = c.oov_live;
     if (__atomic_load_n(&h->mb_host->extract_abort, __ATOMIC_ACQUIRE) != 0u) {
         __atomic_store_n(&h->mb_host->extract_abort, 0u, __ATOMIC_RELEASE);
-        h->err = "a resident relabelling launch could not get all its workgroups onto the GPU and gave up (the GPU is oversubscribed: "
-                 "several processes? SSF_RESIDENT_PASSES=0 selects per-pass launches); the frames of that batch are invalid";
+        h->err = "a team launch of the relabelling passes could not get all its workgroups onto the GPU and gave up (the GPU is oversubscribed: "
+                 "several processes?); the frames of that batch are invalid";
         return SSF_ERR_DEVICE;
     }
     if (h->p2p.on && __atomic_load_n(&h->mb_host->p2p_timeout, __ATOMIC_ACQUIRE) != 0u) {
@@ -1425,7 +1398,8 @@ static int comm_gather_counts(ssf_handle* h) {
     if (h->p2p.on) launch_p2p_counts(h->stream, p2p_view(h, ++h->p2p.seq_cnt), h->d_cnt, h->mb_dev, seq);
     else {
         RcclApi* api = rccl_api();
-        NCK(api->AllGather(h->d_cnt->last, h->d_all5, 5, ncclInt32, h->comm, h->stream));
+        { ScopedKernel sk("exchange_counts", h->stream);      // (cfg.profile = 1: the collective's time on the track stream, bench.py's exchange_us_per_frame)
+          NCK(api->AllGather(h->d_cnt->last, h->d_all5, 5, ncclInt32, h->comm, h->stream)); }
         launch_publish_all_counts(h->stream, h->d_all5, h->cfg.nranks, h->mb_dev, seq);
     }
     HCK(hipGetLastError());
@@ -1604,7 +1578,8 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
             // shard record -> SUM over the ranks in HBM (exact: int64) -> mailbox -> host solve
             rc = icp_accumulate(h, false);
             if (rc) return rc;
-            NCK(api->AllReduce(h->d_icp, h->d_icp, SSF_ICP_RECORD, ncclInt64, ncclSum, h->comm, h->stream));
+            { ScopedKernel sk("exchange_icp_record", h->stream);
+              NCK(api->AllReduce(h->d_icp, h->d_icp, SSF_ICP_RECORD, ncclInt64, ncclSum, h->comm, h->stream)); }
             const unsigned long long seq = ++h->icp_seq;
             launch_publish_icp(h->stream, h->d_icp, h->mb_dev, seq);
             HCK(hipGetLastError());
@@ -1647,6 +1622,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     else { rc = do_match(h, 1); if (rc) return rc; }
     if (h->comm) {
         // best key over the ranks (keys < 2^63: signed MIN == unsigned MIN), matched = OR over the ranks
+        ScopedKernel sk("exchange_association", h->stream);
         NCK(api->AllReduce(h->cc->d_best, h->cc->d_best, h->S, ncclInt64, ncclMin, h->comm, h->stream));
         NCK(api->AllReduce(h->cc->d_matched, h->cc->d_matched, h->S, ncclUint8, ncclMax, h->comm, h->stream));
     }
@@ -1659,6 +1635,7 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
         if (rc) { h->fusing = false; return rc; }
         if (h->fuse_migrate && h->p2p.on) launch_p2p_migrants(h->stream, p2p_view(h, ++h->p2p.seq_migr), h->d_migrants, h->d_tickets + 320, h->mb_dev);
         else if (h->fuse_migrate) {
+            ScopedKernel sk("exchange_migrants", h->stream);
             const ncclResult_t nr = api->AllReduce(h->d_migrants, h->d_migrants, (size_t)SSF_MIGRANT_WORDS * h->S, ncclInt32, ncclSum, h->comm, h->stream);
             if (nr != ncclSuccess) {          // the frame cannot be completed: the handle must not stay "between the two halves"
                 h->fusing = false;
@@ -1768,7 +1745,6 @@ void ssf_destroy(ssf_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->mb_host) (void)hipHostFree(h->mb_host);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    if (h->ev_resident) (void)hipEventDestroy(h->ev_resident);
     for (auto& r : h->timer.pool_free) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_pool().give(h->stream, h->cfg.device_id, h->stream_prio); }
     delete h;
@@ -1853,8 +1829,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
         };
         FrameMaps& m = c.maps;
         take(m.rgba, P); take(m.disp, P); take(m.label, P); take(m.inlier, P); take(m.plane_depth, P);
-        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 64); take(m.bstamp, (size_t)(((h->cfg.width + 31) >> 5) * ((h->cfg.height + 31) >> 5))); take(m.pix2, P); take(m.fpack, 4 * S);
-        take(m.label_alt, P); take(m.pbar, 16);
+        take(m.sp, S); take(m.samples, NS); take(m.sample_score, NS); take(m.moments, 13 * S); take(m.filt, 11 * S); take(m.epoch, 64); take(m.pix2, P); take(m.fpack, 4 * S);
         for (int b = 0; b < 2; b++) take(m.sums[b].r, S);
         for (int b = 0; b < 3; b++) { take(m.log.ent[b], NT * 256); take(m.log.disp[b], NT * 256); take(m.log.count[b], NT); }
         SurfelSoA& f = c.frame;
@@ -3002,10 +2977,11 @@ int ssf_upload_stats(ssf_handle* h, double* out6) {
     return SSF_OK;
 }
 #ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
-int ssf_dbg_pass_skips(ssf_handle* h, uint32_t* out64) {
+// the relabelling statistics of the frame just processed (FrameMaps::epoch, SSF_PASS_STAT_* in ssf_extract.hip): out64[8 .. 12]
+int ssf_dbg_pass_stats(ssf_handle* h, uint32_t* out64) {
     if (!h || !h->active.ctx || !out64) return SSF_ERR_INVALID_ARG;
     HCK(hipStreamSynchronize(h->active.ctx->stream));
-    HCK(hipMemcpy(out64, h->active.ctx->maps.epoch, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HCK(hipMemcpy(out64, h->active.maps.epoch, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return SSF_OK;
 }
 double ssf_dbg_time_pass(ssf_handle* h, int reps, int rgbd, int dbg, int nb) {

@@ -1,6 +1,6 @@
 // ssf_pass_tile.hpp -- ONE TILE OF ONE RELABELLING PASS: the body of k_update_pass (ssf_extract.hip), as text.
 // Included inside a function whose scope provides: constexpr bool RGBD, COH; constexpr int NPX; SegParams p; FrameMaps m (a copy: it
-// is shifted to the frame's slot here); PassArgs pa; int pass, OX, OY, dbg, skip_from; TileOrder ord; unsigned int bx, by, bz (the
+// is shifted to the frame's slot here); PassArgs pa; int pass, OX, OY, dbg; TileOrder ord; unsigned int bx, by, bz (the
 // tile's column, row and frame slot).  The product includes it once, in the kernel (COH = false); the lab build a second time, in
 // update_pass_tile -- the body its resident arm walks tile by tile (lab/passes_team.inc; COH = true: what another workgroup wrote in
 // an earlier pass of the same launch is read past the L1, ld_coh).  As a function called from the kernel the same text ran 1-1.5 %
@@ -12,16 +12,9 @@
     __shared__ int w_label[WIN_MAX];                          // label of a window slot (-1: outside the grid)
     __shared__ __attribute__((aligned(16))) unsigned int w_acc[WIN_MAX * PASS_ACC_DW];      // this tile's sum deltas (own + replayed), flushed once
     __shared__ unsigned int s_nlog;
-#ifdef SSF_EXPERIMENTS
-    __shared__ int s_clean, s_far;
-#endif
     const size_t slot_off = (size_t)bz * m.slab;                 // this frame's slot of the batch context
-#ifdef SSF_EXPERIMENTS
-    m = batch_slot(m, bz);                                       // (the lab arms read other members)
-#else
     m.rgba = slab_shift(m.rgba, slot_off); m.disp = slab_shift(m.disp, slot_off); m.label = slab_shift(m.label, slot_off);
-    m.inlier = slab_shift(m.inlier, slot_off);
-#endif
+    m.inlier = slab_shift(m.inlier, slot_off); m.epoch = slab_shift(m.epoch, slot_off);
     SpSums sr, sw;
     sr.r = const_cast<SumRec*>(slab_shift(pa.sr, slot_off)); sw.r = slab_shift(pa.sw, slot_off);
     const int X0 = __builtin_amdgcn_readfirstlane((int)bx * TWX - (OX ? 0 : TWX - 2)), Y0 = __builtin_amdgcn_readfirstlane((int)by * TILE);  // OX = 0: tiles start at 2 (mod 4)
@@ -51,14 +44,6 @@
     else if (NPREV_FORM == 0) { if (pass > 0) n_prev_word = pcnt[tile_id]; }
     else if (NPREV_FORM == 1) n_prev_word = pcnt[tile_id];
     else { int lane_zero = 0; asm volatile("" : "+v"(lane_zero)); n_prev_word = pcnt[tile_id + lane_zero]; }
-#ifdef SSF_EXPERIMENTS
-    // (lab: clean-tile skipping, lab/pass_skip.inc -- the change stamps of the image blocks this tile + halo overlaps)
-    const int nbkx = (p.W + 31) >> SSF_CHANGE_BLOCK_LOG2;
-    const bool may_skip = pass >= skip_from && NPX == 1;
-    int stamp_max = may_skip ? skip_block_stamps<TWX>(m, p, X0, Y0, nbkx) : SSF_STAMP_NEVER;
-#else
-    (void)skip_from;
-#endif
     // operands that do not depend on the label tile: in flight while the tile is staged
     uint32_t px[NPX]; float disp[NPX]; unsigned char prev_inlier[NPX];
 #pragma unroll
@@ -155,9 +140,6 @@
             const bool inside = cx >= 0 && cx < p.gx && cy >= 0 && cy < p.gy;
             const int k = cy * p.gx + cx;
             if (threadIdx.x < 64) w_label[i] = inside ? k : -1;
-#ifdef SSF_EXPERIMENTS
-            if (may_skip && inside && threadIdx.x < 64) stamp_max = max(stamp_max, ld_off<int>(sr.r, (unsigned int)(k * (int)sizeof(SumRec) + (int)offsetof(SumRec, stamp))));
-#endif
             if (inside && !SSF_PROBE(dbg, 1)) {
                 if (threadIdx.x < 64) {
                     SpRow row = zero_row;
@@ -189,12 +171,6 @@
         if (RGBD) prev_disp[s] = ld_off_c<COH, float>(pdis, 4u * le);
     }
     if (threadIdx.x == 0) s_nlog = 0;
-#ifdef SSF_EXPERIMENTS
-    if (threadIdx.x < 64) {                        // (wave 0 holds all the stamps: one ballot -- lab/pass_skip.inc "clean tiles")
-        const bool clean = may_skip && window_ok && n_prev == 0u && __ballot(stamp_max > pass - 5) == 0ull && !SSF_PROBE(dbg, 64);
-        if (threadIdx.x == 0) { s_far = 0; s_clean = clean ? 1 : 0; }
-    }
-#endif
     constexpr int ACC_CHUNKS = RGBD ? 6 : 2;                  // 16-byte chunks of a slot that a pass of this kind can touch (RGB: sx .. n)
     // (RGB-D: every chunk of a slot, i.e. the first 6 nslots chunks of the array; RGB: chunks 0 and 1 of each slot)
     for (int i = threadIdx.x; i < nslots * ACC_CHUNKS; i += 256)
@@ -217,16 +193,6 @@
     }
     __syncthreads();
     SSF_PASS_TICK(2);                             // (tile, window rows and accumulators staged)
-#ifdef SSF_EXPERIMENTS
-    if (s_clean) {
-        if (threadIdx.x == 0) {
-            unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
-            ccnt[tile_id] = 0u;
-            atomicAdd(&m.epoch[1 + (pass & 31)], 1u);          // (ssf_dbg_pass_skips)
-        }
-        return;
-    }
-#endif
     const float inv_gx = p.inv_gx;
     auto slot_of = [&](int l) -> int {
         const int cyl = (int)(((float)l + 0.5f) * inv_gx);         // l / gx, exact for l < 2^20
@@ -235,10 +201,8 @@
     };
     auto row_of = [&](int l) -> SpRow {
         const int ws = slot_of(l);
+        SSF_PASS_STAT_LOOKUP(ws < 0);
         if (ws >= 0) return *reinterpret_cast<const SpRow*>(reinterpret_cast<const char*>(w_row) + __umul24((unsigned int)ws, (unsigned int)sizeof(SpRow)));
-#ifdef SSF_EXPERIMENTS
-        s_far = 1;                                            // (its sums are not among the stamps the clean-tile test reads)
-#endif
         SpRow far = row_from_sums<COH>(sr, l, RGBD, zero_row);     // drifted out of the window: exact slow path
         far.pad0 = far.size / (far.size - 1.f);
         return far;
@@ -254,13 +218,13 @@
                 atomicAdd(&a[F_SX], (unsigned int)-px_x); atomicAdd(&a[F_SY], (unsigned int)-px_y); atomicAdd(&a[F_SR], (unsigned int)-ir);
                 atomicAdd(&a[F_SG], (unsigned int)-ig); atomicAdd(&a[F_SB], (unsigned int)-ib); atomicAdd(&a[F_N], 0xFFFFFFFFu);
             } else { atomicAdd(&sw.r[from].sx, -px_x); atomicAdd(&sw.r[from].sy, -px_y); atomicAdd(&sw.r[from].sr, -ir);
-                     atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); SSF_SKIP_STAMP(sw.r[from]); }
+                     atomicAdd(&sw.r[from].sg, -ig); atomicAdd(&sw.r[from].sb, -ib); atomicAdd(&sw.r[from].n, -1); }
             if (wt >= 0) {
                 unsigned int* a = &w_acc[__umul24((unsigned int)wt, PASS_ACC_DW)];
                 atomicAdd(&a[F_SX], (unsigned int)px_x); atomicAdd(&a[F_SY], (unsigned int)px_y); atomicAdd(&a[F_SR], (unsigned int)ir);
                 atomicAdd(&a[F_SG], (unsigned int)ig); atomicAdd(&a[F_SB], (unsigned int)ib); atomicAdd(&a[F_N], 1u);
             } else { atomicAdd(&sw.r[to].sx, px_x); atomicAdd(&sw.r[to].sy, px_y); atomicAdd(&sw.r[to].sr, ir);
-                     atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); SSF_SKIP_STAMP(sw.r[to]); }
+                     atomicAdd(&sw.r[to].sg, ig); atomicAdd(&sw.r[to].sb, ib); atomicAdd(&sw.r[to].n, 1); }
         }
         if (RGBD && (fl & 6u)) {
             // the nine disparity terms of the pixel, converted once: added to `to` (flag 2), taken from `from` (flag 4)
@@ -276,7 +240,7 @@
                     atomicAdd(&a[F_DX], (unsigned int)px_x); atomicAdd(&a[F_DY], (unsigned int)px_y); atomicAdd(&a[F_DN], 1u);
                     lds_add_i64(&b[F_DXX - PASS_F32], xx); lds_add_i64(&b[F_DYY - PASS_F32], yy); lds_add_i64(&b[F_DXY - PASS_F32], xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], xd); lds_add_i64(&b[F_DYD - PASS_F32], yd); lds_add_i64(&b[F_DD - PASS_F32], dd);
-                } else { disp_sums_add(sw, to, px_x, px_y, d, +1); SSF_SKIP_STAMP(sw.r[to]); }
+                } else { disp_sums_add(sw, to, px_x, px_y, d, +1); }
             }
             if (fl & 4u) {
                 if (wf >= 0) {
@@ -284,30 +248,11 @@
                     atomicAdd(&a[F_DX], (unsigned int)-px_x); atomicAdd(&a[F_DY], (unsigned int)-px_y); atomicAdd(&a[F_DN], 0xFFFFFFFFu);
                     lds_add_i64(&b[F_DXX - PASS_F32], -xx); lds_add_i64(&b[F_DYY - PASS_F32], -yy); lds_add_i64(&b[F_DXY - PASS_F32], -xy);
                     lds_add_i64(&b[F_DXD - PASS_F32], -xd); lds_add_i64(&b[F_DYD - PASS_F32], -yd); lds_add_i64(&b[F_DD - PASS_F32], -dd);
-                } else { disp_sums_add(sw, from, px_x, px_y, d, -1); SSF_SKIP_STAMP(sw.r[from]); }
+                } else { disp_sums_add(sw, from, px_x, px_y, d, -1); }
             }
         }
     };
     if (SSF_PROBE(dbg, 2)) return;
-#if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_SJUNK)
-    // measurement only: SSF_PASS_SJUNK extra SCALAR instructions per wave (one scalar unit serves the four SIMDs of a compute unit:
-    // is the pass bound by scalar issue -- its waves execute ~310 scalar instructions beside ~420 vector ones?)
-    {
-        int sj = __builtin_amdgcn_readfirstlane((int)blockIdx.x | 3);
-#pragma unroll
-        for (int i = 0; i < SSF_PASS_SJUNK; i++) asm volatile("s_mul_i32 %0, %0, %0" : "+s"(sj));
-        if (sj == 0x12345677) s_nlog = 1;
-    }
-#endif
-#if defined(SSF_EXPERIMENTS) && defined(SSF_PASS_JUNK)
-    // measurement only: SSF_PASS_JUNK extra vector instructions per wave (is the pass bound by instruction issue?)
-    {
-        float junk = __uint_as_float(threadIdx.x | 0x3f800000u);
-#pragma unroll
-        for (int i = 0; i < SSF_PASS_JUNK; i++) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(junk));
-        if (junk == 12345.678f) s_nlog = 1;
-    }
-#endif
     int4* __restrict__ cent = slab_shift(pa.cent, slot_off);
     float* __restrict__ cdis = slab_shift(pa.cdis, slot_off);
 #pragma unroll
@@ -395,9 +340,6 @@
             }
         }
         if (flags) {
-#ifdef SSF_EXPERIMENTS
-            if (NPX == 1 && skip_from < (1 << 29)) st_off<int>(m.bstamp, 4u * (unsigned int)((y[s] >> SSF_CHANGE_BLOCK_LOG2) * nbkx + (x[s] >> SSF_CHANGE_BLOCK_LOG2)), pass);
-#endif
             const uint32_t rgbf = (px[s] & 0x00FFFFFFu) | (flags << 24);
             add_delta(index, new_index, x[s], y[s], rgbf, disp[s]);
             const unsigned int slot = atomicAdd(&s_nlog, 1u);                 // LDS counter, < LOGN by construction
@@ -415,9 +357,6 @@
     }
     __syncthreads();
     SSF_PASS_TICK(3);                             // (decisions taken, deltas in LDS, log written)
-#ifdef SSF_EXPERIMENTS
-    if (s_far && NPX == 1 && skip_from < (1 << 29)) skip_stamp_blocks<TWX>(m, p, X0, Y0, nbkx, pass);      // (a label from outside the window was met)
-#endif
     // flush: the accumulators are scanned a 16-byte chunk at a time (most are zero); one global atomic per sum that is not.
     // The record's nine int32 sums and six int64 sums are addressed by field number (SumRec: int32 fields from byte 0, int64
     // fields from byte 64)
@@ -428,6 +367,7 @@
             unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
             ccnt[tile_id] = 0u;
         }
+        SSF_PASS_STAT_END(0u);
         SSF_PASS_TICK(4);
         return;
     }
@@ -437,7 +377,6 @@
         const int wi = RGBD ? (int)(__umul24((unsigned int)i, 10923u) >> 16) : (i >> 1);       // i / 6, i / 2
         const int c = i - __mul24(wi, ACC_CHUNKS);
         SumRec* rec = &sw.r[w_label[wi]];
-        SSF_SKIP_STAMP(*rec);
         if (c < 3) {
             int* f = &rec->sx + 4 * c;                             // (chunk 2: dn and three dwords of padding, always zero)
             if (v.x) atomicAdd(f, (int)v.x);
@@ -455,4 +394,5 @@
         unsigned int* __restrict__ ccnt = slab_shift(pa.ccnt, slot_off);
         ccnt[tile_id] = s_nlog;
     }
+    SSF_PASS_STAT_END(s_nlog);
     SSF_PASS_TICK(4);

@@ -42,10 +42,14 @@ def test_sequence_bit_exact(size, oracle_lib, product_lib):
         util.compare_state(fo, fh)
 
 
-def test_every_relabelling_pass_bit_exact(oracle_lib, product_lib):
-    rgb, depth = util.frame(0, 320, 240, holes=0.05)
-    for passes in (1, 2, 3, 4, 7, 20, 21, 33, 40):
-        fo, fh = pair(oracle_lib, product_lib, 320, 240)
+@pytest.mark.parametrize("size,pass_list", [((320, 240), (1, 2, 3, 4, 7, 20, 21, 33, 40)), ((640, 480), (1, 20, 21, 40))])
+def test_every_relabelling_pass_bit_exact(size, pass_list, oracle_lib, product_lib):
+    """the state after k relabelling passes, k across both phases; at the metric's 640 x 480 too (round 6: first and last pass of each
+    phase -- a window overflow or a far-label path that first shows at full size would otherwise only be seen in the end state)"""
+    Wt, Ht = size
+    rgb, depth = util.frame(0, Wt, Ht, holes=0.05)
+    for passes in pass_list:
+        fo, fh = pair(oracle_lib, product_lib, Wt, Ht)
         fo.set_max_passes(passes); fh.set_max_passes(passes)
         fo.stage_extract(rgb, depth); fh.stage_extract(rgb, depth)
         util.assert_same_bits(fo.index_map(), fh.index_map(), "labels after %d passes" % passes)
@@ -725,13 +729,11 @@ def test_a_late_word_to_the_waiting_launch_is_repaired_not_trusted(oracle_lib, l
     assert L.ssf_waiter_match_repairs(fh.h) >= 1, "no frame ended its ICP loop with a launch waiting: the path was not taken"
 
 
-@pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_SKIP=1", "SSF_PASS_TEAM=1"])
+@pytest.mark.parametrize("switch", ["SSF_PASS_XCD=0", "SSF_PASS_TEAM=1"])
 def test_relabelling_passes_bit_exact_under_the_lab_switches(switch):
     """Two arms of the relabelling pass that only exist in the LAB build of the sources (the product reads no environment variable),
     each in a process of its own (the switches are read once per process):
       SSF_PASS_XCD=0   tiles in plain grid order instead of the XCD-aware order (DESIGN.md section 4.1.3): only speed may differ;
-      SSF_PASS_SKIP=1  clean-tile skipping (lab/pass_skip.inc, section 4.1.5): a tile that can prove that nothing it depends on has
-                       changed for four passes leaves after its loads -- exact by construction, measured useless.
       SSF_PASS_TEAM=1  the passes of a phase in ONE launch whose workgroups stay, a frame per XCD, meeting inside their XCD between
                        passes and reading the previous pass' output past the L1 (lab/passes_team.inc): built in
                        round 5, exact, slower (profiles/pass_team_r05.txt).  Whole frames, batches and pipelined sequences.

@@ -307,3 +307,36 @@ def test_rehoming_over_torch_distributed(oracle_lib, tmp_path):
         assert (synthetic.tile_owner(d["positions"][ok], world, 0.25) == r).all()
     merged = {name: np.concatenate([d[name] for d in ranks]) for name, _, _ in binding.SURFEL_FIELDS}
     assert np.array_equal(util.rows_multiset(merged), util.rows_multiset(single.get_model()))
+
+
+# ---- bench.py's own N > 1 loop at world size 2 (round 6) -------------------------------------------------------------------------
+# `python bench.py --gpus N` falls through RCCL -> peer-to-peer regions -> the torch.distributed driver; the last form, and
+# `--py-driver`, run bench.drive_pipelined over a sharded.ShardedFusion.  No box this build has seen has two GPUs, so that loop is run
+# HERE: two gloo ranks, the CPU checker as the engine, frames submitted ahead (pipeline_depth 1, two frames per extract batch).
+def _bench_loop_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    lib = binding.Library(ORACLE_LIB)
+    f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=4096, rank=rank, nranks=world, shard_tile=0.25, pipeline_depth=1, extract_batch=2))
+    drv = sharded.ShardedFusion(f)
+    frames = [util.frame(k, W, H) for k in range(NF)]
+    res = bench.drive_pipelined(drv, lambda i: frames[i], 0, NF, on_device=False)
+    m = f.get_model()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), poses=np.array([r["pose"] for r in res]),
+             glob=np.array([[r["global_n_model"], r["global_n_visible"], r["icp_valid"], r["icp_iters"]] for r in res]), **m)
+    dist.destroy_process_group()
+
+
+def test_bench_py_driver_loop_at_world_size_two(oracle_lib, tmp_path):
+    world = 2
+    mp.spawn(_bench_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    fo = binding.Fusion(oracle_lib, util.make_cfg(oracle_lib, W, H, nb_supersurfels_max=4096))
+    want = [fo.process_frame(*util.frame(k, W, H)) for k in range(NF)]
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in ranks:                                   # every rank holds the single-rank pose and the global counters, frame by frame
+        assert np.array_equal(r["poses"].view(np.uint32), np.array([w["pose"] for w in want]).view(np.uint32))
+        assert np.array_equal(r["glob"], np.array([[w["n_model"], w["n_visible"], w["icp_valid"], w["icp_iters"]] for w in want]))
+    union = {name: np.concatenate([r[name] for r in ranks]) for name, _, _ in binding.SURFEL_FIELDS}
+    assert np.array_equal(_rows(union), _rows(fo.get_model()))
