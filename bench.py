@@ -295,6 +295,7 @@ def real_frames_leg(lib, dev, model, nvis, cap):
     try:
         lab = binding.load_lab()
         lab.lib.ssf_dbg_pass_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lab.lib.ssf_dbg_pass_stats_enable(1)
 
         def stats(frames_host, cfg_):
             fl = binding.Fusion(lab, cfg_)

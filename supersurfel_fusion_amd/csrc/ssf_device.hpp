@@ -102,7 +102,9 @@ struct SegParams {
     // lies inside the image (pass_geometry_table: built once per handle on the host; k_update_pass fetches one 8-byte entry
     // instead of working the same ~60 scalar instructions out in every wave of every pass)
     const uint2* pass_geom; int pass_ntile;
+    int win_cells_max;    // the largest cell window of a tile of the plain 32 x 32 grid (tile_window_cells_max): <= 36 selects the small-LDS instantiations of the tile kernels
 };
+int tile_window_cells_max(const SegParams& p);
 // entry: x = (wcx0 & 0xFFFF) | (wcy0 << 16) (first window cell, may be negative), y = nwx | nwy << 8 | interior << 16 (nwx = nwy = 0: no window)
 int pass_geometry_entries(int W, int H);                                  // 2 x tiles of the shifted 32-wide grid
 void pass_geometry_table(const SegParams& p, uint2* host_out);
@@ -309,6 +311,7 @@ void launch_fuse(hipStream_t st, SurfelSoA model /* visible array */, SurfelSoA 
 // launch_move_rows(totals != nullptr): the fuse launch ended without its tail; every block of the move kernel takes the old
 // counts from here (the host mirrors them) and the class totals from the partition's replicas, block 0 finalises the counters
 #ifdef SSF_EXPERIMENTS
+void set_pass_stats(int on);         // (lab: the relabelling statistics of ssf_dbg_pass_stats are collected only while set)
 void set_pass_trace(unsigned long long* device_words /* 5 per workgroup of a relabelling pass launch; nullptr: off */);     // (lab: tools/pass_trace.py)
 void set_fuse_trace(unsigned long long* device_words /* 3 per workgroup of the fuse launch; nullptr: off */);      // (lab: tools/fuse_probe.py)
 #endif

@@ -179,6 +179,9 @@ __device__ __forceinline__ void row_plane_from_sums(const SpSums& s, int k, floa
 #define TILE 32
 #define TW (TILE + 2)
 #define WIN_MAX 64
+#ifndef WIN_SMALL
+#define WIN_SMALL 36          // the window of a 32 x 32 tile at cell size 16 with its margin of two cells: (2 + 4)^2
+#endif
 static inline dim3 tile_grid(const SegParams& p) { return dim3((p.W + TILE - 1) / TILE, (p.H + TILE - 1) / TILE); }
 
 __device__ __forceinline__ void load_label_tile(int* tile, const int32_t* __restrict__ src, int X0, int Y0, int W, int H) {
@@ -365,6 +368,24 @@ static inline TileOrder tile_order(dim3 grid) {
     o.xcd = on;
     return o;
 }
+// the same order for the other tile kernels of the extract stage (round 6: k_eval_samples, k_init_disp, k_render_moments fetch a
+// label tile WITH its halo -- three 128-byte lines per tile row instead of one -- and share the inlier lines four tiles to a line;
+// in grid order the neighbours of a tile run on seven other XCDs and every one of those lines is pulled into several L2s)
+#ifndef SSF_TILE_XCD
+#define SSF_TILE_XCD 1
+#endif
+struct TileIdx { unsigned int bx, by, bz; };
+__device__ __forceinline__ TileIdx tile_index(const TileOrder& ord) {
+    TileIdx t; t.bx = blockIdx.x; t.by = blockIdx.y; t.bz = blockIdx.z;
+    if (SSF_TILE_XCD && ord.xcd) {
+        const unsigned int lin = blockIdx.x + ord.ntx * blockIdx.y + ord.ntile * blockIdx.z;
+        const unsigned int u = xcd_share(lin, ord.total);
+        t.bz = __umulhi(u, ord.magic_ntile);
+        const unsigned int r = u - t.bz * ord.ntile;
+        t.by = __umulhi(r, ord.magic_ntx); t.bx = r - t.by * ord.ntx;
+    }
+    return t;
+}
 #ifndef SSF_PASS_NPREV_RGBD
 #define SSF_PASS_NPREV_RGBD 1
 #endif
@@ -403,8 +424,11 @@ void set_pass_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(
 // lab: statistics of a frame's relabelling passes in FrameMaps::epoch[8 ..] (ssf_dbg_pass_stats; bench.py's real-frame leg, round 6):
 // [8] log entries written (sum over tiles and passes), [9] the largest log of a tile in a pass, [10] tiles x passes, [11] superpixel-row
 // lookups that found their label OUTSIDE the tile's LDS window (the exact global path), [12] all row lookups
-#define SSF_PASS_STAT_LOOKUP(far) do { atomicAdd(&m.epoch[12], 1u); if (far) atomicAdd(&m.epoch[11], 1u); } while (0)
-#define SSF_PASS_STAT_END(nlog) do { if (threadIdx.x == 0) { atomicAdd(&m.epoch[8], (nlog)); atomicMax(&m.epoch[9], (nlog)); atomicAdd(&m.epoch[10], 1u); } } while (0)
+// (only while g_pass_stats is set -- ssf_dbg_pass_stats_enable: a global atomic per lookup is not something an A/B of the lab build should pay)
+__device__ int g_pass_stats = 0;
+void set_pass_stats(int on) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pass_stats), &on, sizeof(on)); }
+#define SSF_PASS_STAT_LOOKUP(far) do { if (g_pass_stats) { atomicAdd(&m.epoch[12], 1u); if (far) atomicAdd(&m.epoch[11], 1u); } } while (0)
+#define SSF_PASS_STAT_END(nlog) do { if (g_pass_stats && threadIdx.x == 0) { atomicAdd(&m.epoch[8], (nlog)); atomicMax(&m.epoch[9], (nlog)); atomicAdd(&m.epoch[10], 1u); } } while (0)
 #else
 #define SSF_PASS_TICK_BEGIN() ((void)0)
 #define SSF_PASS_TICK(i) ((void)0)
@@ -553,22 +577,27 @@ __global__ __launch_bounds__(256) void k_init_samples(SegParams p, FrameMaps m, 
 // lanes of different superpixels on different banks (with [cell][sample][replica] the bank was (8 sample + replica) % 32
 // whatever the cell: every atomic of a wave fought over eight banks), and 16 KB of counters instead of 32 (five workgroups
 // per CU instead of three).
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) {
+// WCAP (round 6): the window capacity the LDS tables are sized for -- 36 cells when no tile of the handle's grid needs more (cell
+// size 16, every launch file: 2 x 2 cells of the tile + a margin of two), 64 otherwise.  At 64 the three accumulator kernels held
+// 34-38 KB of LDS and four workgroups per compute unit, and all three get slower with fewer (25 -> 29 -> 36 us, 50 -> 54 -> 62 us at
+// 4 / 3 / 2, round 5); at 36 they hold 19-23 KB: six to eight workgroups.
+template <bool FAST, int WCAP>
+__global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m, TileOrder ord) {
     // (FAST: the sixteen planes of a window cell 17 float4 apart, not 16: the lanes of a wave read plane sk of a handful of DIFFERENT
     // cells in one ds_read_b128, and with a stride of 64 dwords every cell's plane sk sits on the same four banks -- the counters
     // put 53 % of this kernel's LDS cycles down to bank conflicts.  Round 5, same box, alternated: 33.2-34.4 us per 8-frame launch
     // at a stride of 16, 26.0-26.9 at 17, 32.5-32.8 at 24 (cells two apart collide again; three workgroups per compute unit instead
     // of four).)
     constexpr int PLANE_STRIDE = FAST ? SSF_EVAL_PLANE_STRIDE : EVAL_NS;
-    __shared__ float4 w_plane[EVAL_WIN * (FAST ? SSF_EVAL_PLANE_STRIDE : EVAL_NS)];
+    __shared__ float4 w_plane[WCAP * (FAST ? SSF_EVAL_PLANE_STRIDE : EVAL_NS)];
     // EVAL_REP replicas of every counter (lane & 7): the 64 pixels of a wave sit in a handful of superpixels, and
     // same-address LDS atomics serialise (SQ_LDS_BANK_CONFLICT was 80 % of the LDS cycles with one replica)
-    __shared__ __attribute__((aligned(16))) int w_cnt[EVAL_WIN * (FAST ? EVAL_NS / 2 : EVAL_NS) * EVAL_REP];
-    m = batch_slot(m, blockIdx.z);
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
+    __shared__ __attribute__((aligned(16))) int w_cnt[WCAP * (FAST ? EVAL_NS / 2 : EVAL_NS) * EVAL_REP];
+    const TileIdx ti = tile_index(ord);                // (XCD-aware tile order: see tile_index)
+    m = batch_slot(m, ti.bz);
+    const int X0 = ti.bx * TILE, Y0 = ti.by * TILE;
     const int ns = p.nb_samples;
-    CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? EVAL_WIN : 0);
+    CellWindow win; win.init(p, X0, Y0, ns <= EVAL_NS ? WCAP : 0);
     const int32_t* __restrict__ label = m.label;
     // this thread's pixels: requested up front, in flight while the window's planes are staged
     constexpr int PX = TILE * TILE / 256;
@@ -583,7 +612,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
         const unsigned int q = __umul24((unsigned int)y, (unsigned int)p.W) + (unsigned int)x;
         pl[k] = label[q]; pd[k] = m.disp[q];
     }
-    constexpr int PLANE_ROUNDS = EVAL_WIN * EVAL_NS / 256;
+    constexpr int PLANE_ROUNDS = (WCAP * EVAL_NS + 255) / 256;
     float4 wp[PLANE_ROUNDS]; bool wp_ok[PLANE_ROUNDS];
     const int n_planes = win.size() * ns;
 #pragma unroll
@@ -595,7 +624,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
         wp[k] = m.samples[(size_t)(l >= 0 ? l : 0) * ns + sk];
     }
     if (FAST) {
-        for (int i = threadIdx.x; i < EVAL_WIN * (EVAL_NS / 2) * EVAL_REP / 4; i += 256) reinterpret_cast<int4*>(w_cnt)[i] = make_int4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < WCAP * (EVAL_NS / 2) * EVAL_REP / 4; i += 256) reinterpret_cast<int4*>(w_cnt)[i] = make_int4(0, 0, 0, 0);
     } else
         for (int i = threadIdx.x; i < n_planes * EVAL_REP; i += blockDim.x) w_cnt[i] = 0;
 #pragma unroll
@@ -634,7 +663,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
 #pragma unroll
                 for (int pr = 0; pr < EVAL_NS / 2; pr++) {        // samples pr (low half) and pr + 8 (high half) share a counter
                     const unsigned int v = ((votes >> pr) & 1u) | (((votes >> (pr + EVAL_NS / 2)) & 1u) << 16);
-                    if (v) atomicAdd(&c[pr * EVAL_WIN * EVAL_REP], (int)v);
+                    if (v) atomicAdd(&c[pr * WCAP * EVAL_REP], (int)v);
                 }
             } else {
                 for (int sk = 0; sk < EVAL_NS; sk++) {             // label outside the window: exact global path
@@ -677,7 +706,7 @@ __global__ __launch_bounds__(256) void k_eval_samples(SegParams p, FrameMaps m) 
             const int wi = i / EVAL_NS, sk = i % EVAL_NS, pr = sk & (EVAL_NS / 2 - 1);
             unsigned int packed = 0u;
 #pragma unroll
-            for (int r = 0; r < EVAL_REP; r++) packed += (unsigned int)w_cnt[(pr * EVAL_WIN + wi) * EVAL_REP + r];   // (fields < 2^13 each: no carry)
+            for (int r = 0; r < EVAL_REP; r++) packed += (unsigned int)w_cnt[(pr * WCAP + wi) * EVAL_REP + r];   // (fields < 2^13 each: no carry)
             c = (int)(sk < EVAL_NS / 2 ? (packed & 0xFFFFu) : (packed >> 16));
         } else {
 #pragma unroll
@@ -717,12 +746,14 @@ __device__ __forceinline__ float4 select_sample(const FrameMaps& m, int l, int n
 // initDispCoeffsRansacRGBD_kernel (:112-155) / initDispCoeffsRGBD_kernel (:157-190).  Tile kernel:
 // the 9 exact integer sums of every inlier go into LDS accumulators of the window's superpixels and
 // are flushed once per tile into BOTH sums buffers (they must agree when the RGB-D passes start).
-__global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int ransac) {
-    __shared__ unsigned long long w_acc[WIN_MAX * 9 * ACC_REP];     // ACC_REP replicas (lane id) against same-address serialisation
-    __shared__ float4 w_theta[WIN_MAX];
-    m = batch_slot(m, blockIdx.z);
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    CellWindow win; win.init(p, X0, Y0, WIN_MAX);
+template <int WCAP>
+__global__ __launch_bounds__(256) void k_init_disp(SegParams p, FrameMaps m, int ransac, TileOrder ord) {
+    __shared__ unsigned long long w_acc[WCAP * 9 * ACC_REP];     // ACC_REP replicas (lane id) against same-address serialisation
+    __shared__ float4 w_theta[WCAP];
+    const TileIdx ti = tile_index(ord);                // (XCD-aware tile order: see tile_index)
+    m = batch_slot(m, ti.bz);
+    const int X0 = ti.bx * TILE, Y0 = ti.by * TILE;
+    CellWindow win; win.init(p, X0, Y0, WCAP);
     const int32_t* __restrict__ label = m.label;
     // this thread's pixels: requested up front, in flight while the window's planes are selected
     constexpr int PX = TILE * TILE / 256;
@@ -1102,17 +1133,19 @@ __global__ __launch_bounds__(1024) void k_plane_filter_tiled(SegParams p, FrameM
 #ifndef MOM_REP
 #define MOM_REP 4        // replicas of the 13 moment accumulators of a window cell (8: 53 KB of LDS, two waves per SIMD; measured 8 / 4 / 2: 69.6 / 60.9 / 67.0 us per 8-frame launch)
 #endif
-__global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m) {
+template <int WCAP>
+__global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m, TileOrder ord) {
     __shared__ int tile[TW * TW];
-    __shared__ __attribute__((aligned(16))) SpRow w_row[WIN_MAX];
-    __shared__ unsigned long long w_acc[WIN_MAX * 13 * MOM_REP];    // MOM_REP replicas (lane id) against same-address serialisation
-    m = batch_slot(m, blockIdx.z);
-    const int X0 = blockIdx.x * TILE, Y0 = blockIdx.y * TILE;
-    CellWindow win; win.init(p, X0, Y0, WIN_MAX);
+    __shared__ __attribute__((aligned(16))) SpRow w_row[WCAP];
+    __shared__ unsigned long long w_acc[WCAP * 13 * MOM_REP];    // MOM_REP replicas (lane id) against same-address serialisation
+    const TileIdx ti = tile_index(ord);                // (XCD-aware tile order: see tile_index)
+    m = batch_slot(m, ti.bz);
+    const int X0 = ti.bx * TILE, Y0 = ti.by * TILE;
+    CellWindow win; win.init(p, X0, Y0, WCAP);
     // Everything the workgroup needs from memory is requested first -- the window's rows, the gamma table, this thread's
     // pixels, the label tile -- and stored to LDS afterwards: ONE round trip.  (Staged piece by piece, each piece was a
     // trip of its own: four of them in front of the first useful instruction.)
-    static_assert(WIN_MAX <= 256, "one window row per thread");
+    static_assert(WCAP <= 256, "one window row per thread");
     const int wl = (int)threadIdx.x < win.size() ? win.label_of(threadIdx.x, p.gy) : -1;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     {
@@ -1577,6 +1610,20 @@ int pass_tile_npx(int nb) {
                     // the algorithmic bytes but not its time -- the kernel is bound by instruction issue, not by memory or by
                     // how many workgroups are resident -- and cost a single-frame launch 50 % more (8 -> 12 us)
 }
+// the largest cell window CellWindow::init gives a tile of the plain 32 x 32 grid (same formulas, host integers): SegParams::win_cells_max
+int tile_window_cells_max(const SegParams& p) {
+    auto cell_of = [&](int x) { return p.cell_magic ? (int)(((uint64_t)(uint32_t)x * p.cell_magic) >> 32) : x; };
+    int best = 0;
+    for (int Y0 = 0; Y0 < p.H; Y0 += TILE)
+        for (int X0 = 0; X0 < p.W; X0 += TILE) {
+            int margin = 2;
+            const int tcx0 = cell_of(X0), tcy0 = cell_of(Y0), tcx1 = cell_of(std::min(X0 + TILE - 1, p.W - 1)), tcy1 = cell_of(std::min(Y0 + TILE - 1, p.H - 1));
+            while (margin > 0 && (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin) > WIN_MAX) margin--;
+            const int n = (tcx1 - tcx0 + 1 + 2 * margin) * (tcy1 - tcy0 + 1 + 2 * margin);
+            best = std::max(best, n <= WIN_MAX ? n : WIN_MAX + 1);          // (no window at all: the large instantiation, which then takes the exact path)
+        }
+    return best;
+}
 // the table behind SegParams::pass_geom: exactly what k_update_pass<., 1, .> works out for a tile (same formulas, host integers)
 int pass_geometry_entries(int W, int H) { return 2 * ((W + (TILE - 2) + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
 void pass_geometry_table(const SegParams& p, uint2* out) {
@@ -1645,12 +1692,18 @@ void launch_init_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 static inline dim3 batch_tile_grid(const SegParams& p, int nb) { dim3 g = tile_grid(p); g.z = nb; return g; }
 void launch_eval_samples(hipStream_t st, const SegParams& p, FrameMaps& m, int nb) {
     ScopedKernel sk("eval_samples", st);
-    if (p.nb_samples == EVAL_NS) hipLaunchKernelGGL(k_eval_samples<true>, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
-    else hipLaunchKernelGGL(k_eval_samples<false>, batch_tile_grid(p, nb), dim3(256), 0, st, p, m);
+    const dim3 grid = batch_tile_grid(p, nb);
+    const bool small = p.win_cells_max <= WIN_SMALL;
+    if (p.nb_samples == EVAL_NS) {
+        if (small) hipLaunchKernelGGL((k_eval_samples<true, WIN_SMALL>), grid, dim3(256), 0, st, p, m, tile_order(grid));
+        else hipLaunchKernelGGL((k_eval_samples<true, EVAL_WIN>), grid, dim3(256), 0, st, p, m, tile_order(grid));
+    } else hipLaunchKernelGGL((k_eval_samples<false, EVAL_WIN>), grid, dim3(256), 0, st, p, m, tile_order(grid));
 }
 void launch_init_disp(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, bool ransac) {
     ScopedKernel sk("init_disp", st);
-    hipLaunchKernelGGL(k_init_disp, batch_tile_grid(p, nb), dim3(256), SSF_INITDISP_DYN_LDS, st, p, m, ransac ? 1 : 0);
+    const dim3 grid = batch_tile_grid(p, nb);
+    if (p.win_cells_max <= WIN_SMALL) hipLaunchKernelGGL(k_init_disp<WIN_SMALL>, grid, dim3(256), SSF_INITDISP_DYN_LDS, st, p, m, ransac ? 1 : 0, tile_order(grid));
+    else hipLaunchKernelGGL(k_init_disp<WIN_MAX>, grid, dim3(256), SSF_INITDISP_DYN_LDS, st, p, m, ransac ? 1 : 0, tile_order(grid));
 }
 void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, int true_buf) {
     ScopedKernel sk("plane_filter", st);
@@ -1697,7 +1750,9 @@ void launch_plane_filter(hipStream_t st, const SegParams& p, FrameMaps& m, int n
 }
 void launch_render_moments(hipStream_t st, const SegParams& p, const Cam& cam, FrameMaps& m, int nb) {
     ScopedKernel sk("render_moments", st);
-    hipLaunchKernelGGL(k_render_moments, batch_tile_grid(p, nb), dim3(256), SSF_RENDER_DYN_LDS, st, p, cam, m);
+    const dim3 grid = batch_tile_grid(p, nb);
+    if (p.win_cells_max <= WIN_SMALL) hipLaunchKernelGGL(k_render_moments<WIN_SMALL>, grid, dim3(256), SSF_RENDER_DYN_LDS, st, p, cam, m, tile_order(grid));
+    else hipLaunchKernelGGL(k_render_moments<WIN_MAX>, grid, dim3(256), SSF_RENDER_DYN_LDS, st, p, cam, m, tile_order(grid));
 }
 void launch_import_frame(hipStream_t st, const SegParams& p, FrameMaps& m, int nb, SurfelSoA frame, const float* wire, unsigned long long* best, uint8_t* matched) {
     ScopedKernel sk("import_frame", st);

@@ -1798,6 +1798,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
     p.filter_iter = cfg->filter_iter; p.seed = cfg->rng_seed;
     p.inv_gx = 1.0f / (float)h->gx;
     p.cell_magic = c > 1 ? (uint32_t)((0x100000000ull + (uint64_t)c - 1) / (uint64_t)c) : 0u;
+    p.win_cells_max = tile_window_cells_max(p);          // (selects the LDS footprint of the tile kernels: ssf_extract.hip, WCAP)
     h->cam.fx = cfg->fx; h->cam.fy = cfg->fy; h->cam.cx = cfg->cx; h->cam.cy = cfg->cy; h->cam.W = W; h->cam.H = H;
     const size_t P = (size_t)W * H, S = h->S, N = cfg->nb_supersurfels_max, NS = S * cfg->nb_samples;
     // relabelling tiles (the shifted grid has one more column): 32-wide tiles with 256 log entries each, or 64-wide
@@ -2977,7 +2978,9 @@ int ssf_upload_stats(ssf_handle* h, double* out6) {
     return SSF_OK;
 }
 #ifdef SSF_EXPERIMENTS          // (laboratory build only: probes of tools/, not part of the product)
-// the relabelling statistics of the frame just processed (FrameMaps::epoch, SSF_PASS_STAT_* in ssf_extract.hip): out64[8 .. 12]
+// the relabelling statistics of the frame just processed (FrameMaps::epoch, SSF_PASS_STAT_* in ssf_extract.hip): out64[8 .. 12];
+// collected only after ssf_dbg_pass_stats_enable(1)
+int ssf_dbg_pass_stats_enable(int on) { set_pass_stats(on ? 1 : 0); return SSF_OK; }
 int ssf_dbg_pass_stats(ssf_handle* h, uint32_t* out64) {
     if (!h || !h->active.ctx || !out64) return SSF_ERR_INVALID_ARG;
     HCK(hipStreamSynchronize(h->active.ctx->stream));
