@@ -1130,14 +1130,17 @@ __global__ __launch_bounds__(1024) void k_plane_filter_tiled(SegParams p, FrameM
 // (supersurfel_fusion_kernels.cu:113-167): one read of the label tile serves the depth render, the
 // boundary test and the 13 moment sums (fixed point 2^24, exact), which are accumulated with LDS
 // integer atomics per window superpixel and flushed once per tile.
+// replicas of the 13 moment accumulators of a window cell (lane id): at a window capacity of 64 cells 8 / 4 / 2 replicas measured
+// 69.6 / 60.9 / 67.0 us per 8-frame launch (8: 53 KB of LDS, two workgroups per compute unit); at 36 cells 8 replicas are 37 KB and
+// four workgroups: 47.4-47.5 against 48.9-49.8 us with 4, 58.9-59.7 with 2 (round 6, profiles/tile_kernels_r06.txt)
 #ifndef MOM_REP
-#define MOM_REP 4        // replicas of the 13 moment accumulators of a window cell (8: 53 KB of LDS, two waves per SIMD; measured 8 / 4 / 2: 69.6 / 60.9 / 67.0 us per 8-frame launch)
+#define MOM_REP(wcap) ((wcap) <= WIN_SMALL ? 8 : 4)
 #endif
 template <int WCAP>
 __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, FrameMaps m, TileOrder ord) {
     __shared__ int tile[TW * TW];
     __shared__ __attribute__((aligned(16))) SpRow w_row[WCAP];
-    __shared__ unsigned long long w_acc[WCAP * 13 * MOM_REP];    // MOM_REP replicas (lane id) against same-address serialisation
+    __shared__ unsigned long long w_acc[WCAP * 13 * MOM_REP(WCAP)];    // MOM_REP replicas (lane id) against same-address serialisation
     const TileIdx ti = tile_index(ord);                // (XCD-aware tile order: see tile_index)
     m = batch_slot(m, ti.bz);
     const int X0 = ti.bx * TILE, Y0 = ti.by * TILE;
@@ -1164,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         pin[k] = m.inlier[q]; prgba[k] = m.rgba[q];
     }
     const TileRegs treg = tile_request(m.label, X0, Y0, p.W, p.H);
-    for (int i = threadIdx.x; i < win.size() * 13 * MOM_REP; i += blockDim.x) w_acc[i] = 0ull;
+    for (int i = threadIdx.x; i < win.size() * 13 * MOM_REP(WCAP); i += blockDim.x) w_acc[i] = 0ull;
     // the gamma table in LDS: three lookups per pixel would otherwise be global loads queued behind this thread's
     // stores (the maps may alias as far as the compiler knows)
     __shared__ float s_lut[256];
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
         const Sym3 c = sym_outer(pos);
         const float v[12] = {pos.x, pos.y, pos.z, lab.x, lab.y, lab.z, c.xx, c.xy, c.xz, c.yy, c.yz, c.zz};
         if (ws >= 0) {
-            unsigned long long* a = &w_acc[(ws * MOM_REP + (lane_id() & (MOM_REP - 1))) * 13];
+            unsigned long long* a = &w_acc[(ws * MOM_REP(WCAP) + (lane_id() & (MOM_REP(WCAP) - 1))) * 13];
 #pragma unroll
             for (int j = 0; j < 12; j++) lds_add_i64(&a[j], fx64((double)v[j], SSF_MOM_SCALE, SSF_MOM_LIM));
             lds_add_i64(&a[12], 1);
@@ -1218,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_render_moments(SegParams p, Cam cam, Fr
     for (int i = threadIdx.x; i < win.size() * 13; i += blockDim.x) {
         long long v = 0;
 #pragma unroll
-        for (int r = 0; r < MOM_REP; r++) v += (long long)w_acc[((i / 13) * MOM_REP + r) * 13 + i % 13];
+        for (int r = 0; r < MOM_REP(WCAP); r++) v += (long long)w_acc[((i / 13) * MOM_REP(WCAP) + r) * 13 + i % 13];
         if (v != 0) atomic_add_i64(&m.moments[(size_t)win.label_of(i / 13, p.gy) * 13 + i % 13], v);
     }
 }
