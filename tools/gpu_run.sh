@@ -28,9 +28,9 @@ PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --war
 lastline() { [ -s "$1" ] && tail -n 1 "$1" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$2', round(d['value'],1), d.get('unit'), 'frac', round(d['roofline']['frac'],4), d['roofline'].get('kernel'), 'seq_ms', d.get('sequential_ms_per_frame'))" 2>/dev/null >> $O/summary.txt; }
 for step in "$@"; do
   case $step in
-    prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; TAG="_config3";;
-    prof5) PROF="python $R/bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (TUM-shaped frames, pre-filter in the frame, pipelined 2 x 12)"; export PMC_EXTRACT_BATCH=12; TAG="_config5";;
-    prof2) PROF="python $R/bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; TAG="";;
+    prof3) PROF="python $R/bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8"; PROFNOTE="bench.py --config 3 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 32 --warmup 8 (1280x960, pipelined 2 x 4)"; export PMC_EXTRACT_BATCH=4; export PROFPIX=1228800; TAG="_config3";;
+    prof5) PROF="python $R/bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --config 5 --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (TUM-shaped frames, pre-filter in the frame, pipelined 2 x 12)"; export PMC_EXTRACT_BATCH=12; export PROFPIX=307200; TAG="_config5";;
+    prof2) PROF="python $R/bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8"; PROFNOTE="bench.py --cpu-frames 0 --profile-frames 0 --extras 0 --steps 96 --warmup 8 (pipelined 2 x 8)"; export PMC_EXTRACT_BATCH=8; export PROFPIX=307200; TAG="";;
     driver)
       timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err; lastline $O/bench_driver_command.json driver_command;;
     gpus2)
