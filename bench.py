@@ -815,6 +815,19 @@ def main():
                 roofline["frac_from_rocprof_note"] = ("%s: %d launches, %.2f frames per launch on average, %.2f us per launch (rocprofv3 --kernel-trace durations; "
                                                       "algorithmic bytes of every launch by its own frame count)" % (rname, mixk["launches"], mixk["mean_frames_per_launch"], mixk["avg_us"]))
                 roofline["rocprof_top_kernels_by_name"] = [dict(kernel=t["kernel"], share=round(t["share"], 4), avg_us=round(t["avg_us"], 3)) for t in rj.get("top_kernels_by_name", [])[:4]]
+                # the trace's largest single kernel NAME with its own roofline figures (its launch time in the trace, this run's
+                # algorithmic bytes per launch, the stamped PMC traffic): `kernel` above is the dominant FAMILY's larger instantiation
+                sym2name = (("k_icp", "icp_accumulate"), ("k_update_pass<true", "update_pass_rgbd"), ("k_update_pass<false", "update_pass_rgb"), ("k_match", "match"),
+                            ("k_update_insert", "update_insert"), ("k_move_rows", "reorder_move"), ("k_render_moments", "render_moments"))
+                t0 = (rj.get("top_kernels_by_name") or [None])[0]
+                nm = next((b for a_, b in sym2name if t0 and t0["kernel"].startswith(a_)), None)
+                if nm and nm in per_kernel and per_kernel[nm].get("algo_bytes_per_launch"):
+                    ab = per_kernel[nm]["algo_bytes_per_launch"]; ach_t = ab / (t0["avg_us"] * 1e-6) / 1e9
+                    tr = pmc["kernels"].get(nm, {}).get("hbm_bytes_per_launch") if (pmcs and traffic is not None) else None
+                    roofline["rocprof_top_kernel"] = dict(kernel=t0["kernel"], bench_name=nm, share_of_gpu_time=t0["share"], avg_launch_us=t0["avg_us"], launches=t0["launches"],
+                                                          algo_bytes_per_launch=ab, achieved=ach_t, frac=ach_t / HBM_PEAK_GBS, traffic=tr,
+                                                          traffic_over_algorithmic=(tr / ab) if tr else None,
+                                                          note="launch time from the trace (launches made ahead include their wait for the host's word), bytes from this run's row counts")
     # nominal AND measured-achievable peak: a stream copy on this box, outside every timed region
     hbm_measured = measured_hbm_peak(dev) if (rank == 0 and a.extras) else None          # (--extras 0: profiling runs stay free of the copy kernels)
     # ... and by a plain 16-bytes-per-lane copy kernel of the library's own (the form MI355X_MICROARCH.md quotes at 6.29 TB/s):
