@@ -96,7 +96,7 @@ def kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "supersurfel_fusion_amd", "csrc")
-    for f in ("ssf_extract.hip", "ssf_pass_tile.hpp", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
+    for f in ("ssf_extract.hip", "ssf_pass_tile.hpp", "ssf_track_fuse.hip", "ssf_tile_rows.inc", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
         h.update(strip_comments(open(os.path.join(d, f), "r").read()).encode())
     return h.hexdigest()[:16]
 

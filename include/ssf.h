@@ -246,9 +246,9 @@ int ssf_stage_extract(ssf_handle* h, const void* rgb, const void* depth_m, int o
                       const uint8_t* dynamic_mask);
 /* Stop the segmentation after max_passes relabelling passes (0 = all); test/bisect aid. */
 int ssf_debug_set_max_passes(ssf_handle* h, int max_passes);
-/* Test / measurement hook: from how many visible rows on a frame's tracking streams a TILE-SORTED copy of their ICP /
- * association fields (product: never by default -- measured slower at BASELINE config 3 --; 0 = always, < 0 = never; results are the same
- * bit for bit either way: DESIGN.md section 4.  The checker accepts and ignores it). */
+/* Test / tuning hook: from how many visible rows on a frame's tracking streams a TILE-SORTED copy of their ICP /
+ * association fields (default 400 000: the copy pays at BASELINE config 3's million visible rows, not at the metric's 120 k;
+ * 0 = always, < 0 = never; results are the same bit for bit either way: DESIGN.md section 4.4.  The checker accepts and ignores it). */
 int ssf_debug_set_bin_min_rows(ssf_handle* h, int min_rows);
 /* Product-internal upkeep made callable for tests: compact the out-of-view row store now (DESIGN.md
  * section 3; a no-op for the results).  The CPU checker has no such store and returns SSF_OK. */

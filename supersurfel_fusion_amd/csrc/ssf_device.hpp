@@ -281,10 +281,8 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
 // streams of `out`; out_idx[j] = the row's index in the visible array) under transform T (model -> camera): see k_bin_* in
 // ssf_track_fuse.hip.  count / cursor: bin_buffer_words(cam, capacity) words each.  launch_icp(by_tile = 1) /
 // launch_match(orig = out_idx) then take `out` as their rows.
-#ifdef SSF_EXPERIMENTS
 void launch_bin_rows(hipStream_t st, const Cam& cam, SurfelSoA model, int n, Rt T, uint32_t* count, uint32_t* cursor, SurfelSoA out);
 size_t bin_buffer_words(const Cam& cam, size_t capacity);
-#endif
 void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, const uint2* pix2, const float4* fpack,
                   Rt pose, float zmin, float zmax, long long id_offset,
                   unsigned long long* best, uint8_t* matched, int32_t* cand /* per row: frame supersurfel bid for, -1 none */, int S,

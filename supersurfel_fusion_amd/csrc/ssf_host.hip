@@ -536,6 +536,13 @@ struct ActiveFrame {
     ExtractCtx* ctx = nullptr; int slot = 0;
 };
 
+// Round 6: the tile-sorted copy (ssf_tile_rows.inc) in the product, for LARGE visible sets.  At BASELINE config 3 (940 k visible
+// rows, ten iterations) it takes k_icp from 23.0 to 18.8 us per iteration and the association from 55.6 to 29.9 us for a 35 us sort
+// (profiles/config3_sorted_rows_r06.txt); at the metric's 120 k visible rows and four iterations the sort costs more than it saves,
+// hence the threshold.  -DSSF_BIN_MIN_ROWS_DEFAULT=-1 builds a product without it (the A/B).
+#ifndef SSF_BIN_MIN_ROWS_DEFAULT
+#define SSF_BIN_MIN_ROWS_DEFAULT 400000
+#endif
 struct ssf_handle {
     ssf_config cfg;
     int S = 0, gx = 0, gy = 0;
@@ -604,7 +611,7 @@ struct ssf_handle {
     // tile-sorted copy of the visible rows' ICP / association fields (launch_bin_rows), made at the start of a frame's
     // tracking when the visible set is large (bin_min_rows); valid for that frame only
     SurfelSoA bins{}; int32_t* d_bin_idx = nullptr; uint32_t* d_bin_count = nullptr; uint32_t* d_bin_cursor = nullptr;
-    bool bins_valid = false; int bin_min_rows = -1;      // OFF: measured a loss at BASELINE config 3 (k_icp is bound by its LDS atomics, not by the gathers; sorted rows pile k_match's atomicMin onto the same words)
+    bool bins_valid = false; int bin_min_rows = SSF_BIN_MIN_ROWS_DEFAULT;      // visible rows from which a frame's tracking streams the tile-sorted copy (< 0: never)
     // pass_team: the relabelling passes of a phase as ONE launch with a frame per XCD (k_passes_team) instead of a launch per pass.
     // Its workgroups must all be on the chip at once, so whole batches take turns across the contexts (launch_batch: a batch's
     // chain waits for the previous batch's ev_done).
@@ -1511,24 +1518,27 @@ static int process_oldest(ssf_handle* h, const float* prior, ssf_frame_result* o
     // a large visible set: its ICP / association fields once more, sorted by the image tile they project to under the
     // frame's initial transform (ssf_track_fuse.hip, k_bin_*): the iterations and the association stream that copy
     h->bins_valid = false;
-#ifdef SSF_EXPERIMENTS
-    if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0 && !exchanging && h->cfg.nranks == 1) {
+    // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
+    // already launched and waits on the device for its transform
+    // (with the peer-to-peer exchange too: there an iteration is one launch as well; every rank takes the same decisions)
+    const bool chain = h->icp_chain && h->go && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.profile != 1;
+    if (h->icp.active && h->bin_min_rows >= 0 && h->n_visible >= h->bin_min_rows && h->n_visible > 0 && !exchanging && h->cfg.nranks == 1 &&
+        bin_buffer_words(h->cam, 1) != 0) {
         if (!h->d_bin_idx) {                       // first use: the copy's buffers (48 B per row of capacity; d_bin_idx: only the flag "this is the sorted copy" of launch_match)
             const size_t N = (size_t)h->cfg.nb_supersurfels_max, bw = bin_buffer_words(h->cam, N);
             const bool ok = bw && dalloc(h, &h->bins.pos, 12 * N) && dalloc(h, &h->d_bin_idx, 1) && dalloc(h, &h->d_bin_count, bw) && dalloc(h, &h->d_bin_cursor, bw);
             if (!ok) { h->err = "allocation of the tile-sorted copy failed"; return SSF_ERR_DEVICE; }
         }
         Rt T0; T0.R = h->icp.R_init; T0.t = h->icp.t_init;
+        // In front of the loop, on the track stream.  (Measured and removed, round 6: the sort on a stream of its own beside the
+        // frame's first two iterations, the launch made ahead for iteration 3 the first to wait for it -- 2 003-2 026 frames/s at
+        // BASELINE config 3 against 2 351-2 366 in front and 2 286-2 301 without the copy: launches made ahead hold their workgroups'
+        // places while they wait for the host's word, and the sort's three launches queue behind them.  profiles/config3_sorted_rows_r06.txt)
         launch_bin_rows(h->stream, h->cam, h->model[h->mcur], h->n_visible, T0, h->d_bin_count, h->d_bin_cursor, h->bins);
         HCK(hipGetLastError());
         h->bins_valid = true;
     }
-#endif
     int again = h->icp.active ? 1 : 0, valid = 0;
-    // chained launches (single GPU, kernels not individually timed): while iteration i runs, iteration i + 1 is
-    // already launched and waits on the device for its transform
-    // (with the peer-to-peer exchange too: there an iteration is one launch as well; every rank takes the same decisions)
-    const bool chain = h->icp_chain && h->go && !h->comm && (h->cfg.nranks == 1 || h->p2p.on) && h->cfg.profile != 1;
     bool waiting = false; unsigned long long wait_seq_rec = 0, wait_go_seq = 0; IcpGo* wait_slot = nullptr;
     while (again) {
         if (chain) {
@@ -1899,7 +1909,7 @@ int ssf_create(const ssf_config* cfg, ssf_handle** out) {
          dalloc(h, &h->d_icp, 64) && dalloc(h, &h->d_state, N + 16) && dalloc(h, &h->d_cand, N) &&
          dalloc(h, &h->d_cnt, 2) && dalloc(h, &h->d_migrants, (size_t)SSF_MIGRANT_WORDS * S) && dalloc(h, &h->d_scratch_map, P) && dalloc(h, &h->d_icp_replicas, 2 * SSF_ICP_REPLICAS * 32)     /* second half: the counted record of k_icp */;
 #ifdef SSF_EXPERIMENTS
-    h->bin_min_rows = SSF_ENV_INT("BIN_MIN_ROWS", -1);          // (lab, lab/tile_bins.inc: < 0 never; its buffers are allocated on first use)
+    h->bin_min_rows = SSF_ENV_INT("BIN_MIN_ROWS", SSF_BIN_MIN_ROWS_DEFAULT);          // (lab: the threshold by environment; < 0 never.  The copy's buffers are allocated on first use)
 #endif
     if (ok) {
         ok = hipHostMalloc((void**)&h->mb_host, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess ||
@@ -2342,14 +2352,8 @@ int ssf_debug_set_max_passes(ssf_handle* h, int n) { if (!h) return SSF_ERR_INVA
 // visible rows from which a frame's tracking streams a tile-sorted copy of them (default: never; 0: always)
 int ssf_debug_set_bin_min_rows(ssf_handle* h, int n) {
     if (!h) return SSF_ERR_INVALID_ARG;
-#ifdef SSF_EXPERIMENTS
     h->bin_min_rows = bin_buffer_words(h->cam, 1) == 0 ? -1 : n;
     return SSF_OK;
-#else
-    if (n < 0) return SSF_OK;                      // "never" is what the product does
-    h->err = "the tile-sorted copy of the visible rows is a measurement arm of the lab build (csrc/variants/lab), not of this library";
-    return SSF_ERR_STATE;
-#endif
 }
 int ssf_stage_set_shard(ssf_handle* h, int64_t off, int64_t gm, int64_t gv) {
     if (!h) return SSF_ERR_INVALID_ARG;

@@ -385,6 +385,40 @@ __device__ __forceinline__ void icp_collect_counted(unsigned long long* __restri
             __hip_atomic_store(&mb->icp_rec[threadIdx.x], SSF_ICP_REC_WORD(threadIdx.x, pay, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- rows in image-tile order (ssf_tile_rows.inc, further down): helpers of the launches that stream the tile-sorted copy ------------
+// Rows sorted by image tile (k_bin_* below) are handed to the launch's workgroups so that ONE XCD works on one contiguous
+// eighth of them -- an eighth of the image: its L2 then holds an eighth of the frame's (label, depth) table instead of
+// all of it.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends on it): logical block =
+// the (b / 8)-th block of that XCD's share.  Bijective for any grid size.
+__device__ __forceinline__ unsigned int xcd_block(unsigned int b, unsigned int nb) {
+    const unsigned int q = nb >> 3, r = nb & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+// ---- association of tile-sorted rows (ssf_tile_rows.inc; round 4, in the product since round 6) -------------------------------------------------------------
+// Sorted rows pile their atomicMin onto the same words (k_match 55 -> 88 us at BASELINE config 3).  Here the lanes of a wave that bid for the same frame supersurfel agree on their minimum
+// first -- one global atomicMin per distinct frame supersurfel and wave.  Called by the lanes that have a bid (any subset of the
+// wave: ballots and cross-lane reads only see active lanes' values for active lanes).
+__device__ __forceinline__ int match_bid_wave(int f, unsigned long long key, unsigned long long* __restrict__ best) {
+    unsigned long long todo = __ballot(1);                       // the lanes with a bid (the others have left match_row)
+    const unsigned int klo = (unsigned int)key, khi = (unsigned int)(key >> 32);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int f0 = __builtin_amdgcn_readlane(f, leader);
+        const unsigned long long same = __ballot(f == f0) & todo;
+        // minimum key of the group, on the scalar unit: one pair of lane reads per member (uniform loop: `same` is a ballot)
+        unsigned long long m = ~0ull, rest = same;
+        while (rest) {
+            const int o = __ffsll((long long)rest) - 1;
+            const unsigned long long ko = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)khi, o) << 32) |
+                                          (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)klo, o);
+            m = ko < m ? ko : m;
+            rest &= rest - 1ull;
+        }
+        if (lane() == leader) atomicMin(&best[f0], m);
+        todo &= ~same;
+    }
+    return f;
+}
 #ifdef SSF_EXPERIMENTS
 #include "lab/icp_arms.inc"
 #endif
@@ -396,8 +430,7 @@ __device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const 
                                             const uint2* __restrict__ pix2, const float4* __restrict__ fpack, const Rt& pose, float zmin,
                                             float zmax, long long id_offset, unsigned long long* __restrict__ best,
                                             uint8_t* __restrict__ matched, bool wave_agg);
-#ifdef SSF_EXPERIMENTS
-// (lab) the association over the tile-sorted copy's 48-byte records, workgroups dealt to the XCDs in contiguous shares
+// the association over the tile-sorted copy's 48-byte records, workgroups dealt to the XCDs in contiguous shares
 __device__ __forceinline__ void match_sorted_rows(const Cam& cam, const SurfelSoA& sorted, int n_visible, const uint2* __restrict__ pix2,
                                                   const float4* __restrict__ fpack, const Rt& pose, const MatchArgs& ma) {
     for (int j = (int)(xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x); j < n_visible; j += gridDim.x * blockDim.x) {
@@ -408,7 +441,6 @@ __device__ __forceinline__ void match_sorted_rows(const Cam& cam, const SurfelSo
         ma.cand[oid] = match_values(cam, a.w, v3(a.x, a.y, a.z), v3(c.x, c.y, c.z), v3(b.x, b.y, b.z), oid, pix2, fpack, pose, ma.zmin, ma.zmax, ma.id_offset, ma.best, ma.matched, true);
     }
 }
-#endif
 #define SSF_ICP_DBG_COUNTED 0x40000000          // bit of k_icp's `dbg` argument: end the launch with the counted record
 #ifndef SSF_ICP_GO_WAIT_TICKS
 #define SSF_ICP_GO_WAIT_TICKS 25000000ull     // 0.25 s of the 100 MHz wall clock: how long a launch made ahead waits for the host's word
@@ -420,7 +452,7 @@ __device__ __forceinline__ void match_sorted_rows(const Cam& cam, const SurfelSo
 #ifndef SSF_ICP_NUM_SGPR
 #define SSF_ICP_NUM_SGPR 80
 #endif
-template <bool P2P, int MODE>          // MODE 0: the product's form; 1: rows' terms summed in registers (SSF_ICP_PER_LANE); 2: DPP row reduction (SSF_ICP_WRED)
+template <bool P2P, int MODE>          // MODE 0: rows from the visible array; 3: rows from the tile-sorted copy (by_tile launches, large visible sets); lab: 1 = rows' terms summed in registers (SSF_ICP_PER_LANE), 2 = DPP row reduction (SSF_ICP_WRED)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SSF_ICP_NUM_SGPR))) void k_icp(Cam cam, SurfelSoA model, int n_visible,
                                              const uint2* __restrict__ pix2, const float4* __restrict__ fpack,
                                              Rt T, long long* __restrict__ replicas, unsigned int* ticket,
@@ -503,9 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SSF_ICP_NUM_SGP
                 auto sT = [&](int i) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_T[i]))); };
                 T.R = m3(v3(sT(0), sT(1), sT(2)), v3(sT(3), sT(4), sT(5)), v3(sT(6), sT(7), sT(8)));
                 T.t = v3(sT(9), sT(10), sT(11));
-#ifdef SSF_EXPERIMENTS
-                if (MODE == 3) { if (ma.best) match_sorted_rows(cam, model, n_visible, pix2, fpack, T, ma); return; }
-#endif
+                if constexpr (MODE == 3) { if (ma.best) match_sorted_rows(cam, model, n_visible, pix2, fpack, T, ma); return; }
                 if (ma.best && !by_tile)
                     for (int id = blockIdx.x * WG + threadIdx.x; id < n_visible; id += n_wg * WG)
                         ma.cand[id] = match_row(cam, model, id, id, pix2, fpack, T, ma.zmin, ma.zmax, ma.id_offset, ma.best, ma.matched);
@@ -522,11 +552,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SSF_ICP_NUM_SGP
     // iteration, not a trip to HBM.)
     // (by_tile: `model` is the tile-sorted copy of the visible rows -- pos / lab / r2 streams only -- and the blocks are dealt
     // to the XCDs in contiguous shares; the sums are exact integers, so the order of the rows does not matter)
-#ifdef SSF_EXPERIMENTS
-    const unsigned int blk = by_tile ? xcd_block(blockIdx.x, n_wg) : blockIdx.x;
-#else
-    const unsigned int blk = blockIdx.x; (void)by_tile;
-#endif
+    unsigned int blk = blockIdx.x; (void)by_tile;
+    if constexpr (MODE == 3) {
+        // rows from the tile-sorted copy (ssf_tile_rows.inc): 48-byte records, (position, confidence) (Lab, index) (normal, 0);
+        // one XCD works on one contiguous eighth of them -- an eighth of the image
+        blk = xcd_block(blockIdx.x, n_wg);
+        const float4* __restrict__ rec = reinterpret_cast<const float4*>(model.pos);
+        for (int id = blk * WG + threadIdx.x; id < n_visible; id += n_wg * WG) {
+            float4 a = rec[3 * id], b = rec[3 * id + 1], c = rec[3 * id + 2];
+            asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x));
+            icp_row(cam, pix2, fpack, R, t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), red, slot, 0);
+        }
+    } else
 #ifdef SSF_EXPERIMENTS
     if (MODE != 0) icp_lab_arm<MODE>(cam, model, n_visible, pix2, fpack, R, t, red, slot, blk);
     else
@@ -741,9 +778,7 @@ __device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const 
     // that case back to 57 us, but the ballots push the WAITING launch this function is inlined into from 86 to 102 scalar
     // registers and the whole chain loses 4-6 % on every BASELINE workload (10 968 against 11 647 frames/s, config 3 2102 against
     // 2193, same box): profiles/track_chain_r04b.txt.)
-#ifdef SSF_EXPERIMENTS
-    if (wave_agg) return match_bid_wave(f, key, best);        // (lab: tile-sorted rows -- the lanes of a wave that bid for one frame supersurfel agree first)
-#endif
+    if (wave_agg) return match_bid_wave(f, key, best);        // (tile-sorted rows: the lanes of a wave that bid for one frame supersurfel agree first; a compile-time `false` everywhere else)
     atomicMin(&best[f], key);
     return f;
 }
@@ -751,6 +786,7 @@ __device__ __forceinline__ int match_values(const Cam& cam, float m_conf, const 
 // in a launch of its own.  The matched flags then have to reach that workgroup through device-scope atomics, and 100 k
 // of them on 300-1200 hot addresses cost 50-100 us: memory-side atomics serialise per address at ~0.1 us -- which is also
 // what bounds this kernel's own atomicMin.  The separate exchange launch costs ~8 us.)
+template <bool SORTED>
 __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_visible, const uint2* __restrict__ pix2,
                                                const float4* __restrict__ fpack, Rt pose, float zmin, float zmax,
                                                long long id_offset, unsigned long long* __restrict__ best,
@@ -758,27 +794,21 @@ __global__ __launch_bounds__(256) void k_match(Cam cam, SurfelSoA model, int n_v
     __builtin_amdgcn_s_setprio(3);            // the track chain is the critical path: its waves issue ahead of the extract waves sharing a SIMD
     // (orig != nullptr: `model` is the tile-sorted copy, orig[j] the row's index in the visible array; blocks dealt to the XCDs
     // in contiguous shares -- see xcd_block)
-#ifdef SSF_EXPERIMENTS
-    const int j = (orig ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
-    if (j >= n_visible) return;
-    if (orig) {                                   // (the copy's 48-byte records: lab/tile_bins.inc)
+    if constexpr (SORTED) {                       // (the copy's 48-byte records: ssf_tile_rows.inc)
+        (void)orig;
         const MatchArgs ma{zmin, zmax, id_offset, best, matched, cand};
         match_sorted_rows(cam, model, n_visible, pix2, fpack, pose, ma);
         return;
+    } else {
+        const int j = blockIdx.x * blockDim.x + threadIdx.x, id = j; (void)orig;
+        if (j >= n_visible) return;
+        cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched, false);
     }
-    const int id = j;
-#else
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, id = j; (void)orig;
-    if (j >= n_visible) return;
-#endif
-    cand[id] = match_row(cam, model, j, id, pix2, fpack, pose, zmin, zmax, id_offset, best, matched, orig != nullptr);
 }
 
-// ---- image-space order for the model side of ICP / association: a tile-sorted copy of the visible rows (k_bin_*), measured
-// a loss at BASELINE config 3 -- lab/tile_bins.inc, compiled only into the lab variant
-#ifdef SSF_EXPERIMENTS
-#include "lab/tile_bins.inc"
-#endif
+// ---- image-space order for the model side of ICP / association: a tile-sorted copy of the visible rows (k_bin_*), made for
+// large visible sets (BASELINE config 3): ssf_tile_rows.inc
+#include "ssf_tile_rows.inc"
 
 // ---- classification of one model row (used by the update/insert launch and by k_classify) --------------------
 // filterModel for one row, supersurfel_fusion_kernels.cu:397-467: 0 visible, 1 out of view, 2 removed (conf := -1)
@@ -2081,8 +2111,8 @@ void launch_icp(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible, 
     const int dbg = (dbg_arg < 0 ? 0 : dbg_arg) | ((counted && !pv && dbg_arg < 0) ? SSF_ICP_DBG_COUNTED : 0);
     const P2PView none{};
     const P2PView& v = pv ? *pv : none;
-#ifdef SSF_EXPERIMENTS
     if (by_tile && !pv) { hipLaunchKernelGGL((k_icp<false, 3>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
+#ifdef SSF_EXPERIMENTS
     if (mode == 2 && !pv) { hipLaunchKernelGGL((k_icp<false, 2>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
     if (mode == 1 && pv) { hipLaunchKernelGGL((k_icp<true, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
     if (mode == 1) { hipLaunchKernelGGL((k_icp<false, 1>), dim3(grid), dim3(256), 0, st, cam, model, n_visible, pix2, fpack, T, replicas, ticket, sums29, mb, seq, dbg, go, go_seq, v, by_tile, ma); return; }
@@ -2096,8 +2126,10 @@ void launch_match(hipStream_t st, const Cam& cam, SurfelSoA model, int n_visible
     (void)S;                                   // best/matched were initialised by k_finalize_surfels of this frame
     if (n_visible <= 0) return;
     ScopedKernel sk("match", st);
-    hipLaunchKernelGGL(k_match, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
-                       pose, zmin, zmax, id_offset, best, matched, cand, orig);
+    if (orig) hipLaunchKernelGGL(k_match<true>, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
+                                 pose, zmin, zmax, id_offset, best, matched, cand, orig);
+    else hipLaunchKernelGGL(k_match<false>, dim3((n_visible + 255) / 256), dim3(256), 0, st, cam, model, n_visible, pix2, fpack,
+                            pose, zmin, zmax, id_offset, best, matched, cand, orig);
 }
 void launch_fuse(hipStream_t st, SurfelSoA model, SurfelSoA frame, Rt pose, int stamp, long long id_offset,
                  int n_visible, const unsigned long long* best, const uint8_t* matched, const int32_t* cand, int S, int do_update,
