@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: the relabelling pass with the replay ahead of the decisions (64 registers) and direct-to-LDS tile loads, against the product
+# (the arms it compares -- -DSSF_PASS_LDSDMA / -DSSF_PASS_REPLAY_FIRST -- exist in the tree at the commit named in profiles/pass_ldsdma_r06.txt; they were removed afterwards)
 #   gpurun -- 'bash tools/ab_pass_r06.sh <outdir> <rounds> <variant> [<variant> ...]'
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OD=${1:?outdir}; O=$R/gpurun_out/$OD; mkdir -p $O; cd $R
 N=${2:?rounds}; shift 2
