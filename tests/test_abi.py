@@ -80,7 +80,7 @@ def test_the_product_library_reads_no_environment_variable(product_lib):
     import subprocess
     out = subprocess.run(["strings", product_lib.path], stdout=subprocess.PIPE, text=True).stdout.splitlines()
     assert [l for l in out if l.startswith("SSF_")] == []
-    for src in ("ssf_extract.hip", "ssf_pass_tile.hpp", "ssf_track_fuse.hip", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
+    for src in ("ssf_extract.hip", "ssf_pass_tile.hpp", "ssf_track_fuse.hip", "ssf_tile_rows.inc", "ssf_host.hip", "ssf_device.hpp", "ssf_math.hpp"):
         txt = open(os.path.join(ROOT, "supersurfel_fusion_amd", "csrc", src)).read()
         body = txt.split("#ifdef SSF_EXPERIMENTS\n#include <stdlib.h>")[0] if src == "ssf_device.hpp" else txt
         assert "getenv(" not in body, src
@@ -107,3 +107,13 @@ def test_the_product_exports_no_probe_entry_points(product_lib):
 def test_comm_info_without_an_exchange(oracle_lib):
     f = binding.Fusion(oracle_lib, oracle_lib.default_config(width=160, height=128, fx=131.25, fy=131.25, cx=79.5, cy=63.5, nb_supersurfels_max=2048))
     assert f.comm_info() == dict(backend="none", ranks=1, rank=0)
+
+
+def test_stream_copy_rate_refuses_sizes_its_forms_would_overrun(product_lib):
+    """advisor, round 5: the grid-stride forms of the copy move whole rounds of 128 / 256 MiB with an unguarded first round; sizes
+    below 256 MiB (and reps < 1) are refused before any device call -- so this runs without a GPU"""
+    import ctypes
+    f = product_lib.lib.ssf_stream_copy_rate
+    f.restype = ctypes.c_double; f.argtypes = [ctypes.c_int, ctypes.c_int]
+    for mib, reps in ((16, 3), (32, 3), (128, 3), (255, 3), (1024, 0)):
+        assert f(mib, reps) == -1.0, (mib, reps)
