@@ -336,13 +336,14 @@ def test_stated_tolerance_arithmetic_arms(tolerance_study):
 
 def test_stated_tolerance_schedule_arms(tolerance_study):
     """The other extreme of each race the reference leaves open (blocks of a relabelling pass strictly in sequence; the plane filter in
-    place; the torn arg-min's worst outcome), and everything at once: at most 2 % of the labels, 0.5 % of the inlier flags, the pose
-    within 1e-2.  This -- not 1e-4 -- is how far two valid executions of the reference's own CUDA code can lie apart; the product's
+    place; the torn arg-min's worst outcome), another random stream for the RANSAC initialisation (cuRAND's cannot be reproduced), and
+    the races + arithmetic at once: at most 2 % of the labels, 1 % of the inlier flags, the pose within 1e-2.  This -- not 1e-4 -- is how far two valid executions of the reference's own CUDA code can lie apart; the product's
     1e-4 (in fact 0-bit) agreement is with the specification, one member of that family."""
     r = tolerance_study
     for seq in ("tum_fr1_xyz", "synthetic"):
-        for arm in ("schedule", "filter-gs", "argmin-torn", "all"):
+        for arm in ("schedule", "filter-gs", "argmin-torn", "rng-stream", "all"):
             d = r[(seq, arm)]
-            assert d["labels"] <= 0.02 * d["px"] and d["inliers"] <= 0.005 * d["px"], (seq, arm, d)
+            assert d["labels"] <= 0.02 * d["px"] and d["inliers"] <= 0.01 * d["px"], (seq, arm, d)
             assert d["pose_t"] <= 1e-2 and d["pose_r"] <= 2e-2, (seq, arm, d)
+        assert r[(seq, "rng-stream")]["labels"] > 0           # (another RANSAC stream is the largest single source of differing labels)
         assert r[(seq, "schedule")]["labels"] > 0 and r[(seq, "filter-gs")]["pose_t"] > 0 and r[(seq, "argmin-torn")]["row_diff"] > 0

@@ -48,6 +48,9 @@ ARMS = [
     ("tie-high", "std", {"tie": 1}, "association: equal distances go to the highest model id"),
     ("argmin-torn", "std", {"tie": 2}, "association: every candidate saw the initial 0.05, the last store stays (worst valid outcome of the torn arg-min)"),
     ("insert-rev", "std", {"insert_rev": 1}, "insertion in descending frame id (another atomic arrival order)"),
+    ("rng-stream", "std", {"rng_seed": 4321}, "another random stream for the RANSAC plane initialisation (the reference's cuRAND XORWOW sequence -- curand_init(1234, id, 0), "
+                                              "TPS_RGBD_kernels.cu:321 -- cannot be reproduced without the toolkit's skip-ahead tables: this build's counter-based "
+                                              "generator is part of its specification, and this arm is what ANY other stream does)"),
     ("all", "fma", {"ftz": 1, "div_ulp": 3, "rsqrt_ulp": 3, "pow_ulp": 3, "schedule": 1, "filter_gs": 1, "tie": 1},
      "everything above at once except argmin-torn and insert-rev"),
 ]
@@ -70,7 +73,7 @@ def set_arms(lib, arms):
 def run(lib, make, frames, arms):
     set_arms(lib, arms)
     try:
-        f = make(lib)
+        f = make(lib, **({"rng_seed": int(arms["rng_seed"])} if "rng_seed" in arms else {}))
         out = []
         for rgb, depth in frames:
             r = f.process_frame(rgb, depth)
@@ -128,15 +131,15 @@ def sequences(quick):
     import util
     frames_tum = [(rgb, depth) for _, rgb, depth in list(replay.frames_from_npz(TUM))[: (4 if quick else 8)]]
 
-    def make_tum(lib):
-        cfg = dict(replay.BENCHMARK_LAUNCH, nb_supersurfels_max=100000)
+    def make_tum(lib, **kw):
+        cfg = dict(replay.BENCHMARK_LAUNCH, nb_supersurfels_max=100000); cfg.update(kw)
         return binding.Fusion(lib, lib.default_config(**cfg))
     W, H = 320, 240
     frames_syn = [util.frame(k, W, H, noise=True, holes=0.03) for k in range(3 if quick else 6)]
     model, nvis = synthetic.seed_model_cam0(20000, W, H, stamp=30)
 
-    def make_syn(lib):
-        f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=40000))
+    def make_syn(lib, **kw):
+        f = binding.Fusion(lib, util.make_cfg(lib, W, H, nb_supersurfels_max=40000, **kw))
         f.set_model(model, nvis, 30)
         return f
     return [("tum_fr1_xyz (8 real frames, 640x480, benchmark-launch parameters, pre-filter on, map grown by the frames)", make_tum, frames_tum),
